@@ -1,0 +1,376 @@
+/*
+ * rdfgpu.h — C ABI of the MI355X-native BGP-scan + hash-join + FILTER path.
+ *
+ * This is the drop-in boundary for the one hot path of tobixdev/rdf-fusion that this
+ * repository accelerates: triple-pattern scan over sorted u32 quad
+ * indexes -> cross/hash join of binding tables -> SPARQL FILTER.  Everything in here is
+ * plain C: pointers, sizes, PODs.  No C++/torch/Arrow-library types cross the boundary;
+ * result batches leave through the Arrow C Data Interface structs declared below.
+ *
+ * Every entry point names the reference interface (file:line, relative to the
+ * rdf-fusion tree) that it replaces.  INTEGRATION.md shows the Rust-side binding.
+ *
+ * Conventions
+ *   - All functions return an rdfgpu_status (0 ok, >0 informational, <0 error) unless
+ *     stated otherwise.  On error, rdfgpu_last_error() returns a thread-local message.
+ *   - Object ids are u32.  Id 0 is the default graph AND the null / unbound marker,
+ *     exactly as in the reference (lib/storage/src/memory/object_id.rs:21,80;
+ *     quad_index_data.rs:438-440 stores 0 as an Arrow null).
+ *   - The caller owns every input buffer; the library copies what it keeps.
+ *   - A handle may be used from any thread, one in-flight call per handle.
+ *   - There is NO CPU fallback: entry points that touch data fail with
+ *     RDFGPU_ERR_NO_DEVICE when no gfx950 device is usable.  The host-logic entry
+ *     points (section 5) never touch the device.
+ */
+#ifndef RDFGPU_H
+#define RDFGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RDFGPU_ABI_VERSION 1u
+
+/* ------------------------------------------------------------------------------------ */
+/* 0. Status codes                                                                       */
+/* ------------------------------------------------------------------------------------ */
+typedef enum rdfgpu_status {
+  RDFGPU_OK = 0,
+  RDFGPU_END = 1,              /* rdfgpu_plan_next: stream exhausted                      */
+  RDFGPU_ERR_INVALID = -1,     /* malformed argument / plan (DataFusionError::Plan)       */
+  RDFGPU_ERR_DEVICE = -2,      /* HIP runtime error (DataFusionError::External)           */
+  RDFGPU_ERR_UNSUPPORTED = -3, /* valid but not implemented on device                     */
+  RDFGPU_ERR_OOM = -4,         /* device allocation failed                                */
+  RDFGPU_ERR_NO_DEVICE = -5    /* no usable gfx950 device; there is no CPU fallback       */
+} rdfgpu_status;
+
+/* Thread-local text of the last error raised on the calling thread ("" if none). */
+const char* rdfgpu_last_error(void);
+uint32_t rdfgpu_abi_version(void);
+
+/* ------------------------------------------------------------------------------------ */
+/* 1. Arrow C Data Interface (verbatim ABI structs, https://arrow.apache.org/docs/format/CDataInterface.html) */
+/* ------------------------------------------------------------------------------------ */
+#ifndef ARROW_C_DATA_INTERFACE
+#define ARROW_C_DATA_INTERFACE
+struct ArrowSchema {
+  const char* format;
+  const char* name;
+  const char* metadata;
+  int64_t flags;
+  int64_t n_children;
+  struct ArrowSchema** children;
+  struct ArrowSchema* dictionary;
+  void (*release)(struct ArrowSchema*);
+  void* private_data;
+};
+struct ArrowArray {
+  int64_t length;
+  int64_t null_count;
+  int64_t offset;
+  int64_t n_buffers;
+  int64_t n_children;
+  const void** buffers;
+  struct ArrowArray** children;
+  struct ArrowArray* dictionary;
+  void (*release)(struct ArrowArray*);
+  void* private_data;
+};
+#endif
+
+/* ------------------------------------------------------------------------------------ */
+/* 2. Store: three sorted u32 quad permutations + typed-value table, resident in HBM     */
+/*    replaces MemQuadStorage (lib/storage/src/memory/storage/mem_storage.rs:22-102)     */
+/*    and the MemIndexData layout (quad_index_data.rs:57-64)                             */
+/* ------------------------------------------------------------------------------------ */
+typedef struct rdfgpu_store rdfgpu_store;
+
+typedef struct rdfgpu_config {
+  int32_t device;        /* HIP device ordinal; -1 = current device                       */
+  uint32_t batch_size;   /* rows per exported batch; 0 = 8192 (store.rs:102)              */
+  uint32_t flags;        /* reserved, 0                                                   */
+  uint32_t reserved;
+} rdfgpu_config;
+
+/* Index permutations, in the reference's listing order (mem_storage.rs:41-45).          */
+enum { RDFGPU_GSPO = 0, RDFGPU_GPOS = 1, RDFGPU_GOSP = 2, RDFGPU_N_INDEXES = 3 };
+
+/*
+ * Device-side typed value of one object id: the FILTER side table.
+ * Mirrors TypedValueEncodingField type ids (lib/encoding/src/typed_value/encoding.rs:248-268)
+ * and the id -> typed value decode of object_id_mapping.rs:376-399.
+ *   tag 0 null/invalid (parse failure => null, typed_value.rs:349-411)
+ *   tag 1 named node, 2 blank node: lo = rank of the IRI / label in str order
+ *   tag 3 string: lo = rank of the lexical value in str order; aux = language id
+ *                 (0 = simple literal); flags bit0 = value is the empty string
+ *   tag 4 boolean: lo = 0/1
+ *   tag 5 float:   lo = IEEE-754 binary32 bits (zero-extended)
+ *   tag 6 double:  lo = IEEE-754 binary64 bits
+ *   tag 7 decimal: lo = index into the i128 side table (value * 10^18, decimal.rs:9-21)
+ *   tag 8 int (i32, sign-extended), tag 9 integer (i64)
+ *   tag 10..14 (dateTime, time, date, duration, other literal): opaque on device; any
+ *              operator that would need their value yields an error (null) -> the plan
+ *              compiler rejects such programs with RDFGPU_ERR_UNSUPPORTED unless
+ *              RDFGPU_PLAN_ALLOW_OPAQUE is set.
+ */
+typedef struct rdfgpu_typed_value {
+  int64_t lo;
+  uint32_t aux;
+  uint8_t tag;
+  uint8_t flags;
+  uint16_t reserved;
+} rdfgpu_typed_value; /* 16 bytes, one aligned dwordx4 gather per row */
+
+enum {
+  RDFGPU_TV_NULL = 0, RDFGPU_TV_NAMED_NODE = 1, RDFGPU_TV_BLANK_NODE = 2, RDFGPU_TV_STRING = 3,
+  RDFGPU_TV_BOOLEAN = 4, RDFGPU_TV_FLOAT = 5, RDFGPU_TV_DOUBLE = 6, RDFGPU_TV_DECIMAL = 7,
+  RDFGPU_TV_INT = 8, RDFGPU_TV_INTEGER = 9, RDFGPU_TV_DATE_TIME = 10, RDFGPU_TV_TIME = 11,
+  RDFGPU_TV_DATE = 12, RDFGPU_TV_DURATION = 13, RDFGPU_TV_OTHER = 14
+};
+#define RDFGPU_TVF_EMPTY_STRING 1u
+
+/* MemQuadStorage::new (mem_storage.rs:31-65): creates the store on `cfg->device`. */
+int rdfgpu_store_create(const rdfgpu_config* cfg, rdfgpu_store** out);
+void rdfgpu_store_destroy(rdfgpu_store* store);
+
+/*
+ * QuadStorage::extend (lib/extensions/src/storage/quad_storage.rs:30; mem_storage.rs:95-102;
+ * IndexPermutations::insert permutations.rs:102-118): merges `n` encoded quads (host
+ * buffers, ids assigned by the host dictionary) into all three permutations; duplicates
+ * are ignored.  `*inserted` receives the number of quads that were new.
+ */
+int rdfgpu_store_extend(rdfgpu_store* store, const uint32_t* g, const uint32_t* s,
+                        const uint32_t* p, const uint32_t* o, uint64_t n, uint64_t* inserted);
+/* Same, with the four columns already resident in this device's HBM. */
+int rdfgpu_store_extend_device(rdfgpu_store* store, const uint32_t* g, const uint32_t* s,
+                               const uint32_t* p, const uint32_t* o, uint64_t n,
+                               uint64_t* inserted);
+/* QuadStorage::remove (quad_storage.rs:33; permutations.rs:120-128). */
+int rdfgpu_store_remove(rdfgpu_store* store, const uint32_t* g, const uint32_t* s,
+                        const uint32_t* p, const uint32_t* o, uint64_t n, uint64_t* removed);
+/* QuadStorage::clear (quad_storage.rs:60). */
+int rdfgpu_store_clear(rdfgpu_store* store);
+/* QuadStorage::len (quad_storage.rs:69). */
+int rdfgpu_store_len(const rdfgpu_store* store, uint64_t* out);
+
+/*
+ * Installs the id -> typed value table (MemObjectIdMapping::decode_array_to_typed_value,
+ * object_id_mapping.rs:376-399).  values[i] describes object id i (values[0] is ignored:
+ * id 0 is null).  `decimals` holds n_decimals little-endian i128 as (lo,hi) int64 pairs.
+ */
+int rdfgpu_store_set_typed_values(rdfgpu_store* store, const rdfgpu_typed_value* values,
+                                  uint64_t n_ids, const int64_t* decimals, uint64_t n_decimals);
+
+/*
+ * Test / debug access to a sorted permutation (MemIndexData, quad_index_data.rs:57-64):
+ * copies up to `cap` rows of index `components` (RDFGPU_GSPO..) into four host columns,
+ * in index order (e.g. g,p,o,s for GPOS).  `*n` receives the index length.
+ */
+int rdfgpu_store_read_index(const rdfgpu_store* store, uint32_t components, uint32_t* c0,
+                            uint32_t* c1, uint32_t* c2, uint32_t* c3, uint64_t cap, uint64_t* n);
+
+/* ------------------------------------------------------------------------------------ */
+/* 3. Plan description: what DataFusion hands over for this path                         */
+/* ------------------------------------------------------------------------------------ */
+
+/*
+ * One level of a quad pattern scan = MemIndexScanInstruction + MemIndexScanPredicate
+ * (lib/storage/src/memory/storage/scan_instructions.rs:157-166, 247-252).
+ */
+enum { RDFGPU_TRAVERSE = 0, RDFGPU_SCAN = 1 };
+enum { RDFGPU_PRED_NONE = 0, RDFGPU_PRED_FALSE = 1, RDFGPU_PRED_IN = 2, RDFGPU_PRED_BETWEEN = 3,
+       RDFGPU_PRED_EQUAL_TO = 4 };
+
+typedef struct rdfgpu_scan_instruction {
+  uint8_t kind;      /* RDFGPU_TRAVERSE | RDFGPU_SCAN                                     */
+  uint8_t pred;      /* RDFGPU_PRED_*                                                     */
+  uint16_t reserved;
+  uint32_t var;      /* SCAN: variable slot this level binds                              */
+  uint32_t a;        /* IN: offset into the plan's u32 pool (sorted ascending, unique);
+                        BETWEEN: from;  EQUAL_TO: variable slot it must equal             */
+  uint32_t b;        /* IN: number of ids;  BETWEEN: to (inclusive)                       */
+} rdfgpu_scan_instruction;
+
+/*
+ * Expression programs (postfix) = the PhysicalExpr trees DataFusion evaluates in
+ * FilterExec / JoinFilter for this path, with the reference's UDF names
+ * (lib/extensions/src/functions/builtin.rs:101-186).  Three value kinds live on the
+ * evaluation stack: ID (u32 object id, 0 = null), TV (typed value, tag 0 = null/error),
+ * BOOL (native nullable boolean).
+ */
+enum {
+  RDFGPU_EX_COLUMN = 1,       /* -> ID      push input column `u` (join filters: left columns first, then right) */
+  RDFGPU_EX_LIT_ID = 2,       /* -> ID      push object id literal `u`                                         */
+  RDFGPU_EX_LIT_TV = 3,       /* -> TV      push typed literal (tag, lo, aux, flags), plan text "9:120"       */
+  RDFGPU_EX_ENC_TV = 4,       /* ID -> TV   ENC_TV: with_typed_value_encoding.rs:71-79                         */
+  RDFGPU_EX_GT = 5,           /* TV TV -> TV(boolean|null)  greater_than.rs:41-64                              */
+  RDFGPU_EX_LT = 6,           /*            less_than.rs                                                        */
+  RDFGPU_EX_GEQ = 7,
+  RDFGPU_EX_LEQ = 8,
+  RDFGPU_EX_EQ = 9,           /*            equal.rs (typed `=`)                                                */
+  RDFGPU_EX_ADD = 10,         /* TV TV -> TV  add.rs:40-86                                                      */
+  RDFGPU_EX_SUB = 11,         /*              sub.rs                                                            */
+  RDFGPU_EX_EBV = 12,         /* TV -> BOOL   effective_boolean_value.rs:99-119                                 */
+  RDFGPU_EX_ID_EQ = 13,       /* ID ID -> BOOL  native UInt32 `=`  (expression_simplifier.rs:162-257)          */
+  RDFGPU_EX_ID_NEQ = 14,      /* ID ID -> BOOL  native `!=` (the `product != <object id>` FilterExec)          */
+  RDFGPU_EX_AND = 15,         /* BOOL BOOL -> BOOL  SQL three-valued (expr_builder_context.rs:393-434)         */
+  RDFGPU_EX_OR = 16,
+  RDFGPU_EX_NOT = 17,         /* BOOL -> BOOL                                                                   */
+  RDFGPU_EX_IS_COMPATIBLE = 18, /* ID ID -> BOOL  is_compatible.rs:97-136                                      */
+  RDFGPU_EX_BOUND = 19,       /* ID -> BOOL   functional_form/bound.rs:21                                       */
+  RDFGPU_EX_BOOL_AS_TV = 20,  /* BOOL -> TV   BOOLEAN_AS_TERM (expr_builder.rs:694-698)                        */
+  RDFGPU_EX_LIT_BOOL = 21,    /* -> BOOL      literal true (u=1) / false (u=0) / null (u=2)                    */
+  RDFGPU_EX_NEQ = 22,         /* TV TV -> TV  NOT(EQ) kept as one op for convenience                            */
+  RDFGPU_EX__COUNT
+};
+
+typedef struct rdfgpu_expr_node {
+  uint8_t op;       /* RDFGPU_EX_*                                                        */
+  uint8_t tag;      /* LIT_TV: typed value tag                                            */
+  uint8_t flags;    /* LIT_TV: rdfgpu_typed_value.flags                                   */
+  uint8_t reserved;
+  uint32_t u;       /* COLUMN: column index; LIT_ID: id; LIT_TV: aux; LIT_BOOL: 0/1/2     */
+  int64_t lo;       /* LIT_TV payload (decimal literals: low 64 bits)                     */
+  int64_t hi;       /* LIT_TV decimal literal: high 64 bits                               */
+} rdfgpu_expr_node; /* 24 bytes */
+
+/* Physical operators of the path, named as in the reference's execution plans
+   (bench/tests/plans/snapshots/..Q5 (Execution Plan).snap:10-30). */
+enum {
+  RDFGPU_NODE_DATA_SOURCE = 1, /* DataSourceExec(MemQuadPatternDataSource), pattern_data_source.rs:21-58  */
+  RDFGPU_NODE_FILTER = 2,      /* FilterExec: keep rows whose predicate is true; optional projection       */
+  RDFGPU_NODE_HASH_JOIN = 3,   /* HashJoinExec(CollectLeft), inner | left, NullEqualsNothing, filter, projection */
+  RDFGPU_NODE_CROSS_JOIN = 4,  /* CrossJoinExec                                                            */
+  RDFGPU_NODE_NESTED_LOOP_JOIN = 5, /* NestedLoopJoinExec: inner | left with a filter and no equi keys     */
+  RDFGPU_NODE_PROJECTION = 6,  /* ProjectionExec of plain columns                                          */
+  RDFGPU_NODE_TABLE = 7        /* bindings supplied by the caller (device columns), e.g. all-gathered rows */
+};
+enum { RDFGPU_JOIN_INNER = 0, RDFGPU_JOIN_LEFT = 1 };
+#define RDFGPU_MAX_KEYS 4u
+#define RDFGPU_MAX_COLUMNS 16u
+#define RDFGPU_NO_PROJECTION 0xFFFFFFFFu
+
+typedef struct rdfgpu_plan_node {
+  uint32_t kind;                          /* RDFGPU_NODE_*                                */
+  int32_t left;                           /* child node index (or -1)                     */
+  int32_t right;                          /* second child (joins) or -1                   */
+  uint32_t join_type;                     /* RDFGPU_JOIN_*                                */
+  rdfgpu_scan_instruction scan[4];        /* DATA_SOURCE: instructions in G,S,P,O order   */
+  uint32_t n_keys;                        /* HASH_JOIN: number of equi-key pairs          */
+  uint32_t left_keys[RDFGPU_MAX_KEYS];    /* column indices in the left child             */
+  uint32_t right_keys[RDFGPU_MAX_KEYS];   /* column indices in the right child            */
+  uint32_t expr_off;                      /* FILTER / join filter: offset into exprs      */
+  uint32_t expr_len;                      /* 0 = no filter                                */
+  uint32_t proj_off;                      /* projection: offset into the u32 pool         */
+  uint32_t n_proj;                        /* RDFGPU_NO_PROJECTION = keep all columns      */
+  uint32_t table_slot;                    /* TABLE: which bound table (rdfgpu_plan_bind_table) */
+  uint32_t table_cols;                    /* TABLE: number of columns                     */
+} rdfgpu_plan_node;
+
+typedef struct rdfgpu_plan_desc {
+  const rdfgpu_plan_node* nodes;
+  uint32_t n_nodes;
+  uint32_t root;                          /* index of the root node                       */
+  const rdfgpu_expr_node* exprs;
+  uint32_t n_exprs;
+  const uint32_t* pool;                   /* IN-set ids and projection lists              */
+  uint32_t n_pool;
+  uint32_t flags;                         /* RDFGPU_PLAN_*                                */
+} rdfgpu_plan_desc;
+#define RDFGPU_PLAN_ALLOW_OPAQUE 1u
+
+/* ------------------------------------------------------------------------------------ */
+/* 4. Plans: compile, execute on device, stream result batches                           */
+/*    replaces plan_extension (lib/storage/src/memory/planner.rs:31-64),                 */
+/*    DataSource::open (pattern_data_source.rs:42-58), the stream's poll_next             */
+/*    (stream.rs:39-63) and ExecutionPlan::execute of the join/filter subtree             */
+/* ------------------------------------------------------------------------------------ */
+typedef struct rdfgpu_plan rdfgpu_plan;
+
+typedef struct rdfgpu_metrics {
+  uint64_t output_rows;      /* BaselineMetrics::output_rows (stream.rs:48-63)            */
+  uint64_t input_rows;       /* index rows covered by the located scan ranges             */
+  uint64_t intermediate_rows;/* sum of rows produced by all non-root operators            */
+  uint64_t device_bytes;     /* bytes of HBM held by this plan's intermediates            */
+  double elapsed_compute_ms; /* device time of the last execute (HIP events)              */
+  uint32_t kernels_launched;
+  uint32_t host_syncs;
+} rdfgpu_metrics;
+
+/* Validates the description, chooses an index per data source (IndexPermutations::choose_index,
+   permutations.rs:81-96) and allocates a HIP stream.  Does not launch kernels. */
+int rdfgpu_plan_compile(rdfgpu_store* store, const rdfgpu_plan_desc* desc, rdfgpu_plan** out);
+void rdfgpu_plan_destroy(rdfgpu_plan* plan);
+
+/* Supplies the columns of a RDFGPU_NODE_TABLE (device pointers into this device's HBM,
+   n rows each; must stay valid until the next execute finishes). */
+int rdfgpu_plan_bind_table(rdfgpu_plan* plan, uint32_t slot, const uint32_t* const* cols,
+                           uint32_t n_cols, uint64_t n_rows);
+
+/* Runs the whole operator tree on the device.  The result stays in HBM.  Re-executable. */
+int rdfgpu_plan_execute(rdfgpu_plan* plan);
+
+/* Result shape (waits for the stream). */
+int rdfgpu_plan_result_info(rdfgpu_plan* plan, uint64_t* n_rows, uint32_t* n_cols);
+/* Device pointers of the result columns (valid until the next execute / destroy). */
+int rdfgpu_plan_result_device(rdfgpu_plan* plan, const uint32_t** cols, uint32_t cap_cols);
+/* Copies the whole result to caller-owned host columns (each with room for n_rows). */
+int rdfgpu_plan_fetch(rdfgpu_plan* plan, uint32_t* const* host_cols, uint32_t n_cols);
+/*
+ * SendableRecordBatchStream::poll_next (stream.rs:39-63): exports the next batch of at
+ * most batch_size rows as an Arrow struct array of UInt32 children (format "+s" / "I");
+ * id 0 becomes a null.  Never yields an empty batch (scan.rs:195-198).  Returns
+ * RDFGPU_END once drained.  `schema` may be NULL.
+ */
+int rdfgpu_plan_next(rdfgpu_plan* plan, struct ArrowArray* out, struct ArrowSchema* schema);
+/* Restarts the batch stream over the current result. */
+int rdfgpu_plan_rewind(rdfgpu_plan* plan);
+int rdfgpu_plan_metrics(rdfgpu_plan* plan, rdfgpu_metrics* out);
+/* Index chosen for a DATA_SOURCE node (RDFGPU_GSPO..), for plan display ("[GPOS] subject=…"). */
+int rdfgpu_plan_selected_index(const rdfgpu_plan* plan, uint32_t node, uint32_t* components);
+/* Opaque hipStream_t of the plan, so the host can order its own work after it. */
+int rdfgpu_plan_stream(rdfgpu_plan* plan, void** hip_stream);
+
+/* ------------------------------------------------------------------------------------ */
+/* 5. Host logic of the scan planner (no device access)                                  */
+/* ------------------------------------------------------------------------------------ */
+/*
+ * MemQuadIndex::compute_scan_score (quad_index.rs:100-130): `instr` is in the order of the
+ * index being scored.
+ */
+uint64_t rdfgpu_scan_score(const rdfgpu_scan_instruction instr[4]);
+/*
+ * IndexPermutations::choose_index (permutations.rs:81-96): `gspo` is in G,S,P,O order;
+ * `available` is a bit mask of RDFGPU_GSPO.. permutations the store keeps; returns the
+ * chosen permutation (ties prefer the first listed).
+ */
+uint32_t rdfgpu_choose_index(const rdfgpu_scan_instruction gspo[4], uint32_t available);
+/*
+ * MemIndexScanPredicate::try_and_with (scan_instructions.rs:170-210).  Predicates are given
+ * as (pred, a, b) triples where IN sets are explicit arrays.  Writes the combined predicate;
+ * `out_ids` needs room for min(na, nb) ids.  Returns 1 if combinable, 0 if not (EqualTo).
+ */
+typedef struct rdfgpu_predicate {
+  uint32_t pred;        /* RDFGPU_PRED_*                                                  */
+  uint32_t from, to;    /* BETWEEN                                                        */
+  const uint32_t* ids;  /* IN (sorted unique)                                             */
+  uint32_t n_ids;
+  uint32_t equal_to;    /* EQUAL_TO variable slot                                         */
+} rdfgpu_predicate;
+int rdfgpu_predicate_and(const rdfgpu_predicate* lhs, const rdfgpu_predicate* rhs,
+                         rdfgpu_predicate* out, uint32_t* out_ids);
+/*
+ * MemStoragePredicateExpr::to_scan_predicate (predicate_pushdown.rs:120-157): rewrites
+ * `column <op> value` into a scan predicate.  op: 0 Eq, 1 Gt, 2 GtEq, 3 Lt, 4 LtEq.
+ * Returns 1 and fills `out` (BETWEEN / IN with one id in out->from / FALSE).
+ */
+enum { RDFGPU_OP_EQ = 0, RDFGPU_OP_GT = 1, RDFGPU_OP_GTEQ = 2, RDFGPU_OP_LT = 3, RDFGPU_OP_LTEQ = 4 };
+int rdfgpu_pushdown_to_scan_predicate(uint32_t op, uint32_t value, rdfgpu_predicate* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RDFGPU_H */

@@ -1,0 +1,259 @@
+"""ctypes binding of the CPU oracle (oracle/librdf_oracle.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg.  The product package never imports this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+import rdf_fusion_amd.abi as abi
+from rdf_fusion_amd.plan import MemIndexScanPredicate as P
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+FR_BEFORE, FR_NOT_CONTAINED, FR_CONTAINED, FR_AFTER = 0, 1, 2, 3
+
+
+class ScanResult(C.Structure):
+    _fields_ = [("n_cols", C.c_uint32), ("vars", C.c_uint32 * 4), ("n_rows", C.c_uint64),
+                ("cols", C.POINTER(C.c_uint32) * 4), ("n_batches", C.c_uint32),
+                ("batch_rows", C.POINTER(C.c_uint32)), ("chosen_index", C.c_uint32)]
+
+
+class Table(C.Structure):
+    _fields_ = [("n_cols", C.c_uint32), ("n_rows", C.c_uint64),
+                ("cols", C.POINTER(C.c_uint32) * abi.MAX_COLUMNS)]
+
+
+class BoundTable(C.Structure):
+    _fields_ = [("cols", C.POINTER(C.c_void_p)), ("n_cols", C.c_uint32), ("n_rows", C.c_uint64)]
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "librdf_oracle.so")
+    src = os.path.join(_HERE, "rdf_oracle.c")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        l = C.CDLL(build())
+        vp, u64p, u32p = C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)
+        l.orc_store_new.restype = vp
+        l.orc_store_new.argtypes = [C.c_uint32]
+        l.orc_store_free.argtypes = [vp]
+        l.orc_store_extend.restype = C.c_uint64
+        l.orc_store_extend.argtypes = [vp, vp, vp, vp, vp, C.c_uint64]
+        l.orc_store_remove.restype = C.c_uint64
+        l.orc_store_remove.argtypes = [vp, vp, vp, vp, vp, C.c_uint64]
+        l.orc_store_clear.argtypes = [vp]
+        l.orc_store_len.restype = C.c_uint64
+        l.orc_store_len.argtypes = [vp]
+        l.orc_store_adopt_sorted.argtypes = [vp, C.c_uint32, vp, vp, vp, vp, C.c_uint64]
+        l.orc_store_read_index.argtypes = [vp, C.c_uint32, vp, vp, vp, vp, C.c_uint64, u64p]
+        l.orc_store_set_typed_values.argtypes = [vp, vp, C.c_uint64, vp, C.c_uint64]
+        l.orc_store_set_faithful_decode.argtypes = [vp, C.c_int]
+        l.orc_scan_score.restype = C.c_uint64
+        l.orc_scan_score.argtypes = [C.POINTER(abi.ScanInstruction)]
+        l.orc_choose_index.restype = C.c_uint32
+        l.orc_choose_index.argtypes = [C.POINTER(abi.ScanInstruction), C.c_uint32]
+        l.orc_predicate_and.argtypes = [C.POINTER(abi.Predicate)] * 3 + [u32p]
+        l.orc_pushdown_to_scan_predicate.argtypes = [C.c_uint32, C.c_uint32, C.POINTER(abi.Predicate)]
+        l.orc_find_range_between.argtypes = [vp, C.c_uint64, C.c_uint32, C.c_uint32, u64p, u64p]
+        l.orc_prune.argtypes = [vp, C.c_uint32, C.POINTER(abi.ScanInstruction), u32p, u64p, u64p,
+                                C.c_uint32, u32p]
+        l.orc_scan.argtypes = [vp, C.POINTER(abi.ScanInstruction), u32p, C.c_int, C.POINTER(ScanResult)]
+        l.orc_scan_result_free.argtypes = [C.POINTER(ScanResult)]
+        l.orc_plan_execute.argtypes = [vp, C.POINTER(abi.PlanDesc), C.POINTER(BoundTable), C.c_uint32,
+                                       C.POINTER(Table), C.POINTER(abi.Metrics)]
+        l.orc_table_free.argtypes = [C.POINTER(Table)]
+        l.orc_last_error.restype = C.c_char_p
+        l.orc_eval_bool.argtypes = [vp, C.POINTER(abi.ExprNode), C.c_uint32, C.POINTER(vp), C.c_uint32,
+                                    C.c_uint64, vp]
+        l.orc_eval_tv.argtypes = [vp, C.POINTER(abi.ExprNode), C.c_uint32, C.POINTER(vp), C.c_uint32,
+                                  C.c_uint64, vp, vp]
+        _LIB = l
+    return _LIB
+
+
+def _err():
+    return RuntimeError("oracle: " + lib().orc_last_error().decode())
+
+
+def _u32(a):
+    a = np.ascontiguousarray(a, dtype=np.uint32)
+    return a, a.ctypes.data_as(C.c_void_p)
+
+
+def find_range_between(values, lo, hi):
+    """MemColumnChunk::find_range_between; None values = nulls (stored as 0)."""
+    v = np.array([0 if x is None else x for x in values], dtype=np.uint32)
+    a, b = C.c_uint64(), C.c_uint64()
+    r = lib().orc_find_range_between(v.ctypes.data_as(C.c_void_p), len(v), lo, hi, C.byref(a), C.byref(b))
+    return r, a.value, b.value
+
+
+def scan_score(instrs):
+    return int(lib().orc_scan_score((abi.ScanInstruction * 4)(*instrs)))
+
+
+def choose_index(gspo, available=0b111):
+    return int(lib().orc_choose_index((abi.ScanInstruction * 4)(*gspo), available))
+
+
+def predicate_and(a, b):
+    from rdf_fusion_amd.engine import predicate_and as _pa
+    return _pa(a, b, lib_fn=lib().orc_predicate_and)
+
+
+def pushdown_to_scan_predicate(op, value):
+    from rdf_fusion_amd.engine import pushdown_to_scan_predicate as _pd
+    return _pd(op, value, lib_fn=lib().orc_pushdown_to_scan_predicate)
+
+
+class OracleStore:
+    def __init__(self, batch_size=8192):
+        self._l = lib()
+        self._h = C.c_void_p(self._l.orc_store_new(batch_size))
+        self.batch_size = batch_size
+
+    def close(self):
+        if self._h:
+            self._l.orc_store_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def extend(self, g, s, p, o):
+        (g, gp), (s, sp), (p, pp), (o, op) = _u32(g), _u32(s), _u32(p), _u32(o)
+        return self._l.orc_store_extend(self._h, gp, sp, pp, op, len(g))
+
+    def remove(self, g, s, p, o):
+        (g, gp), (s, sp), (p, pp), (o, op) = _u32(g), _u32(s), _u32(p), _u32(o)
+        return self._l.orc_store_remove(self._h, gp, sp, pp, op, len(g))
+
+    def clear(self):
+        self._l.orc_store_clear(self._h)
+
+    def __len__(self):
+        return self._l.orc_store_len(self._h)
+
+    def adopt_sorted(self, components, cols):
+        ptrs = [_u32(c) for c in cols]
+        if self._l.orc_store_adopt_sorted(self._h, components, *[p[1] for p in ptrs], len(ptrs[0][0])):
+            raise _err()
+
+    def read_index(self, components):
+        n = C.c_uint64()
+        self._l.orc_store_read_index(self._h, components, None, None, None, None, 0, C.byref(n))
+        cols = [np.empty(n.value, np.uint32) for _ in range(4)]
+        self._l.orc_store_read_index(self._h, components, *[c.ctypes.data_as(C.c_void_p) for c in cols],
+                                     n.value, C.byref(n))
+        return cols
+
+    def set_typed_values(self, values, decimals=None):
+        values = np.ascontiguousarray(values)
+        assert values.dtype.itemsize == 16
+        dec = np.ascontiguousarray(decimals if decimals is not None else np.zeros((0, 2), np.int64), dtype=np.int64)
+        self._l.orc_store_set_typed_values(self._h, values.ctypes.data_as(C.c_void_p), len(values),
+                                           dec.ctypes.data_as(C.c_void_p), len(dec))
+
+    def set_faithful_decode(self, on):
+        self._l.orc_store_set_faithful_decode(self._h, int(on))
+
+    # -- scan ---------------------------------------------------------------------------------
+    def _build_instrs(self, instructions):
+        """instructions: 4 plan.MemIndexScanInstruction -> (ctypes array, pool array)"""
+        from rdf_fusion_amd.plan import PlanBuilder
+        pb = PlanBuilder()
+        arr = (abi.ScanInstruction * 4)(*[pb._instr(i) for i in instructions])
+        pool = (C.c_uint32 * max(1, len(pb.pool)))(*pb.pool)
+        return arr, pool, pb
+
+    def prune(self, components, instructions):
+        """instructions in index order. -> ([(start,end)...], dropped_mask)"""
+        arr, pool, _ = self._build_instrs(instructions)
+        cap = 1 << 16
+        st, en = (C.c_uint64 * cap)(), (C.c_uint64 * cap)()
+        dropped = C.c_uint32()
+        n = self._l.orc_prune(self._h, components, arr, pool, st, en, cap, C.byref(dropped))
+        if n < 0:
+            raise _err()
+        return [(st[i], en[i]) for i in range(n)], dropped.value
+
+    def scan(self, instructions, force_index=-1):
+        """instructions in G,S,P,O order -> dict(columns={var: np.array}, batches=[..], index=..)"""
+        arr, pool, pb = self._build_instrs(instructions)
+        res = ScanResult()
+        if self._l.orc_scan(self._h, arr, pool, force_index, C.byref(res)):
+            raise _err()
+        names = {v: k for k, v in pb.vars.items()}
+        cols = {}
+        order = []
+        for c in range(res.n_cols):
+            a = np.ctypeslib.as_array(res.cols[c], shape=(res.n_rows,)).copy() if res.n_rows else np.zeros(0, np.uint32)
+            cols[names[res.vars[c]]] = a
+            order.append(names[res.vars[c]])
+        batches = [res.batch_rows[i] for i in range(res.n_batches)]
+        out = dict(columns=cols, order=order, n_rows=res.n_rows, batches=batches, index=res.chosen_index)
+        self._l.orc_scan_result_free(C.byref(res))
+        return out
+
+    # -- plans --------------------------------------------------------------------------------
+    def execute(self, description, tables=None):
+        """description: plan.PlanDescription -> (list of numpy columns, metrics)"""
+        out, m = Table(), abi.Metrics()
+        bt = None
+        keep = []
+        n_tables = 0
+        if tables:
+            n_tables = len(tables)
+            bt = (BoundTable * n_tables)()
+            for i, cols in enumerate(tables):
+                cols = [np.ascontiguousarray(c, dtype=np.uint32) for c in cols]
+                ptrs = (C.c_void_p * max(1, len(cols)))(*[c.ctypes.data_as(C.c_void_p) for c in cols])
+                keep.append((cols, ptrs))
+                bt[i].cols, bt[i].n_cols, bt[i].n_rows = ptrs, len(cols), (len(cols[0]) if cols else 0)
+        if self._l.orc_plan_execute(self._h, C.byref(description.desc), bt, n_tables, C.byref(out), C.byref(m)):
+            raise _err()
+        cols = [np.ctypeslib.as_array(out.cols[c], shape=(out.n_rows,)).copy() if out.n_rows else np.zeros(0, np.uint32)
+                for c in range(out.n_cols)]
+        n_rows = out.n_rows
+        self._l.orc_table_free(C.byref(out))
+        return cols, n_rows, m
+
+    def eval_bool(self, expr, cols, n_rows=None):
+        nodes = (abi.ExprNode * len(expr.nodes))(*[abi.ExprNode(op, tag, fl, 0, u, lo, hi)
+                                                    for (op, tag, fl, u, lo, hi) in expr.nodes])
+        cols = [np.ascontiguousarray(c, dtype=np.uint32) for c in cols]
+        n = n_rows if n_rows is not None else (len(cols[0]) if cols else 1)
+        ptrs = (C.c_void_p * max(1, len(cols)))(*[c.ctypes.data_as(C.c_void_p) for c in cols])
+        out = np.empty(n, np.uint8)
+        if self._l.orc_eval_bool(self._h, nodes, len(expr.nodes), ptrs, len(cols), n, out.ctypes.data_as(C.c_void_p)):
+            raise _err()
+        return out
+
+    def eval_tv(self, expr, cols, n_rows=None):
+        from rdf_fusion_amd.engine import TV_DTYPE
+        nodes = (abi.ExprNode * len(expr.nodes))(*[abi.ExprNode(op, tag, fl, 0, u, lo, hi)
+                                                    for (op, tag, fl, u, lo, hi) in expr.nodes])
+        cols = [np.ascontiguousarray(c, dtype=np.uint32) for c in cols]
+        n = n_rows if n_rows is not None else (len(cols[0]) if cols else 1)
+        ptrs = (C.c_void_p * max(1, len(cols)))(*[c.ctypes.data_as(C.c_void_p) for c in cols])
+        out = np.zeros(n, TV_DTYPE)
+        hi = np.zeros(n, np.int64)
+        if self._l.orc_eval_tv(self._h, nodes, len(expr.nodes), ptrs, len(cols), n,
+                               out.ctypes.data_as(C.c_void_p), hi.ctypes.data_as(C.c_void_p)):
+            raise _err()
+        return out, hi

@@ -1,0 +1,10 @@
+"""rdf-fusion_amd — MI355X-native BGP-scan + hash-join + FILTER path behind RDF Fusion's
+DataFusion surface.  The product is ``lib/librdfgpu.so`` (hand-written HIP for gfx950 + C++
+host orchestration behind the C ABI of ``include/rdfgpu.h``); this package is the thin Python
+binding used by the tests and the benchmark."""
+from . import abi, plan  # noqa: F401
+from .engine import (RdfGpuError, GpuQuadStore, GpuPlan, load_library, library_path,  # noqa: F401
+                     choose_index, scan_score, predicate_and, pushdown_to_scan_predicate)
+
+__all__ = ["abi", "plan", "RdfGpuError", "GpuQuadStore", "GpuPlan", "load_library", "library_path",
+           "choose_index", "scan_score", "predicate_and", "pushdown_to_scan_predicate"]

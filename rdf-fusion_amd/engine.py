@@ -1,0 +1,305 @@
+"""ctypes binding of ``lib/librdfgpu.so`` — the product path.
+
+There is no fallback of any kind in here: if the HIP library is missing or no gfx950 device is
+usable, every call that touches data raises ``RdfGpuError``.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import abi
+
+_LIB = None
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+class RdfGpuError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__(f"rdfgpu status {status}: {message}")
+        self.status = status
+
+
+def library_path():
+    return os.path.join(_HERE, "lib", "librdfgpu.so")
+
+
+def load_library():
+    """Loads the in-tree HIP library; fails loudly when it has not been built."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = library_path()
+    if not os.path.exists(path):
+        raise RdfGpuError(abi.ERR_NO_DEVICE,
+                          f"{path} is missing: build it with `python __graft_entry__.py build` "
+                          "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    lib = C.CDLL(path)
+    u32p, u64p, vp = C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.c_void_p
+    lib.rdfgpu_last_error.restype = C.c_char_p
+    lib.rdfgpu_abi_version.restype = C.c_uint32
+    lib.rdfgpu_store_create.argtypes = [C.POINTER(abi.Config), C.POINTER(vp)]
+    lib.rdfgpu_store_destroy.argtypes = [vp]
+    lib.rdfgpu_store_destroy.restype = None
+    lib.rdfgpu_store_extend.argtypes = [vp, vp, vp, vp, vp, C.c_uint64, u64p]
+    lib.rdfgpu_store_extend_device.argtypes = [vp, vp, vp, vp, vp, C.c_uint64, u64p]
+    lib.rdfgpu_store_remove.argtypes = [vp, vp, vp, vp, vp, C.c_uint64, u64p]
+    lib.rdfgpu_store_clear.argtypes = [vp]
+    lib.rdfgpu_store_len.argtypes = [vp, u64p]
+    lib.rdfgpu_store_set_typed_values.argtypes = [vp, vp, C.c_uint64, vp, C.c_uint64]
+    lib.rdfgpu_store_read_index.argtypes = [vp, C.c_uint32, vp, vp, vp, vp, C.c_uint64, u64p]
+    lib.rdfgpu_plan_compile.argtypes = [vp, C.POINTER(abi.PlanDesc), C.POINTER(vp)]
+    lib.rdfgpu_plan_destroy.argtypes = [vp]
+    lib.rdfgpu_plan_destroy.restype = None
+    lib.rdfgpu_plan_bind_table.argtypes = [vp, C.c_uint32, C.POINTER(vp), C.c_uint32, C.c_uint64]
+    lib.rdfgpu_plan_execute.argtypes = [vp]
+    lib.rdfgpu_plan_result_info.argtypes = [vp, u64p, u32p]
+    lib.rdfgpu_plan_result_device.argtypes = [vp, C.POINTER(vp), C.c_uint32]
+    lib.rdfgpu_plan_fetch.argtypes = [vp, C.POINTER(vp), C.c_uint32]
+    lib.rdfgpu_plan_next.argtypes = [vp, C.POINTER(abi.ArrowArray), C.POINTER(abi.ArrowSchema)]
+    lib.rdfgpu_plan_rewind.argtypes = [vp]
+    lib.rdfgpu_plan_metrics.argtypes = [vp, C.POINTER(abi.Metrics)]
+    lib.rdfgpu_plan_selected_index.argtypes = [vp, C.c_uint32, u32p]
+    lib.rdfgpu_plan_stream.argtypes = [vp, C.POINTER(vp)]
+    lib.rdfgpu_scan_score.argtypes = [C.POINTER(abi.ScanInstruction)]
+    lib.rdfgpu_scan_score.restype = C.c_uint64
+    lib.rdfgpu_choose_index.argtypes = [C.POINTER(abi.ScanInstruction), C.c_uint32]
+    lib.rdfgpu_choose_index.restype = C.c_uint32
+    lib.rdfgpu_predicate_and.argtypes = [C.POINTER(abi.Predicate), C.POINTER(abi.Predicate),
+                                         C.POINTER(abi.Predicate), u32p]
+    lib.rdfgpu_pushdown_to_scan_predicate.argtypes = [C.c_uint32, C.c_uint32, C.POINTER(abi.Predicate)]
+    if lib.rdfgpu_abi_version() != abi.ABI_VERSION:
+        raise RdfGpuError(abi.ERR_INVALID, "ABI version mismatch between abi.py and librdfgpu.so")
+    _LIB = lib
+    return lib
+
+
+def _check(status):
+    if status < 0:
+        raise RdfGpuError(status, load_library().rdfgpu_last_error().decode("utf-8", "replace"))
+    return status
+
+
+def _u32(a):
+    a = np.ascontiguousarray(a, dtype=np.uint32)
+    return a, a.ctypes.data_as(C.c_void_p)
+
+
+# ------------------------------------------------------------------------------------------------
+# host logic (no device access): choose_index / score / predicate algebra / push-down
+# ------------------------------------------------------------------------------------------------
+def _instr_array(builder_instrs):
+    arr = (abi.ScanInstruction * 4)(*builder_instrs)
+    return arr
+
+
+def scan_score(instrs):
+    """MemQuadIndex::compute_scan_score (quad_index.rs:100-130); `instrs` = 4 abi.ScanInstruction
+    in the order of the index being scored."""
+    return int(load_library().rdfgpu_scan_score(_instr_array(instrs)))
+
+
+def choose_index(gspo_instrs, available=0b111):
+    """IndexPermutations::choose_index (permutations.rs:81-96)."""
+    return int(load_library().rdfgpu_choose_index(_instr_array(gspo_instrs), available))
+
+
+def _pred_struct(p, keep):
+    s = abi.Predicate()
+    s.pred = p.kind
+    if p.kind == abi.PRED_IN:
+        ids = (C.c_uint32 * len(p.ids))(*p.ids)
+        keep.append(ids)
+        s.ids, s.n_ids = ids, len(p.ids)
+    elif p.kind == abi.PRED_BETWEEN:
+        s.from_, s.to = p.lo, p.hi
+    elif p.kind == abi.PRED_EQUAL_TO:
+        s.equal_to = 0
+    return s
+
+
+def _pred_from_struct(s, ids_buf):
+    from .plan import MemIndexScanPredicate as P
+    if s.pred == abi.PRED_FALSE:
+        return P.false()
+    if s.pred == abi.PRED_IN:
+        if s.n_ids == 1 and not ids_buf:
+            return P.in_([s.from_])
+        return P.in_([ids_buf[i] for i in range(s.n_ids)])
+    if s.pred == abi.PRED_BETWEEN:
+        return P.between(s.from_, s.to)
+    return None
+
+
+def predicate_and(lhs, rhs, lib_fn=None):
+    """MemIndexScanPredicate::try_and_with (scan_instructions.rs:170-210); None = not combinable."""
+    keep = []
+    a, b, out = _pred_struct(lhs, keep), _pred_struct(rhs, keep), abi.Predicate()
+    n = max(1, len(lhs.ids or []), len(rhs.ids or []))
+    ids = (C.c_uint32 * n)()
+    fn = lib_fn or load_library().rdfgpu_predicate_and
+    ok = fn(C.byref(a), C.byref(b), C.byref(out), ids)
+    if ok < 0:
+        _check(ok)
+    if ok == 0:
+        return None
+    return _pred_from_struct(out, ids)
+
+
+def pushdown_to_scan_predicate(op, value, lib_fn=None):
+    """MemStoragePredicateExpr::to_scan_predicate (predicate_pushdown.rs:120-157)."""
+    out = abi.Predicate()
+    fn = lib_fn or load_library().rdfgpu_pushdown_to_scan_predicate
+    ok = fn(op, value, C.byref(out))
+    if ok < 0:
+        _check(ok)
+    return _pred_from_struct(out, None)
+
+
+# ------------------------------------------------------------------------------------------------
+# store and plans
+# ------------------------------------------------------------------------------------------------
+class GpuQuadStore:
+    """The QuadStorage of this path (lib/extensions/src/storage/quad_storage.rs:14-78): three sorted
+    u32 permutations + the typed-value table, resident in HBM."""
+
+    def __init__(self, device=-1, batch_size=8192):
+        self._lib = load_library()
+        self._h = C.c_void_p()
+        cfg = abi.Config(device, batch_size, 0, 0)
+        _check(self._lib.rdfgpu_store_create(C.byref(cfg), C.byref(self._h)))
+        self.batch_size = batch_size
+
+    def close(self):
+        if self._h:
+            self._lib.rdfgpu_store_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def extend(self, g, s, p, o):
+        (g, gp), (s, sp), (p, pp), (o, op) = _u32(g), _u32(s), _u32(p), _u32(o)
+        n = C.c_uint64()
+        _check(self._lib.rdfgpu_store_extend(self._h, gp, sp, pp, op, len(g), C.byref(n)))
+        return n.value
+
+    def extend_device(self, g_ptr, s_ptr, p_ptr, o_ptr, n_rows):
+        n = C.c_uint64()
+        _check(self._lib.rdfgpu_store_extend_device(self._h, g_ptr, s_ptr, p_ptr, o_ptr, n_rows, C.byref(n)))
+        return n.value
+
+    def remove(self, g, s, p, o):
+        (g, gp), (s, sp), (p, pp), (o, op) = _u32(g), _u32(s), _u32(p), _u32(o)
+        n = C.c_uint64()
+        _check(self._lib.rdfgpu_store_remove(self._h, gp, sp, pp, op, len(g), C.byref(n)))
+        return n.value
+
+    def clear(self):
+        _check(self._lib.rdfgpu_store_clear(self._h))
+
+    def __len__(self):
+        n = C.c_uint64()
+        _check(self._lib.rdfgpu_store_len(self._h, C.byref(n)))
+        return n.value
+
+    def set_typed_values(self, values, decimals=None):
+        """values: numpy structured array / bytes of rdfgpu_typed_value, index = object id."""
+        values = np.ascontiguousarray(values)
+        assert values.dtype.itemsize == 16, "rdfgpu_typed_value is 16 bytes"
+        dec = np.ascontiguousarray(decimals if decimals is not None else np.zeros((0, 2), np.int64), dtype=np.int64)
+        _check(self._lib.rdfgpu_store_set_typed_values(
+            self._h, values.ctypes.data_as(C.c_void_p), len(values), dec.ctypes.data_as(C.c_void_p), len(dec)))
+
+    def read_index(self, components):
+        n = C.c_uint64()
+        _check(self._lib.rdfgpu_store_read_index(self._h, components, None, None, None, None, 0, C.byref(n)))
+        cols = [np.empty(n.value, np.uint32) for _ in range(4)]
+        ptrs = [c.ctypes.data_as(C.c_void_p) for c in cols]
+        _check(self._lib.rdfgpu_store_read_index(self._h, components, *ptrs, n.value, C.byref(n)))
+        return cols
+
+    def plan(self, description):
+        return GpuPlan(self, description)
+
+
+TV_DTYPE = np.dtype([("lo", "<i8"), ("aux", "<u4"), ("tag", "u1"), ("flags", "u1"), ("reserved", "<u2")])
+
+
+class GpuPlan:
+    """A compiled operator tree (DataSourceExec / FilterExec / HashJoinExec / CrossJoinExec ...)."""
+
+    def __init__(self, store, description):
+        self._lib = store._lib
+        self._store = store
+        self._desc = description
+        self._h = C.c_void_p()
+        self._keep = []
+        _check(self._lib.rdfgpu_plan_compile(store._h, C.byref(description.desc), C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            self._lib.rdfgpu_plan_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def bind_table(self, slot, device_ptrs, n_rows):
+        arr = (C.c_void_p * len(device_ptrs))(*device_ptrs)
+        _check(self._lib.rdfgpu_plan_bind_table(self._h, slot, arr, len(device_ptrs), n_rows))
+
+    def execute(self):
+        _check(self._lib.rdfgpu_plan_execute(self._h))
+        return self
+
+    def result_info(self):
+        n, c = C.c_uint64(), C.c_uint32()
+        _check(self._lib.rdfgpu_plan_result_info(self._h, C.byref(n), C.byref(c)))
+        return n.value, c.value
+
+    def result_device(self):
+        n, c = self.result_info()
+        ptrs = (C.c_void_p * max(1, c))()
+        _check(self._lib.rdfgpu_plan_result_device(self._h, ptrs, c))
+        return [ptrs[i] or 0 for i in range(c)], n
+
+    def fetch(self):
+        """Whole result as host numpy columns."""
+        n, c = self.result_info()
+        cols = [np.empty(n, np.uint32) for _ in range(c)]
+        ptrs = (C.c_void_p * max(1, c))(*[x.ctypes.data_as(C.c_void_p) for x in cols])
+        _check(self._lib.rdfgpu_plan_fetch(self._h, ptrs, c))
+        return cols
+
+    def batches(self):
+        """Drains the Arrow batch stream; yields pyarrow StructArrays of UInt32 children."""
+        import pyarrow as pa
+        _check(self._lib.rdfgpu_plan_rewind(self._h))
+        while True:
+            arr, sch = abi.ArrowArray(), abi.ArrowSchema()
+            st = _check(self._lib.rdfgpu_plan_next(self._h, C.byref(arr), C.byref(sch)))
+            if st == abi.END:
+                return
+            yield pa.Array._import_from_c(C.addressof(arr), C.addressof(sch))
+
+    def metrics(self):
+        m = abi.Metrics()
+        _check(self._lib.rdfgpu_plan_metrics(self._h, C.byref(m)))
+        return m
+
+    def selected_index(self, node):
+        out = C.c_uint32()
+        _check(self._lib.rdfgpu_plan_selected_index(self._h, node, C.byref(out)))
+        return out.value
+
+    def stream(self):
+        out = C.c_void_p()
+        _check(self._lib.rdfgpu_plan_stream(self._h, C.byref(out)))
+        return out.value

@@ -1,0 +1,291 @@
+"""Host-side plan description, named after the reference's types.
+
+This is the Python mirror of what the Rust host hands over the C ABI: scan instructions
+(`MemIndexScanInstruction`, lib/storage/src/memory/storage/scan_instructions.rs:247-318),
+expression programs (the `PhysicalExpr` trees of FilterExec / JoinFilter built from the UDFs in
+lib/extensions/src/functions/builtin.rs:101-186) and the operator tree
+(DataSourceExec / FilterExec / HashJoinExec / CrossJoinExec / NestedLoopJoinExec as printed in
+bench/tests/plans/snapshots/*Q5 (Execution Plan).snap).  It only builds ``rdfgpu_plan_desc``
+structs; it computes nothing.
+"""
+import ctypes as C
+import struct
+
+from . import abi
+
+
+# ----------------------------------------------------------------------------------------------
+# scan instructions
+# ----------------------------------------------------------------------------------------------
+class MemIndexScanPredicate:
+    """scan_instructions.rs:157-166"""
+
+    def __init__(self, kind, ids=None, lo=0, hi=0, var=None):
+        self.kind, self.ids, self.lo, self.hi, self.var = kind, ids, lo, hi, var
+
+    @staticmethod
+    def false():
+        return MemIndexScanPredicate(abi.PRED_FALSE)
+
+    @staticmethod
+    def in_(ids):
+        return MemIndexScanPredicate(abi.PRED_IN, ids=sorted(set(int(i) for i in ids)))
+
+    @staticmethod
+    def between(lo, hi):
+        return MemIndexScanPredicate(abi.PRED_BETWEEN, lo=int(lo), hi=int(hi))
+
+    @staticmethod
+    def equal_to(var):
+        return MemIndexScanPredicate(abi.PRED_EQUAL_TO, var=var)
+
+    def __repr__(self):  # Display impl scan_instructions.rs:213-237
+        if self.kind == abi.PRED_FALSE:
+            return "false"
+        if self.kind == abi.PRED_IN:
+            return f"== {self.ids[0]}" if len(self.ids) == 1 else "in (" + ", ".join(map(str, self.ids)) + ")"
+        if self.kind == abi.PRED_BETWEEN:
+            return f"in ({self.lo}..{self.hi})"
+        return f"== {self.var}"
+
+
+class MemIndexScanInstruction:
+    """scan_instructions.rs:247-318"""
+
+    def __init__(self, kind, var=None, predicate=None):
+        self.kind, self.var, self.predicate = kind, var, predicate
+
+    @staticmethod
+    def traverse(object_id=None):
+        """`traverse(1)` in the reference tests = Traverse(Some(In{1}))."""
+        if object_id is None:
+            return MemIndexScanInstruction(abi.TRAVERSE)
+        return MemIndexScanInstruction(abi.TRAVERSE, predicate=MemIndexScanPredicate.in_([object_id]))
+
+    @staticmethod
+    def traverse_with_predicate(predicate):
+        return MemIndexScanInstruction(abi.TRAVERSE, predicate=predicate)
+
+    @staticmethod
+    def scan(var):
+        return MemIndexScanInstruction(abi.SCAN, var=var)
+
+    @staticmethod
+    def scan_with_predicate(var, predicate):
+        return MemIndexScanInstruction(abi.SCAN, var=var, predicate=predicate)
+
+
+def quad_pattern(subject, predicate, obj, graph="default", graph_variable=None):
+    """MemQuadStorageSnapshot::plan_pattern_evaluation (snapshot.rs:84-131): int = constant object
+    id, str = variable.  `graph`: "default" | "all" | "named" | list of graph ids
+    (MemIndexScanInstruction::from_active_graph, scan_instructions.rs:323-355)."""
+    P, I = MemIndexScanPredicate, MemIndexScanInstruction
+    if graph == "default":
+        gp = P.in_([0])
+    elif graph == "all":
+        gp = None
+    elif graph == "named":
+        gp = P.between(1, 0xFFFFFFFF)
+    else:
+        gp = P.in_(list(graph))
+    g = I(abi.SCAN, var=graph_variable, predicate=gp) if graph_variable else I(abi.TRAVERSE, predicate=gp)
+
+    def term(t):
+        return I.scan(t) if isinstance(t, str) else I.traverse(int(t))
+
+    return [g, term(subject), term(predicate), term(obj)]
+
+
+# ----------------------------------------------------------------------------------------------
+# expressions (postfix programs)
+# ----------------------------------------------------------------------------------------------
+class Expr:
+    def __init__(self, nodes):
+        self.nodes = nodes  # list of (op, tag, flags, u, lo, hi)
+
+    def _bin(self, other, op):
+        return Expr(self.nodes + other.nodes + [(op, 0, 0, 0, 0, 0)])
+
+    def _un(self, op):
+        return Expr(self.nodes + [(op, 0, 0, 0, 0, 0)])
+
+
+def col(i):
+    return Expr([(abi.EX_COLUMN, 0, 0, int(i), 0, 0)])
+
+
+def lit_id(object_id):
+    return Expr([(abi.EX_LIT_ID, 0, 0, int(object_id), 0, 0)])
+
+
+def lit_tv(tag, lo=0, aux=0, flags=0, hi=0):
+    return Expr([(abi.EX_LIT_TV, int(tag), int(flags), int(aux), int(lo), int(hi))])
+
+
+def lit_bool(v):
+    return Expr([(abi.EX_LIT_BOOL, 0, 0, 2 if v is None else int(bool(v)), 0, 0)])
+
+
+def integer(v):          # plan text "9:120"
+    return lit_tv(abi.TV_INTEGER, int(v))
+
+
+def int32(v):
+    return lit_tv(abi.TV_INT, int(v))
+
+
+def boolean(v):
+    return lit_tv(abi.TV_BOOLEAN, int(bool(v)))
+
+
+def double(v):
+    return lit_tv(abi.TV_DOUBLE, struct.unpack("<q", struct.pack("<d", float(v)))[0])
+
+
+def float32(v):
+    return lit_tv(abi.TV_FLOAT, struct.unpack("<I", struct.pack("<f", float(v)))[0])
+
+
+def decimal(scaled_i128):
+    """scaled_i128 = value * 10**18 (decimal.rs:9-21)."""
+    v = int(scaled_i128) & ((1 << 128) - 1)
+    lo, hi = v & ((1 << 64) - 1), v >> 64
+    to_i64 = lambda x: x - (1 << 64) if x >= (1 << 63) else x
+    return lit_tv(abi.TV_DECIMAL, to_i64(lo), hi=to_i64(hi))
+
+
+def ENC_TV(e): return e._un(abi.EX_ENC_TV)
+def GT(a, b): return a._bin(b, abi.EX_GT)
+def LT(a, b): return a._bin(b, abi.EX_LT)
+def GEQ(a, b): return a._bin(b, abi.EX_GEQ)
+def LEQ(a, b): return a._bin(b, abi.EX_LEQ)
+def EQ(a, b): return a._bin(b, abi.EX_EQ)
+def NEQ(a, b): return a._bin(b, abi.EX_NEQ)
+def ADD(a, b): return a._bin(b, abi.EX_ADD)
+def SUB(a, b): return a._bin(b, abi.EX_SUB)
+def EBV(e): return e._un(abi.EX_EBV)
+def ID_EQ(a, b): return a._bin(b, abi.EX_ID_EQ)
+def ID_NEQ(a, b): return a._bin(b, abi.EX_ID_NEQ)
+def AND(a, b): return a._bin(b, abi.EX_AND)
+def OR(a, b): return a._bin(b, abi.EX_OR)
+def NOT(e): return e._un(abi.EX_NOT)
+def IS_COMPATIBLE(a, b): return a._bin(b, abi.EX_IS_COMPATIBLE)
+def BOUND(e): return e._un(abi.EX_BOUND)
+def BOOLEAN_AS_TERM(e): return e._un(abi.EX_BOOL_AS_TV)
+
+
+# ----------------------------------------------------------------------------------------------
+# operator tree
+# ----------------------------------------------------------------------------------------------
+class PlanDescription:
+    """Owns the ctypes arrays behind one ``rdfgpu_plan_desc``."""
+
+    def __init__(self, nodes, exprs, pool, root, n_columns):
+        self.n_columns = n_columns  # output width per node (host-side bookkeeping)
+        self._nodes = (abi.PlanNode * max(1, len(nodes)))(*nodes)
+        self._exprs = (abi.ExprNode * max(1, len(exprs)))(*exprs)
+        self._pool = (C.c_uint32 * max(1, len(pool)))(*pool)
+        self.desc = abi.PlanDesc(self._nodes, len(nodes), root, self._exprs, len(exprs), self._pool,
+                                 len(pool), 0)
+        self.root = root
+
+    @property
+    def width(self):
+        return self.n_columns[self.root]
+
+
+class PlanBuilder:
+    def __init__(self):
+        self.nodes, self.exprs, self.pool, self.width = [], [], [], []
+        self.vars = {}
+
+    # -- helpers -------------------------------------------------------------------------------
+    def _var(self, name):
+        return self.vars.setdefault(name, len(self.vars))
+
+    def _instr(self, ins):
+        out = abi.ScanInstruction()
+        out.kind = ins.kind
+        out.var = self._var(ins.var) if ins.kind == abi.SCAN else 0
+        p = ins.predicate
+        if p is None:
+            out.pred = abi.PRED_NONE
+        elif p.kind == abi.PRED_IN:
+            out.pred, out.a, out.b = abi.PRED_IN, len(self.pool), len(p.ids)
+            self.pool.extend(p.ids)
+        elif p.kind == abi.PRED_BETWEEN:
+            out.pred, out.a, out.b = abi.PRED_BETWEEN, p.lo, p.hi
+        elif p.kind == abi.PRED_EQUAL_TO:
+            out.pred, out.a = abi.PRED_EQUAL_TO, self._var(p.var)
+        else:
+            out.pred = abi.PRED_FALSE
+        return out
+
+    def _expr(self, node, e):
+        if e is None:
+            node.expr_off, node.expr_len = 0, 0
+            return
+        node.expr_off, node.expr_len = len(self.exprs), len(e.nodes)
+        for (op, tag, flags, u, lo, hi) in e.nodes:
+            self.exprs.append(abi.ExprNode(op, tag, flags, 0, u, lo, hi))
+
+    def _proj(self, node, projection, full):
+        if projection is None:
+            node.proj_off, node.n_proj = 0, abi.NO_PROJECTION
+            return full
+        node.proj_off, node.n_proj = len(self.pool), len(projection)
+        self.pool.extend(int(c) for c in projection)
+        return len(projection)
+
+    def _push(self, node, width):
+        self.nodes.append(node)
+        self.width.append(width)
+        return len(self.nodes) - 1
+
+    # -- operators -----------------------------------------------------------------------------
+    def data_source(self, instructions):
+        """DataSourceExec(MemQuadPatternDataSource): four instructions in G,S,P,O order."""
+        n = abi.PlanNode(kind=abi.NODE_DATA_SOURCE, left=-1, right=-1)
+        seen, width = set(), 0
+        for i, ins in enumerate(instructions):
+            n.scan[i] = self._instr(ins)
+            if ins.kind == abi.SCAN and ins.var not in seen:
+                seen.add(ins.var)
+                width += 1
+        n.n_proj = abi.NO_PROJECTION
+        return self._push(n, width)
+
+    def filter(self, child, predicate, projection=None):
+        n = abi.PlanNode(kind=abi.NODE_FILTER, left=child, right=-1)
+        self._expr(n, predicate)
+        return self._push(n, self._proj(n, projection, self.width[child]))
+
+    def projection(self, child, columns):
+        n = abi.PlanNode(kind=abi.NODE_PROJECTION, left=child, right=-1)
+        return self._push(n, self._proj(n, columns, self.width[child]))
+
+    def hash_join(self, left, right, on, join_type=abi.JOIN_INNER, filter=None, projection=None):
+        n = abi.PlanNode(kind=abi.NODE_HASH_JOIN, left=left, right=right, join_type=join_type)
+        n.n_keys = len(on)
+        for k, (l, r) in enumerate(on):
+            n.left_keys[k], n.right_keys[k] = l, r
+        self._expr(n, filter)
+        return self._push(n, self._proj(n, projection, self.width[left] + self.width[right]))
+
+    def cross_join(self, left, right):
+        n = abi.PlanNode(kind=abi.NODE_CROSS_JOIN, left=left, right=right, join_type=abi.JOIN_INNER)
+        n.n_proj = abi.NO_PROJECTION
+        return self._push(n, self.width[left] + self.width[right])
+
+    def nested_loop_join(self, left, right, join_type=abi.JOIN_INNER, filter=None, projection=None):
+        n = abi.PlanNode(kind=abi.NODE_NESTED_LOOP_JOIN, left=left, right=right, join_type=join_type)
+        self._expr(n, filter)
+        return self._push(n, self._proj(n, projection, self.width[left] + self.width[right]))
+
+    def table(self, slot, n_cols):
+        n = abi.PlanNode(kind=abi.NODE_TABLE, left=-1, right=-1, table_slot=slot, table_cols=n_cols)
+        n.n_proj = abi.NO_PROJECTION
+        return self._push(n, n_cols)
+
+    def build(self, root):
+        return PlanDescription(self.nodes, self.exprs, self.pool, root, list(self.width))

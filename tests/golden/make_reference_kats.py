@@ -1,0 +1,188 @@
+#!/usr/bin/env python3
+"""Writes tests/golden/reference_kats.json: the literal known-answer vectors of the reference's own
+unit tests for the scan path, transcribed by hand as DATA (inputs + expected outputs; no source).
+
+Sources (relative to the rdf-fusion tree):
+  S  = lib/storage/src/memory/storage/mod.rs            (scan KATs, predicate algebra, index choice)
+  D  = lib/storage/src/memory/storage/quad_index_data.rs (row-group build / prune / find_range)
+  C  = lib/storage/src/memory/storage/scan.rs            (dynamic-filter scan tests)
+  P  = lib/storage/src/memory/storage/predicate_pushdown.rs + pattern_data_source.rs (push-down)
+  Q  = lib/storage/src/memory/storage/quad_index.rs      (scan-score ordering)
+
+Instruction notation (index order unless a case says "gspo"):
+  ["T"]                traverse, no predicate          ["T", 7]            traverse(In{7})
+  ["T", {"in":[..]}]   traverse with In                ["T", {"between":[a,b]}]
+  ["S", "x"]           scan binding variable x         ["S", "x", {"in":[..]}] / {"between":[a,b]}
+"""
+import json
+import os
+
+T = lambda *a: ["T", *a]
+S = lambda *a: ["S", *a]
+q4 = lambda v: [v, v, v, v]
+
+D3 = [[1, 2, 3, 4], [1, 2, 5, 6], [1, 7, 3, 4]]
+
+scan_cases = [
+    # name, S line, batch size, quads (GSPO index order), instructions, expected
+    dict(name="insert_and_scan_triple", src="S:36", batch=10, quads=[[1, 2, 3, 4]],
+         instr=[T(1), T(2), T(3), T(4)], n_rows=1, columns={}, first_batch_rows=1),
+    dict(name="scan_returns_sorted_results_on_last_level", src="S:52", batch=10,
+         quads=[[1, 2, 3, 4], [1, 2, 3, 3]], instr=[T(1), T(2), T(3), S("d")], columns={"d": [3, 4]}),
+    dict(name="scan_returns_sorted_results_on_intermediate_level", src="S:79", batch=10,
+         quads=[[1, 2, 3, 4], [1, 2, 2, 4]], instr=[T(1), T(2), S("c"), T(4)], columns={"c": [2, 3]}),
+    dict(name="scan_with_no_match", src="S:106", batch=10, quads=[[1, 2, 3, 4]],
+         instr=[T(2), S("b"), T(3), T(4)], n_rows=0, batches=[]),
+    dict(name="scan_subject_var", src="S:123", batch=10, quads=D3, instr=[T(1), S("b"), T(3), T(4)],
+         n_cols=1, n_rows=2),
+    dict(name="scan_predicate_var", src="S:145", batch=10, quads=D3, instr=[T(1), T(2), S("c"), T(4)],
+         n_cols=1, n_rows=1),
+    dict(name="scan_object_var", src="S:167", batch=10, quads=D3, instr=[T(1), T(2), T(3), S("d")],
+         n_cols=1, n_rows=1),
+    dict(name="scan_multi_vars", src="S:189", batch=10, quads=D3, instr=[T(1), S("b"), T(3), S("d")],
+         n_cols=2, n_rows=2),
+    dict(name="scan_all_vars", src="S:211", batch=10, quads=D3, instr=[S("a"), S("b"), S("c"), S("d")],
+         n_cols=4, n_rows=3),
+    dict(name="scan_same_var_appearing_twice", src="S:233", batch=10,
+         quads=[[1, 3, 3, 4], [1, 2, 2, 4], [1, 3, 2, 4]],
+         instr=[S("a"), S("same"), S("same"), S("d")], n_cols=3, n_rows=2),
+    dict(name="scan_considers_predicates", src="S:255", batch=10,
+         quads=[[1, 2, 3, 4], [2, 2, 5, 6], [3, 7, 3, 4]],
+         instr=[S("a", {"in": [1, 3]}), S("b"), S("c"), S("d")], n_cols=4, n_rows=2),
+    dict(name="scan_batches_for_batch_size", src="S:280", batch=10,
+         quads=[[1, 2, 3, i + 1] for i in range(25)], instr=[T(1), T(2), T(3), S("d")],
+         batches=[10, 10, 5]),
+    dict(name="scan_multi_level_batches_coalesce_results", src="S:303", batch=10,
+         quads=[[1, 2, i, 3] for i in range(25)], instr=[T(1), T(2), S("c"), T(3)],
+         batches=[10, 10, 5]),
+    dict(name="test_dynamic_filters", src="C:617", batch=100,
+         quads=[[0, 1, 10, 100], [0, 2, 10, 100], [0, 2, 10, 200], [0, 3, 10, 100]],
+         # static Between(2,3) AND dynamic Between(1,2) on subject => Between(2,2)
+         instr=[T(0), S("subject", {"between": [2, 2]}), T(), T(200)], n_rows=1,
+         note="the dynamic filter Between(subject,1,2) is AND-ed into Between(2,3) first (scan.rs:241-261)"),
+]
+
+remove_cases = [
+    dict(name="delete_triple_removes_it", src="S:327", insert=D3, remove=D3, remaining=0, removed=3),
+    dict(name="delete_triple_non_existing_returns_zero", src="S:349", insert=[], remove=[[1, 2, 3, 4]],
+         remaining=0, removed=0),
+]
+
+# store-level (three permutations; instructions in G,S,P,O order)
+store_cases = [
+    dict(name="scan_gpos_subject_and_object", src="S:486", quads_gspo=[[1, 2, 3, 4]],
+         instr=[T(1), S("subject"), T(3), S("object")], chosen="GPOS",
+         columns={"subject": [2], "object": [4]}, order=["subject", "object"]),
+    dict(name="insert_quad_then_read", src="lib/storage/tests/memory/mem_quad_storage.rs:29",
+         quads_gspo=[[0, 1, 2, 3]], instr=[S("g", {"in": [0]}), S("s"), S("p"), S("o")],
+         columns={"g": [0], "s": [1], "p": [2], "o": [3]}, order=["g", "s", "p", "o"],
+         note="g = 0 is exported as an Arrow null; schema g nullable, s/p/o non-null"),
+]
+
+predicate_and_cases = [  # S:357-436
+    dict(lhs={"in": [1, 2, 3]}, rhs="false", out="false"),
+    dict(lhs="false", rhs={"between": [1, 2]}, out="false"),
+    dict(lhs={"in": [1, 2, 3]}, rhs={"in": [2, 3, 4]}, out={"in": [2, 3]}),
+    dict(lhs={"in": [1]}, rhs={"in": [2]}, out="false"),
+    dict(lhs={"in": [1, 2, 3]}, rhs={"between": [2, 3]}, out={"in": [2, 3]}),
+    dict(lhs={"between": [2, 4]}, rhs={"in": [3, 4, 5]}, out={"in": [3, 4]}),
+    dict(lhs={"between": [2, 5]}, rhs={"between": [3, 4]}, out={"between": [3, 4]}),
+    dict(lhs={"between": [1, 2]}, rhs={"between": [3, 4]}, out="false"),
+    dict(lhs={"in": [1]}, rhs={"equal_to": "x"}, out=None),
+]
+
+index_choice_cases = [  # S:439-483 ; store keeps GSPO, GPOS, GOSP ; instructions in G,S,P,O order
+    dict(instr=[T(0), T(1), T(2), T(3)], chosen="GSPO"),
+    dict(instr=[T(0), T(1), S("predicate"), T(3)], chosen="GOSP"),
+    dict(instr=[T(0), S("subject"), T(2), S("object")], chosen="GPOS"),
+    # C:674 test_collect_relevant_batches_dynamic_filters_choose_better_index (GSPO + GOSP only)
+    dict(instr=[T(0), S("subject"), S("predicate"), S("object", {"between": [1, 200]})],
+         available=["GSPO", "GOSP"], chosen="GOSP"),
+]
+
+score_order_cases = [  # Q:205-315: instructions in index order
+    dict(name="test_in_predicate_better_than_nothing",
+         greater=[S("g", {"in": [10]}), T(), T(), T()], lesser=[T(), T(), T(), T()]),
+    dict(name="test_in_predicate_following_none_equal_to_nothing",
+         equal=[T(), S("g", {"in": [10]}), T(), T()], to=[T(), T(), T(), T()]),
+    dict(name="test_in_predicate_better_than_between",
+         greater=[S("g", {"in": [10]}), S("s", {"in": [10]}), S("p"), S("o")],
+         lesser=[S("g", {"equal_to": "x"}), S("s", {"between": [1, 10]}), S("p"), S("o")]),
+]
+
+pushdown_cases = [  # P: predicate_pushdown.rs:324-507
+    dict(op="Eq", value=123, out={"in": [123]}),
+    dict(op="Gt", value=100, out={"between": [101, 4294967295]}),
+    dict(op="GtEq", value=100, out={"between": [100, 4294967295]}),
+    dict(op="Lt", value=100, out={"between": [0, 99]}),
+    dict(op="LtEq", value=100, out={"between": [0, 100]}),
+    dict(op="Gt", value=4294967295, out="false"),
+    dict(op="Lt", value=0, out="false"),
+]
+pushdown_display_cases = [  # pattern_data_source.rs:192-234 (display of the combined scan predicate)
+    dict(filters=[["Eq", 1]], display="== 1"),
+    dict(filters=[["Gt", 1]], display="in (2..4294967295)"),
+    dict(filters=[["Gt", 1], ["Lt", 10]], display="in (2..9)"),
+]
+
+rowgroup_cases = [  # D:703-757
+    dict(src="D:703", size=4, values=[1, 2, 3], groups=[3]),
+    dict(src="D:714", size=2, values=[10, 20, 30, 40, 50], groups=[2, 2, 1]),
+    dict(src="D:737", size=3, values=[11, 12, 13, 14, 15, 16], groups=[3, 3]),
+]
+dedupe_cases = [dict(src="D:748", size=3, first=[1, 2, 3], second=[2, 3, 4], length=4)]
+
+prune_cases = [  # D:857-1200 ; instructions in index order (GSPO)
+    dict(src="D:841", size=2, quads=[q4(v) for v in [1, 2, 3, 4]], instr=[T(), T(), T(), T()],
+         group_lens=[2, 2], dropped=[]),
+    dict(src="D:857", size=2, quads=[q4(v) for v in [10, 20, 30, 40]], instr=[T(30), T(), T(), T()],
+         group_lens=[1], dropped=[0], rows=[[30, 30, 30, 30]]),
+    dict(src="D:918", size=5,
+         quads=[[10, 10, 10, v] for v in range(10, 19)] + [[20, 5, 5, 5], [20, 5, 5, 6], [20, 5, 5, 7]],
+         instr=[T(10), T(10), T(), T()], group_lens=[5, 4], dropped=[0, 1]),
+    dict(src="D:969", size=5,
+         quads=[[10, 10, 10, 10], [10, 10, 10, 11], [10, 10, 10, 12], [10, 10, 10, 13], [11, 10, 10, 14],
+                [11, 10, 10, 15]],
+         instr=[T(10), T(), T(), T()], group_lens=[4], dropped=[0]),
+    dict(src="D:1007", size=5,
+         quads=[[0, 10, 10, 10]] + [[0, 11, 10, v] for v in [11, 12, 13, 14, 21, 22, 23, 24, 25, 31]] +
+               [[0, 11, 12, 32]],
+         instr=[T(0), T(11), T(10), T()], group_lens=[4, 5, 1]),
+    dict(src="D:1054", size=5, quads=[[10, 10, 10, 10], [10, 10, 12, 11], [10, 11, 12, 12], [20, 20, 20, 20]],
+         instr=[T(10), T(10), T(10), T()], group_lens=[1]),
+    dict(src="D:1083", size=5, quads=[[10, 9, 9, 10], [10, 10, 9, 10], [10, 10, 10, 10], [20, 20, 20, 20]],
+         instr=[T(10), T(10), T(10), T()], group_lens=[1]),
+    dict(src="D:1112", size=2, quads=[q4(v) for v in [1, 2, 3, 4]], instr=[T(99), T(), T(), T()],
+         group_lens=[]),
+    dict(src="D:1131", size=2, quads=[q4(v) for v in [1, 2, 3, 4]],
+         instr=[T({"between": [1, 2]}), T({"between": [1, 2]}), T(), T()], group_lens=[2], dropped=[0],
+         kept=[1]),
+    dict(src="D:1156", size=2, quads=[q4(v) for v in [1, 2, 3, 4]],
+         instr=[T({"between": [1, 1]}), T({"between": [1, 1]}), T(), T()], n_groups=1, dropped=[0, 1]),
+    dict(src="D:1182", size=2, quads=[q4(v) for v in [1, 2, 3, 4]], instr=[T({"in": [2, 3]}), T(), T(), T()],
+         n_groups_is_all=True),
+]
+
+find_range_cases = [  # D:1202-1250 ; None = null
+    dict(values=[None, None, None], value=0, result=["Contained", 0, 3]),
+    dict(values=[None, None, 3, 5, 7], value=0, result=["Contained", 0, 2]),
+    dict(values=[None, None, 3, 5, 7], value=5, result=["Contained", 3, 4]),
+    dict(values=[2, 4, 6], value=4, result=["Contained", 1, 2]),
+    dict(values=[4, 4, 4, 5], value=4, result=["Contained", 0, 3]),
+    dict(values=[1, 3, 5, 7], value=4, result=["NotContained", 2]),
+    dict(values=[10, 20, 30], value=2, result=["Before"]),
+    dict(values=[10, 20, 30], value=50, result=["After"]),
+]
+
+out = dict(
+    _about="Known-answer vectors transcribed from the reference's unit tests (see make_reference_kats.py).",
+    scan=scan_cases, remove=remove_cases, store=store_cases, predicate_and=predicate_and_cases,
+    index_choice=index_choice_cases, score_order=score_order_cases, pushdown=pushdown_cases,
+    pushdown_display=pushdown_display_cases, rowgroups=rowgroup_cases, dedupe=dedupe_cases,
+    prune=prune_cases, find_range=find_range_cases)
+
+if __name__ == "__main__":
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "reference_kats.json")
+    with open(path, "w") as f:
+        json.dump(out, f, indent=1)
+    print("wrote", path)
