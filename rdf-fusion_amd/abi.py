@@ -1,7 +1,7 @@
 """ctypes mirror of ``include/rdfgpu.h`` (the C ABI of the hot path).
 
 Only plain data definitions live here, so both the product binding (``engine.py``) and the
-test-only oracle binding (``oracle/oracle.py``) can describe a plan with the same structs.
+test-only CPU checker binding can describe a plan with the same structs.
 """
 import ctypes as C
 

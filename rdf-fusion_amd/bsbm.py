@@ -1,0 +1,249 @@
+"""Synthetic BSBM-shaped triple stores and the reference's Q1 / Q5 physical plans.
+
+The reference benchmarks on datasets produced by the Java ``bsbm-tools`` generator
+(bench/src/benchmarks/bsbm/requirements.rs:9-44), which cannot run here (no Java, no network).
+This module generates a store of the same SHAPE (≈350 triples per product,
+productFeature fan-out U{9..28}, integer numeric properties ~N(1000,333) clipped to 1..2000,
+20 offers and 10 reviews per product) with dense object ids from 1, the default graph only, and a
+typed-value table (tag 9 xsd:integer for numerics, tag 6 doubles for prices, tag 3 strings,
+tag 1 IRIs), deterministically from a seed.
+
+``q1_plan`` / ``q5_plan`` build the operator trees the reference's planner produces for
+bench/tests/query_results/queries/explore-q{1,5}.sparql, transcribed from
+bench/tests/plans/snapshots/*Q1 / Q5 (Execution Plan).snap (DataFusion's dynamic-filter push-down,
+a superset filter on raw ids, is not reproduced: it never changes results).
+"""
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import abi
+from .engine import TV_DTYPE
+from .plan import (PlanBuilder, quad_pattern, col, lit_id, integer, ENC_TV, GT, LT, ADD, SUB, EBV, AND,
+                   ID_NEQ)
+
+PREDICATES = ["rdf:type", "rdfs:label", "rdfs:comment", "bsbm:producer", "bsbm:productFeature",
+              "bsbm:productPropertyNumeric1", "bsbm:productPropertyNumeric2", "bsbm:productPropertyNumeric3",
+              "bsbm:productPropertyNumeric4", "bsbm:productPropertyNumeric5",
+              "bsbm:productPropertyTextual1", "bsbm:productPropertyTextual2", "bsbm:productPropertyTextual3",
+              "bsbm:productPropertyTextual4", "bsbm:productPropertyTextual5", "dc:publisher", "dc:date",
+              "bsbm:product", "bsbm:vendor", "bsbm:price", "bsbm:validFrom", "bsbm:validTo",
+              "bsbm:deliveryDays", "bsbm:offerWebpage", "bsbm:reviewFor", "rev:reviewer", "dc:title",
+              "rev:text", "bsbm:rating1", "bsbm:rating2", "bsbm:rating3", "bsbm:rating4", "bsbm:reviewDate"]
+
+
+@dataclass
+class BsbmDataset:
+    n_products: int
+    g: np.ndarray
+    s: np.ndarray
+    p: np.ndarray
+    o: np.ndarray
+    typed_values: np.ndarray          # TV_DTYPE, index = object id
+    pred: dict                        # predicate name -> object id
+    product_base: int                 # products are ids product_base .. product_base + n_products - 1
+    feature_base: int
+    n_features: int
+    type_base: int
+    n_types: int
+    int_base: int                     # integer literal v (1..2000) has id int_base + v - 1
+    n_ids: int
+    class_ids: dict = field(default_factory=dict)
+
+    @property
+    def n_triples(self):
+        return len(self.s)
+
+    def product(self, i):
+        return self.product_base + int(i)
+
+
+def generate(n_products, seed=None, offers_per_product=20, reviews_per_product=10):
+    """Returns a BsbmDataset with ≈350 * n_products triples."""
+    P = int(n_products)
+    rng = np.random.default_rng(P if seed is None else seed)
+    next_id = [1]
+
+    def take(n):
+        b = next_id[0]
+        next_id[0] += int(n)
+        return b
+
+    pred = {name: take(1) for name in PREDICATES}
+    cls = {name: take(1) for name in ["bsbm:Product", "bsbm:Offer", "rev:Review", "bsbm:Producer", "bsbm:Vendor"]}
+    n_leaf = max(4, P // 150)
+    n_types = n_leaf + max(1, n_leaf // 4) + max(1, n_leaf // 16) + 1     # leaf, two inner levels, root
+    type_base = take(n_types)
+    n_features = int(np.clip(P // 6, 20, 47_000))
+    feature_base = take(n_features)
+    n_producers = max(1, P // 50)
+    producer_base = take(n_producers)
+    n_vendors = max(1, P // 100)
+    vendor_base = take(n_vendors)
+    n_reviewers = max(1, P // 2)
+    reviewer_base = take(n_reviewers)
+    product_base = take(P)
+    n_offers = P * offers_per_product
+    offer_base = take(n_offers)
+    n_reviews = P * reviews_per_product
+    review_base = take(n_reviews)
+    int_base = take(2000)                 # "1"^^xsd:integer .. "2000"^^xsd:integer
+    n_words = 20_000
+    word_base = take(n_words)             # shared textual literals
+    label_base = take(P)                  # one rdfs:label literal per product
+    n_prices = 100_000
+    price_base = take(n_prices)           # xsd:double price literals
+    n_dates = 4000
+    date_base = take(n_dates)             # xsd:date literals (opaque on device)
+    n_ids = next_id[0]
+
+    S, Pc, O = [], [], []
+
+    def emit(s, p, o):
+        s = np.asarray(s, dtype=np.uint32)
+        S.append(s)
+        Pc.append(np.full(len(s), p, dtype=np.uint32))
+        O.append(np.asarray(o, dtype=np.uint32))
+
+    prod = np.arange(product_base, product_base + P, dtype=np.uint32)
+    # --- products ---------------------------------------------------------------------------------
+    emit(prod, pred["rdfs:label"], label_base + np.arange(P))
+    emit(prod, pred["rdfs:comment"], word_base + rng.integers(0, n_words, P))
+    leaf = rng.integers(0, n_leaf, P)
+    lvl1 = n_leaf + leaf // 4 % max(1, n_leaf // 4)
+    lvl2 = n_leaf + max(1, n_leaf // 4) + leaf // 16 % max(1, n_leaf // 16)
+    root = np.full(P, n_types - 1)
+    for t in (leaf, lvl1, lvl2, root):     # forward-chained type ancestors (`-fc`, requirements.rs:28)
+        emit(prod, pred["rdf:type"], type_base + t)
+    emit(prod, pred["bsbm:producer"], producer_base + rng.integers(0, n_producers, P))
+    fan = rng.integers(9, 29, P)                                  # U{9..28}
+    fs = np.repeat(prod, fan)
+    fo = feature_base + rng.integers(0, n_features, fan.sum())
+    emit(fs, pred["bsbm:productFeature"], fo)                     # duplicates collapse in the store (set semantics)
+    for k, prob in ((1, 1.0), (2, 1.0), (3, 1.0), (4, 0.7), (5, 0.5)):
+        keep = rng.random(P) < prob
+        v = np.clip(np.rint(rng.normal(1000, 333, P)), 1, 2000).astype(np.int64)
+        emit(prod[keep], pred[f"bsbm:productPropertyNumeric{k}"], int_base + v[keep] - 1)
+    for k, prob in ((1, 1.0), (2, 1.0), (3, 1.0), (4, 0.7), (5, 0.8)):
+        keep = rng.random(P) < prob
+        emit(prod[keep], pred[f"bsbm:productPropertyTextual{k}"], word_base + rng.integers(0, n_words, keep.sum()))
+    emit(prod, pred["dc:publisher"], producer_base + rng.integers(0, n_producers, P))
+    emit(prod, pred["dc:date"], date_base + rng.integers(0, n_dates, P))
+    # --- offers -----------------------------------------------------------------------------------
+    off = np.arange(offer_base, offer_base + n_offers, dtype=np.uint32)
+    emit(off, pred["rdf:type"], np.full(n_offers, cls["bsbm:Offer"]))
+    emit(off, pred["bsbm:product"], np.repeat(prod, offers_per_product))
+    ov = vendor_base + rng.integers(0, n_vendors, n_offers)
+    emit(off, pred["bsbm:vendor"], ov)
+    emit(off, pred["bsbm:price"], price_base + rng.integers(0, n_prices, n_offers))
+    emit(off, pred["bsbm:validFrom"], date_base + rng.integers(0, n_dates, n_offers))
+    emit(off, pred["bsbm:validTo"], date_base + rng.integers(0, n_dates, n_offers))
+    emit(off, pred["bsbm:deliveryDays"], int_base + rng.integers(1, 22, n_offers) - 1)
+    emit(off, pred["bsbm:offerWebpage"], word_base + rng.integers(0, n_words, n_offers))
+    emit(off, pred["dc:publisher"], ov)
+    emit(off, pred["dc:date"], date_base + rng.integers(0, n_dates, n_offers))
+    # --- reviews ----------------------------------------------------------------------------------
+    rev = np.arange(review_base, review_base + n_reviews, dtype=np.uint32)
+    emit(rev, pred["rdf:type"], np.full(n_reviews, cls["rev:Review"]))
+    emit(rev, pred["bsbm:reviewFor"], np.repeat(prod, reviews_per_product))
+    rr = reviewer_base + rng.integers(0, n_reviewers, n_reviews)
+    emit(rev, pred["rev:reviewer"], rr)
+    emit(rev, pred["dc:title"], word_base + rng.integers(0, n_words, n_reviews))
+    emit(rev, pred["rev:text"], word_base + rng.integers(0, n_words, n_reviews))
+    for k in (1, 2, 3, 4):
+        keep = rng.random(n_reviews) < 0.7
+        emit(rev[keep], pred[f"bsbm:rating{k}"], int_base + rng.integers(1, 11, keep.sum()) - 1)
+    emit(rev, pred["bsbm:reviewDate"], date_base + rng.integers(0, n_dates, n_reviews))
+    emit(rev, pred["dc:publisher"], rr)
+    emit(rev, pred["dc:date"], date_base + rng.integers(0, n_dates, n_reviews))
+
+    s = np.concatenate(S)
+    p = np.concatenate(Pc)
+    o = np.concatenate(O)
+    g = np.zeros(len(s), dtype=np.uint32)      # default graph only
+    del S, Pc, O
+
+    # --- typed-value table (index = object id) ----------------------------------------------------
+    tv = np.zeros(n_ids, dtype=TV_DTYPE)
+    tv["tag"][1:] = abi.TV_NAMED_NODE           # IRIs unless overwritten below
+    tv["lo"][1:] = np.arange(1, n_ids)          # rank of the IRI in str order (any total order works)
+    ints = slice(int_base, int_base + 2000)
+    tv["tag"][ints] = abi.TV_INTEGER
+    tv["lo"][ints] = np.arange(1, 2001)
+    for base, n in ((word_base, n_words), (label_base, P)):
+        sl = slice(base, base + n)
+        tv["tag"][sl] = abi.TV_STRING           # simple literals; lo = rank of the lexical form
+        tv["lo"][sl] = np.arange(n)
+        tv["aux"][sl] = 0
+    pr = slice(price_base, price_base + n_prices)
+    tv["tag"][pr] = abi.TV_DOUBLE
+    tv["lo"][pr] = (rng.random(n_prices) * 10_000.0).view(np.int64)
+    tv["tag"][date_base:date_base + n_dates] = abi.TV_DATE
+    tv["lo"][date_base:date_base + n_dates] = 0
+
+    return BsbmDataset(P, g, s, p, o, tv, pred, product_base, feature_base, n_features, type_base, n_types,
+                       int_base, n_ids, cls)
+
+
+# --------------------------------------------------------------------------------------------------
+# The reference's physical plans (bench/tests/plans/snapshots/*.snap)
+# --------------------------------------------------------------------------------------------------
+def q5_plan(ds, product_id, w1=120, w2=170):
+    """BSBM Explore Q5 ("similar products"), 7 triple patterns, as planned by the reference:
+    J3(J2(J1(label x features(X), productFeature), numeric1), numeric2) — Q5 (Execution Plan).snap:10-30.
+    Output: (product, productLabel) bindings before DISTINCT / ORDER BY / LIMIT."""
+    X = int(product_id)
+    pr = ds.pred
+    pb = PlanBuilder()
+    not_x = lambda: ID_NEQ(col(0), lit_id(X))                       # FilterExec: product@0 != <object id>
+    label = pb.filter(pb.data_source(quad_pattern("product", pr["rdfs:label"], "productLabel")), not_x())
+    x_feat = pb.data_source(quad_pattern(X, pr["bsbm:productFeature"], "prodFeature"))
+    c1 = pb.cross_join(label, x_feat)                               # product, productLabel, prodFeature
+    pf = pb.filter(pb.data_source(quad_pattern("product", pr["bsbm:productFeature"], "prodFeature")), not_x())
+    j1 = pb.hash_join(c1, pf, on=[(2, 1), (0, 0)], projection=[0, 1])
+    node = j1
+    for k, w in ((1, w1), (2, w2)):
+        x_num = pb.data_source(quad_pattern(X, pr[f"bsbm:productPropertyNumeric{k}"], f"origProperty{k}"))
+        cx = pb.cross_join(node, x_num)                             # product, productLabel, origPropertyK
+        sim = pb.filter(pb.data_source(quad_pattern("product", pr[f"bsbm:productPropertyNumeric{k}"], f"simProperty{k}")), not_x())
+        # EBV(LT(ENC_TV(sim), ADD(ENC_TV(orig), 9:w))) AND EBV(GT(ENC_TV(sim), SUB(ENC_TV(orig), 9:w)))
+        flt = AND(EBV(LT(ENC_TV(col(4)), ADD(ENC_TV(col(2)), integer(w)))),
+                  EBV(GT(ENC_TV(col(4)), SUB(ENC_TV(col(2)), integer(w)))))
+        node = pb.hash_join(cx, sim, on=[(0, 0)], filter=flt, projection=[0, 1])
+    return pb.build(node)
+
+
+def q1_plan(ds, type_id, feature1, feature2, threshold):
+    """BSBM Explore Q1: four chained single-key hash joins on ?product and the numeric FILTER
+    (Q1 (Execution Plan).snap:10-19).  Output: (product, label)."""
+    pr = ds.pred
+    pb = PlanBuilder()
+    label = pb.data_source(quad_pattern("product", pr["rdfs:label"], "label"))
+    ptype = pb.data_source(quad_pattern("product", pr["rdf:type"], int(type_id)))
+    j = pb.hash_join(label, ptype, on=[(0, 0)], projection=[0, 1])
+    for f in (feature1, feature2):
+        pf = pb.data_source(quad_pattern("product", pr["bsbm:productFeature"], int(f)))
+        j = pb.hash_join(j, pf, on=[(0, 0)], projection=[0, 1])
+    num = pb.data_source(quad_pattern("product", pr["bsbm:productPropertyNumeric1"], "value1"))
+    flt = pb.filter(num, EBV(GT(ENC_TV(col(1)), integer(threshold))), projection=[0])
+    j = pb.hash_join(j, flt, on=[(0, 0)], projection=[0, 1])
+    return pb.build(j)
+
+
+def q1_scan_filter_plan(ds, threshold):
+    """BASELINE config 2: the single-pattern scan + numeric FILTER of Q1
+    (FilterExec: EBV(GT(ENC_TV(value1@1), 9:c)), projection=[product@0] over the GPOS slice)."""
+    pb = PlanBuilder()
+    num = pb.data_source(quad_pattern("product", ds.pred["bsbm:productPropertyNumeric1"], "value1"))
+    return pb.build(pb.filter(num, EBV(GT(ENC_TV(col(1)), integer(threshold))), projection=[0]))
+
+
+def q1_instance(ds, rng):
+    """Query constants drawn so the query has answers: type/features of a random product."""
+    i = int(rng.integers(0, ds.n_products))
+    x = ds.product(i)
+    sel = ds.s == x
+    types = ds.o[sel & (ds.p == ds.pred["rdf:type"])]
+    feats = np.unique(ds.o[sel & (ds.p == ds.pred["bsbm:productFeature"])])
+    f = rng.choice(feats, size=2, replace=False) if len(feats) >= 2 else np.array([feats[0], feats[0]])
+    return int(types.min()), int(f[0]), int(f[1]), int(rng.integers(1, 501))

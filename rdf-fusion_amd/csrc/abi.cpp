@@ -1,0 +1,300 @@
+// abi.cpp — the extern "C" boundary of include/rdfgpu.h.  No exception crosses it.
+#include <cstdlib>
+#include <cstring>
+#include <string>
+
+#include "host_logic.hpp"
+#include "plan.hpp"
+#include "store.hpp"
+
+namespace rdfgpu {
+static thread_local std::string g_last_error;
+void set_last_error(const std::string& msg) { g_last_error = msg; }
+}  // namespace rdfgpu
+
+using namespace rdfgpu;
+
+#define ABI_BEGIN try {
+#define ABI_END                                              \
+  }                                                          \
+  catch (const Error& e) { set_last_error(e.what()); return e.status; } \
+  catch (const std::bad_alloc&) { set_last_error("host allocation failed"); return RDFGPU_ERR_OOM; } \
+  catch (const std::exception& e) { set_last_error(e.what()); return RDFGPU_ERR_INVALID; } \
+  return RDFGPU_OK;
+
+static Store* S(rdfgpu_store* s) { if (!s) fail(RDFGPU_ERR_INVALID, "null store handle"); return reinterpret_cast<Store*>(s); }
+static const Store* S(const rdfgpu_store* s) { if (!s) fail(RDFGPU_ERR_INVALID, "null store handle"); return reinterpret_cast<const Store*>(s); }
+static Plan* P(rdfgpu_plan* p) { if (!p) fail(RDFGPU_ERR_INVALID, "null plan handle"); return reinterpret_cast<Plan*>(p); }
+
+extern "C" {
+
+const char* rdfgpu_last_error(void) { return g_last_error.c_str(); }
+uint32_t rdfgpu_abi_version(void) { return RDFGPU_ABI_VERSION; }
+
+// ---- store ---------------------------------------------------------------------------------------
+int rdfgpu_store_create(const rdfgpu_config* cfg, rdfgpu_store** out) {
+  ABI_BEGIN
+  if (!out) fail(RDFGPU_ERR_INVALID, "null out pointer");
+  *out = reinterpret_cast<rdfgpu_store*>(store_create(cfg));
+  ABI_END
+}
+void rdfgpu_store_destroy(rdfgpu_store* store) { delete reinterpret_cast<Store*>(store); }
+
+int rdfgpu_store_extend(rdfgpu_store* store, const uint32_t* g, const uint32_t* s, const uint32_t* p, const uint32_t* o, uint64_t n, uint64_t* inserted) {
+  ABI_BEGIN
+  if (n && (!g || !s || !p || !o)) fail(RDFGPU_ERR_INVALID, "null quad column");
+  const u64 r = S(store)->extend_host(g, s, p, o, n);
+  if (inserted) *inserted = r;
+  ABI_END
+}
+int rdfgpu_store_extend_device(rdfgpu_store* store, const uint32_t* g, const uint32_t* s, const uint32_t* p, const uint32_t* o, uint64_t n, uint64_t* inserted) {
+  ABI_BEGIN
+  if (n && (!g || !s || !p || !o)) fail(RDFGPU_ERR_INVALID, "null quad column");
+  const u64 r = S(store)->extend_device(g, s, p, o, n);
+  if (inserted) *inserted = r;
+  ABI_END
+}
+int rdfgpu_store_remove(rdfgpu_store* store, const uint32_t* g, const uint32_t* s, const uint32_t* p, const uint32_t* o, uint64_t n, uint64_t* removed) {
+  ABI_BEGIN
+  if (n && (!g || !s || !p || !o)) fail(RDFGPU_ERR_INVALID, "null quad column");
+  const u64 r = S(store)->remove_host(g, s, p, o, n);
+  if (removed) *removed = r;
+  ABI_END
+}
+int rdfgpu_store_clear(rdfgpu_store* store) { ABI_BEGIN S(store)->clear(); ABI_END }
+int rdfgpu_store_len(const rdfgpu_store* store, uint64_t* out) {
+  ABI_BEGIN
+  if (!out) fail(RDFGPU_ERR_INVALID, "null out pointer");
+  *out = S(store)->idx[0].n;
+  ABI_END
+}
+int rdfgpu_store_set_typed_values(rdfgpu_store* store, const rdfgpu_typed_value* values, uint64_t n_ids, const int64_t* decimals, uint64_t n_decimals) {
+  ABI_BEGIN
+  if ((n_ids && !values) || (n_decimals && !decimals)) fail(RDFGPU_ERR_INVALID, "null typed-value table");
+  S(store)->set_typed_values(values, n_ids, decimals, n_decimals);
+  ABI_END
+}
+int rdfgpu_store_read_index(const rdfgpu_store* store, uint32_t components, uint32_t* c0, uint32_t* c1, uint32_t* c2, uint32_t* c3, uint64_t cap, uint64_t* n) {
+  ABI_BEGIN
+  const Store* st = S(store);
+  if (components >= RDFGPU_N_INDEXES) fail(RDFGPU_ERR_INVALID, "bad index components %u", components);
+  st->activate();
+  const Permutation& ix = st->idx[components];
+  if (n) *n = ix.n;
+  uint32_t* dst[4] = {c0, c1, c2, c3};
+  const u64 m = ix.n < cap ? ix.n : cap;
+  for (int k = 0; k < 4; k++) if (dst[k] && m) RDFGPU_HIP(hipMemcpy(dst[k], ix.col[k], m * 4, hipMemcpyDeviceToHost));
+  ABI_END
+}
+
+// ---- plans ---------------------------------------------------------------------------------------
+int rdfgpu_plan_compile(rdfgpu_store* store, const rdfgpu_plan_desc* desc, rdfgpu_plan** out) {
+  ABI_BEGIN
+  if (!out) fail(RDFGPU_ERR_INVALID, "null out pointer");
+  *out = reinterpret_cast<rdfgpu_plan*>(plan_compile(S(store), desc));
+  ABI_END
+}
+void rdfgpu_plan_destroy(rdfgpu_plan* plan) { delete reinterpret_cast<Plan*>(plan); }
+
+int rdfgpu_plan_bind_table(rdfgpu_plan* plan, uint32_t slot, const uint32_t* const* cols, uint32_t n_cols, uint64_t n_rows) {
+  ABI_BEGIN
+  Plan* p = P(plan);
+  if (slot >= p->tables.size()) fail(RDFGPU_ERR_INVALID, "plan has no table slot %u", slot);
+  if (n_cols && !cols) fail(RDFGPU_ERR_INVALID, "null column array");
+  BoundTable& b = p->tables[slot];
+  b.cols.assign(cols, cols + n_cols);
+  b.n_rows = n_rows; b.bound = true;
+  ABI_END
+}
+int rdfgpu_plan_execute(rdfgpu_plan* plan) { ABI_BEGIN P(plan)->execute(); ABI_END }
+
+int rdfgpu_plan_result_info(rdfgpu_plan* plan, uint64_t* n_rows, uint32_t* n_cols) {
+  ABI_BEGIN
+  Plan* p = P(plan);
+  if (!p->executed) fail(RDFGPU_ERR_INVALID, "plan has not been executed");
+  if (n_rows) *n_rows = p->result_rows;
+  if (n_cols) *n_cols = p->result.n_cols;
+  ABI_END
+}
+int rdfgpu_plan_result_device(rdfgpu_plan* plan, const uint32_t** cols, uint32_t cap_cols) {
+  ABI_BEGIN
+  Plan* p = P(plan);
+  if (!p->executed) fail(RDFGPU_ERR_INVALID, "plan has not been executed");
+  if (cap_cols < p->result.n_cols) fail(RDFGPU_ERR_INVALID, "room for %u columns, result has %u", cap_cols, p->result.n_cols);
+  for (u32 c = 0; c < p->result.n_cols; c++) cols[c] = p->result_rows ? p->result.cols[c] : nullptr;
+  ABI_END
+}
+int rdfgpu_plan_fetch(rdfgpu_plan* plan, uint32_t* const* host_cols, uint32_t n_cols) {
+  ABI_BEGIN
+  Plan* p = P(plan);
+  if (!p->executed) fail(RDFGPU_ERR_INVALID, "plan has not been executed");
+  if (n_cols != p->result.n_cols) fail(RDFGPU_ERR_INVALID, "caller passed %u columns, result has %u", n_cols, p->result.n_cols);
+  p->store->activate();
+  for (u32 c = 0; c < n_cols; c++)
+    if (p->result_rows) RDFGPU_HIP(hipMemcpyAsync(host_cols[c], p->result.cols[c], p->result_rows * 4, hipMemcpyDeviceToHost, p->stream));
+  RDFGPU_HIP(hipStreamSynchronize(p->stream));
+  ABI_END
+}
+
+// Arrow C Data Interface export -----------------------------------------------------------------
+namespace {
+struct ChildPriv { void* buffers[2]; };
+void release_child_array(struct ArrowArray* a) {
+  if (!a || !a->release) return;
+  ChildPriv* pr = static_cast<ChildPriv*>(a->private_data);
+  std::free(pr->buffers[0]); std::free(pr->buffers[1]);
+  delete pr;
+  a->release = nullptr;
+}
+struct StructPriv { const void* buffers[1]; struct ArrowArray** children; u32 n; };
+void release_struct_array(struct ArrowArray* a) {
+  if (!a || !a->release) return;
+  StructPriv* pr = static_cast<StructPriv*>(a->private_data);
+  for (u32 i = 0; i < pr->n; i++) { if (pr->children[i]->release) pr->children[i]->release(pr->children[i]); delete pr->children[i]; }
+  delete[] pr->children;
+  delete pr;
+  a->release = nullptr;
+}
+struct SchemaPriv { struct ArrowSchema** children; u32 n; std::string* names; };
+void release_schema(struct ArrowSchema* s) {
+  if (!s || !s->release) return;
+  SchemaPriv* pr = static_cast<SchemaPriv*>(s->private_data);
+  if (pr) {
+    for (u32 i = 0; i < pr->n; i++) { if (pr->children[i]->release) pr->children[i]->release(pr->children[i]); delete pr->children[i]; }
+    delete[] pr->children; delete[] pr->names; delete pr;
+  }
+  s->release = nullptr;
+}
+}  // namespace
+
+int rdfgpu_plan_next(rdfgpu_plan* plan, struct ArrowArray* out, struct ArrowSchema* schema) {
+  try {
+    Plan* p = P(plan);
+    if (!out) fail(RDFGPU_ERR_INVALID, "null out array");
+    p->ensure_host_copy();
+    if (p->cursor >= p->result_rows) return RDFGPU_END;   // never an empty batch (scan.rs:195-198)
+    const u64 len = std::min<u64>(p->store->batch_size, p->result_rows - p->cursor);
+    const u32 nc = p->result.n_cols;
+    StructPriv* sp = new StructPriv();
+    sp->buffers[0] = nullptr; sp->n = nc; sp->children = new ArrowArray*[nc ? nc : 1];
+    for (u32 c = 0; c < nc; c++) {
+      ArrowArray* ch = new ArrowArray();
+      std::memset(ch, 0, sizeof *ch);
+      ChildPriv* cp = new ChildPriv();
+      const u32* src = p->host_cols[c].data() + p->cursor;
+      u32* data = static_cast<u32*>(std::malloc(len * 4 ? len * 4 : 4));
+      std::memcpy(data, src, len * 4);
+      int64_t nulls = 0;
+      for (u64 i = 0; i < len; i++) nulls += src[i] == 0;
+      uint8_t* valid = nullptr;
+      if (nulls) {   // object id 0 is the null marker (quad_index_data.rs:438-440)
+        valid = static_cast<uint8_t*>(std::calloc((len + 7) / 8, 1));
+        for (u64 i = 0; i < len; i++) if (src[i]) valid[i >> 3] |= (uint8_t)(1u << (i & 7));
+      }
+      cp->buffers[0] = valid; cp->buffers[1] = data;
+      ch->length = (int64_t)len; ch->null_count = nulls; ch->n_buffers = 2;
+      ch->buffers = const_cast<const void**>(reinterpret_cast<void**>(cp->buffers));
+      ch->release = release_child_array; ch->private_data = cp;
+      sp->children[c] = ch;
+    }
+    std::memset(out, 0, sizeof *out);
+    out->length = (int64_t)len; out->n_buffers = 1; out->buffers = sp->buffers;
+    out->n_children = nc; out->children = sp->children;
+    out->release = release_struct_array; out->private_data = sp;
+    if (schema) {
+      std::memset(schema, 0, sizeof *schema);
+      SchemaPriv* pr = new SchemaPriv();
+      pr->n = nc; pr->children = new ArrowSchema*[nc ? nc : 1]; pr->names = new std::string[nc ? nc : 1];
+      for (u32 c = 0; c < nc; c++) {
+        ArrowSchema* cs = new ArrowSchema();
+        std::memset(cs, 0, sizeof *cs);
+        pr->names[c] = "c" + std::to_string(c);
+        cs->format = "I"; cs->name = pr->names[c].c_str(); cs->flags = 2 /* ARROW_FLAG_NULLABLE */;
+        cs->release = release_schema; cs->private_data = nullptr;
+        pr->children[c] = cs;
+      }
+      schema->format = "+s"; schema->name = ""; schema->n_children = nc; schema->children = pr->children;
+      schema->release = release_schema; schema->private_data = pr;
+    }
+    p->cursor += len;
+    return RDFGPU_OK;
+  } catch (const Error& e) { set_last_error(e.what()); return e.status; }
+  catch (const std::exception& e) { set_last_error(e.what()); return RDFGPU_ERR_INVALID; }
+}
+int rdfgpu_plan_rewind(rdfgpu_plan* plan) { ABI_BEGIN P(plan)->cursor = 0; ABI_END }
+int rdfgpu_plan_metrics(rdfgpu_plan* plan, rdfgpu_metrics* out) {
+  ABI_BEGIN
+  if (!out) fail(RDFGPU_ERR_INVALID, "null out pointer");
+  *out = P(plan)->metrics;
+  ABI_END
+}
+int rdfgpu_plan_selected_index(const rdfgpu_plan* plan, uint32_t node, uint32_t* components) {
+  ABI_BEGIN
+  const Plan* p = reinterpret_cast<const Plan*>(plan);
+  if (!p) fail(RDFGPU_ERR_INVALID, "null plan handle");
+  if (node >= p->nodes.size() || p->nodes[node].source < 0) fail(RDFGPU_ERR_INVALID, "node %u is not a data source", node);
+  if (components) *components = p->sources[p->nodes[node].source].components;
+  ABI_END
+}
+int rdfgpu_plan_stream(rdfgpu_plan* plan, void** hip_stream) {
+  ABI_BEGIN
+  if (!hip_stream) fail(RDFGPU_ERR_INVALID, "null out pointer");
+  *hip_stream = P(plan)->stream;
+  ABI_END
+}
+
+// ---- host logic ----------------------------------------------------------------------------------
+static void decode4(const rdfgpu_scan_instruction raw[4], ScanInstruction out[4]) {
+  // host-logic entry points take explicit (pred, a, b) without a pool: an IN with b ids is scored as
+  // b synthetic ids a..a+b-1 (only "one id or several" matters to the score)
+  for (int i = 0; i < 4; i++) {
+    rdfgpu_scan_instruction r = raw[i];
+    if (r.pred == RDFGPU_PRED_IN) {
+      out[i].kind = r.kind; out[i].var = r.var; out[i].pred.kind = RDFGPU_PRED_IN;
+      out[i].pred.ids.clear();
+      for (u32 q = 0; q < (r.b ? r.b : 1); q++) out[i].pred.ids.push_back(q);
+    } else out[i] = decode_instruction(r, nullptr, 0);
+  }
+}
+uint64_t rdfgpu_scan_score(const rdfgpu_scan_instruction instr[4]) {
+  try { ScanInstruction in[4]; decode4(instr, in); return scan_score(in); }
+  catch (const std::exception& e) { set_last_error(e.what()); return 0; }
+}
+uint32_t rdfgpu_choose_index(const rdfgpu_scan_instruction gspo[4], uint32_t available) {
+  try {
+    ScanInstructions g; g.components = RDFGPU_GSPO; decode4(gspo, g.in);
+    return choose_index(g, available);
+  } catch (const std::exception& e) { set_last_error(e.what()); return 0xFFFFFFFFu; }
+}
+static ScanPredicate from_abi(const rdfgpu_predicate* p) {
+  ScanPredicate r; r.kind = p->pred; r.from = p->from; r.to = p->to; r.equal_to = p->equal_to;
+  if (p->pred == RDFGPU_PRED_IN) { if (p->ids) r.ids.assign(p->ids, p->ids + p->n_ids); else r.ids = {p->from}; }
+  return r;
+}
+int rdfgpu_predicate_and(const rdfgpu_predicate* lhs, const rdfgpu_predicate* rhs, rdfgpu_predicate* out, uint32_t* out_ids) {
+  try {
+    if (!lhs || !rhs || !out) fail(RDFGPU_ERR_INVALID, "null predicate");
+    ScanPredicate r;
+    if (!predicate_and(from_abi(lhs), from_abi(rhs), &r)) return 0;
+    std::memset(out, 0, sizeof *out);
+    out->pred = r.kind; out->from = r.from; out->to = r.to;
+    if (r.kind == RDFGPU_PRED_IN) {
+      if (!out_ids) fail(RDFGPU_ERR_INVALID, "null out_ids");
+      for (size_t i = 0; i < r.ids.size(); i++) out_ids[i] = r.ids[i];
+      out->ids = out_ids; out->n_ids = (u32)r.ids.size();
+    }
+    return 1;
+  } catch (const Error& e) { set_last_error(e.what()); return e.status; }
+}
+int rdfgpu_pushdown_to_scan_predicate(uint32_t op, uint32_t value, rdfgpu_predicate* out) {
+  try {
+    if (!out) fail(RDFGPU_ERR_INVALID, "null out predicate");
+    const ScanPredicate r = pushdown_to_scan_predicate(op, value);
+    std::memset(out, 0, sizeof *out);
+    out->pred = r.kind; out->from = r.from; out->to = r.to;
+    if (r.kind == RDFGPU_PRED_IN) { out->from = out->to = r.ids[0]; out->n_ids = 1; }
+    return 1;
+  } catch (const Error& e) { set_last_error(e.what()); return e.status; }
+}
+
+}  // extern "C"

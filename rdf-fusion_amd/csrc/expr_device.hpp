@@ -1,0 +1,263 @@
+// expr_device.hpp — per-row evaluation of SPARQL FILTER / join-filter programs on gfx950.
+//
+// Device restatement of the reference's typed-value semantics (one row = one lane; the program is
+// wave-uniform, so every branch on the opcode is a scalar branch):
+//   ENC_TV   lib/functions/src/builtin/encoding/with_typed_value_encoding.rs:71-79
+//            (id -> typed value; here ONE aligned 16-byte gather from the HBM side table)
+//   GT/LT/.. lib/functions/src/scalar/comparison/*.rs via PartialOrd lib/model/src/typed_value.rs:162-261
+//   promotion lib/model/src/xsd/numeric.rs:127-201
+//   ADD/SUB  lib/functions/src/scalar/numeric/add.rs:40-86 (checked int/decimal, IEEE float/double)
+//   EBV      lib/functions/src/builtin/native/effective_boolean_value.rs:99-119
+//   AND/OR   SQL three-valued logic on native booleans (lib/logical/src/expr_builder_context.rs:393-434)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/rdfgpu.h"
+
+namespace rdfgpu {
+
+constexpr int kMaxExpr = 40;   // nodes per program (kernarg resident: 40 * 24 B)
+constexpr int kMaxStack = 8;
+
+struct ExprProgram {
+  uint32_t n;
+  uint32_t pad;
+  rdfgpu_expr_node nodes[kMaxExpr];
+};
+
+struct TypedTable {
+  const rdfgpu_typed_value* tv;  // indexed by object id
+  uint64_t n_ids;
+  const int64_t* dec;            // (lo, hi) pairs of i128 decimals
+  uint64_t n_dec;
+};
+
+// Value kinds on the evaluation stack.
+enum : uint32_t { VK_ID = 0, VK_TV = 1, VK_BOOL = 2 };
+
+struct Val {
+  int64_t lo;     // ID: object id; TV: payload; BOOL: 0 false / 1 true / 2 null
+  int64_t hi;     // TV decimal: high 64 bits
+  uint32_t aux;   // TV: language id / datatype id
+  uint8_t kind, tag, flags, pad;
+};
+
+typedef __int128 i128_t;
+typedef unsigned __int128 u128_t;
+
+__device__ __forceinline__ Val val_tv_null() { Val v; v.lo = 0; v.hi = 0; v.aux = 0; v.kind = VK_TV; v.tag = RDFGPU_TV_NULL; v.flags = 0; v.pad = 0; return v; }
+__device__ __forceinline__ Val val_tv_bool(bool b) { Val v = val_tv_null(); v.tag = RDFGPU_TV_BOOLEAN; v.lo = b ? 1 : 0; return v; }
+__device__ __forceinline__ Val val_bool(uint32_t b) { Val v = val_tv_null(); v.kind = VK_BOOL; v.lo = b; return v; }
+__device__ __forceinline__ Val val_id(uint32_t id) { Val v = val_tv_null(); v.kind = VK_ID; v.lo = id; return v; }
+
+__device__ __forceinline__ i128_t val_dec(const Val& v) { return (i128_t)(((u128_t)(uint64_t)v.hi << 64) | (u128_t)(uint64_t)v.lo); }
+__device__ __forceinline__ void set_dec(Val& v, i128_t d) { v.lo = (int64_t)(uint64_t)(u128_t)d; v.hi = (int64_t)(uint64_t)((u128_t)d >> 64); }
+
+// ENC_TV: one 16-byte gather (global_load_dwordx4) per row.
+__device__ __forceinline__ Val enc_tv(const TypedTable& t, uint32_t id) {
+  Val v = val_tv_null();
+  if (id == 0 || id >= t.n_ids) return v;
+  const int4 raw = *reinterpret_cast<const int4*>(t.tv + id);
+  v.lo = (int64_t)(((uint64_t)(uint32_t)raw.y << 32) | (uint32_t)raw.x);
+  v.aux = (uint32_t)raw.z;
+  v.tag = (uint8_t)((uint32_t)raw.w & 0xff);
+  v.flags = (uint8_t)(((uint32_t)raw.w >> 8) & 0xff);
+  if (v.tag == RDFGPU_TV_DECIMAL) {
+    if ((uint64_t)v.lo >= t.n_dec) return val_tv_null();
+    const int64_t* d = t.dec + 2 * v.lo;
+    v.lo = d[0]; v.hi = d[1];
+  }
+  return v;
+}
+
+// ---- decimal (i128 * 10^-18) -> f64, From<Decimal> for Double lib/model/src/xsd/decimal.rs:445-462 ----
+// No 128-bit division / int->fp libcalls exist on the device, so both are spelled out.
+__device__ __forceinline__ uint32_t u128_divmod10(u128_t& v) {  // v /= 10, returns v % 10
+  uint32_t limb[4] = {(uint32_t)(v >> 96), (uint32_t)(v >> 64), (uint32_t)(v >> 32), (uint32_t)v};
+  uint64_t rem = 0;
+#pragma unroll
+  for (int i = 0; i < 4; i++) { uint64_t cur = (rem << 32) | limb[i]; limb[i] = (uint32_t)(cur / 10u); rem = cur % 10u; }
+  v = ((u128_t)limb[0] << 96) | ((u128_t)limb[1] << 64) | ((u128_t)limb[2] << 32) | (u128_t)limb[3];
+  return (uint32_t)rem;
+}
+__device__ __forceinline__ double u128_to_f64(u128_t v) {  // round-to-nearest-even, like Rust `as f64`
+  uint64_t hi = (uint64_t)(v >> 64), lo = (uint64_t)v;
+  if (hi == 0) return (double)lo;
+  int lz = __clzll((long long)hi);
+  u128_t n = v << lz;
+  uint64_t m = (uint64_t)(n >> 64);
+  if ((uint64_t)n != 0) m |= 1;  // sticky bit (11 guard bits below the 53-bit mantissa)
+  return ldexp((double)m, 64 - lz);
+}
+__device__ __forceinline__ double dec_to_f64(i128_t value) {
+  bool neg = value < 0;
+  u128_t mag = neg ? (u128_t)(-(value + 1)) + 1 : (u128_t)value;
+  uint64_t shift = 1000000000000000000ull;
+  if (mag != 0) {
+    while (shift != 1) {
+      u128_t q = mag;
+      uint32_t r = u128_divmod10(q);
+      if (r != 0) break;
+      mag = q; shift /= 10;
+    }
+  }
+  double d = u128_to_f64(mag) / (double)shift;
+  return neg ? -d : d;
+}
+
+enum { NK_INT, NK_INTEGER, NK_FLOAT, NK_DOUBLE, NK_DECIMAL, NK_NONE };
+__device__ __forceinline__ int num_kind(uint8_t tag) {
+  switch (tag) {
+    case RDFGPU_TV_INT: return NK_INT;
+    case RDFGPU_TV_INTEGER: return NK_INTEGER;
+    case RDFGPU_TV_FLOAT: return NK_FLOAT;
+    case RDFGPU_TV_DOUBLE: return NK_DOUBLE;
+    case RDFGPU_TV_DECIMAL: return NK_DECIMAL;
+    default: return NK_NONE;
+  }
+}
+// NumericPair::with_casts_from numeric.rs:127-201
+__device__ __forceinline__ int pair_kind(int a, int b) {
+  if (a == NK_DOUBLE || b == NK_DOUBLE) return NK_DOUBLE;
+  if (a == NK_FLOAT || b == NK_FLOAT) return NK_FLOAT;
+  if (a == NK_DECIMAL || b == NK_DECIMAL) return NK_DECIMAL;
+  if (a == NK_INTEGER || b == NK_INTEGER) return NK_INTEGER;
+  return NK_INT;
+}
+__device__ __forceinline__ double to_f64(const Val& v, int k) {
+  switch (k) {
+    case NK_INT: case NK_INTEGER: return (double)v.lo;             // i64 as f64, double.rs:196-201
+    case NK_FLOAT: return (double)__uint_as_float((uint32_t)v.lo);
+    case NK_DOUBLE: return __longlong_as_double(v.lo);
+    default: return dec_to_f64(val_dec(v));
+  }
+}
+__device__ __forceinline__ float to_f32(const Val& v, int k) {
+  switch (k) {
+    case NK_INT: return (float)(int32_t)v.lo;                      // float.rs:156-161
+    case NK_INTEGER: return (float)v.lo;                           // float.rs:164-169
+    case NK_FLOAT: return __uint_as_float((uint32_t)v.lo);
+    case NK_DECIMAL: return (float)dec_to_f64(val_dec(v));         // decimal.rs:437-443
+    default: return (float)__longlong_as_double(v.lo);
+  }
+}
+__device__ __forceinline__ i128_t to_dec(const Val& v, int k) {
+  return k == NK_DECIMAL ? val_dec(v) : (i128_t)v.lo * (i128_t)1000000000000000000ll;  // decimal.rs:363-375
+}
+
+constexpr int ORD_NONE = 2;
+// PartialOrd for TypedValueRef, typed_value.rs:162-261 : -1 / 0 / 1 or ORD_NONE (incomparable => error)
+__device__ __forceinline__ int tv_partial_cmp(const Val& a, const Val& b) {
+  if (a.tag == RDFGPU_TV_NULL || b.tag == RDFGPU_TV_NULL) return ORD_NONE;
+  if (a.tag == RDFGPU_TV_BLANK_NODE) return b.tag == RDFGPU_TV_BLANK_NODE ? (a.lo < b.lo ? -1 : a.lo > b.lo) : -1;
+  if (a.tag == RDFGPU_TV_NAMED_NODE) {
+    if (b.tag == RDFGPU_TV_BLANK_NODE) return 1;
+    if (b.tag == RDFGPU_TV_NAMED_NODE) return a.lo < b.lo ? -1 : a.lo > b.lo;
+    return -1;
+  }
+  if (b.tag == RDFGPU_TV_NAMED_NODE || b.tag == RDFGPU_TV_BLANK_NODE) return 1;
+  if (a.tag == RDFGPU_TV_STRING) {
+    if (b.tag != RDFGPU_TV_STRING || a.aux != b.aux) return ORD_NONE;  // simple vs lang / other language
+    return a.lo < b.lo ? -1 : a.lo > b.lo;
+  }
+  if (a.tag == RDFGPU_TV_BOOLEAN) return b.tag == RDFGPU_TV_BOOLEAN ? (int)(a.lo != 0) - (int)(b.lo != 0) : ORD_NONE;
+  const int ka = num_kind(a.tag), kb = num_kind(b.tag);
+  if (ka != NK_NONE) {
+    if (kb == NK_NONE) return ORD_NONE;
+    switch (pair_kind(ka, kb)) {
+      case NK_INT: case NK_INTEGER: return a.lo < b.lo ? -1 : a.lo > b.lo;
+      case NK_FLOAT: { float x = to_f32(a, ka), y = to_f32(b, kb); return x < y ? -1 : x > y ? 1 : x == y ? 0 : ORD_NONE; }
+      case NK_DOUBLE: { double x = to_f64(a, ka), y = to_f64(b, kb); return x < y ? -1 : x > y ? 1 : x == y ? 0 : ORD_NONE; }
+      default: { i128_t x = to_dec(a, ka), y = to_dec(b, kb); return x < y ? -1 : x > y; }
+    }
+  }
+  if (a.tag == RDFGPU_TV_OTHER) return (b.tag == RDFGPU_TV_OTHER && a.aux == b.aux && a.lo == b.lo) ? 0 : ORD_NONE;
+  return ORD_NONE;  // dateTime / time / date / duration are opaque on device
+}
+
+// ADD / SUB, add.rs:40-86
+__device__ __forceinline__ Val tv_arith(const Val& a, const Val& b, bool sub) {
+  const int ka = num_kind(a.tag), kb = num_kind(b.tag);
+  Val r = val_tv_null();
+  if (ka == NK_NONE || kb == NK_NONE) return r;
+  switch (pair_kind(ka, kb)) {
+    case NK_INT: {
+      int32_t x = (int32_t)a.lo, y = (int32_t)b.lo, z;
+      if (sub ? __builtin_sub_overflow(x, y, &z) : __builtin_add_overflow(x, y, &z)) return r;
+      r.tag = RDFGPU_TV_INT; r.lo = z; return r; }
+    case NK_INTEGER: {
+      long long z;
+      if (sub ? __builtin_sub_overflow((long long)a.lo, (long long)b.lo, &z) : __builtin_add_overflow((long long)a.lo, (long long)b.lo, &z)) return r;
+      r.tag = RDFGPU_TV_INTEGER; r.lo = z; return r; }
+    case NK_FLOAT: {
+      float x = to_f32(a, ka), y = to_f32(b, kb);
+      float z = sub ? __fsub_rn(x, y) : __fadd_rn(x, y);
+      r.tag = RDFGPU_TV_FLOAT; r.lo = (int64_t)(uint64_t)__float_as_uint(z); return r; }
+    case NK_DOUBLE: {
+      double x = to_f64(a, ka), y = to_f64(b, kb);
+      double z = sub ? __dsub_rn(x, y) : __dadd_rn(x, y);
+      r.tag = RDFGPU_TV_DOUBLE; r.lo = __double_as_longlong(z); return r; }
+    default: {
+      i128_t x = to_dec(a, ka), y = to_dec(b, kb), z;
+      if (sub ? __builtin_sub_overflow(x, y, &z) : __builtin_add_overflow(x, y, &z)) return r;
+      r.tag = RDFGPU_TV_DECIMAL; set_dec(r, z); return r; }
+  }
+}
+
+// EBV, effective_boolean_value.rs:99-119 : 0 / 1 / 2 (error => null)
+__device__ __forceinline__ uint32_t tv_ebv(const Val& v) {
+  switch (v.tag) {
+    case RDFGPU_TV_BOOLEAN: case RDFGPU_TV_INT: case RDFGPU_TV_INTEGER: return v.lo != 0;
+    case RDFGPU_TV_FLOAT: return __uint_as_float((uint32_t)v.lo) != 0.0f;   // NaN != 0 is true (IEEE), as in the reference
+    case RDFGPU_TV_DOUBLE: return __longlong_as_double(v.lo) != 0.0;
+    case RDFGPU_TV_DECIMAL: return (v.lo | v.hi) != 0;
+    case RDFGPU_TV_STRING: return v.aux != 0 ? 2u : ((v.flags & RDFGPU_TVF_EMPTY_STRING) ? 0u : 1u);
+    default: return 2u;
+  }
+}
+
+// Evaluates `prog` for one row.  `col(c)` returns the u32 value of input column c.  The program was
+// type-checked on the host (plan compile), so the stack discipline is not re-checked here.
+// Returns the final value (BOOL for predicates).
+template <class ColFn>
+__device__ __forceinline__ Val eval_program(const ExprProgram& prog, const TypedTable& tt, ColFn col) {
+  Val st[kMaxStack];
+  int sp = 0;
+  for (uint32_t pc = 0; pc < prog.n; pc++) {
+    const rdfgpu_expr_node& e = prog.nodes[pc];
+    Val v;
+    switch (e.op) {
+      case RDFGPU_EX_COLUMN: v = val_id(col(e.u)); break;
+      case RDFGPU_EX_LIT_ID: v = val_id(e.u); break;
+      case RDFGPU_EX_LIT_TV: v = val_tv_null(); v.tag = e.tag; v.flags = e.flags; v.aux = e.u; v.lo = e.lo; v.hi = e.hi; break;
+      case RDFGPU_EX_LIT_BOOL: v = val_bool(e.u > 2 ? 2 : e.u); break;
+      case RDFGPU_EX_ENC_TV: v = enc_tv(tt, (uint32_t)st[--sp].lo); break;
+      case RDFGPU_EX_GT: case RDFGPU_EX_LT: case RDFGPU_EX_GEQ: case RDFGPU_EX_LEQ: case RDFGPU_EX_EQ: case RDFGPU_EX_NEQ: {
+        const Val b = st[--sp]; const Val a = st[--sp];
+        const int o = tv_partial_cmp(a, b);
+        if (o == ORD_NONE) { v = val_tv_null(); break; }
+        const bool r = e.op == RDFGPU_EX_GT ? o > 0 : e.op == RDFGPU_EX_LT ? o < 0 : e.op == RDFGPU_EX_GEQ ? o >= 0
+                     : e.op == RDFGPU_EX_LEQ ? o <= 0 : e.op == RDFGPU_EX_EQ ? o == 0 : o != 0;
+        v = val_tv_bool(r); break; }
+      case RDFGPU_EX_ADD: case RDFGPU_EX_SUB: { const Val b = st[--sp]; const Val a = st[--sp]; v = tv_arith(a, b, e.op == RDFGPU_EX_SUB); break; }
+      case RDFGPU_EX_EBV: v = val_bool(tv_ebv(st[--sp])); break;
+      case RDFGPU_EX_ID_EQ: case RDFGPU_EX_ID_NEQ: {
+        const uint32_t b = (uint32_t)st[--sp].lo, a = (uint32_t)st[--sp].lo;
+        v = val_bool((a == 0 || b == 0) ? 2u : (uint32_t)((a == b) == (e.op == RDFGPU_EX_ID_EQ))); break; }
+      case RDFGPU_EX_AND: { const uint32_t b = (uint32_t)st[--sp].lo, a = (uint32_t)st[--sp].lo;
+        v = val_bool((a == 0 || b == 0) ? 0u : (a == 2 || b == 2) ? 2u : 1u); break; }
+      case RDFGPU_EX_OR: { const uint32_t b = (uint32_t)st[--sp].lo, a = (uint32_t)st[--sp].lo;
+        v = val_bool((a == 1 || b == 1) ? 1u : (a == 2 || b == 2) ? 2u : 0u); break; }
+      case RDFGPU_EX_NOT: { const uint32_t a = (uint32_t)st[--sp].lo; v = val_bool(a == 2 ? 2u : 1u - a); break; }
+      case RDFGPU_EX_IS_COMPATIBLE: { const uint32_t b = (uint32_t)st[--sp].lo, a = (uint32_t)st[--sp].lo; v = val_bool(a == 0 || b == 0 || a == b); break; }
+      case RDFGPU_EX_BOUND: v = val_bool(st[--sp].lo != 0); break;
+      case RDFGPU_EX_BOOL_AS_TV: { const uint32_t a = (uint32_t)st[--sp].lo; v = a == 2 ? val_tv_null() : val_tv_bool(a != 0); break; }
+      default: v = val_bool(2); break;
+    }
+    st[sp++] = v;
+  }
+  return st[0];
+}
+
+}  // namespace rdfgpu

@@ -1,0 +1,444 @@
+// kernels.hip — hand-written gfx950 (CDNA4, wave64) kernels of the scan / filter / join path.
+//
+// All of this is HBM-bound integer work (no MFMA): the rules that matter are coalesced streaming
+// access, wave64 ballot + mbcnt prefix sums for the variable-cardinality outputs, one atomic per
+// workgroup (never per lane / per wave) when reserving output space, and grids of >> 256
+// workgroups so all 8 XCDs stay busy.
+#include <hip/hip_runtime.h>
+#include <cstring>
+#include <rocprim/rocprim.hpp>
+
+#include "kernels.hpp"
+
+namespace rdfgpu {
+
+constexpr int kBlock = 256;          // 4 waves of 64
+constexpr int kItems = 4;            // rows per lane
+constexpr int kTile = kBlock * kItems;
+static_assert(kTile == (int)kScanTile, "tile size");
+
+__device__ __forceinline__ u32 lane_prefix(unsigned long long mask) {
+  return __builtin_amdgcn_mbcnt_hi((u32)(mask >> 32), __builtin_amdgcn_mbcnt_lo((u32)mask, 0u));
+}
+__device__ __forceinline__ u64 live_rows(const u64* n_dev, u64 cap) {
+  if (!n_dev) return cap;
+  const u64 n = *n_dev;
+  return n < cap ? n : cap;
+}
+static inline dim3 grid_for(u64 rows) { u64 g = (rows + kTile - 1) / kTile; return dim3((unsigned)(g ? g : 1)); }
+
+// --------------------------------------------------------------------------------------------------
+// K1 range locate: successive binary searches narrow [lo, hi) on the leading levels.
+// Behavioural twin of MemIndexData::prune_relevant_row_groups (quad_index_data.rs:155-284) on a flat
+// sorted column (the reference walks 8192-row groups linearly; here it is O(log n) per level).
+// --------------------------------------------------------------------------------------------------
+__global__ void locate_kernel(const LocateJob* jobs, u32 n_jobs, u64* lo_hi) {
+  const u32 j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n_jobs) return;
+  const LocateJob job = jobs[j];
+  u64 lo = 0, hi = job.n;
+  for (u32 k = 0; k < job.n_levels && lo < hi; k++) {
+    const u32* c = job.col[k];
+    const u32 from = job.from[k], to = job.to[k];
+    u64 a = lo, b = hi;               // lower_bound(from)
+    while (a < b) { u64 m = (a + b) >> 1; if (c[m] < from) a = m + 1; else b = m; }
+    const u64 nlo = a;
+    b = hi;                           // upper_bound(to)
+    while (a < b) { u64 m = (a + b) >> 1; if (c[m] <= to) a = m + 1; else b = m; }
+    lo = nlo; hi = a;
+    if (from != to) break;            // below a proper range the inner levels are not contiguous (:240)
+  }
+  if (lo > hi) lo = hi;
+  lo_hi[2 * j] = lo; lo_hi[2 * j + 1] = hi;
+}
+void launch_locate(const LocateJob* jobs_dev, u32 n_jobs, u64* lo_hi_dev, hipStream_t s) {
+  if (!n_jobs) return;
+  hipLaunchKernelGGL(locate_kernel, dim3((n_jobs + 63) / 64), dim3(64), 0, s, jobs_dev, n_jobs, lo_hi_dev);
+}
+
+// --------------------------------------------------------------------------------------------------
+// K2 ordered scan with residual predicates (compute_selection_vector / apply_predicate scan.rs:264-340):
+// pass 1 counts matches per 1024-row tile, a device scan turns counts into offsets, pass 2 re-evaluates
+// and writes in index order (so the output stays sorted like the reference's).
+// --------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool scan_match(const ScanJob& j, u64 row) {
+  bool ok = true;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const ScanLevelPred& p = j.pred[k];
+    if (p.kind == RDFGPU_PRED_NONE) continue;
+    if (p.kind == RDFGPU_PRED_FALSE) { ok = false; continue; }
+    const u32 v = j.col[k][row];
+    if (p.kind == RDFGPU_PRED_BETWEEN) ok = ok && (v >= p.a && v <= p.b);
+    else if (p.kind == RDFGPU_PRED_IN) { bool any = false; for (u32 q = 0; q < p.b; q++) any = any || (p.ids[q] == v); ok = ok && any; }
+    else ok = ok && (j.col[p.a][row] == v);  // EQUAL_TO another level
+  }
+  return ok;
+}
+
+__global__ __launch_bounds__(kBlock) void scan_count_kernel(const ScanJob job, u32* block_counts) {
+  __shared__ u32 wave_tot[kBlock / 64];
+  const u64 base = (u64)blockIdx.x * kTile;
+  u32 tot = 0;
+#pragma unroll
+  for (int k = 0; k < kItems; k++) {
+    const u64 row = base + (u64)k * kBlock + threadIdx.x;
+    const bool m = row < job.n && scan_match(job, row);
+    tot += (u32)__popcll(__ballot(m));
+  }
+  if ((threadIdx.x & 63) == 0) wave_tot[threadIdx.x >> 6] = tot;
+  __syncthreads();
+  if (threadIdx.x == 0) block_counts[blockIdx.x] = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+}
+
+__global__ __launch_bounds__(kBlock) void scan_write_kernel(const ScanJob job, const u32* block_offsets) {
+  __shared__ u32 cnt[kItems][kBlock / 64];
+  const u64 base = (u64)blockIdx.x * kTile;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  bool keep[kItems]; u32 pre[kItems];
+#pragma unroll
+  for (int k = 0; k < kItems; k++) {
+    const u64 row = base + (u64)k * kBlock + threadIdx.x;
+    keep[k] = row < job.n && scan_match(job, row);
+    const unsigned long long mask = __ballot(keep[k]);
+    pre[k] = lane_prefix(mask);
+    if (lane == 0) cnt[k][wave] = (u32)__popcll(mask);
+  }
+  __syncthreads();
+  u32 off = block_offsets[blockIdx.x];
+#pragma unroll
+  for (int k = 0; k < kItems; k++) {
+    u32 before = 0;
+    for (int w = 0; w < wave; w++) before += cnt[k][w];
+    if (keep[k]) {
+      const u64 row = base + (u64)k * kBlock + threadIdx.x;
+      for (u32 c = 0; c < job.n_out; c++) job.out[c][off + before + pre[k]] = job.col[job.out_level[c]][row];
+    }
+    off += cnt[k][0] + cnt[k][1] + cnt[k][2] + cnt[k][3];
+  }
+}
+void launch_scan_count(const ScanJob& job, u32* block_counts, hipStream_t s) {
+  hipLaunchKernelGGL(scan_count_kernel, grid_for(job.n), dim3(kBlock), 0, s, job, block_counts);
+}
+void launch_scan_write(const ScanJob& job, const u32* block_offsets, hipStream_t s) {
+  hipLaunchKernelGGL(scan_write_kernel, grid_for(job.n), dim3(kBlock), 0, s, job, block_offsets);
+}
+
+// --------------------------------------------------------------------------------------------------
+// K3 FilterExec: predicate + projection + compaction in ONE pass over the input.
+// Each lane tests 4 rows (coalesced 256-B wave loads), wave ballots give the lane prefix, the four
+// waves meet once in LDS and ONE atomicAdd per 1024-row workgroup reserves the output range
+// (FILTER keeps a row iff its EBV is true: logical_plan_builder.rs:114-129).
+// --------------------------------------------------------------------------------------------------
+template <int SHAPE>
+__device__ __forceinline__ bool filter_pred(const FilterArgs& a, u64 row) {
+  if constexpr (SHAPE == 1) {  // col <ID_EQ|ID_NEQ> object-id literal; null on either side => dropped
+    const u32 v = a.in[a.prog.nodes[0].u][row];
+    const u32 lit = a.prog.nodes[1].u;
+    if (v == 0 || lit == 0) return false;
+    return (v == lit) == (a.prog.nodes[2].op == RDFGPU_EX_ID_EQ);
+  } else if constexpr (SHAPE == 2) {  // EBV(cmp(ENC_TV(col), typed literal)) — the BSBM Q1 numeric FILTER
+    const Val x = enc_tv(a.tt, a.in[a.prog.nodes[0].u][row]);
+    const rdfgpu_expr_node& l = a.prog.nodes[2];
+    Val y = val_tv_null(); y.tag = l.tag; y.flags = l.flags; y.aux = l.u; y.lo = l.lo; y.hi = l.hi;
+    const int o = tv_partial_cmp(x, y);
+    if (o == ORD_NONE) return false;
+    const u8 op = a.prog.nodes[3].op;
+    return op == RDFGPU_EX_GT ? o > 0 : op == RDFGPU_EX_LT ? o < 0 : op == RDFGPU_EX_GEQ ? o >= 0
+         : op == RDFGPU_EX_LEQ ? o <= 0 : op == RDFGPU_EX_EQ ? o == 0 : o != 0;
+  } else {
+    if (a.prog.n == 0) return true;
+    const Val r = eval_program(a.prog, a.tt, [&](u32 c) { return a.in[c][row]; });
+    return r.lo == 1;
+  }
+}
+
+template <int SHAPE>
+__global__ __launch_bounds__(kBlock) void filter_kernel(const FilterArgs a) {
+  __shared__ u32 wave_tot[kBlock / 64];
+  __shared__ u64 block_base;
+  const u64 n = live_rows(a.n_in_dev, a.n_in_cap);
+  const u64 base = (u64)blockIdx.x * kTile;
+  if (base >= n) return;  // uniform per workgroup
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  bool keep[kItems]; u32 pre[kItems]; u32 wtot = 0;
+#pragma unroll
+  for (int k = 0; k < kItems; k++) {
+    const u64 row = base + (u64)k * kBlock + threadIdx.x;
+    keep[k] = row < n && filter_pred<SHAPE>(a, row);
+    const unsigned long long mask = __ballot(keep[k]);
+    pre[k] = wtot + lane_prefix(mask);
+    wtot += (u32)__popcll(mask);
+  }
+  if (lane == 0) wave_tot[wave] = wtot;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const u32 t = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+    block_base = t ? atomicAdd((unsigned long long*)a.n_out_dev, (unsigned long long)t) : 0ull;
+  }
+  __syncthreads();
+  u64 off = block_base;
+  for (int w = 0; w < wave; w++) off += wave_tot[w];
+#pragma unroll
+  for (int k = 0; k < kItems; k++) {
+    if (keep[k]) {
+      const u64 row = base + (u64)k * kBlock + threadIdx.x;
+      for (u32 c = 0; c < a.n_out_cols; c++) a.out[c][off + pre[k]] = a.in[a.proj[c]][row];
+    }
+  }
+}
+void launch_filter(const FilterArgs& a, int shape, hipStream_t s) {
+  const dim3 g = grid_for(a.n_in_cap);
+  if (shape == 1) hipLaunchKernelGGL(filter_kernel<1>, g, dim3(kBlock), 0, s, a);
+  else if (shape == 2) hipLaunchKernelGGL(filter_kernel<2>, g, dim3(kBlock), 0, s, a);
+  else hipLaunchKernelGGL(filter_kernel<0>, g, dim3(kBlock), 0, s, a);
+}
+
+// --------------------------------------------------------------------------------------------------
+// K6 CrossJoinExec: output row r = (left r / m, right r % m); writes are fully coalesced, the small
+// side is re-read from L2.  (join/rewrite.rs:74-96: no shared variable => cross product)
+// --------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void cross_kernel(const CrossArgs a) {
+  const u64 nl = live_rows(a.n_left_dev, a.n_left_cap), nr = live_rows(a.n_right_dev, a.n_right_cap);
+  const u64 n = nl * nr;
+  if (blockIdx.x == 0 && threadIdx.x == 0 && a.n_out_dev) *a.n_out_dev = n;
+  const u64 base = (u64)blockIdx.x * kTile;
+  if (base >= n) return;
+#pragma unroll
+  for (int k = 0; k < kItems; k++) {
+    const u64 r = base + (u64)k * kBlock + threadIdx.x;
+    if (r >= n) break;
+    const u64 i = r / nr, j = r - i * nr;
+    for (u32 c = 0; c < a.n_out_cols; c++) {
+      const u32 p = a.proj[c];
+      a.out[c][r] = p < a.n_left_cols ? a.left[p][i] : a.right[p - a.n_left_cols][j];
+    }
+  }
+}
+void launch_cross(const CrossArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(cross_kernel, grid_for(a.n_left_cap * a.n_right_cap), dim3(kBlock), 0, s, a);
+}
+
+// --------------------------------------------------------------------------------------------------
+// K4/K5 HashJoinExec(CollectLeft), v1: chained hash table in HBM.
+//   build : next[i] = atomicExch(&heads[h(keys_i)], i)            (rows with a null key never enter:
+//           NullEqualsNothing, join/rewrite.rs:89,217)
+//   count : per probe row, walk the chain, compare keys, run the residual filter program -> counts[j]
+//   scan  : device inclusive scan of counts (rocPRIM) -> offsets ; the total sizes the output
+//   write : walk again, write matches at offsets (deterministic, probe order)
+// Multiplicity-exact (bag semantics before DISTINCT).
+// --------------------------------------------------------------------------------------------------
+__device__ __forceinline__ u32 hash_keys(const u32* k, u32 n) {
+  u64 h = 0x9E3779B97F4A7C15ull;
+  for (u32 i = 0; i < n; i++) { h ^= k[i]; h *= 0xff51afd7ed558ccdull; h ^= h >> 32; }
+  h *= 0xc4ceb9fe1a85ec53ull; h ^= h >> 29;
+  return (u32)h;
+}
+
+__global__ __launch_bounds__(kBlock) void join_build_kernel(const JoinArgs a) {
+  const u64 n = live_rows(a.n_left_dev, a.n_left_cap);
+  const u64 base = (u64)blockIdx.x * kTile;
+#pragma unroll
+  for (int k = 0; k < kItems; k++) {
+    const u64 i = base + (u64)k * kBlock + threadIdx.x;
+    if (i >= a.n_left_cap) break;
+    u32 key[RDFGPU_MAX_KEYS]; bool null_key = i >= n;
+    if (!null_key) for (u32 q = 0; q < a.n_keys; q++) { key[q] = a.left[a.left_keys[q]][i]; null_key = null_key || key[q] == 0; }
+    u32 nx = kNil;
+    if (!null_key) nx = atomicExch(&a.heads[hash_keys(key, a.n_keys) & a.bucket_mask], (u32)i);
+    a.next[i] = nx;
+    if (a.visited) a.visited[i] = 0;
+  }
+}
+
+template <bool WRITE>
+__global__ __launch_bounds__(kBlock) void join_probe_kernel(const JoinArgs a) {
+  const u64 n = live_rows(a.n_right_dev, a.n_right_cap);
+  const u64 base = (u64)blockIdx.x * kTile;
+#pragma unroll 1
+  for (int k = 0; k < kItems; k++) {
+    const u64 j = base + (u64)k * kBlock + threadIdx.x;
+    if (j >= a.n_right_cap) break;
+    u32 c = 0;
+    u64 pos = 0;
+    if (WRITE) pos = j ? a.counts[j - 1] : 0;
+    if (j < n) {
+      u32 key[RDFGPU_MAX_KEYS]; bool null_key = false;
+      for (u32 q = 0; q < a.n_keys; q++) { key[q] = a.right[a.right_keys[q]][j]; null_key = null_key || key[q] == 0; }
+      if (!null_key) {
+        for (u32 i = a.heads[hash_keys(key, a.n_keys) & a.bucket_mask]; i != kNil; i = a.next[i]) {
+          bool eq = true;
+          for (u32 q = 0; q < a.n_keys; q++) eq = eq && a.left[a.left_keys[q]][i] == key[q];
+          if (!eq) continue;
+          if (a.has_filter) {
+            const Val r = eval_program(a.prog, a.tt, [&](u32 col) { return col < a.n_left_cols ? a.left[col][i] : a.right[col - a.n_left_cols][j]; });
+            if (r.lo != 1) continue;
+          }
+          if (WRITE) {
+            for (u32 oc = 0; oc < a.n_out_cols; oc++) {
+              const u32 p = a.proj[oc];
+              a.out[oc][pos] = p < a.n_left_cols ? a.left[p][i] : a.right[p - a.n_left_cols][j];
+            }
+            pos++;
+            if (a.visited) a.visited[i] = 1;
+          }
+          c++;
+        }
+      }
+    }
+    if (!WRITE) a.counts[j] = c;
+  }
+}
+
+// NestedLoopJoinExec: no equi keys; every probe row meets every build row (small inputs only).
+template <bool WRITE>
+__global__ __launch_bounds__(kBlock) void nlj_kernel(const JoinArgs a) {
+  const u64 n = live_rows(a.n_right_dev, a.n_right_cap);
+  const u64 nl = live_rows(a.n_left_dev, a.n_left_cap);
+  const u64 base = (u64)blockIdx.x * kTile;
+#pragma unroll 1
+  for (int k = 0; k < kItems; k++) {
+    const u64 j = base + (u64)k * kBlock + threadIdx.x;
+    if (j >= a.n_right_cap) break;
+    u32 c = 0;
+    u64 pos = 0;
+    if (WRITE) pos = j ? a.counts[j - 1] : 0;
+    if (j < n) {
+      for (u64 i = 0; i < nl; i++) {
+        if (a.has_filter) {
+          const Val r = eval_program(a.prog, a.tt, [&](u32 col) { return col < a.n_left_cols ? a.left[col][i] : a.right[col - a.n_left_cols][j]; });
+          if (r.lo != 1) continue;
+        }
+        if (WRITE) {
+          for (u32 oc = 0; oc < a.n_out_cols; oc++) {
+            const u32 p = a.proj[oc];
+            a.out[oc][pos] = p < a.n_left_cols ? a.left[p][i] : a.right[p - a.n_left_cols][j];
+          }
+          pos++;
+          if (a.visited) a.visited[i] = 1;
+        }
+        c++;
+      }
+    }
+    if (!WRITE) a.counts[j] = c;
+  }
+}
+
+// Left join tail: build rows that met no probe row are emitted once with nulls on the right
+// (join/logical.rs:262-277).  Block-aggregated append behind the matched rows.
+__global__ __launch_bounds__(kBlock) void join_left_unmatched_kernel(const JoinArgs a) {
+  __shared__ u32 wave_tot[kBlock / 64];
+  __shared__ u64 block_base;
+  const u64 n = live_rows(a.n_left_dev, a.n_left_cap);
+  const u64 base = (u64)blockIdx.x * kTile;
+  if (base >= n) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  bool keep[kItems]; u32 pre[kItems]; u32 wtot = 0;
+#pragma unroll
+  for (int k = 0; k < kItems; k++) {
+    const u64 i = base + (u64)k * kBlock + threadIdx.x;
+    keep[k] = i < n && a.visited[i] == 0;
+    const unsigned long long mask = __ballot(keep[k]);
+    pre[k] = wtot + lane_prefix(mask);
+    wtot += (u32)__popcll(mask);
+  }
+  if (lane == 0) wave_tot[wave] = wtot;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const u32 t = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+    block_base = t ? atomicAdd((unsigned long long*)a.n_out_dev, (unsigned long long)t) : 0ull;
+  }
+  __syncthreads();
+  u64 off = block_base;
+  for (int w = 0; w < wave; w++) off += wave_tot[w];
+#pragma unroll
+  for (int k = 0; k < kItems; k++) {
+    if (keep[k]) {
+      const u64 i = base + (u64)k * kBlock + threadIdx.x;
+      for (u32 oc = 0; oc < a.n_out_cols; oc++) {
+        const u32 p = a.proj[oc];
+        a.out[oc][off + pre[k]] = p < a.n_left_cols ? a.left[p][i] : 0u;
+      }
+    }
+  }
+}
+
+void launch_join_build(const JoinArgs& a, hipStream_t s) { hipLaunchKernelGGL(join_build_kernel, grid_for(a.n_left_cap), dim3(kBlock), 0, s, a); }
+void launch_join_count(const JoinArgs& a, hipStream_t s) { hipLaunchKernelGGL(join_probe_kernel<false>, grid_for(a.n_right_cap), dim3(kBlock), 0, s, a); }
+void launch_join_write(const JoinArgs& a, hipStream_t s) { hipLaunchKernelGGL(join_probe_kernel<true>, grid_for(a.n_right_cap), dim3(kBlock), 0, s, a); }
+void launch_join_left_unmatched(const JoinArgs& a, hipStream_t s) { hipLaunchKernelGGL(join_left_unmatched_kernel, grid_for(a.n_left_cap), dim3(kBlock), 0, s, a); }
+void launch_nlj_count(const JoinArgs& a, hipStream_t s) { hipLaunchKernelGGL(nlj_kernel<false>, grid_for(a.n_right_cap), dim3(kBlock), 0, s, a); }
+void launch_nlj_write(const JoinArgs& a, hipStream_t s) { hipLaunchKernelGGL(nlj_kernel<true>, grid_for(a.n_right_cap), dim3(kBlock), 0, s, a); }
+
+// --------------------------------------------------------------------------------------------------
+// Load-path utilities (index build = radix sort of three permutations + dedupe)
+// --------------------------------------------------------------------------------------------------
+__global__ void fill_u32_kernel(u32* p, u32 v, u64 n) { u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; if (i < n) p[i] = v; }
+__global__ void iota_u32_kernel(u32* p, u64 n) { u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; if (i < n) p[i] = (u32)i; }
+__global__ void gather_u32_kernel(const u32* src, const u32* idx, u32* dst, u64 n) { u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; if (i < n) dst[i] = src[idx[i]]; }
+__global__ void pack_key_kernel(const u32* hi, const u32* lo, const u32* idx, u64* key, u64 n) {
+  u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) { const u64 r = idx ? idx[i] : i; key[i] = ((u64)hi[r] << 32) | lo[r]; }
+}
+__global__ void unique_flags_kernel(const u32* c0, const u32* c1, const u32* c2, const u32* c3, u32* flags, u64 n) {
+  u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) flags[i] = (i == 0 || c0[i] != c0[i - 1] || c1[i] != c1[i - 1] || c2[i] != c2[i - 1] || c3[i] != c3[i - 1]) ? 1u : 0u;
+}
+__global__ void scatter_if_kernel(const u32* src, const u32* flags, const u32* excl, u32* dst, u64 n) {
+  u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && flags[i]) dst[excl[i]] = src[i];
+}
+struct Ptr4 { const u32* p[4]; };
+__global__ void mark_removed_kernel(Ptr4 ix, u64 n_ix, Ptr4 rm, u64 n_rm, u32* keep) {
+  u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n_rm) return;
+  u32 q[4] = {rm.p[0][r], rm.p[1][r], rm.p[2][r], rm.p[3][r]};
+  u64 a = 0, b = n_ix;
+  while (a < b) {
+    const u64 m = (a + b) >> 1;
+    int c = 0;
+    for (int k = 0; k < 4 && c == 0; k++) { const u32 v = ix.p[k][m]; c = v < q[k] ? -1 : v > q[k] ? 1 : 0; }
+    if (c < 0) a = m + 1; else b = m;
+  }
+  if (a < n_ix && ix.p[0][a] == q[0] && ix.p[1][a] == q[1] && ix.p[2][a] == q[2] && ix.p[3][a] == q[3]) keep[a] = 0;
+}
+static inline dim3 flat_grid(u64 n) { u64 g = (n + 255) / 256; return dim3((unsigned)(g ? g : 1)); }
+void launch_fill_u32(u32* p, u32 v, u64 n, hipStream_t s) { if (n) hipLaunchKernelGGL(fill_u32_kernel, flat_grid(n), dim3(256), 0, s, p, v, n); }
+void launch_iota_u32(u32* p, u64 n, hipStream_t s) { if (n) hipLaunchKernelGGL(iota_u32_kernel, flat_grid(n), dim3(256), 0, s, p, n); }
+void launch_gather_u32(const u32* src, const u32* idx, u32* dst, u64 n, hipStream_t s) { if (n) hipLaunchKernelGGL(gather_u32_kernel, flat_grid(n), dim3(256), 0, s, src, idx, dst, n); }
+void launch_pack_key(const u32* hi, const u32* lo, const u32* idx, u64* key, u64 n, hipStream_t s) { if (n) hipLaunchKernelGGL(pack_key_kernel, flat_grid(n), dim3(256), 0, s, hi, lo, idx, key, n); }
+void launch_unique_flags(const u32* c0, const u32* c1, const u32* c2, const u32* c3, u32* flags, u64 n, hipStream_t s) { if (n) hipLaunchKernelGGL(unique_flags_kernel, flat_grid(n), dim3(256), 0, s, c0, c1, c2, c3, flags, n); }
+void launch_scatter_if(const u32* src, const u32* flags, const u32* excl, u32* dst, u64 n, hipStream_t s) { if (n) hipLaunchKernelGGL(scatter_if_kernel, flat_grid(n), dim3(256), 0, s, src, flags, excl, dst, n); }
+void launch_mark_removed(const u32* const ix[4], u64 n_ix, const u32* const rm[4], u64 n_rm, u32* keep, hipStream_t s) {
+  if (!n_rm || !n_ix) return;
+  Ptr4 a{{ix[0], ix[1], ix[2], ix[3]}}, b{{rm[0], rm[1], rm[2], rm[3]}};
+  hipLaunchKernelGGL(mark_removed_kernel, flat_grid(n_rm), dim3(256), 0, s, a, n_ix, b, n_rm, keep);
+}
+
+// rocPRIM device-wide primitives: prefix sums of per-row / per-tile counts and the load-path radix sort.
+size_t scan_temp_bytes(u64 n) {
+  size_t bytes = 0;
+  (void)rocprim::exclusive_scan(nullptr, bytes, (const u32*)nullptr, (u32*)nullptr, 0u, (size_t)(n ? n : 1), rocprim::plus<u32>());
+  size_t b2 = 0;
+  (void)rocprim::inclusive_scan(nullptr, b2, (const u32*)nullptr, (u32*)nullptr, (size_t)(n ? n : 1), rocprim::plus<u32>());
+  return (bytes > b2 ? bytes : b2) + 256;
+}
+void exclusive_scan_u32(const u32* in, u32* out, u64 n, void* temp, size_t temp_bytes, hipStream_t s) {
+  if (!n) return;
+  RDFGPU_HIP(rocprim::exclusive_scan(temp, temp_bytes, in, out, 0u, (size_t)n, rocprim::plus<u32>(), s));
+}
+void inclusive_scan_u32(const u32* in, u32* out, u64 n, void* temp, size_t temp_bytes, hipStream_t s) {
+  if (!n) return;
+  RDFGPU_HIP(rocprim::inclusive_scan(temp, temp_bytes, in, out, (size_t)n, rocprim::plus<u32>(), s));
+}
+size_t sort_temp_bytes(u64 n) {
+  size_t bytes = 0;
+  (void)rocprim::radix_sort_pairs(nullptr, bytes, (const u64*)nullptr, (u64*)nullptr, (const u32*)nullptr, (u32*)nullptr, (size_t)(n ? n : 1), 0, 64);
+  return bytes + 256;
+}
+void sort_pairs_u64_u32(const u64* kin, u64* kout, const u32* vin, u32* vout, u64 n, void* temp, size_t temp_bytes, hipStream_t s) {
+  if (!n) return;
+  RDFGPU_HIP(rocprim::radix_sort_pairs(temp, temp_bytes, kin, kout, vin, vout, (size_t)n, 0, 64, s));
+}
+
+}  // namespace rdfgpu

@@ -1,0 +1,116 @@
+// kernels.hpp — host-callable launchers of the gfx950 kernels (definitions in kernels.hip).
+#pragma once
+#include "common.hpp"
+#include "expr_device.hpp"
+
+namespace rdfgpu {
+
+constexpr u32 kNil = 0xFFFFFFFFu;
+constexpr int kMaxCols = RDFGPU_MAX_COLUMNS;
+
+// A binding table resident in HBM: u32 columns, 0 = null.  `cap` is an upper bound of the row
+// count known on the host; when `n_dev` is non-null the exact count lives on the device (the host
+// never waits for it unless it must size an allocation).
+struct DevTable {
+  u32 n_cols = 0;
+  const u32* cols[kMaxCols] = {};
+  u64 cap = 0;
+  const u64* n_dev = nullptr;
+};
+
+// ---- K1: range locate on a sorted permutation (prune_relevant_row_groups, quad_index_data.rs:155-284) ----
+struct LocateJob {
+  const u32* col[4];   // index-order columns
+  u64 n;               // index length
+  u32 n_levels;        // leading levels with a pruning predicate
+  u32 from[4], to[4];  // inclusive id ranges per level (EqualTo => from == to)
+};
+void launch_locate(const LocateJob* jobs_dev, u32 n_jobs, u64* lo_hi_dev /* 2 per job */, hipStream_t s);
+
+// ---- K2: ordered scan + residual predicates + compaction (scan.rs:264-340) ----
+struct ScanLevelPred {
+  u32 kind;        // RDFGPU_PRED_*
+  u32 a, b;        // BETWEEN: from,to ; IN: n ids in `ids` ; EQUAL_TO: a = other level
+  const u32* ids;  // IN set (device)
+};
+struct ScanJob {
+  const u32* col[4];   // index-order columns, already offset to the located range start
+  u64 n;               // rows in the located range
+  ScanLevelPred pred[4];
+  u32 n_out;           // bound variables
+  u32 out_level[4];    // index level feeding output column k
+  u32* out[4];
+};
+constexpr u32 kScanTile = 1024;  // rows per workgroup
+void launch_scan_count(const ScanJob& job, u32* block_counts, hipStream_t s);
+void launch_scan_write(const ScanJob& job, const u32* block_offsets, hipStream_t s);
+
+// ---- K3: FilterExec — fused per-row predicate + projection + block-aggregated compaction ----
+struct FilterArgs {
+  const u32* in[kMaxCols];
+  u32* out[kMaxCols];
+  u32 n_in_cols, n_out_cols;
+  u32 proj[kMaxCols];
+  const u64* n_in_dev; u64 n_in_cap;
+  u64* n_out_dev;       // zeroed before launch
+  TypedTable tt;
+  ExprProgram prog;
+};
+// shape 0 = generic VM; 1 = `col <op> object-id literal` (ID_EQ / ID_NEQ); 2 = EBV(cmp(ENC_TV(col), literal))
+void launch_filter(const FilterArgs& a, int shape, hipStream_t s);
+
+// ---- K6: CrossJoinExec ----
+struct CrossArgs {
+  const u32* left[kMaxCols]; const u32* right[kMaxCols];
+  u32* out[kMaxCols];
+  u32 n_left_cols, n_right_cols, n_out_cols;
+  u32 proj[kMaxCols];
+  const u64* n_left_dev; u64 n_left_cap;
+  const u64* n_right_dev; u64 n_right_cap;
+  u64* n_out_dev;
+};
+void launch_cross(const CrossArgs& a, hipStream_t s);
+
+// ---- K4/K5: HashJoinExec(CollectLeft) — chained table in HBM (v1) ----
+struct JoinArgs {
+  const u32* left[kMaxCols]; const u32* right[kMaxCols];
+  u32* out[kMaxCols];
+  u32 n_left_cols, n_right_cols, n_out_cols;
+  u32 proj[kMaxCols];
+  u32 n_keys; u32 left_keys[RDFGPU_MAX_KEYS]; u32 right_keys[RDFGPU_MAX_KEYS];
+  const u64* n_left_dev; u64 n_left_cap;
+  const u64* n_right_dev; u64 n_right_cap;
+  u32* heads; u32 bucket_mask;  // heads[bucket_mask + 1], kNil-filled
+  u32* next;                    // next[n_left_cap]
+  u32* counts;                  // per probe row match count / inclusive offsets [n_right_cap]
+  u8* visited;                  // left join: per build row
+  u64* n_out_dev;               // left join: final count
+  u64 matched_total;            // write pass (left join): rows produced by matches
+  u32 has_filter;
+  TypedTable tt;
+  ExprProgram prog;
+};
+void launch_join_build(const JoinArgs& a, hipStream_t s);
+void launch_join_count(const JoinArgs& a, hipStream_t s);   // fills counts[j]
+void launch_join_write(const JoinArgs& a, hipStream_t s);   // counts[] holds INCLUSIVE offsets
+void launch_join_left_unmatched(const JoinArgs& a, hipStream_t s);
+// NestedLoopJoinExec (no equi keys): same args, heads/next unused
+void launch_nlj_count(const JoinArgs& a, hipStream_t s);
+void launch_nlj_write(const JoinArgs& a, hipStream_t s);
+
+// ---- utilities ----
+void launch_fill_u32(u32* p, u32 v, u64 n, hipStream_t s);
+void launch_gather_u32(const u32* src, const u32* idx, u32* dst, u64 n, hipStream_t s);
+void launch_iota_u32(u32* p, u64 n, hipStream_t s);
+void launch_pack_key(const u32* hi, const u32* lo, const u32* idx /*nullable*/, u64* key, u64 n, hipStream_t s);
+void launch_unique_flags(const u32* c0, const u32* c1, const u32* c2, const u32* c3, u32* flags, u64 n, hipStream_t s);
+void launch_scatter_if(const u32* src, const u32* flags, const u32* excl, u32* dst, u64 n, hipStream_t s);
+void launch_mark_removed(const u32* const ix[4], u64 n_ix, const u32* const rm[4], u64 n_rm, u32* keep, hipStream_t s);
+// device-wide scans (rocPRIM; load path + per-join offsets)
+size_t scan_temp_bytes(u64 n);
+void exclusive_scan_u32(const u32* in, u32* out, u64 n, void* temp, size_t temp_bytes, hipStream_t s);
+void inclusive_scan_u32(const u32* in, u32* out, u64 n, void* temp, size_t temp_bytes, hipStream_t s);
+size_t sort_temp_bytes(u64 n);
+void sort_pairs_u64_u32(const u64* kin, u64* kout, const u32* vin, u32* vout, u64 n, void* temp, size_t temp_bytes, hipStream_t s);
+
+}  // namespace rdfgpu

@@ -1,0 +1,476 @@
+// plan.cpp — plan compilation (host) and execution (device) of the scan / filter / join subtree.
+//
+// What replaces what (reference paths relative to the rdf-fusion tree):
+//   plan_compile            MemQuadStorePlanner::plan_extension  lib/storage/src/memory/planner.rs:31-64
+//                           + plan_pattern_evaluation             storage/snapshot.rs:84-131
+//   Plan::exec_source       DataSource::open + MemQuadIndexScanIterator::next  pattern_data_source.rs:42-58, scan.rs:104-212
+//   Plan::exec_filter       FilterExec over ENC_TV/GT/ADD/EBV UDFs  (DataFusion 52 + lib/functions)
+//   Plan::exec_join         HashJoinExec(CollectLeft) / CrossJoinExec / NestedLoopJoinExec (DataFusion 52),
+//                           semantics from lib/logical/src/join/rewrite.rs:71-221
+#include "plan.hpp"
+
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <shared_mutex>
+
+namespace rdfgpu {
+
+// ------------------------------------------------------------------------------------------------
+// compile
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+bool is_cmp(u8 op) {
+  return op == RDFGPU_EX_GT || op == RDFGPU_EX_LT || op == RDFGPU_EX_GEQ || op == RDFGPU_EX_LEQ || op == RDFGPU_EX_EQ || op == RDFGPU_EX_NEQ;
+}
+
+// Type-checks a postfix program against `n_cols` input columns; returns the kind it leaves.
+u32 check_program(const rdfgpu_expr_node* p, u32 n, u32 n_cols) {
+  if (n > (u32)kMaxExpr) fail(RDFGPU_ERR_UNSUPPORTED, "expression has %u nodes (max %d)", n, kMaxExpr);
+  u32 st[kMaxStack]; int sp = 0;
+  auto pop = [&](u32 kind, const char* what) {
+    if (sp < 1) fail(RDFGPU_ERR_INVALID, "expression: stack underflow at %s", what);
+    if (st[--sp] != kind) fail(RDFGPU_ERR_INVALID, "expression: %s got an operand of the wrong kind", what);
+  };
+  for (u32 i = 0; i < n; i++) {
+    const rdfgpu_expr_node& e = p[i];
+    u32 out;
+    switch (e.op) {
+      case RDFGPU_EX_COLUMN: if (e.u >= n_cols) fail(RDFGPU_ERR_INVALID, "expression: column %u out of range (%u columns)", e.u, n_cols); out = VK_ID; break;
+      case RDFGPU_EX_LIT_ID: out = VK_ID; break;
+      case RDFGPU_EX_LIT_TV: if (e.tag > RDFGPU_TV_OTHER) fail(RDFGPU_ERR_INVALID, "expression: bad literal tag %u", e.tag); out = VK_TV; break;
+      case RDFGPU_EX_LIT_BOOL: out = VK_BOOL; break;
+      case RDFGPU_EX_ENC_TV: pop(VK_ID, "ENC_TV"); out = VK_TV; break;
+      case RDFGPU_EX_GT: case RDFGPU_EX_LT: case RDFGPU_EX_GEQ: case RDFGPU_EX_LEQ: case RDFGPU_EX_EQ: case RDFGPU_EX_NEQ:
+      case RDFGPU_EX_ADD: case RDFGPU_EX_SUB: pop(VK_TV, "binary typed op"); pop(VK_TV, "binary typed op"); out = VK_TV; break;
+      case RDFGPU_EX_EBV: pop(VK_TV, "EBV"); out = VK_BOOL; break;
+      case RDFGPU_EX_ID_EQ: case RDFGPU_EX_ID_NEQ: case RDFGPU_EX_IS_COMPATIBLE: pop(VK_ID, "id comparison"); pop(VK_ID, "id comparison"); out = VK_BOOL; break;
+      case RDFGPU_EX_AND: case RDFGPU_EX_OR: pop(VK_BOOL, "AND/OR"); pop(VK_BOOL, "AND/OR"); out = VK_BOOL; break;
+      case RDFGPU_EX_NOT: pop(VK_BOOL, "NOT"); out = VK_BOOL; break;
+      case RDFGPU_EX_BOUND: pop(VK_ID, "BOUND"); out = VK_BOOL; break;
+      case RDFGPU_EX_BOOL_AS_TV: pop(VK_BOOL, "BOOLEAN_AS_TERM"); out = VK_TV; break;
+      default: fail(RDFGPU_ERR_INVALID, "expression: unknown op %u", e.op);
+    }
+    if (sp >= kMaxStack) fail(RDFGPU_ERR_UNSUPPORTED, "expression: stack deeper than %d", kMaxStack);
+    st[sp++] = out;
+  }
+  if (sp != 1) fail(RDFGPU_ERR_INVALID, "expression leaves %d values on the stack", sp);
+  return st[0];
+}
+
+int detect_shape(const ExprProgram& pr) {
+  if (std::getenv("RDFGPU_FORCE_GENERIC_VM")) return 0;
+  const rdfgpu_expr_node* e = pr.nodes;
+  if (pr.n == 3 && e[0].op == RDFGPU_EX_COLUMN && e[1].op == RDFGPU_EX_LIT_ID && (e[2].op == RDFGPU_EX_ID_EQ || e[2].op == RDFGPU_EX_ID_NEQ)) return 1;
+  if (pr.n == 5 && e[0].op == RDFGPU_EX_COLUMN && e[1].op == RDFGPU_EX_ENC_TV && e[2].op == RDFGPU_EX_LIT_TV && is_cmp(e[3].op) && e[4].op == RDFGPU_EX_EBV) return 2;
+  return 0;
+}
+
+void load_program(NodeInfo& nd, const rdfgpu_plan_desc* d, u32 n_cols, const char* what) {
+  const rdfgpu_plan_node& r = nd.d;
+  nd.prog.n = 0;
+  if (r.expr_len == 0) return;
+  if ((u64)r.expr_off + r.expr_len > d->n_exprs) fail(RDFGPU_ERR_INVALID, "%s: expression outside the expression array", what);
+  if (check_program(d->exprs + r.expr_off, r.expr_len, n_cols) != VK_BOOL) fail(RDFGPU_ERR_INVALID, "%s: predicate does not yield a boolean", what);
+  nd.prog.n = r.expr_len;
+  std::memcpy(nd.prog.nodes, d->exprs + r.expr_off, r.expr_len * sizeof(rdfgpu_expr_node));
+}
+
+void load_projection(NodeInfo& nd, const rdfgpu_plan_desc* d, u32 full, const char* what) {
+  const rdfgpu_plan_node& r = nd.d;
+  if (r.n_proj == RDFGPU_NO_PROJECTION) {
+    if (full > (u32)kMaxCols) fail(RDFGPU_ERR_UNSUPPORTED, "%s: %u columns (max %d)", what, full, kMaxCols);
+    nd.n_proj = full;
+    for (u32 i = 0; i < full; i++) nd.proj[i] = i;
+  } else {
+    if (r.n_proj > (u32)kMaxCols) fail(RDFGPU_ERR_UNSUPPORTED, "%s: %u columns (max %d)", what, r.n_proj, kMaxCols);
+    if ((u64)r.proj_off + r.n_proj > d->n_pool) fail(RDFGPU_ERR_INVALID, "%s: projection outside the pool", what);
+    nd.n_proj = r.n_proj;
+    for (u32 i = 0; i < r.n_proj; i++) {
+      nd.proj[i] = d->pool[r.proj_off + i];
+      if (nd.proj[i] >= full) fail(RDFGPU_ERR_INVALID, "%s: projection column %u out of range (%u columns)", what, nd.proj[i], full);
+    }
+  }
+  nd.width = nd.n_proj;
+}
+
+}  // namespace
+
+Plan* plan_compile(Store* store, const rdfgpu_plan_desc* d) {
+  if (!store) fail(RDFGPU_ERR_INVALID, "plan_compile: null store");
+  if (!d || !d->nodes || d->n_nodes == 0) fail(RDFGPU_ERR_INVALID, "plan_compile: empty plan");
+  if (d->root >= d->n_nodes) fail(RDFGPU_ERR_INVALID, "plan_compile: root %u out of range", d->root);
+  std::unique_ptr<Plan> plan(new Plan());
+  plan->store = store;
+  plan->root = d->root;
+  plan->nodes.resize(d->n_nodes);
+  std::vector<u32> scan_ids;  // sorted IN sets of all sources, uploaded once
+
+  for (u32 i = 0; i < d->n_nodes; i++) {
+    NodeInfo& nd = plan->nodes[i];
+    nd.d = d->nodes[i];
+    const rdfgpu_plan_node& r = nd.d;
+    auto child = [&](int32_t c, const char* what) -> const NodeInfo& {
+      if (c < 0 || (u32)c >= i) fail(RDFGPU_ERR_INVALID, "node %u: %s child %d must precede the node", i, what, c);
+      return plan->nodes[c];
+    };
+    switch (r.kind) {
+      case RDFGPU_NODE_DATA_SOURCE: {
+        SourceInfo src;
+        src.node = i;
+        const ScanInstructions gspo = make_gspo(r.scan, d->pool, d->n_pool);
+        src.components = choose_index(gspo, 0b111);
+        src.ix = reorder(gspo, src.components);
+        src.prune = plan_pruning(src.ix);
+        for (int k = 0; k < 4; k++) {   // bound variables in G,S,P,O order (patterns/mod.rs:68-107)
+          if (gspo.in[k].kind != RDFGPU_SCAN) continue;
+          for (int lvl = 0; lvl < 4; lvl++)
+            if (src.ix.in[lvl].kind == RDFGPU_SCAN && src.ix.in[lvl].var == gspo.in[k].var) src.out_level[src.n_out] = lvl;
+          src.n_out++;
+        }
+        for (int k = 0; k < 4; k++)
+          if (src.ix.in[k].pred.kind != RDFGPU_PRED_NONE && !(src.prune.dropped_mask & (1u << k))) src.has_residual = true;
+        nd.width = src.n_out;
+        nd.source = (int)plan->sources.size();
+        plan->sources.push_back(src);
+        break;
+      }
+      case RDFGPU_NODE_FILTER: {
+        const NodeInfo& c = child(r.left, "input");
+        load_program(nd, d, c.width, "FilterExec");
+        load_projection(nd, d, c.width, "FilterExec");
+        nd.shape = detect_shape(nd.prog);
+        break;
+      }
+      case RDFGPU_NODE_PROJECTION: {
+        const NodeInfo& c = child(r.left, "input");
+        load_projection(nd, d, c.width, "ProjectionExec");
+        break;
+      }
+      case RDFGPU_NODE_HASH_JOIN: case RDFGPU_NODE_CROSS_JOIN: case RDFGPU_NODE_NESTED_LOOP_JOIN: {
+        const NodeInfo& l = child(r.left, "left");
+        const NodeInfo& rr = child(r.right, "right");
+        if (r.join_type != RDFGPU_JOIN_INNER && r.join_type != RDFGPU_JOIN_LEFT) fail(RDFGPU_ERR_UNSUPPORTED, "node %u: join type %u", i, r.join_type);
+        if (r.kind == RDFGPU_NODE_HASH_JOIN) {
+          if (r.n_keys == 0 || r.n_keys > RDFGPU_MAX_KEYS) fail(RDFGPU_ERR_INVALID, "node %u: HashJoinExec needs 1..%u keys", i, RDFGPU_MAX_KEYS);
+          for (u32 k = 0; k < r.n_keys; k++)
+            if (r.left_keys[k] >= l.width || r.right_keys[k] >= rr.width) fail(RDFGPU_ERR_INVALID, "node %u: join key out of range", i);
+        }
+        if (r.kind == RDFGPU_NODE_CROSS_JOIN && (r.expr_len || r.join_type != RDFGPU_JOIN_INNER)) fail(RDFGPU_ERR_INVALID, "node %u: CrossJoinExec takes no filter / join type", i);
+        if (l.width + rr.width > 2u * kMaxCols) fail(RDFGPU_ERR_UNSUPPORTED, "node %u: too many columns", i);
+        load_program(nd, d, l.width + rr.width, "join filter");
+        load_projection(nd, d, l.width + rr.width, "join");
+        if (l.width > (u32)kMaxCols || rr.width > (u32)kMaxCols) fail(RDFGPU_ERR_UNSUPPORTED, "node %u: too many columns", i);
+        break;
+      }
+      case RDFGPU_NODE_TABLE: {
+        if (r.table_cols > (u32)kMaxCols) fail(RDFGPU_ERR_UNSUPPORTED, "node %u: table with %u columns", i, r.table_cols);
+        nd.width = r.table_cols;
+        if (plan->tables.size() <= r.table_slot) plan->tables.resize(r.table_slot + 1);
+        break;
+      }
+      default: fail(RDFGPU_ERR_INVALID, "node %u: unknown kind %u", i, r.kind);
+    }
+  }
+
+  store->activate();
+  RDFGPU_HIP(hipStreamCreateWithFlags(&plan->stream, hipStreamNonBlocking));
+  RDFGPU_HIP(hipEventCreate(&plan->ev_start));
+  RDFGPU_HIP(hipEventCreate(&plan->ev_stop));
+  // IN sets of residual predicates live on the device for the plan's lifetime
+  for (SourceInfo& s : plan->sources)
+    for (int k = 0; k < 4; k++)
+      if (s.ix.in[k].pred.kind == RDFGPU_PRED_IN) { s.ix.in[k].pred.from = (u32)plan->pool.size(); plan->pool.insert(plan->pool.end(), s.ix.in[k].pred.ids.begin(), s.ix.in[k].pred.ids.end()); }
+  if (!plan->pool.empty()) {
+    RDFGPU_HIP(hipMalloc((void**)&plan->pool_dev, plan->pool.size() * 4));
+    RDFGPU_HIP(hipMemcpy(plan->pool_dev, plan->pool.data(), plan->pool.size() * 4, hipMemcpyHostToDevice));
+  }
+  RDFGPU_HIP(hipMalloc((void**)&plan->counters, 256 * sizeof(u64)));
+  const size_t ns = plan->sources.empty() ? 1 : plan->sources.size();
+  RDFGPU_HIP(hipMalloc((void**)&plan->jobs_dev, ns * sizeof(LocateJob)));
+  RDFGPU_HIP(hipMalloc((void**)&plan->lohi_dev, ns * 2 * sizeof(u64)));
+  return plan.release();
+}
+
+Plan::~Plan() {
+  if (store) (void)hipSetDevice(store->device);
+  if (stream) (void)hipStreamSynchronize(stream);
+  release_intermediates();
+  if (pool_dev) (void)hipFree(pool_dev);
+  if (counters) (void)hipFree(counters);
+  if (jobs_dev) (void)hipFree(jobs_dev);
+  if (lohi_dev) (void)hipFree(lohi_dev);
+  if (ev_start) (void)hipEventDestroy(ev_start);
+  if (ev_stop) (void)hipEventDestroy(ev_stop);
+  if (stream) (void)hipStreamDestroy(stream);
+}
+
+// ------------------------------------------------------------------------------------------------
+// execute
+// ------------------------------------------------------------------------------------------------
+void Plan::release_intermediates() {
+  for (void* p : allocs) store->pool.free(p);
+  allocs.clear();
+}
+template <class T> T* Plan::scratch(u64 n) {
+  void* p = store->pool.alloc((n ? n : 1) * sizeof(T));
+  allocs.push_back(p);
+  metrics.device_bytes += (n ? n : 1) * sizeof(T);
+  return (T*)p;
+}
+u64* Plan::new_counter() {
+  if (counters_used >= 256) fail(RDFGPU_ERR_UNSUPPORTED, "plan needs more than 256 cardinality counters");
+  return counters + counters_used++;
+}
+u64 Plan::read_u64(const u64* dev) {
+  u64 v = 0;
+  RDFGPU_HIP(hipMemcpyAsync(&v, dev, sizeof v, hipMemcpyDeviceToHost, stream));
+  RDFGPU_HIP(hipStreamSynchronize(stream));
+  metrics.host_syncs++;
+  return v;
+}
+
+void Plan::execute() {
+  store->activate();
+  std::shared_lock<std::shared_mutex> lock(store->mu);   // a plan holds the snapshot while it runs (snapshot.rs:35-37)
+  RDFGPU_HIP(hipStreamSynchronize(stream));
+  release_intermediates();
+  metrics = rdfgpu_metrics{};
+  counters_used = 0;
+  host_valid = false; cursor = 0; executed = false;
+  RDFGPU_HIP(hipEventRecord(ev_start, stream));
+  RDFGPU_HIP(hipMemsetAsync(counters, 0, 256 * sizeof(u64), stream));
+
+  // K1: locate every data source's range in one launch, one host round trip for all of them
+  if (!sources.empty()) {
+    std::vector<LocateJob> jobs(sources.size());
+    for (size_t i = 0; i < sources.size(); i++) {
+      const SourceInfo& s = sources[i];
+      const Permutation& ix = store->idx[s.components];
+      LocateJob& j = jobs[i];
+      for (int k = 0; k < 4; k++) j.col[k] = ix.col[k];
+      j.n = ix.n;
+      j.n_levels = s.prune.n_levels;
+      for (int k = 0; k < 4; k++) { j.from[k] = s.prune.from[k]; j.to[k] = s.prune.to[k]; }
+    }
+    std::vector<u64> lohi(sources.size() * 2);
+    RDFGPU_HIP(hipMemcpyAsync(jobs_dev, jobs.data(), jobs.size() * sizeof(LocateJob), hipMemcpyHostToDevice, stream));
+    launch_locate(jobs_dev, (u32)jobs.size(), lohi_dev, stream); metrics.kernels_launched++;
+    RDFGPU_HIP(hipMemcpyAsync(lohi.data(), lohi_dev, lohi.size() * sizeof(u64), hipMemcpyDeviceToHost, stream));
+    RDFGPU_HIP(hipStreamSynchronize(stream)); metrics.host_syncs++;
+    for (size_t i = 0; i < sources.size(); i++) { sources[i].lo = lohi[2 * i]; sources[i].hi = lohi[2 * i + 1]; metrics.input_rows += sources[i].hi - sources[i].lo; }
+  }
+
+  result = exec_node(root);
+  result_rows = result.n_dev ? read_u64(result.n_dev) : result.cap;
+  if (result_rows > result.cap) result_rows = result.cap;
+  RDFGPU_HIP(hipEventRecord(ev_stop, stream));
+  RDFGPU_HIP(hipStreamSynchronize(stream)); metrics.host_syncs++;
+  RDFGPU_HIP(hipGetLastError());
+  float ms = 0;
+  RDFGPU_HIP(hipEventElapsedTime(&ms, ev_start, ev_stop));
+  metrics.elapsed_compute_ms = ms;
+  metrics.output_rows = result_rows;
+  executed = true;
+}
+
+DevTable Plan::exec_node(u32 idx) {
+  NodeInfo& nd = nodes[idx];
+  DevTable t;
+  switch (nd.d.kind) {
+    case RDFGPU_NODE_DATA_SOURCE: t = exec_source(nd); break;
+    case RDFGPU_NODE_FILTER: t = exec_filter(nd); break;
+    case RDFGPU_NODE_PROJECTION: {
+      const DevTable in = exec_node((u32)nd.d.left);
+      t.n_cols = nd.n_proj; t.cap = in.cap; t.n_dev = in.n_dev;
+      for (u32 c = 0; c < nd.n_proj; c++) t.cols[c] = in.cols[nd.proj[c]];
+      break;
+    }
+    case RDFGPU_NODE_HASH_JOIN: case RDFGPU_NODE_CROSS_JOIN: case RDFGPU_NODE_NESTED_LOOP_JOIN: t = exec_join(nd); break;
+    case RDFGPU_NODE_TABLE: {
+      const BoundTable& b = tables[nd.d.table_slot];
+      if (!b.bound) fail(RDFGPU_ERR_INVALID, "table slot %u is not bound", nd.d.table_slot);
+      if (b.cols.size() != nd.d.table_cols) fail(RDFGPU_ERR_INVALID, "table slot %u: %zu columns bound, node declares %u", nd.d.table_slot, b.cols.size(), nd.d.table_cols);
+      t.n_cols = nd.d.table_cols; t.cap = b.n_rows;
+      for (u32 c = 0; c < t.n_cols; c++) t.cols[c] = b.cols[c];
+      break;
+    }
+    default: fail(RDFGPU_ERR_INVALID, "unknown node kind");
+  }
+  if (idx != root) metrics.intermediate_rows += t.cap;   // upper bound when the exact count stays on the device
+  return t;
+}
+
+// DataSourceExec: a prefix-bound pattern is a zero-copy slice of the permutation (like the
+// reference's untouched row-group slices, scan.rs:146-170); residual predicates go through K2.
+DevTable Plan::exec_source(NodeInfo& nd) {
+  SourceInfo& s = sources[nd.source];
+  const Permutation& ix = store->idx[s.components];
+  DevTable t;
+  t.n_cols = s.n_out;
+  const u64 n = s.hi - s.lo;
+  if (n == 0) { t.cap = 0; return t; }
+  if (!s.has_residual) {
+    for (u32 c = 0; c < s.n_out; c++) t.cols[c] = ix.col[s.out_level[c]] + s.lo;
+    t.cap = n;
+    return t;
+  }
+  ScanJob job{};
+  for (int k = 0; k < 4; k++) {
+    job.col[k] = ix.col[k] + s.lo;
+    const ScanPredicate& p = s.ix.in[k].pred;
+    ScanLevelPred& q = job.pred[k];
+    q.kind = (s.prune.dropped_mask & (1u << k)) ? (u32)RDFGPU_PRED_NONE : p.kind;
+    if (q.kind == RDFGPU_PRED_BETWEEN) { q.a = p.from; q.b = p.to; }
+    else if (q.kind == RDFGPU_PRED_IN) { q.b = (u32)p.ids.size(); q.ids = pool_dev + p.from; }
+    else if (q.kind == RDFGPU_PRED_EQUAL_TO) {
+      int other = -1;
+      for (int l = 0; l < 4; l++) if (s.ix.in[l].kind == RDFGPU_SCAN && s.ix.in[l].var == p.equal_to) { other = l; break; }
+      if (other < 0) q.kind = RDFGPU_PRED_NONE;   // `position(..)?` => no mask (scan.rs:310-313)
+      else q.a = (u32)other;
+    }
+  }
+  job.n = n;
+  job.n_out = s.n_out;
+  for (u32 c = 0; c < s.n_out; c++) job.out_level[c] = s.out_level[c];
+  const u64 n_blocks = (n + kScanTile - 1) / kScanTile;
+  u32* counts = scratch<u32>(n_blocks + 1);
+  u32* offs = scratch<u32>(n_blocks + 1);
+  const size_t tb = scan_temp_bytes(n_blocks + 1);
+  void* temp = scratch<u8>(tb);
+  RDFGPU_HIP(hipMemsetAsync(counts + n_blocks, 0, 4, stream));
+  launch_scan_count(job, counts, stream); metrics.kernels_launched++;
+  exclusive_scan_u32(counts, offs, n_blocks + 1, temp, tb, stream); metrics.kernels_launched++;
+  u32 total = 0;
+  RDFGPU_HIP(hipMemcpyAsync(&total, offs + n_blocks, 4, hipMemcpyDeviceToHost, stream));
+  RDFGPU_HIP(hipStreamSynchronize(stream)); metrics.host_syncs++;
+  t.cap = total;
+  if (total == 0) return t;
+  for (u32 c = 0; c < s.n_out; c++) { job.out[c] = scratch<u32>(total); t.cols[c] = job.out[c]; }
+  if (s.n_out) { launch_scan_write(job, offs, stream); metrics.kernels_launched++; }
+  return t;
+}
+
+DevTable Plan::exec_filter(NodeInfo& nd) {
+  const DevTable in = exec_node((u32)nd.d.left);
+  DevTable t;
+  t.n_cols = nd.n_proj;
+  if (in.cap == 0) { t.cap = 0; return t; }
+  if (nd.prog.n == 0) {   // no predicate: a projection
+    t.cap = in.cap; t.n_dev = in.n_dev;
+    for (u32 c = 0; c < nd.n_proj; c++) t.cols[c] = in.cols[nd.proj[c]];
+    return t;
+  }
+  FilterArgs a{};
+  for (u32 c = 0; c < in.n_cols; c++) a.in[c] = in.cols[c];
+  a.n_in_cols = in.n_cols; a.n_out_cols = nd.n_proj;
+  for (u32 c = 0; c < nd.n_proj; c++) { a.proj[c] = nd.proj[c]; a.out[c] = scratch<u32>(in.cap); t.cols[c] = a.out[c]; }
+  a.n_in_dev = in.n_dev; a.n_in_cap = in.cap;
+  a.n_out_dev = new_counter();
+  a.tt = store->typed_table();
+  a.prog = nd.prog;
+  launch_filter(a, nd.shape, stream); metrics.kernels_launched++;
+  t.cap = in.cap; t.n_dev = a.n_out_dev;
+  return t;
+}
+
+static u32 pow2_at_least(u64 v) { u64 p = 1024; while (p < v && p < (1ull << 31)) p <<= 1; return (u32)p; }
+
+DevTable Plan::exec_join(NodeInfo& nd) {
+  const DevTable L = exec_node((u32)nd.d.left);
+  const DevTable R = exec_node((u32)nd.d.right);
+  const bool left_join = nd.d.join_type == RDFGPU_JOIN_LEFT;
+  DevTable t;
+  t.n_cols = nd.n_proj;
+
+  if (nd.d.kind == RDFGPU_NODE_CROSS_JOIN) {
+    const u64 cap = L.cap * R.cap;
+    if (cap == 0) { t.cap = 0; return t; }
+    if (cap >= (1ull << 40)) fail(RDFGPU_ERR_UNSUPPORTED, "cross join of %llu x %llu rows", (unsigned long long)L.cap, (unsigned long long)R.cap);
+    CrossArgs a{};
+    for (u32 c = 0; c < L.n_cols; c++) a.left[c] = L.cols[c];
+    for (u32 c = 0; c < R.n_cols; c++) a.right[c] = R.cols[c];
+    a.n_left_cols = L.n_cols; a.n_right_cols = R.n_cols; a.n_out_cols = nd.n_proj;
+    for (u32 c = 0; c < nd.n_proj; c++) { a.proj[c] = nd.proj[c]; a.out[c] = scratch<u32>(cap); t.cols[c] = a.out[c]; }
+    a.n_left_dev = L.n_dev; a.n_left_cap = L.cap; a.n_right_dev = R.n_dev; a.n_right_cap = R.cap;
+    const bool dyn = L.n_dev || R.n_dev;
+    a.n_out_dev = dyn ? new_counter() : nullptr;
+    launch_cross(a, stream); metrics.kernels_launched++;
+    t.cap = cap; t.n_dev = a.n_out_dev;
+    return t;
+  }
+
+  // HashJoinExec / NestedLoopJoinExec
+  if (L.cap == 0 || (R.cap == 0 && !left_join)) { t.cap = 0; return t; }
+  const bool hash = nd.d.kind == RDFGPU_NODE_HASH_JOIN;
+  JoinArgs a{};
+  for (u32 c = 0; c < L.n_cols; c++) a.left[c] = L.cols[c];
+  for (u32 c = 0; c < R.n_cols; c++) a.right[c] = R.cols[c];
+  a.n_left_cols = L.n_cols; a.n_right_cols = R.n_cols; a.n_out_cols = nd.n_proj;
+  for (u32 c = 0; c < nd.n_proj; c++) a.proj[c] = nd.proj[c];
+  a.n_keys = hash ? nd.d.n_keys : 0;
+  for (u32 k = 0; k < a.n_keys; k++) { a.left_keys[k] = nd.d.left_keys[k]; a.right_keys[k] = nd.d.right_keys[k]; }
+  a.n_left_dev = L.n_dev; a.n_left_cap = L.cap; a.n_right_dev = R.n_dev; a.n_right_cap = R.cap;
+  a.has_filter = nd.prog.n ? 1 : 0;
+  a.prog = nd.prog;
+  a.tt = store->typed_table();
+  if (L.cap >= 0xFFFFFFF0ull) fail(RDFGPU_ERR_UNSUPPORTED, "build side of %llu rows", (unsigned long long)L.cap);
+  if (left_join) { a.visited = scratch<u8>(L.cap); if (!hash) RDFGPU_HIP(hipMemsetAsync(a.visited, 0, L.cap, stream)); }
+  if (hash) {
+    const u32 nb = pow2_at_least(2 * L.cap);
+    a.heads = scratch<u32>(nb); a.bucket_mask = nb - 1;
+    a.next = scratch<u32>(L.cap);
+    RDFGPU_HIP(hipMemsetAsync(a.heads, 0xFF, (size_t)nb * 4, stream));
+    launch_join_build(a, stream); metrics.kernels_launched++;
+  }
+  u64 total = 0;
+  u32* offs = nullptr;
+  if (R.cap) {
+    u32* counts = scratch<u32>(R.cap);
+    offs = scratch<u32>(R.cap);
+    const size_t tb = scan_temp_bytes(R.cap);
+    void* temp = scratch<u8>(tb);
+    a.counts = counts;
+    if (hash) launch_join_count(a, stream); else launch_nlj_count(a, stream);
+    metrics.kernels_launched++;
+    inclusive_scan_u32(counts, offs, R.cap, temp, tb, stream); metrics.kernels_launched++;
+    u32 tot32 = 0;
+    RDFGPU_HIP(hipMemcpyAsync(&tot32, offs + R.cap - 1, 4, hipMemcpyDeviceToHost, stream));
+    RDFGPU_HIP(hipStreamSynchronize(stream)); metrics.host_syncs++;
+    total = tot32;
+  }
+  const u64 cap = total + (left_join ? L.cap : 0);
+  if (cap == 0) { t.cap = 0; return t; }
+  for (u32 c = 0; c < nd.n_proj; c++) { a.out[c] = scratch<u32>(cap); t.cols[c] = a.out[c]; }
+  if (total) {
+    a.counts = offs;
+    if (hash) launch_join_write(a, stream); else launch_nlj_write(a, stream);
+    metrics.kernels_launched++;
+  }
+  t.cap = cap;
+  if (left_join) {
+    a.n_out_dev = new_counter();
+    RDFGPU_HIP(hipMemcpyAsync(a.n_out_dev, &total, sizeof(u64), hipMemcpyHostToDevice, stream));
+    RDFGPU_HIP(hipStreamSynchronize(stream)); metrics.host_syncs++;   // `total` is a stack variable
+    launch_join_left_unmatched(a, stream); metrics.kernels_launched++;
+    t.n_dev = a.n_out_dev;
+  }
+  return t;
+}
+
+void Plan::ensure_host_copy() {
+  if (host_valid) return;
+  if (!executed) fail(RDFGPU_ERR_INVALID, "plan has not been executed");
+  store->activate();
+  host_cols.assign(result.n_cols, std::vector<u32>());
+  for (u32 c = 0; c < result.n_cols; c++) {
+    host_cols[c].resize(result_rows);
+    if (result_rows) RDFGPU_HIP(hipMemcpyAsync(host_cols[c].data(), result.cols[c], result_rows * 4, hipMemcpyDeviceToHost, stream));
+  }
+  RDFGPU_HIP(hipStreamSynchronize(stream));
+  host_valid = true;
+}
+
+}  // namespace rdfgpu

@@ -1,0 +1,242 @@
+// store.cpp — see store.hpp.  Index build = device radix sort of three permutations + dedupe.
+#include "store.hpp"
+
+#include <vector>
+
+#include "kernels.hpp"
+
+namespace rdfgpu {
+
+// ------------------------------------------------------------------------------------------------
+// DevicePool
+// ------------------------------------------------------------------------------------------------
+static size_t bucket_of(size_t bytes) {
+  size_t b = 256;
+  while (b < bytes) b <<= 1;
+  // above 64 MiB round to 16 MiB multiples instead of powers of two (288 GB is big, not infinite)
+  if (bytes > (64ull << 20)) b = (bytes + (16ull << 20) - 1) / (16ull << 20) * (16ull << 20);
+  return b;
+}
+DevicePool::~DevicePool() {
+  trim();
+  for (auto& kv : live_) (void)hipFree(kv.first);
+}
+void* DevicePool::alloc(size_t bytes) {
+  const size_t b = bucket_of(bytes ? bytes : 1);
+  std::lock_guard<std::mutex> g(mu_);
+  auto it = free_.find(b);
+  void* p = nullptr;
+  if (it != free_.end()) { p = it->second; free_.erase(it); }
+  else {
+    hipError_t e = hipMalloc(&p, b);
+    if (e != hipSuccess) {
+      // give cached blocks back and retry once
+      for (auto& kv : free_) (void)hipFree(kv.second);
+      free_.clear();
+      (void)hipGetLastError();
+      RDFGPU_HIP(hipMalloc(&p, b));
+    }
+  }
+  live_[p] = b;
+  in_use_ += b;
+  return p;
+}
+void DevicePool::free(void* p) {
+  if (!p) return;
+  std::lock_guard<std::mutex> g(mu_);
+  auto it = live_.find(p);
+  if (it == live_.end()) return;
+  in_use_ -= it->second;
+  free_.emplace(it->second, p);
+  live_.erase(it);
+}
+void DevicePool::trim() {
+  std::lock_guard<std::mutex> g(mu_);
+  for (auto& kv : free_) (void)hipFree(kv.second);
+  free_.clear();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Store
+// ------------------------------------------------------------------------------------------------
+Store* store_create(const rdfgpu_config* cfg) {
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count == 0) {
+    (void)hipGetLastError();
+    fail(RDFGPU_ERR_NO_DEVICE, "no usable HIP device (%s); this library has no CPU fallback",
+         e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
+  }
+  int dev = cfg ? cfg->device : -1;
+  if (dev < 0) RDFGPU_HIP(hipGetDevice(&dev));
+  if (dev >= count) fail(RDFGPU_ERR_NO_DEVICE, "device %d does not exist (%d devices)", dev, count);
+  RDFGPU_HIP(hipSetDevice(dev));
+  hipDeviceProp_t prop;
+  RDFGPU_HIP(hipGetDeviceProperties(&prop, dev));
+  if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
+    fail(RDFGPU_ERR_NO_DEVICE, "device %d is %s; the kernels are built for gfx950 only", dev, prop.gcnArchName);
+  Store* s = new Store();
+  s->device = dev;
+  s->batch_size = (cfg && cfg->batch_size) ? cfg->batch_size : 8192;
+  RDFGPU_HIP(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+  return s;
+}
+
+void Store::activate() const { RDFGPU_HIP(hipSetDevice(device)); }
+
+Store::~Store() {
+  (void)hipSetDevice(device);
+  for (auto& ix : idx) for (auto& c : ix.col) if (c) (void)hipFree(c);
+  if (tv) (void)hipFree(tv);
+  if (dec) (void)hipFree(dec);
+  if (stream) (void)hipStreamDestroy(stream);
+}
+
+void Store::clear() {
+  std::unique_lock<std::shared_mutex> lock(mu);
+  activate();
+  for (auto& ix : idx) { for (auto& c : ix.col) { if (c) RDFGPU_HIP(hipFree(c)); c = nullptr; } ix.n = 0; }
+}
+
+namespace {
+struct Scratch {  // pool-backed temporaries released together
+  DevicePool& pool; std::vector<void*> ptrs;
+  explicit Scratch(DevicePool& p) : pool(p) {}
+  template <class T> T* get(u64 n) { void* p = pool.alloc((n ? n : 1) * sizeof(T)); ptrs.push_back(p); return (T*)p; }
+  ~Scratch() { for (void* p : ptrs) pool.free(p); }
+};
+}  // namespace
+
+// Sorted-unique compaction shared by extend / remove: keeps rows with flags[i] != 0.
+static u64 compact_columns(Store& st, Scratch& sc, u32* const src[4], const u32* flags, u64 n, u32* dst_out[4]) {
+  hipStream_t s = st.stream;
+  u32* excl = sc.get<u32>(n);
+  const size_t tb = scan_temp_bytes(n);
+  void* temp = sc.get<u8>(tb);
+  exclusive_scan_u32(flags, excl, n, temp, tb, s);
+  u32 last_excl = 0, last_flag = 0;
+  if (n) {
+    RDFGPU_HIP(hipMemcpyAsync(&last_excl, excl + n - 1, 4, hipMemcpyDeviceToHost, s));
+    RDFGPU_HIP(hipMemcpyAsync(&last_flag, flags + n - 1, 4, hipMemcpyDeviceToHost, s));
+    RDFGPU_HIP(hipStreamSynchronize(s));
+  }
+  const u64 total = (u64)last_excl + (last_flag ? 1 : 0);
+  for (int k = 0; k < 4; k++) {
+    dst_out[k] = nullptr;
+    if (total) {
+      RDFGPU_HIP(hipMalloc((void**)&dst_out[k], total * sizeof(u32)));
+      launch_scatter_if(src[k], flags, excl, dst_out[k], n, s);
+    }
+  }
+  RDFGPU_HIP(hipStreamSynchronize(s));
+  return total;
+}
+
+// IndexPermutations::insert (permutations.rs:102-118) + MemIndexData::insert (quad_index_data.rs:287-332),
+// bulk form: concatenate, LSD radix sort on (c0,c1 | c2,c3) as two stable 64-bit passes, drop duplicates.
+u64 Store::extend_device(const u32* g, const u32* s_, const u32* p, const u32* o, u64 n) {
+  std::unique_lock<std::shared_mutex> lock(mu);
+  activate();
+  if (n == 0) return 0;
+  const u32* in[4] = {g, s_, p, o};
+  hipStream_t s = stream;
+  u64 inserted = 0;
+  for (u32 comp = 0; comp < RDFGPU_N_INDEXES; comp++) {
+    Permutation& ix = idx[comp];
+    const u64 N = ix.n + n;
+    if (N >= 0xFFFFFFFFull) fail(RDFGPU_ERR_UNSUPPORTED, "index would exceed 2^32-1 rows");
+    Scratch sc(pool);
+    u32* cat[4];
+    for (int k = 0; k < 4; k++) {
+      cat[k] = sc.get<u32>(N);
+      if (ix.n) RDFGPU_HIP(hipMemcpyAsync(cat[k], ix.col[k], ix.n * 4, hipMemcpyDeviceToDevice, s));
+      RDFGPU_HIP(hipMemcpyAsync(cat[k] + ix.n, in[PERM[comp][k]], n * 4, hipMemcpyDeviceToDevice, s));
+    }
+    u64* key_a = sc.get<u64>(N); u64* key_b = sc.get<u64>(N);
+    u32* idx_a = sc.get<u32>(N); u32* idx_b = sc.get<u32>(N);
+    const size_t tb = sort_temp_bytes(N);
+    void* temp = sc.get<u8>(tb);
+    launch_iota_u32(idx_a, N, s);
+    launch_pack_key(cat[2], cat[3], nullptr, key_a, N, s);
+    sort_pairs_u64_u32(key_a, key_b, idx_a, idx_b, N, temp, tb, s);       // by (c2, c3)
+    launch_pack_key(cat[0], cat[1], idx_b, key_a, N, s);
+    sort_pairs_u64_u32(key_a, key_b, idx_b, idx_a, N, temp, tb, s);       // stable by (c0, c1)
+    u32* sorted[4];
+    for (int k = 0; k < 4; k++) { sorted[k] = sc.get<u32>(N); launch_gather_u32(cat[k], idx_a, sorted[k], N, s); }
+    u32* flags = sc.get<u32>(N);
+    launch_unique_flags(sorted[0], sorted[1], sorted[2], sorted[3], flags, N, s);
+    u32* fresh[4];
+    const u64 total = compact_columns(*this, sc, sorted, flags, N, fresh);
+    inserted = total - ix.n;
+    for (int k = 0; k < 4; k++) { if (ix.col[k]) RDFGPU_HIP(hipFree(ix.col[k])); ix.col[k] = fresh[k]; }
+    ix.n = total;
+  }
+  pool.trim();  // the load path's big temporaries go back to the driver
+  return inserted;
+}
+
+u64 Store::extend_host(const u32* g, const u32* s_, const u32* p, const u32* o, u64 n) {
+  activate();
+  if (n == 0) return 0;
+  u32* d[4];
+  const u32* h[4] = {g, s_, p, o};
+  for (int k = 0; k < 4; k++) {
+    d[k] = (u32*)pool.alloc(n * 4);
+    RDFGPU_HIP(hipMemcpy(d[k], h[k], n * 4, hipMemcpyHostToDevice));
+  }
+  u64 r = 0;
+  try { r = extend_device(d[0], d[1], d[2], d[3], n); } catch (...) { for (auto q : d) pool.free(q); throw; }
+  for (auto q : d) pool.free(q);
+  pool.trim();
+  return r;
+}
+
+// IndexPermutations::remove (permutations.rs:120-128): binary-search every quad in each permutation,
+// clear its keep flag, compact.
+u64 Store::remove_host(const u32* g, const u32* s_, const u32* p, const u32* o, u64 n) {
+  std::unique_lock<std::shared_mutex> lock(mu);
+  activate();
+  if (n == 0 || idx[0].n == 0) return 0;
+  hipStream_t s = stream;
+  const u32* h[4] = {g, s_, p, o};
+  u64 removed = 0;
+  for (u32 comp = 0; comp < RDFGPU_N_INDEXES; comp++) {
+    Permutation& ix = idx[comp];
+    Scratch sc(pool);
+    u32* rm[4];
+    for (int k = 0; k < 4; k++) {
+      rm[k] = sc.get<u32>(n);
+      RDFGPU_HIP(hipMemcpyAsync(rm[k], h[PERM[comp][k]], n * 4, hipMemcpyHostToDevice, s));
+    }
+    u32* keep = sc.get<u32>(ix.n);
+    launch_fill_u32(keep, 1u, ix.n, s);
+    const u32* ixc[4] = {ix.col[0], ix.col[1], ix.col[2], ix.col[3]};
+    const u32* rmc[4] = {rm[0], rm[1], rm[2], rm[3]};
+    launch_mark_removed(ixc, ix.n, rmc, n, keep, s);
+    u32* fresh[4];
+    const u64 total = compact_columns(*this, sc, ix.col, keep, ix.n, fresh);
+    removed = ix.n - total;
+    for (int k = 0; k < 4; k++) { RDFGPU_HIP(hipFree(ix.col[k])); ix.col[k] = fresh[k]; }
+    ix.n = total;
+  }
+  pool.trim();
+  return removed;
+}
+
+void Store::set_typed_values(const rdfgpu_typed_value* v, u64 n, const int64_t* d, u64 nd) {
+  std::unique_lock<std::shared_mutex> lock(mu);
+  activate();
+  if (tv) { RDFGPU_HIP(hipFree(tv)); tv = nullptr; }
+  if (dec) { RDFGPU_HIP(hipFree(dec)); dec = nullptr; }
+  n_ids = n; n_dec = nd;
+  if (n) {
+    RDFGPU_HIP(hipMalloc((void**)&tv, n * sizeof(rdfgpu_typed_value)));
+    RDFGPU_HIP(hipMemcpy(tv, v, n * sizeof(rdfgpu_typed_value), hipMemcpyHostToDevice));
+  }
+  if (nd) {
+    RDFGPU_HIP(hipMalloc((void**)&dec, nd * 16));
+    RDFGPU_HIP(hipMemcpy(dec, d, nd * 16, hipMemcpyHostToDevice));
+  }
+}
+
+}  // namespace rdfgpu

@@ -1,0 +1,60 @@
+// store.hpp — the HBM-resident quad store: three sorted u32 permutations + typed-value side table.
+// Replaces MemQuadStorage / IndexPermutations<MemQuadIndex> / MemIndexData
+// (lib/storage/src/memory/storage/mem_storage.rs:22-102, quad_index_data.rs:57-64).
+#pragma once
+#include <map>
+#include <mutex>
+#include <shared_mutex>
+#include <vector>
+
+#include "common.hpp"
+#include "expr_device.hpp"
+
+namespace rdfgpu {
+
+// Size-bucketed caching device allocator: intermediates of successive plan executions reuse the
+// same HBM blocks instead of paying hipMalloc/hipFree per operator.
+class DevicePool {
+ public:
+  ~DevicePool();
+  void* alloc(size_t bytes);
+  void free(void* p);
+  void trim();
+  u64 bytes_in_use() const { return in_use_; }
+
+ private:
+  std::mutex mu_;
+  std::multimap<size_t, void*> free_;
+  std::map<void*, size_t> live_;
+  u64 in_use_ = 0;
+};
+
+struct Permutation {
+  u32* col[4] = {nullptr, nullptr, nullptr, nullptr};  // index-order columns (flat, sorted, unique)
+  u64 n = 0;
+};
+
+struct Store {
+  int device = 0;
+  u32 batch_size = 8192;
+  Permutation idx[RDFGPU_N_INDEXES];
+  // typed-value side table (object_id_mapping.rs:376-399), 16 B per id
+  rdfgpu_typed_value* tv = nullptr; u64 n_ids = 0;
+  int64_t* dec = nullptr; u64 n_dec = 0;
+  DevicePool pool;
+  hipStream_t stream = nullptr;  // load-path stream
+  std::shared_mutex mu;   // readers = running plans (a snapshot), writers = extend / remove / clear
+
+  ~Store();
+  void activate() const;
+  u64 extend_device(const u32* g, const u32* s, const u32* p, const u32* o, u64 n);
+  u64 extend_host(const u32* g, const u32* s, const u32* p, const u32* o, u64 n);
+  u64 remove_host(const u32* g, const u32* s, const u32* p, const u32* o, u64 n);
+  void clear();
+  void set_typed_values(const rdfgpu_typed_value* v, u64 n_ids, const int64_t* dec, u64 n_dec);
+  TypedTable typed_table() const { return TypedTable{tv, n_ids, dec, n_dec}; }
+};
+
+Store* store_create(const rdfgpu_config* cfg);
+
+}  // namespace rdfgpu
