@@ -34,6 +34,15 @@ def load_library():
         raise RdfGpuError(abi.ERR_NO_DEVICE,
                           f"{path} is missing: build it with `python __graft_entry__.py build` "
                           "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    # One HIP runtime per process: PyTorch-ROCm wheels bundle their own libamdhip64 (same SONAME as
+    # /opt/rocm's).  If ours were mapped first, torch would later map a second runtime and report no
+    # device.  Importing torch first makes the dynamic loader resolve librdfgpu.so's libamdhip64
+    # dependency to the copy already in the process.  torch is plumbing here (streams / RCCL), not a
+    # dependency of the library: without torch installed, /opt/rocm's runtime is used.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(path)
     u32p, u64p, vp = C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.c_void_p
     lib.rdfgpu_last_error.restype = C.c_char_p
