@@ -1,0 +1,225 @@
+#!/usr/bin/env python3
+"""bench.py — BSBM Q5 join pipeline (BGP scan -> cross/hash joins -> FILTER) on MI355X.
+
+Contract: `python bench.py --gpus N --steps K --warmup W`; for N > 1 the driver launches one rank
+per GPU with torch.distributed.run.  Rank 0 prints ONE JSON line.
+
+A step = one batch of `--queries` BSBM Explore Q5 instances (distinct %Product% constants), each
+planned exactly as the reference plans it (bench/tests/plans/snapshots/*Q5 (Execution Plan).snap) and
+run through the C ABI over a synthetic BSBM-shaped store of `--products` products (285 000 products
+= 98 M triples, "BSBM-100M") whose three sorted permutations and typed-value table are already resident
+in HBM when the timed region starts.  value = solution bindings (rows leaving the top join, before
+DISTINCT / ORDER BY / LIMIT) per second over all ranks.
+
+N > 1: triples are sharded by hash(subject) over the ranks (strong scaling: the dataset is fixed); the
+constant-subject patterns' bindings are all-gathered over RCCL, everything else is local
+(rdf-fusion_amd/sharding.py).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md); measured copy ceiling is 6290 GB/s
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--products", type=int, default=285_000, help="BSBM scale (285000 products = ~100 M triples)")
+    ap.add_argument("--queries", type=int, default=16, help="Q5 instances per step")
+    ap.add_argument("--cpu-sample", type=int, default=4, help="Q5 instances timed on the CPU oracle (rank 0, N=1)")
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import rdf_fusion_amd as rf
+    from rdf_fusion_amd import bsbm, sharding
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ------------------------------------------------------------------ data, resident in HBM
+    t0 = time.time()
+    ds = bsbm.generate(args.products)
+    g, s, p, o = sharding.shard_dataset(ds, rank, world)
+    store = rf.GpuQuadStore(device=local_rank)
+    store.extend(g, s, p, o)
+    store.set_typed_values(ds.typed_values)
+    n_local = len(store)
+    del g, s, p, o
+    load_s = time.time() - t0
+
+    rng = np.random.default_rng(12345)
+    n_batches = args.steps + args.warmup
+    products = [ds.product(i) for i in rng.choice(ds.n_products, size=n_batches * args.queries, replace=False)]
+
+    kstats = {}
+
+    def account(plan):
+        for name, launches, ms, nbytes, rows in plan.kernel_stats():
+            k = kstats.setdefault(name, [0, 0.0, 0, 0])
+            k[0] += launches; k[1] += ms; k[2] += nbytes; k[3] += rows
+
+    lat_ms = []
+
+    def run_plan_count(desc, tables=None, timing=True):
+        plan = store.plan(desc)
+        keep = []
+        if tables is not None:
+            for slot, t in enumerate(tables):
+                dt = torch.from_numpy(np.ascontiguousarray(t, dtype=np.uint32).view(np.int32)).cuda()
+                keep.append(dt)
+                plan.bind_table(slot, [dt.data_ptr()], len(t))
+        if timing:
+            plan.enable_kernel_timing(True)
+        plan.execute()
+        n, _ = plan.result_info()
+        if timing:
+            account(plan)
+        return plan, n
+
+    def step(batch, timing):
+        rows = 0
+        if world == 1:
+            for x in batch:
+                t1 = time.perf_counter()
+                plan, n = run_plan_count(bsbm.q5_plan(ds, x), timing=timing)
+                lat_ms.append((time.perf_counter() - t1) * 1e3)
+                rows += n
+                plan.close()
+        else:
+            def run_const(desc):
+                plan, _ = run_plan_count(desc, timing=timing)
+                out = plan.fetch()[0]
+                plan.close()
+                return out
+
+            def run_local(desc, tables):
+                if any(len(t) == 0 for t in tables):
+                    return 0
+                plan, n = run_plan_count(desc, tables, timing=timing)
+                plan.close()
+                return n
+
+            def all_gather(recs):
+                mine = torch.from_numpy(recs).cuda()
+                out = torch.empty((world,) + tuple(mine.shape), dtype=mine.dtype, device=mine.device)
+                dist.all_gather_into_tensor(out, mine)
+                return out.cpu().numpy()
+
+            rows = sharding.run_q5_batch_sharded(ds, batch, run_const, run_local, all_gather)
+        return rows
+
+    batches = [products[i * args.queries:(i + 1) * args.queries] for i in range(n_batches)]
+    for b in batches[:args.warmup]:
+        step(b, timing=False)
+    kstats.clear(); lat_ms.clear()
+    barrier()
+    t0 = time.perf_counter()
+    local_rows = 0
+    for b in batches[args.warmup:]:
+        local_rows += step(b, timing=True)
+    barrier()
+    elapsed = time.perf_counter() - t0
+
+    total_rows = local_rows
+    if dist is not None:
+        t = torch.tensor([elapsed, float(local_rows)], dtype=torch.float64, device="cuda")
+        tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = t.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        elapsed = float(tmax[0].item()); total_rows = int(tsum[1].item())
+
+    # ------------------------------------------------------------------ roofline of the dominant kernel
+    roofline = None
+    if kstats:
+        name, (launches, ms, nbytes, rows) = max(kstats.items(), key=lambda kv: kv[1][1])
+        achieved = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        roofline = {"bound": "hbm", "kernel": name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                    "launches": launches, "avg_us": round(ms * 1e3 / max(1, launches), 2),
+                    "algorithmic_bytes_per_launch": int(nbytes / max(1, launches))}
+    kernel_table = {k: {"launches": v[0], "total_ms": round(v[1], 3), "algorithmic_GBps": round(v[2] / (v[1] * 1e-3) / 1e9, 1) if v[1] > 0 else None}
+                    for k, v in sorted(kstats.items(), key=lambda kv: -kv[1][1])}
+
+    # ------------------------------------------------------------------ CPU baseline (oracle = restated reference), rank 0, N=1
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu and args.cpu_sample > 0:
+        from oracle import oracle as orc
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import kat_util as ku
+        os_ = orc.OracleStore()
+        for comp in (0, 1, 2):   # adopt the device-built permutations: no second 100 M-row sort on the host
+            os_.adopt_sorted(comp, store.read_index(comp))
+        os_.set_typed_values(ds.typed_values)
+        sample = products[:args.cpu_sample]
+        cpu_rows, t_cpu = 0, 0.0
+        for x in sample:
+            desc = bsbm.q5_plan(ds, x)
+            t1 = time.perf_counter()
+            cols, n, _ = os_.execute(desc)
+            t_cpu += time.perf_counter() - t1
+            cpu_rows += n
+            plan, n_gpu = run_plan_count(desc, timing=False)   # full-size parity on the sampled instances
+            assert n_gpu == n, (n_gpu, n)
+            np.testing.assert_array_equal(ku.multiset(plan.fetch(), n), ku.multiset(cols, n))
+            plan.close()
+        cpu = {"value": round(cpu_rows / t_cpu, 2) if t_cpu > 0 else None, "unit": "bindings/s", "cores": 1, "kind": "port",
+               "sample": f"{len(sample)} Q5 instances of this workload ({cpu_rows} bindings, {t_cpu:.1f} s on one host core); "
+                         "C restatement of the reference's operators (oracle/rdf_oracle.c), single thread like the "
+                         "reference's default target_partitions=1; GPU results on these instances compared multiset-equal",
+               "queries_per_s": round(len(sample) / t_cpu, 3) if t_cpu > 0 else None}
+
+    if rank == 0:
+        n_q = args.steps * args.queries
+        out = {
+            "metric": "solution bindings/sec + achieved HBM GB/s, BSBM Q5 at 1/2/4/8 GPUs",
+            "value": round(total_rows / elapsed, 2),
+            "unit": "bindings/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed * 1e3 / args.steps, 3),
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "u32 ids / i64 typed values",
+            "data": "synthetic",
+            "config": {"workload": f"BSBM-shaped store, {args.products} products ({ds.n_triples} triples), Explore Q5 "
+                                   f"(7 triple patterns, 3 hash joins + 3 cross joins + 4 filters), {args.queries} instances/step",
+                       "triples_per_gpu": n_local, "sharding": "hash(subject) mod N" if world > 1 else "none",
+                       "queries_per_s": round(n_q / elapsed, 2), "bindings": total_rows,
+                       "median_query_latency_ms": round(float(np.median(lat_ms)), 3) if lat_ms else None,
+                       "load_seconds": round(load_s, 1)},
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+            "kernels": kernel_table,
+        }
+        if cpu and cpu.get("queries_per_s"):
+            out["config"]["speedup_vs_cpu_port"] = round((n_q / elapsed) / cpu["queries_per_s"], 1)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

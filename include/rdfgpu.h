@@ -334,6 +334,23 @@ int rdfgpu_plan_selected_index(const rdfgpu_plan* plan, uint32_t node, uint32_t*
 /* Opaque hipStream_t of the plan, so the host can order its own work after it. */
 int rdfgpu_plan_stream(rdfgpu_plan* plan, void** hip_stream);
 
+/*
+ * Per-kernel device timing of the last execute (HIP events on the plan's stream, around every
+ * launch) with the algorithmic bytes each kernel class had to move (formulas: DESIGN.md,
+ * from SURVEY.md §8d).  The equivalent of DataFusion's per-operator BaselineMetrics
+ * (elapsed_compute, stream.rs:48-63), at kernel granularity.  Off by default.
+ */
+typedef struct rdfgpu_kernel_stat {
+  const char* kernel;        /* device function name as rocprofv3 prints it (prefix match)  */
+  uint32_t launches;
+  uint32_t reserved;
+  double total_ms;           /* sum of HIP-event durations of those launches                */
+  uint64_t algorithmic_bytes;/* sum over those launches                                     */
+  uint64_t rows_in;          /* rows streamed by those launches                             */
+} rdfgpu_kernel_stat;
+int rdfgpu_plan_enable_kernel_timing(rdfgpu_plan* plan, int on);
+int rdfgpu_plan_kernel_stats(rdfgpu_plan* plan, rdfgpu_kernel_stat* out, uint32_t cap, uint32_t* n);
+
 /* ------------------------------------------------------------------------------------ */
 /* 5. Host logic of the scan planner (no device access)                                  */
 /* ------------------------------------------------------------------------------------ */

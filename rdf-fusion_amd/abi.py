@@ -81,6 +81,11 @@ class Metrics(C.Structure):
                 ("host_syncs", C.c_uint32)]
 
 
+class KernelStat(C.Structure):
+    _fields_ = [("kernel", C.c_char_p), ("launches", C.c_uint32), ("reserved", C.c_uint32),
+                ("total_ms", C.c_double), ("algorithmic_bytes", C.c_uint64), ("rows_in", C.c_uint64)]
+
+
 class Predicate(C.Structure):
     _fields_ = [("pred", C.c_uint32), ("from_", C.c_uint32), ("to", C.c_uint32),
                 ("ids", C.POINTER(C.c_uint32)), ("n_ids", C.c_uint32), ("equal_to", C.c_uint32)]
@@ -119,6 +124,7 @@ EXPORTED_SYMBOLS = [
     "rdfgpu_plan_compile", "rdfgpu_plan_destroy", "rdfgpu_plan_bind_table", "rdfgpu_plan_execute",
     "rdfgpu_plan_result_info", "rdfgpu_plan_result_device", "rdfgpu_plan_fetch", "rdfgpu_plan_next",
     "rdfgpu_plan_rewind", "rdfgpu_plan_metrics", "rdfgpu_plan_selected_index", "rdfgpu_plan_stream",
+    "rdfgpu_plan_enable_kernel_timing", "rdfgpu_plan_kernel_stats",
     "rdfgpu_scan_score", "rdfgpu_choose_index", "rdfgpu_predicate_and",
     "rdfgpu_pushdown_to_scan_predicate",
 ]

@@ -243,6 +243,22 @@ int rdfgpu_plan_stream(rdfgpu_plan* plan, void** hip_stream) {
   ABI_END
 }
 
+int rdfgpu_plan_enable_kernel_timing(rdfgpu_plan* plan, int on) { ABI_BEGIN P(plan)->timing = on != 0; ABI_END }
+int rdfgpu_plan_kernel_stats(rdfgpu_plan* plan, rdfgpu_kernel_stat* out, uint32_t cap, uint32_t* n) {
+  ABI_BEGIN
+  Plan* p = P(plan);
+  if (!n || (cap && !out)) fail(RDFGPU_ERR_INVALID, "null out pointer");
+  u32 w = 0;
+  for (int k = 0; k < KC__N; k++) {
+    const KernelStat& s = p->kstats[k];
+    if (!s.launches) continue;
+    if (w < cap) { out[w].kernel = kKernelNames[k]; out[w].launches = s.launches; out[w].reserved = 0; out[w].total_ms = s.ms; out[w].algorithmic_bytes = s.bytes; out[w].rows_in = s.rows; }
+    w++;
+  }
+  *n = w < cap ? w : cap;
+  ABI_END
+}
+
 // ---- host logic ----------------------------------------------------------------------------------
 static void decode4(const rdfgpu_scan_instruction raw[4], ScanInstruction out[4]) {
   // host-logic entry points take explicit (pred, a, b) without a pool: an IN with b ids is scored as

@@ -175,22 +175,32 @@ Plan* plan_compile(Store* store, const rdfgpu_plan_desc* d) {
     }
   }
 
-  store->activate();
-  RDFGPU_HIP(hipStreamCreateWithFlags(&plan->stream, hipStreamNonBlocking));
-  RDFGPU_HIP(hipEventCreate(&plan->ev_start));
-  RDFGPU_HIP(hipEventCreate(&plan->ev_stop));
+  // per-node byte accounting inputs: distinct columns read, typed gathers per row
+  for (NodeInfo& nd : plan->nodes) {
+    bool used[2 * kMaxCols] = {};
+    for (u32 i = 0; i < nd.prog.n; i++) {
+      if (nd.prog.nodes[i].op == RDFGPU_EX_COLUMN) used[nd.prog.nodes[i].u] = true;
+      if (nd.prog.nodes[i].op == RDFGPU_EX_ENC_TV) nd.n_enc_tv++;
+    }
+    if (nd.d.kind == RDFGPU_NODE_FILTER) for (u32 c = 0; c < nd.n_proj; c++) used[nd.proj[c]] = true;
+    for (bool b : used) nd.n_cols_read += b;
+  }
+
+  static_assert(sizeof(LocateJob) <= 128, "ExecContext staging assumes LocateJob <= 128 bytes");
+  plan->ctx = store->acquire_context((u32)plan->sources.size());
+  plan->stream = plan->ctx->stream;
+  plan->counters = plan->ctx->counters;
   // IN sets of residual predicates live on the device for the plan's lifetime
   for (SourceInfo& s : plan->sources)
     for (int k = 0; k < 4; k++)
-      if (s.ix.in[k].pred.kind == RDFGPU_PRED_IN) { s.ix.in[k].pred.from = (u32)plan->pool.size(); plan->pool.insert(plan->pool.end(), s.ix.in[k].pred.ids.begin(), s.ix.in[k].pred.ids.end()); }
+      if (s.ix.in[k].pred.kind == RDFGPU_PRED_IN && !(s.prune.dropped_mask & (1u << k))) {
+        s.ix.in[k].pred.from = (u32)plan->pool.size();
+        plan->pool.insert(plan->pool.end(), s.ix.in[k].pred.ids.begin(), s.ix.in[k].pred.ids.end());
+      }
   if (!plan->pool.empty()) {
     RDFGPU_HIP(hipMalloc((void**)&plan->pool_dev, plan->pool.size() * 4));
     RDFGPU_HIP(hipMemcpy(plan->pool_dev, plan->pool.data(), plan->pool.size() * 4, hipMemcpyHostToDevice));
   }
-  RDFGPU_HIP(hipMalloc((void**)&plan->counters, 256 * sizeof(u64)));
-  const size_t ns = plan->sources.empty() ? 1 : plan->sources.size();
-  RDFGPU_HIP(hipMalloc((void**)&plan->jobs_dev, ns * sizeof(LocateJob)));
-  RDFGPU_HIP(hipMalloc((void**)&plan->lohi_dev, ns * 2 * sizeof(u64)));
   return plan.release();
 }
 
@@ -199,12 +209,49 @@ Plan::~Plan() {
   if (stream) (void)hipStreamSynchronize(stream);
   release_intermediates();
   if (pool_dev) (void)hipFree(pool_dev);
-  if (counters) (void)hipFree(counters);
-  if (jobs_dev) (void)hipFree(jobs_dev);
-  if (lohi_dev) (void)hipFree(lohi_dev);
-  if (ev_start) (void)hipEventDestroy(ev_start);
-  if (ev_stop) (void)hipEventDestroy(ev_stop);
-  if (stream) (void)hipStreamDestroy(stream);
+  if (store && ctx) store->release_context(ctx);
+}
+
+const char* const kKernelNames[KC__N] = {
+    "rdfgpu::locate_kernel", "rdfgpu::scan_count_kernel", "rdfgpu::scan_write_kernel",
+    "void rdfgpu::filter_kernel<1>", "void rdfgpu::filter_kernel<2>", "void rdfgpu::filter_kernel<0>",
+    "rdfgpu::cross_kernel", "rdfgpu::join_build_kernel", "void rdfgpu::join_probe_kernel<false>",
+    "void rdfgpu::join_probe_kernel<true>", "rdfgpu::join_left_unmatched_kernel", "void rdfgpu::nlj_kernel<false>",
+    "void rdfgpu::nlj_kernel<true>", "rocprim device scan"};
+
+template <class F>
+void Plan::timed(int kc, u64 fixed_bytes, u64 rows_cap, const u64* rows_dev, u64 bytes_per_row,
+                 const u64* out_dev, u64 out_rows, u64 bytes_per_out, F&& launch) {
+  metrics.kernels_launched++;
+  if (!timing) { launch(); return; }
+  PendingLaunch p{kc, ctx->event(events_used), ctx->event(events_used + 1), fixed_bytes, rows_cap, rows_dev, bytes_per_row, out_dev, out_rows, bytes_per_out};
+  events_used += 2;
+  RDFGPU_HIP(hipEventRecord(p.start, stream));
+  launch();
+  RDFGPU_HIP(hipEventRecord(p.stop, stream));
+  pending.push_back(p);
+}
+
+// After the final sync: event durations + byte counts (device-side cardinalities come from the
+// counters mirror copied back with the result count).
+void Plan::resolve_timing() {
+  for (KernelStat& k : kstats) k = KernelStat{};
+  if (!timing) return;
+  auto live = [&](const u64* dev, u64 fallback) -> u64 {
+    if (!dev) return fallback;
+    const u64 v = ctx->counters_host[dev - counters];
+    return v < fallback || fallback == 0 ? v : fallback;
+  };
+  for (const PendingLaunch& p : pending) {
+    float ms = 0;
+    RDFGPU_HIP(hipEventElapsedTime(&ms, p.start, p.stop));
+    KernelStat& k = kstats[p.kc];
+    const u64 rows = live(p.rows_dev, p.rows_cap);
+    const u64 out = p.out_dev ? ctx->counters_host[p.out_dev - counters] : p.out_rows;
+    k.launches++; k.ms += ms; k.rows += rows;
+    k.bytes += p.fixed_bytes + rows * p.bytes_per_row + out * p.bytes_per_out;
+  }
+  pending.clear();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -239,13 +286,16 @@ void Plan::execute() {
   release_intermediates();
   metrics = rdfgpu_metrics{};
   counters_used = 0;
+  events_used = 2;   // events 0/1 bracket the whole execute
+  pending.clear();
   host_valid = false; cursor = 0; executed = false;
+  const hipEvent_t ev_start = ctx->event(0), ev_stop = ctx->event(1);
   RDFGPU_HIP(hipEventRecord(ev_start, stream));
   RDFGPU_HIP(hipMemsetAsync(counters, 0, 256 * sizeof(u64), stream));
 
   // K1: locate every data source's range in one launch, one host round trip for all of them
   if (!sources.empty()) {
-    std::vector<LocateJob> jobs(sources.size());
+    LocateJob* jobs = static_cast<LocateJob*>(ctx->jobs_host);
     for (size_t i = 0; i < sources.size(); i++) {
       const SourceInfo& s = sources[i];
       const Permutation& ix = store->idx[s.components];
@@ -255,24 +305,27 @@ void Plan::execute() {
       j.n_levels = s.prune.n_levels;
       for (int k = 0; k < 4; k++) { j.from[k] = s.prune.from[k]; j.to[k] = s.prune.to[k]; }
     }
-    std::vector<u64> lohi(sources.size() * 2);
-    RDFGPU_HIP(hipMemcpyAsync(jobs_dev, jobs.data(), jobs.size() * sizeof(LocateJob), hipMemcpyHostToDevice, stream));
-    launch_locate(jobs_dev, (u32)jobs.size(), lohi_dev, stream); metrics.kernels_launched++;
-    RDFGPU_HIP(hipMemcpyAsync(lohi.data(), lohi_dev, lohi.size() * sizeof(u64), hipMemcpyDeviceToHost, stream));
+    LocateJob* jobs_dev = static_cast<LocateJob*>(ctx->jobs_dev);
+    RDFGPU_HIP(hipMemcpyAsync(jobs_dev, jobs, sources.size() * sizeof(LocateJob), hipMemcpyHostToDevice, stream));
+    timed(KC_LOCATE, 0, sources.size(), nullptr, 0, nullptr, 0, 0, [&] { launch_locate(jobs_dev, (u32)sources.size(), ctx->lohi_dev, stream); });
+    RDFGPU_HIP(hipMemcpyAsync(ctx->lohi_host, ctx->lohi_dev, sources.size() * 2 * sizeof(u64), hipMemcpyDeviceToHost, stream));
     RDFGPU_HIP(hipStreamSynchronize(stream)); metrics.host_syncs++;
-    for (size_t i = 0; i < sources.size(); i++) { sources[i].lo = lohi[2 * i]; sources[i].hi = lohi[2 * i + 1]; metrics.input_rows += sources[i].hi - sources[i].lo; }
+    for (size_t i = 0; i < sources.size(); i++) { sources[i].lo = ctx->lohi_host[2 * i]; sources[i].hi = ctx->lohi_host[2 * i + 1]; metrics.input_rows += sources[i].hi - sources[i].lo; }
   }
 
   result = exec_node(root);
-  result_rows = result.n_dev ? read_u64(result.n_dev) : result.cap;
-  if (result_rows > result.cap) result_rows = result.cap;
+  // one copy brings back every device-side cardinality (the result's and, for timing, the others')
+  RDFGPU_HIP(hipMemcpyAsync(ctx->counters_host, counters, 256 * sizeof(u64), hipMemcpyDeviceToHost, stream));
   RDFGPU_HIP(hipEventRecord(ev_stop, stream));
   RDFGPU_HIP(hipStreamSynchronize(stream)); metrics.host_syncs++;
   RDFGPU_HIP(hipGetLastError());
+  result_rows = result.n_dev ? ctx->counters_host[result.n_dev - counters] : result.cap;
+  if (result_rows > result.cap) result_rows = result.cap;
   float ms = 0;
   RDFGPU_HIP(hipEventElapsedTime(&ms, ev_start, ev_stop));
   metrics.elapsed_compute_ms = ms;
   metrics.output_rows = result_rows;
+  resolve_timing();
   executed = true;
 }
 
@@ -341,15 +394,18 @@ DevTable Plan::exec_source(NodeInfo& nd) {
   const size_t tb = scan_temp_bytes(n_blocks + 1);
   void* temp = scratch<u8>(tb);
   RDFGPU_HIP(hipMemsetAsync(counts + n_blocks, 0, 4, stream));
-  launch_scan_count(job, counts, stream); metrics.kernels_launched++;
-  exclusive_scan_u32(counts, offs, n_blocks + 1, temp, tb, stream); metrics.kernels_launched++;
+  u32 n_pred_cols = 0;   // columns the residual predicates read
+  for (int k = 0; k < 4; k++) n_pred_cols += job.pred[k].kind != RDFGPU_PRED_NONE && job.pred[k].kind != RDFGPU_PRED_FALSE;
+  timed(KC_SCAN_COUNT, 0, n, nullptr, 4ull * n_pred_cols, nullptr, 0, 0, [&] { launch_scan_count(job, counts, stream); });
+  timed(KC_DEVICE_SCAN, 0, n_blocks + 1, nullptr, 8, nullptr, 0, 0, [&] { exclusive_scan_u32(counts, offs, n_blocks + 1, temp, tb, stream); });
   u32 total = 0;
   RDFGPU_HIP(hipMemcpyAsync(&total, offs + n_blocks, 4, hipMemcpyDeviceToHost, stream));
   RDFGPU_HIP(hipStreamSynchronize(stream)); metrics.host_syncs++;
   t.cap = total;
   if (total == 0) return t;
   for (u32 c = 0; c < s.n_out; c++) { job.out[c] = scratch<u32>(total); t.cols[c] = job.out[c]; }
-  if (s.n_out) { launch_scan_write(job, offs, stream); metrics.kernels_launched++; }
+  // scan+filter+compact: 4·c_r·N + 4·c_w·σN, c_r = predicate ∪ output columns (upper bound: both)
+  if (s.n_out) timed(KC_SCAN_WRITE, 0, n, nullptr, 4ull * n_pred_cols, nullptr, total, 8ull * s.n_out, [&] { launch_scan_write(job, offs, stream); });
   return t;
 }
 
@@ -371,7 +427,10 @@ DevTable Plan::exec_filter(NodeInfo& nd) {
   a.n_out_dev = new_counter();
   a.tt = store->typed_table();
   a.prog = nd.prog;
-  launch_filter(a, nd.shape, stream); metrics.kernels_launched++;
+  // FilterExec bytes: 4·c_r·N + t·N + 4·c_w·σN with t = 9 B per typed gather (tag + i64)
+  const int kc = nd.shape == 1 ? KC_FILTER_ID : nd.shape == 2 ? KC_FILTER_TV : KC_FILTER_VM;
+  timed(kc, 0, in.cap, in.n_dev, 4ull * nd.n_cols_read + 9ull * nd.n_enc_tv, a.n_out_dev, 0, 4ull * nd.n_proj,
+        [&] { launch_filter(a, nd.shape, stream); });
   t.cap = in.cap; t.n_dev = a.n_out_dev;
   return t;
 }
@@ -397,7 +456,9 @@ DevTable Plan::exec_join(NodeInfo& nd) {
     a.n_left_dev = L.n_dev; a.n_left_cap = L.cap; a.n_right_dev = R.n_dev; a.n_right_cap = R.cap;
     const bool dyn = L.n_dev || R.n_dev;
     a.n_out_dev = dyn ? new_counter() : nullptr;
-    launch_cross(a, stream); metrics.kernels_launched++;
+    // CrossJoinExec bytes: 4·c·N (both inputs read once) + 4·c_o·m·N (every output cell written)
+    timed(KC_CROSS, 4ull * R.n_cols * R.cap, L.cap, L.n_dev, 4ull * L.n_cols, a.n_out_dev, dyn ? 0 : cap, 4ull * nd.n_proj,
+          [&] { launch_cross(a, stream); });
     t.cap = cap; t.n_dev = a.n_out_dev;
     return t;
   }
@@ -423,7 +484,17 @@ DevTable Plan::exec_join(NodeInfo& nd) {
     a.heads = scratch<u32>(nb); a.bucket_mask = nb - 1;
     a.next = scratch<u32>(L.cap);
     RDFGPU_HIP(hipMemsetAsync(a.heads, 0xFF, (size_t)nb * 4, stream));
-    launch_join_build(a, stream); metrics.kernels_launched++;
+    // build: 4·k·N_b keys read + 8·N_b (one head/next slot written per row)   (build half)
+    timed(KC_JOIN_BUILD, 0, L.cap, L.n_dev, 4ull * a.n_keys + 8, nullptr, 0, 0, [&] { launch_join_build(a, stream); });
+  }
+  // columns of the probe side the write pass has to read: keys ∪ projected right columns ∪ filter columns
+  u32 probe_cols = 0;
+  {
+    bool used[kMaxCols] = {};
+    for (u32 k = 0; k < a.n_keys; k++) used[a.right_keys[k]] = true;
+    for (u32 c = 0; c < nd.n_proj; c++) if (nd.proj[c] >= L.n_cols) used[nd.proj[c] - L.n_cols] = true;
+    for (u32 i = 0; i < nd.prog.n; i++) if (nd.prog.nodes[i].op == RDFGPU_EX_COLUMN && nd.prog.nodes[i].u >= L.n_cols) used[nd.prog.nodes[i].u - L.n_cols] = true;
+    for (bool b : used) probe_cols += b;
   }
   u64 total = 0;
   u32* offs = nullptr;
@@ -433,9 +504,10 @@ DevTable Plan::exec_join(NodeInfo& nd) {
     const size_t tb = scan_temp_bytes(R.cap);
     void* temp = scratch<u8>(tb);
     a.counts = counts;
-    if (hash) launch_join_count(a, stream); else launch_nlj_count(a, stream);
-    metrics.kernels_launched++;
-    inclusive_scan_u32(counts, offs, R.cap, temp, tb, stream); metrics.kernels_launched++;
+    // count pass: 4·k·N_p keys + 8·N_p (head + first chain slot read per probe row)
+    timed(hash ? KC_JOIN_COUNT : KC_NLJ_COUNT, 0, R.cap, R.n_dev, 4ull * a.n_keys + 8, nullptr, 0, 0,
+          [&] { if (hash) launch_join_count(a, stream); else launch_nlj_count(a, stream); });
+    timed(KC_DEVICE_SCAN, 0, R.cap, nullptr, 8, nullptr, 0, 0, [&] { inclusive_scan_u32(counts, offs, R.cap, temp, tb, stream); });
     u32 tot32 = 0;
     RDFGPU_HIP(hipMemcpyAsync(&tot32, offs + R.cap - 1, 4, hipMemcpyDeviceToHost, stream));
     RDFGPU_HIP(hipStreamSynchronize(stream)); metrics.host_syncs++;
@@ -446,15 +518,16 @@ DevTable Plan::exec_join(NodeInfo& nd) {
   for (u32 c = 0; c < nd.n_proj; c++) { a.out[c] = scratch<u32>(cap); t.cols[c] = a.out[c]; }
   if (total) {
     a.counts = offs;
-    if (hash) launch_join_write(a, stream); else launch_nlj_write(a, stream);
-    metrics.kernels_launched++;
+    // write pass: 4·(k+p_p)·N_p + 8·N_p + 4·c_o·N_o   (probe half)
+    timed(hash ? KC_JOIN_WRITE : KC_NLJ_WRITE, 0, R.cap, R.n_dev, 4ull * probe_cols + 8, nullptr, total, 4ull * nd.n_proj,
+          [&] { if (hash) launch_join_write(a, stream); else launch_nlj_write(a, stream); });
   }
   t.cap = cap;
   if (left_join) {
     a.n_out_dev = new_counter();
     RDFGPU_HIP(hipMemcpyAsync(a.n_out_dev, &total, sizeof(u64), hipMemcpyHostToDevice, stream));
     RDFGPU_HIP(hipStreamSynchronize(stream)); metrics.host_syncs++;   // `total` is a stack variable
-    launch_join_left_unmatched(a, stream); metrics.kernels_launched++;
+    timed(KC_LEFT_TAIL, 0, L.cap, L.n_dev, 1, nullptr, 0, 0, [&] { launch_join_left_unmatched(a, stream); });
     t.n_dev = a.n_out_dev;
   }
   return t;

@@ -26,29 +26,56 @@ struct NodeInfo {
   u32 n_proj = 0; u32 proj[kMaxCols] = {};
   ExprProgram prog{};             // filter / join filter
   int shape = 0;                  // filter kernel specialisation
+  u32 n_enc_tv = 0;               // ENC_TV gathers per row (algorithmic bytes)
+  u32 n_cols_read = 0;            // distinct input columns the kernel has to read
   int source = -1;                // index into Plan::sources
 };
 
 struct BoundTable { std::vector<const u32*> cols; u64 n_rows = 0; bool bound = false; };
 
+// Kernel classes for per-kernel timing; names are what rocprofv3 --kernel-trace prints.
+enum KernelClass {
+  KC_LOCATE, KC_SCAN_COUNT, KC_SCAN_WRITE, KC_FILTER_ID, KC_FILTER_TV, KC_FILTER_VM, KC_CROSS, KC_JOIN_BUILD,
+  KC_JOIN_COUNT, KC_JOIN_WRITE, KC_LEFT_TAIL, KC_NLJ_COUNT, KC_NLJ_WRITE, KC_DEVICE_SCAN, KC__N
+};
+extern const char* const kKernelNames[KC__N];
+
+struct KernelStat { u32 launches = 0; double ms = 0; u64 bytes = 0; u64 rows = 0; };
+
+// One timed launch whose byte count may depend on device-side row counts, resolved after the run.
+struct PendingLaunch {
+  int kc;
+  hipEvent_t start, stop;
+  u64 fixed_bytes;      // bytes known on the host
+  u64 rows_cap;         // rows streamed if no device count
+  const u64* rows_dev;  // device count of streamed rows (or null)
+  u64 bytes_per_row;    // multiplied by the live streamed rows
+  const u64* out_dev;   // device count of produced rows (or null)
+  u64 out_rows;         // produced rows if known on the host
+  u64 bytes_per_out;    // multiplied by the produced rows
+};
+
 struct Plan {
   Store* store = nullptr;
   std::vector<NodeInfo> nodes;
   std::vector<SourceInfo> sources;
-  std::vector<u32> pool;          // IN-set ids (host copy)
+  std::vector<u32> pool;          // IN-set ids of residual predicates (host copy)
   u32* pool_dev = nullptr;        // same, on device
   u32 root = 0;
+  ExecContext* ctx = nullptr;     // stream, events, counters (pooled per store)
   hipStream_t stream = nullptr;
-  hipEvent_t ev_start = nullptr, ev_stop = nullptr;
   std::vector<BoundTable> tables;
 
   // per-execution state
   std::vector<void*> allocs;      // pool blocks owned by the current result / intermediates
   u64* counters = nullptr;        // device u64 slots for operator output counts
   u32 counters_used = 0;
-  LocateJob* jobs_dev = nullptr; u64* lohi_dev = nullptr;
   DevTable result; u64 result_rows = 0; bool executed = false;
   rdfgpu_metrics metrics{};
+  bool timing = false;
+  std::vector<PendingLaunch> pending;
+  u32 events_used = 0;
+  KernelStat kstats[KC__N];
   // Arrow batch stream over a host copy of the result
   std::vector<std::vector<u32>> host_cols; bool host_valid = false; u64 cursor = 0;
 
@@ -65,6 +92,11 @@ struct Plan {
   template <class T> T* scratch(u64 n);
   u64* new_counter();
   u64 read_u64(const u64* dev);
+  // brackets one launch with HIP events when timing is on
+  template <class F>
+  void timed(int kc, u64 fixed_bytes, u64 rows_cap, const u64* rows_dev, u64 bytes_per_row,
+             const u64* out_dev, u64 out_rows, u64 bytes_per_out, F&& launch);
+  void resolve_timing();
 };
 
 Plan* plan_compile(Store* store, const rdfgpu_plan_desc* desc);

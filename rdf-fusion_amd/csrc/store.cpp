@@ -84,8 +84,61 @@ Store* store_create(const rdfgpu_config* cfg) {
 
 void Store::activate() const { RDFGPU_HIP(hipSetDevice(device)); }
 
+// ------------------------------------------------------------------------------------------------
+// ExecContext pool
+// ------------------------------------------------------------------------------------------------
+hipEvent_t ExecContext::event(u32 i) {
+  while (events.size() <= i) {
+    hipEvent_t e;
+    RDFGPU_HIP(hipEventCreate(&e));
+    events.push_back(e);
+  }
+  return events[i];
+}
+ExecContext::~ExecContext() {
+  for (hipEvent_t e : events) (void)hipEventDestroy(e);
+  if (counters) (void)hipFree(counters);
+  if (counters_host) (void)hipHostFree(counters_host);
+  if (jobs_dev) (void)hipFree(jobs_dev);
+  if (lohi_dev) (void)hipFree(lohi_dev);
+  if (jobs_host) (void)hipHostFree(jobs_host);
+  if (lohi_host) (void)hipHostFree(lohi_host);
+  if (stream) (void)hipStreamDestroy(stream);
+}
+ExecContext* Store::acquire_context(u32 n_sources) {
+  activate();
+  ExecContext* c = nullptr;
+  {
+    std::lock_guard<std::mutex> g(ctx_mu);
+    if (!free_ctx.empty()) { c = free_ctx.back(); free_ctx.pop_back(); }
+  }
+  if (!c) {
+    c = new ExecContext();
+    RDFGPU_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    RDFGPU_HIP(hipMalloc((void**)&c->counters, 256 * sizeof(u64)));
+    RDFGPU_HIP(hipHostMalloc((void**)&c->counters_host, 256 * sizeof(u64), hipHostMallocDefault));
+  }
+  const u32 need = n_sources ? n_sources : 1;
+  if (c->job_cap < need) {
+    if (c->jobs_dev) { (void)hipFree(c->jobs_dev); (void)hipFree(c->lohi_dev); (void)hipHostFree(c->jobs_host); (void)hipHostFree(c->lohi_host); }
+    const u32 cap = need < 16 ? 16 : need;
+    RDFGPU_HIP(hipMalloc(&c->jobs_dev, cap * 128));          // sizeof(LocateJob) <= 128
+    RDFGPU_HIP(hipMalloc((void**)&c->lohi_dev, cap * 2 * sizeof(u64)));
+    RDFGPU_HIP(hipHostMalloc(&c->jobs_host, cap * 128, hipHostMallocDefault));
+    RDFGPU_HIP(hipHostMalloc((void**)&c->lohi_host, cap * 2 * sizeof(u64), hipHostMallocDefault));
+    c->job_cap = cap;
+  }
+  return c;
+}
+void Store::release_context(ExecContext* c) {
+  if (!c) return;
+  std::lock_guard<std::mutex> g(ctx_mu);
+  free_ctx.push_back(c);
+}
+
 Store::~Store() {
   (void)hipSetDevice(device);
+  for (ExecContext* c : free_ctx) delete c;
   for (auto& ix : idx) for (auto& c : ix.col) if (c) (void)hipFree(c);
   if (tv) (void)hipFree(tv);
   if (dec) (void)hipFree(dec);

@@ -29,6 +29,20 @@ class DevicePool {
   u64 in_use_ = 0;
 };
 
+// Per-plan execution resources (a HIP stream, a grow-on-demand event pool, the device counters and
+// the locate staging buffers).  Creating these costs far more than a BSBM query takes, so finished
+// plans hand them back to the store for the next plan.
+struct ExecContext {
+  hipStream_t stream = nullptr;
+  std::vector<hipEvent_t> events;
+  u64* counters = nullptr;      // 256 device u64 slots
+  u64* counters_host = nullptr; // pinned mirror
+  void* jobs_dev = nullptr; u64* lohi_dev = nullptr; u32 job_cap = 0;
+  void* jobs_host = nullptr; u64* lohi_host = nullptr;   // pinned staging
+  hipEvent_t event(u32 i);
+  ~ExecContext();
+};
+
 struct Permutation {
   u32* col[4] = {nullptr, nullptr, nullptr, nullptr};  // index-order columns (flat, sorted, unique)
   u64 n = 0;
@@ -44,6 +58,10 @@ struct Store {
   DevicePool pool;
   hipStream_t stream = nullptr;  // load-path stream
   std::shared_mutex mu;   // readers = running plans (a snapshot), writers = extend / remove / clear
+  std::mutex ctx_mu;
+  std::vector<ExecContext*> free_ctx;
+  ExecContext* acquire_context(u32 n_sources);
+  void release_context(ExecContext* c);
 
   ~Store();
   void activate() const;

@@ -70,6 +70,8 @@ def load_library():
     lib.rdfgpu_plan_metrics.argtypes = [vp, C.POINTER(abi.Metrics)]
     lib.rdfgpu_plan_selected_index.argtypes = [vp, C.c_uint32, u32p]
     lib.rdfgpu_plan_stream.argtypes = [vp, C.POINTER(vp)]
+    lib.rdfgpu_plan_enable_kernel_timing.argtypes = [vp, C.c_int]
+    lib.rdfgpu_plan_kernel_stats.argtypes = [vp, C.POINTER(abi.KernelStat), C.c_uint32, u32p]
     lib.rdfgpu_scan_score.argtypes = [C.POINTER(abi.ScanInstruction)]
     lib.rdfgpu_scan_score.restype = C.c_uint64
     lib.rdfgpu_choose_index.argtypes = [C.POINTER(abi.ScanInstruction), C.c_uint32]
@@ -302,6 +304,18 @@ class GpuPlan:
         m = abi.Metrics()
         _check(self._lib.rdfgpu_plan_metrics(self._h, C.byref(m)))
         return m
+
+    def enable_kernel_timing(self, on=True):
+        _check(self._lib.rdfgpu_plan_enable_kernel_timing(self._h, int(on)))
+        return self
+
+    def kernel_stats(self):
+        """[(kernel name, launches, total ms, algorithmic bytes, rows in)] of the last execute."""
+        arr = (abi.KernelStat * 32)()
+        n = C.c_uint32()
+        _check(self._lib.rdfgpu_plan_kernel_stats(self._h, arr, 32, C.byref(n)))
+        return [(arr[i].kernel.decode(), arr[i].launches, arr[i].total_ms, arr[i].algorithmic_bytes, arr[i].rows_in)
+                for i in range(n.value)]
 
     def selected_index(self, node):
         out = C.c_uint32()
