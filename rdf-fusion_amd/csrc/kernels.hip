@@ -363,6 +363,138 @@ __global__ __launch_bounds__(kBlock) void join_left_unmatched_kernel(const JoinA
   }
 }
 
+// --------------------------------------------------------------------------------------------------
+// K4+K5 fused, LDS-staged: the whole build side (<= 8192 rows) lives in ONE LDS open-addressing table
+// per workgroup ({key0, row} slots, linear probing, load factor <= 0.5), built once per workgroup from
+// L2 and then probed by that workgroup's share of the probe side, 2048 rows per tile.
+// Variable-cardinality output without a count pass over HBM: pass 1 counts each lane's matches out of
+// LDS, a wave64 shuffle scan + one LDS exchange give every lane its offset, ONE atomicAdd per tile
+// reserves the output range, pass 2 re-walks LDS and writes.  The total is always exact; if it exceeds
+// the optimistic capacity the host re-runs with the exact size.
+// This is the path every BSBM Q1/Q5 join takes after the engine's join reordering (build = the
+// smaller input, cross products decomposed): J2/J3 build ~2 k rows and probe 285 k.
+// --------------------------------------------------------------------------------------------------
+constexpr int kLdsBlock = 512;
+constexpr int kLdsItems = 4;
+constexpr int kLdsTile = kLdsBlock * kLdsItems;
+
+__device__ __forceinline__ u32 wave_incl_scan(u32 v) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) { const u32 t = __shfl_up(v, d, 64); if ((int)(threadIdx.x & 63) >= d) v += t; }
+  return v;
+}
+__device__ __forceinline__ u32 ljoin_col(const LdsJoinArgs& a, u32 c, u64 i, u64 j) {  // column c of [left cols, right cols]
+  if (a.build_is_left) return c < a.n_build_cols ? a.build[c][i] : a.probe[c - a.n_build_cols][j];
+  return c < a.n_probe_cols ? a.probe[c][j] : a.build[c - a.n_probe_cols][i];
+}
+
+template <bool WRITE>
+__device__ __forceinline__ u32 lds_probe_row(const LdsJoinArgs& a, const uint2* slots, u64 j, u64 pos) {
+  u32 key[RDFGPU_MAX_KEYS]; bool null_key = false;
+  for (u32 q = 0; q < a.n_keys; q++) { key[q] = a.probe[a.probe_keys[q]][j]; null_key = null_key || key[q] == 0; }
+  if (null_key) return 0;   // NullEqualsNothing
+  if (a.has_probe_filter) {   // fused FilterExec of the probe child
+    const Val r = eval_program(a.probe_prog, a.tt, [&](u32 col) { return a.probe[col][j]; });
+    if (r.lo != 1) return 0;
+  }
+  u32 c = 0;
+  u32 h = hash_keys(key, a.n_keys) & a.tbl_mask;
+  for (;;) {
+    const uint2 s = slots[h];
+    if (s.y == kNil) break;
+    h = (h + 1) & a.tbl_mask;
+    if (s.x != key[0]) continue;
+    bool eq = true;
+    for (u32 q = 1; q < a.n_keys; q++) eq = eq && a.build[a.build_keys[q]][s.y] == key[q];
+    if (!eq) continue;
+    if (a.has_filter) {
+      const Val r = eval_program(a.prog, a.tt, [&](u32 col) { return ljoin_col(a, col, s.y, j); });
+      if (r.lo != 1) continue;
+    }
+    if (WRITE) {
+      if (pos + c < a.out_cap) for (u32 oc = 0; oc < a.n_out_cols; oc++) a.out[oc][pos + c] = ljoin_col(a, a.proj[oc], s.y, j);
+      if (a.visited) a.visited[s.y] = 1;
+    }
+    c++;
+  }
+  return c;
+}
+
+__global__ __launch_bounds__(kLdsBlock) void lds_join_kernel(const LdsJoinArgs a) {
+  extern __shared__ __align__(16) unsigned char lds_raw[];
+  uint2* slots = reinterpret_cast<uint2*>(lds_raw);
+  __shared__ u32 wave_tot[kLdsBlock / 64];
+  __shared__ u64 tile_base;
+  const u32 tid = threadIdx.x;
+  for (u32 s = tid; s <= a.tbl_mask; s += kLdsBlock) slots[s] = make_uint2(0u, kNil);
+  __syncthreads();
+  const u64 nb = live_rows(a.n_build_dev, a.n_build_cap);
+  for (u64 i = tid; i < nb; i += kLdsBlock) {
+    u32 key[RDFGPU_MAX_KEYS]; bool null_key = false;
+    for (u32 q = 0; q < a.n_keys; q++) { key[q] = a.build[a.build_keys[q]][i]; null_key = null_key || key[q] == 0; }
+    if (null_key) continue;
+    u32 h = hash_keys(key, a.n_keys) & a.tbl_mask;
+    for (;;) {
+      if (atomicCAS(&slots[h].y, kNil, (u32)i) == kNil) { slots[h].x = key[0]; break; }
+      h = (h + 1) & a.tbl_mask;
+    }
+  }
+  __syncthreads();
+
+  const u64 np = live_rows(a.n_probe_dev, a.n_probe_cap);
+  const u64 n_tiles = (np + kLdsTile - 1) / kLdsTile;
+  const int lane = tid & 63, wave = tid >> 6;
+  for (u64 tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const u64 base = tile * kLdsTile;
+    u32 cnt[kLdsItems]; u32 mine = 0;
+#pragma unroll
+    for (int k = 0; k < kLdsItems; k++) {
+      const u64 j = base + (u64)k * kLdsBlock + tid;
+      cnt[k] = j < np ? lds_probe_row<false>(a, slots, j, 0) : 0u;
+      mine += cnt[k];
+    }
+    const u32 incl = wave_incl_scan(mine);
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    if (tid == 0) {
+      u32 t = 0;
+      for (int w = 0; w < kLdsBlock / 64; w++) t += wave_tot[w];
+      u64 b = 0;
+      if (t) {
+        b = atomicAdd((unsigned long long*)a.n_out_dev, (unsigned long long)t);
+        if (b + t > a.out_cap) *a.overflow = 1u;
+      }
+      tile_base = b;
+    }
+    __syncthreads();
+    u64 pos = tile_base + (incl - mine);
+    for (int w = 0; w < wave; w++) pos += wave_tot[w];
+#pragma unroll
+    for (int k = 0; k < kLdsItems; k++) {
+      if (cnt[k]) {
+        const u64 j = base + (u64)k * kLdsBlock + tid;
+        lds_probe_row<true>(a, slots, j, pos);
+        pos += cnt[k];
+      }
+    }
+    __syncthreads();   // wave_tot / tile_base are reused by the next tile
+  }
+}
+
+void launch_lds_join(const LdsJoinArgs& a, hipStream_t s) {
+  const u64 n_tiles = (a.n_probe_cap + kLdsTile - 1) / kLdsTile;
+  const size_t lds = (size_t)(a.tbl_mask + 1) * sizeof(uint2);
+  // enough workgroups to cover all 256 CUs; each builds its LDS copy once and strides over the tiles
+  const u64 max_wg = lds > 64 * 1024 ? 256 : lds > 32 * 1024 ? 512 : 1024;
+  const u64 g = n_tiles < max_wg ? (n_tiles ? n_tiles : 1) : max_wg;
+  static bool attr_set = false;
+  if (!attr_set) {   // dynamic LDS above 64 KiB has to be opted into
+    RDFGPU_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lds_join_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(lds_join_kernel, dim3((unsigned)g), dim3(kLdsBlock), lds, s, a);
+}
+
 void launch_join_build(const JoinArgs& a, hipStream_t s) { hipLaunchKernelGGL(join_build_kernel, grid_for(a.n_left_cap), dim3(kBlock), 0, s, a); }
 void launch_join_count(const JoinArgs& a, hipStream_t s) { hipLaunchKernelGGL(join_probe_kernel<false>, grid_for(a.n_right_cap), dim3(kBlock), 0, s, a); }
 void launch_join_write(const JoinArgs& a, hipStream_t s) { hipLaunchKernelGGL(join_probe_kernel<true>, grid_for(a.n_right_cap), dim3(kBlock), 0, s, a); }

@@ -98,6 +98,29 @@ void launch_join_left_unmatched(const JoinArgs& a, hipStream_t s);
 void launch_nlj_count(const JoinArgs& a, hipStream_t s);
 void launch_nlj_write(const JoinArgs& a, hipStream_t s);
 
+// ---- K4+K5 fused: LDS-staged hash join for build sides that fit one workgroup's LDS ----
+constexpr u32 kLdsJoinMaxBuild = 8192;   // rows; 16384 slots x 8 B = 128 KiB of the CU's 160 KiB
+struct LdsJoinArgs {
+  const u32* build[kMaxCols]; const u32* probe[kMaxCols];
+  u32* out[kMaxCols];
+  u32 n_build_cols, n_probe_cols, n_out_cols;
+  u32 proj[kMaxCols];       // into the operator's [left cols, right cols] schema
+  u32 build_is_left;        // 1: build = left input; 0: the engine swapped sides (inner joins only)
+  u32 n_keys; u32 build_keys[RDFGPU_MAX_KEYS]; u32 probe_keys[RDFGPU_MAX_KEYS];
+  const u64* n_build_dev; u64 n_build_cap;
+  const u64* n_probe_dev; u64 n_probe_cap;
+  u32 tbl_mask;             // LDS slots - 1 (power of two >= 2 x build rows)
+  u64* n_out_dev;           // exact number of matches (zeroed before launch)
+  u64 out_cap;              // rows the out columns can hold (optimistic)
+  u32* overflow;            // set when the matches did not fit
+  u8* visited;              // left join: per build row
+  u32 has_filter, has_probe_filter;
+  TypedTable tt;
+  ExprProgram prog;         // join filter over [left cols, right cols]
+  ExprProgram probe_prog;   // fused FilterExec of the probe child, over the probe columns
+};
+void launch_lds_join(const LdsJoinArgs& a, hipStream_t s);
+
 // ---- utilities ----
 void launch_fill_u32(u32* p, u32 v, u64 n, hipStream_t s);
 void launch_gather_u32(const u32* src, const u32* idx, u32* dst, u64 n, hipStream_t s);

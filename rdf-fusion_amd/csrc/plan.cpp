@@ -175,6 +175,50 @@ Plan* plan_compile(Store* store, const rdfgpu_plan_desc* d) {
     }
   }
 
+  // Join reordering (physical rewrite, results unchanged): an inner HashJoinExec whose build child is a
+  // CrossJoinExec(A, B) and whose equi-keys come partly from A and partly from B
+  //     (A x B) JOIN C ON a = c1 AND b = c2          (Q5 (Execution Plan).snap:18-26: label x features(X))
+  // is the join graph A - C - B; it runs as  A JOIN (B JOIN C ON b = c2) ON a = c1  without ever
+  // materialising |A| x |B| rows.  Column order [A, B, C] is preserved, so filter and projection stay valid.
+  if (!std::getenv("RDFGPU_NO_JOIN_REORDER")) {
+    const u32 n0 = (u32)plan->nodes.size();
+    std::vector<u32> refs(n0, 0);
+    for (u32 i = 0; i < n0; i++) {
+      if (plan->nodes[i].d.left >= 0) refs[plan->nodes[i].d.left]++;
+      if (plan->nodes[i].d.right >= 0) refs[plan->nodes[i].d.right]++;
+    }
+    for (u32 i = 0; i < n0; i++) {
+      if (plan->nodes[i].d.kind != RDFGPU_NODE_HASH_JOIN || plan->nodes[i].d.join_type != RDFGPU_JOIN_INNER) continue;
+      const u32 ci = (u32)plan->nodes[i].d.left;
+      if (plan->nodes[ci].d.kind != RDFGPU_NODE_CROSS_JOIN || refs[ci] != 1) continue;
+      const u32 ai = (u32)plan->nodes[ci].d.left, bi = (u32)plan->nodes[ci].d.right, cri = (u32)plan->nodes[i].d.right;
+      const u32 wA = plan->nodes[ai].width, wB = plan->nodes[bi].width, wC = plan->nodes[cri].width;
+      bool identity = plan->nodes[ci].n_proj == wA + wB;
+      for (u32 k = 0; identity && k < wA + wB; k++) identity = plan->nodes[ci].proj[k] == k;
+      if (!identity || wB + wC > (u32)kMaxCols) continue;
+      rdfgpu_plan_node jd = plan->nodes[i].d;
+      u32 nA = 0, nB = 0;
+      rdfgpu_plan_node td{};   // T = B JOIN C
+      td.kind = RDFGPU_NODE_HASH_JOIN; td.join_type = RDFGPU_JOIN_INNER; td.left = (int32_t)bi; td.right = (int32_t)cri;
+      td.n_proj = RDFGPU_NO_PROJECTION;
+      u32 la[RDFGPU_MAX_KEYS], ra[RDFGPU_MAX_KEYS];
+      for (u32 k = 0; k < jd.n_keys; k++) {
+        if (jd.left_keys[k] < wA) { la[nA] = jd.left_keys[k]; ra[nA] = wB + jd.right_keys[k]; nA++; }
+        else { td.left_keys[nB] = jd.left_keys[k] - wA; td.right_keys[nB] = jd.right_keys[k]; nB++; }
+      }
+      if (nA == 0 || nB == 0) continue;
+      td.n_keys = nB;
+      NodeInfo t;
+      t.d = td; t.width = wB + wC; t.n_proj = wB + wC;
+      for (u32 k = 0; k < wB + wC; k++) t.proj[k] = k;
+      plan->nodes.push_back(t);
+      NodeInfo& j = plan->nodes[i];
+      j.d.left = (int32_t)ai; j.d.right = (int32_t)(plan->nodes.size() - 1);
+      j.d.n_keys = nA;
+      for (u32 k = 0; k < nA; k++) { j.d.left_keys[k] = la[k]; j.d.right_keys[k] = ra[k]; }
+    }
+  }
+
   // per-node byte accounting inputs: distinct columns read, typed gathers per row
   for (NodeInfo& nd : plan->nodes) {
     bool used[2 * kMaxCols] = {};
@@ -217,7 +261,7 @@ const char* const kKernelNames[KC__N] = {
     "void rdfgpu::filter_kernel<1>", "void rdfgpu::filter_kernel<2>", "void rdfgpu::filter_kernel<0>",
     "rdfgpu::cross_kernel", "rdfgpu::join_build_kernel", "void rdfgpu::join_probe_kernel<false>",
     "void rdfgpu::join_probe_kernel<true>", "rdfgpu::join_left_unmatched_kernel", "void rdfgpu::nlj_kernel<false>",
-    "void rdfgpu::nlj_kernel<true>", "rocprim device scan"};
+    "void rdfgpu::nlj_kernel<true>", "rocprim device scan", "rdfgpu::lds_join_kernel"};
 
 template <class F>
 void Plan::timed(int kc, u64 fixed_bytes, u64 rows_cap, const u64* rows_dev, u64 bytes_per_row,
@@ -466,6 +510,11 @@ DevTable Plan::exec_join(NodeInfo& nd) {
   // HashJoinExec / NestedLoopJoinExec
   if (L.cap == 0 || (R.cap == 0 && !left_join)) { t.cap = 0; return t; }
   const bool hash = nd.d.kind == RDFGPU_NODE_HASH_JOIN;
+  if (hash && !std::getenv("RDFGPU_NO_LDS_JOIN")) {
+    // build on the smaller input (an inner join is symmetric; a left join must build on the preserved side)
+    const bool build_left = left_join || L.cap <= R.cap;
+    if ((build_left ? L.cap : R.cap) <= kLdsJoinMaxBuild) return exec_lds_join(nd, L, R, build_left);
+  }
   JoinArgs a{};
   for (u32 c = 0; c < L.n_cols; c++) a.left[c] = L.cols[c];
   for (u32 c = 0; c < R.n_cols; c++) a.right[c] = R.cols[c];
@@ -530,6 +579,84 @@ DevTable Plan::exec_join(NodeInfo& nd) {
     timed(KC_LEFT_TAIL, 0, L.cap, L.n_dev, 1, nullptr, 0, 0, [&] { launch_join_left_unmatched(a, stream); });
     t.n_dev = a.n_out_dev;
   }
+  return t;
+}
+
+// HashJoinExec whose build side fits one workgroup's LDS: one fused kernel, optimistic output capacity.
+DevTable Plan::exec_lds_join(NodeInfo& nd, const DevTable& L, const DevTable& R, bool build_left) {
+  const bool left_join = nd.d.join_type == RDFGPU_JOIN_LEFT;
+  const DevTable& B = build_left ? L : R;
+  const DevTable& P = build_left ? R : L;
+  DevTable t;
+  t.n_cols = nd.n_proj;
+  LdsJoinArgs a{};
+  for (u32 c = 0; c < B.n_cols; c++) a.build[c] = B.cols[c];
+  for (u32 c = 0; c < P.n_cols; c++) a.probe[c] = P.cols[c];
+  a.n_build_cols = B.n_cols; a.n_probe_cols = P.n_cols; a.n_out_cols = nd.n_proj;
+  for (u32 c = 0; c < nd.n_proj; c++) a.proj[c] = nd.proj[c];
+  a.build_is_left = build_left ? 1 : 0;
+  a.n_keys = nd.d.n_keys;
+  for (u32 k = 0; k < a.n_keys; k++) {
+    a.build_keys[k] = build_left ? nd.d.left_keys[k] : nd.d.right_keys[k];
+    a.probe_keys[k] = build_left ? nd.d.right_keys[k] : nd.d.left_keys[k];
+  }
+  a.n_build_dev = B.n_dev; a.n_build_cap = B.cap; a.n_probe_dev = P.n_dev; a.n_probe_cap = P.cap;
+  u32 slots = 64;
+  while (slots < 2 * B.cap) slots <<= 1;
+  a.tbl_mask = slots - 1;
+  a.has_filter = nd.prog.n ? 1 : 0;
+  a.prog = nd.prog;
+  a.tt = store->typed_table();
+  if (left_join) a.visited = scratch<u8>(L.cap);
+  u64* n_out = new_counter();
+  u32* overflow = reinterpret_cast<u32*>(new_counter());
+  a.n_out_dev = n_out; a.overflow = overflow;
+  const u64 tail = left_join ? L.cap : 0;
+
+  // columns the kernel reads on the probe side: keys ∪ projected ∪ filter columns
+  u32 probe_cols = 0, build_payload = 0;
+  {
+    bool pu[kMaxCols] = {}, bu[kMaxCols] = {};
+    const u32 nl = L.n_cols;
+    auto mark = [&](u32 c) { const bool from_left = c < nl; const u32 local = from_left ? c : c - nl; ((from_left == build_left) ? bu : pu)[local] = true; };
+    for (u32 k = 0; k < a.n_keys; k++) { pu[a.probe_keys[k]] = true; }
+    for (u32 c = 0; c < nd.n_proj; c++) mark(nd.proj[c]);
+    for (u32 i = 0; i < nd.prog.n; i++) if (nd.prog.nodes[i].op == RDFGPU_EX_COLUMN) mark(nd.prog.nodes[i].u);
+    for (u32 k = 0; k < a.n_keys; k++) bu[a.build_keys[k]] = false;
+    for (bool b : pu) probe_cols += b;
+    for (bool b : bu) build_payload += b;
+  }
+  // SURVEY §8d hash join: 4(k+p_b)N_b + 8N_b + 4(k+p_p)N_p + 8N_p + 4 c_o N_o  (the 8-byte slot lives in LDS here)
+  const u64 fixed = (4ull * (a.n_keys + build_payload) + 8) * B.cap;
+
+  u64 out_cap = P.cap < 1024 ? 1024 : P.cap;   // optimistic: at most one match per probe row on average
+  u64 total = 0;
+  for (int attempt = 0; attempt < 2; attempt++) {
+    a.out_cap = out_cap;
+    for (u32 c = 0; c < nd.n_proj; c++) { a.out[c] = scratch<u32>(out_cap + tail); t.cols[c] = a.out[c]; }
+    if (left_join) RDFGPU_HIP(hipMemsetAsync(a.visited, 0, L.cap, stream));
+    timed(KC_LDS_JOIN, fixed, P.cap, P.n_dev, 4ull * probe_cols + 8, n_out, 0, 4ull * nd.n_proj, [&] { launch_lds_join(a, stream); });
+    const u32 i0 = (u32)(n_out - counters);
+    RDFGPU_HIP(hipMemcpyAsync(ctx->counters_host + i0, counters + i0, 2 * sizeof(u64), hipMemcpyDeviceToHost, stream));
+    RDFGPU_HIP(hipStreamSynchronize(stream)); metrics.host_syncs++;
+    total = ctx->counters_host[i0];
+    const bool ovf = (ctx->counters_host[i0 + 1] & 0xFFFFFFFFull) != 0;
+    if (!ovf) break;
+    if (attempt == 1) fail(RDFGPU_ERR_DEVICE, "LDS join overflowed its exact-size output");
+    out_cap = total;   // the count is exact even when the writes did not fit: run again with room for all
+    RDFGPU_HIP(hipMemsetAsync(n_out, 0, 2 * sizeof(u64), stream));
+  }
+  t.cap = total + tail;
+  if (!left_join) { if (total == 0) t.cap = 0; return t; }
+  // left join tail: unmatched build rows, nulls on the right
+  JoinArgs ja{};
+  for (u32 c = 0; c < L.n_cols; c++) ja.left[c] = L.cols[c];
+  ja.n_left_cols = L.n_cols; ja.n_right_cols = R.n_cols; ja.n_out_cols = nd.n_proj;
+  for (u32 c = 0; c < nd.n_proj; c++) { ja.proj[c] = nd.proj[c]; ja.out[c] = a.out[c]; }
+  ja.n_left_dev = L.n_dev; ja.n_left_cap = L.cap;
+  ja.visited = a.visited; ja.n_out_dev = n_out;
+  timed(KC_LEFT_TAIL, 0, L.cap, L.n_dev, 1, nullptr, 0, 0, [&] { launch_join_left_unmatched(ja, stream); });
+  t.n_dev = n_out;
   return t;
 }
 

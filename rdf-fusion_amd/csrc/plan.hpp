@@ -36,7 +36,7 @@ struct BoundTable { std::vector<const u32*> cols; u64 n_rows = 0; bool bound = f
 // Kernel classes for per-kernel timing; names are what rocprofv3 --kernel-trace prints.
 enum KernelClass {
   KC_LOCATE, KC_SCAN_COUNT, KC_SCAN_WRITE, KC_FILTER_ID, KC_FILTER_TV, KC_FILTER_VM, KC_CROSS, KC_JOIN_BUILD,
-  KC_JOIN_COUNT, KC_JOIN_WRITE, KC_LEFT_TAIL, KC_NLJ_COUNT, KC_NLJ_WRITE, KC_DEVICE_SCAN, KC__N
+  KC_JOIN_COUNT, KC_JOIN_WRITE, KC_LEFT_TAIL, KC_NLJ_COUNT, KC_NLJ_WRITE, KC_DEVICE_SCAN, KC_LDS_JOIN, KC__N
 };
 extern const char* const kKernelNames[KC__N];
 
@@ -88,6 +88,7 @@ struct Plan {
   DevTable exec_source(NodeInfo& nd);
   DevTable exec_filter(NodeInfo& nd);
   DevTable exec_join(NodeInfo& nd);
+  DevTable exec_lds_join(NodeInfo& nd, const DevTable& L, const DevTable& R, bool build_left);
   void release_intermediates();
   template <class T> T* scratch(u64 n);
   u64* new_counter();
