@@ -32,28 +32,47 @@ static inline dim3 grid_for(u64 rows) { u64 g = (rows + kTile - 1) / kTile; retu
 // Behavioural twin of MemIndexData::prune_relevant_row_groups (quad_index_data.rs:155-284) on a flat
 // sorted column (the reference walks 8192-row groups linearly; here it is O(log n) per level).
 // --------------------------------------------------------------------------------------------------
-__global__ void locate_kernel(const LocateJob* jobs, u32 n_jobs, u64* lo_hi) {
-  const u32 j = blockIdx.x * blockDim.x + threadIdx.x;
+// One wave per job; each search step tests 64 pivots at once (a 65-ary search: log65(1e8) ~ 4.4 dependent
+// HBM round trips per bound instead of 27 for a scalar binary search).
+// wave_partition_point returns the first index in [lo, hi) whose value is > key (UPPER) or >= key (!UPPER).
+template <bool UPPER>
+__device__ __forceinline__ u64 wave_partition_point(const u32* c, u64 lo, u64 hi, u32 key) {
+  const u32 lane = threadIdx.x & 63;
+  while (hi - lo > 64) {
+    const u64 step = (hi - lo + 64) / 65;          // 64 pivots split [lo, hi) into 65 pieces
+    const u64 idx = lo + (u64)(lane + 1) * step - 1;
+    bool below = false;                             // "pivot is left of the partition point"
+    if (idx < hi) { const u32 v = c[idx]; below = UPPER ? v <= key : v < key; }
+    const unsigned long long m = __ballot(below);
+    const u32 cnt = (u32)__popcll(m);               // pivots are sorted: the below-lanes are a prefix
+    const u64 nlo = cnt ? lo + (u64)cnt * step : lo;
+    const u64 nhi = cnt < 64 ? lo + (u64)(cnt + 1) * step - 1 : hi;   // pivot cnt (0-based) is >= point
+    lo = nlo; hi = nhi < hi ? nhi : hi;
+  }
+  bool below = false;
+  if (lo + lane < hi) { const u32 v = c[lo + lane]; below = UPPER ? v <= key : v < key; }
+  return lo + (u64)__popcll(__ballot(below));
+}
+
+__global__ __launch_bounds__(64) void locate_kernel(const LocateJob* jobs, u32 n_jobs, u64* lo_hi) {
+  const u32 j = blockIdx.x;
   if (j >= n_jobs) return;
   const LocateJob job = jobs[j];
   u64 lo = 0, hi = job.n;
   for (u32 k = 0; k < job.n_levels && lo < hi; k++) {
     const u32* c = job.col[k];
     const u32 from = job.from[k], to = job.to[k];
-    u64 a = lo, b = hi;               // lower_bound(from)
-    while (a < b) { u64 m = (a + b) >> 1; if (c[m] < from) a = m + 1; else b = m; }
-    const u64 nlo = a;
-    b = hi;                           // upper_bound(to)
-    while (a < b) { u64 m = (a + b) >> 1; if (c[m] <= to) a = m + 1; else b = m; }
-    lo = nlo; hi = a;
+    const u64 nlo = wave_partition_point<false>(c, lo, hi, from);   // lower_bound(from)
+    const u64 nhi = wave_partition_point<true>(c, nlo, hi, to);     // upper_bound(to)
+    lo = nlo; hi = nhi;
     if (from != to) break;            // below a proper range the inner levels are not contiguous (:240)
   }
   if (lo > hi) lo = hi;
-  lo_hi[2 * j] = lo; lo_hi[2 * j + 1] = hi;
+  if (threadIdx.x == 0) { lo_hi[2 * j] = lo; lo_hi[2 * j + 1] = hi; }
 }
 void launch_locate(const LocateJob* jobs_dev, u32 n_jobs, u64* lo_hi_dev, hipStream_t s) {
   if (!n_jobs) return;
-  hipLaunchKernelGGL(locate_kernel, dim3((n_jobs + 63) / 64), dim3(64), 0, s, jobs_dev, n_jobs, lo_hi_dev);
+  hipLaunchKernelGGL(locate_kernel, dim3(n_jobs), dim3(64), 0, s, jobs_dev, n_jobs, lo_hi_dev);
 }
 
 // --------------------------------------------------------------------------------------------------
@@ -130,15 +149,15 @@ void launch_scan_write(const ScanJob& job, const u32* block_offsets, hipStream_t
 // waves meet once in LDS and ONE atomicAdd per 1024-row workgroup reserves the output range
 // (FILTER keeps a row iff its EBV is true: logical_plan_builder.rs:114-129).
 // --------------------------------------------------------------------------------------------------
+// Predicate on a value already in a register (the specialised shapes read exactly one column).
 template <int SHAPE>
-__device__ __forceinline__ bool filter_pred(const FilterArgs& a, u64 row) {
+__device__ __forceinline__ bool filter_pred_value(const FilterArgs& a, u32 v) {
   if constexpr (SHAPE == 1) {  // col <ID_EQ|ID_NEQ> object-id literal; null on either side => dropped
-    const u32 v = a.in[a.prog.nodes[0].u][row];
     const u32 lit = a.prog.nodes[1].u;
     if (v == 0 || lit == 0) return false;
     return (v == lit) == (a.prog.nodes[2].op == RDFGPU_EX_ID_EQ);
-  } else if constexpr (SHAPE == 2) {  // EBV(cmp(ENC_TV(col), typed literal)) — the BSBM Q1 numeric FILTER
-    const Val x = enc_tv(a.tt, a.in[a.prog.nodes[0].u][row]);
+  } else {                     // EBV(cmp(ENC_TV(col), typed literal)) — the BSBM Q1 numeric FILTER
+    const Val x = enc_tv(a.tt, v);
     const rdfgpu_expr_node& l = a.prog.nodes[2];
     Val y = val_tv_null(); y.tag = l.tag; y.flags = l.flags; y.aux = l.u; y.lo = l.lo; y.hi = l.hi;
     const int o = tv_partial_cmp(x, y);
@@ -146,31 +165,58 @@ __device__ __forceinline__ bool filter_pred(const FilterArgs& a, u64 row) {
     const u8 op = a.prog.nodes[3].op;
     return op == RDFGPU_EX_GT ? o > 0 : op == RDFGPU_EX_LT ? o < 0 : op == RDFGPU_EX_GEQ ? o >= 0
          : op == RDFGPU_EX_LEQ ? o <= 0 : op == RDFGPU_EX_EQ ? o == 0 : o != 0;
-  } else {
-    if (a.prog.n == 0) return true;
-    const Val r = eval_program(a.prog, a.tt, [&](u32 c) { return a.in[c][row]; });
-    return r.lo == 1;
   }
 }
 
+// Workgroup = 256 lanes x `iters` rounds x 4 consecutive rows per lane (one 16-byte load per column and
+// round when the columns are 16-B aligned modulo a common head skip `mis`).  Pass 1 keeps each lane's
+// verdicts in a 64-bit register mask, so nothing is read or evaluated twice; ONE atomicAdd per workgroup
+// (<= 16 K rows) reserves the output range — same-address atomics retire at only ~88 per microsecond on
+// this chip, so per-1024-row reservations would cap a 5.5 M-row filter at ~60 us; pass 2 turns the masks
+// into wave ballots and writes each round's survivors contiguously.
+constexpr int kFilterMaxIters = 16;
 template <int SHAPE>
 __global__ __launch_bounds__(kBlock) void filter_kernel(const FilterArgs a) {
   __shared__ u32 wave_tot[kBlock / 64];
   __shared__ u64 block_base;
   const u64 n = live_rows(a.n_in_dev, a.n_in_cap);
-  const u64 base = (u64)blockIdx.x * kTile;
-  if (base >= n) return;  // uniform per workgroup
+  const u64 mis = a.head_skip;                      // virtual row v maps to real row v - mis
+  const u64 nv = n + mis;
+  const u64 chunk = (u64)kTile * a.iters;
+  const u64 base = (u64)blockIdx.x * chunk;
+  if (base >= nv) return;                           // uniform per workgroup
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  bool keep[kItems]; u32 pre[kItems]; u32 wtot = 0;
+  const u32* pcol = (SHAPE != 0) ? a.in[a.prog.nodes[0].u] : nullptr;
+  unsigned long long bits = 0;
+  for (u32 it = 0; it < a.iters; it++) {
+    const u64 v0 = base + (u64)it * kTile + (u64)threadIdx.x * 4;
+    if (v0 >= nv) break;
+    u32 val[4] = {0, 0, 0, 0};
+    if constexpr (SHAPE != 0) {
+      if (a.vec_ok && v0 >= mis && v0 + 4 <= nv) {  // aligned 16-byte load, entirely inside the column
+        const uint4 q = *reinterpret_cast<const uint4*>(pcol + (v0 - mis));
+        val[0] = q.x; val[1] = q.y; val[2] = q.z; val[3] = q.w;
+      } else {
 #pragma unroll
-  for (int k = 0; k < kItems; k++) {
-    const u64 row = base + (u64)k * kBlock + threadIdx.x;
-    keep[k] = row < n && filter_pred<SHAPE>(a, row);
-    const unsigned long long mask = __ballot(keep[k]);
-    pre[k] = wtot + lane_prefix(mask);
-    wtot += (u32)__popcll(mask);
+        for (int r = 0; r < 4; r++) if (v0 + r >= mis && v0 + r < nv) val[r] = pcol[v0 + r - mis];
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const u64 v = v0 + r;
+      bool keep = v >= mis && v < nv;
+      if (keep) {
+        if constexpr (SHAPE != 0) keep = filter_pred_value<SHAPE>(a, val[r]);
+        else if (a.prog.n) { const u64 row = v - mis; const Val res = eval_program(a.prog, a.tt, [&](u32 c) { return a.in[c][row]; }); keep = res.lo == 1; }
+      }
+      bits |= (unsigned long long)keep << (it * 4 + r);
+    }
   }
-  if (lane == 0) wave_tot[wave] = wtot;
+  const u32 mine = (u32)__popcll(bits);
+  u32 wsum = mine;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) wsum += __shfl_xor(wsum, d, 64);
+  if (lane == 0) wave_tot[wave] = wsum;
   __syncthreads();
   if (threadIdx.x == 0) {
     const u32 t = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
@@ -179,19 +225,40 @@ __global__ __launch_bounds__(kBlock) void filter_kernel(const FilterArgs a) {
   __syncthreads();
   u64 off = block_base;
   for (int w = 0; w < wave; w++) off += wave_tot[w];
+  if (wsum == 0) return;                            // wave-uniform
+  for (u32 it = 0; it < a.iters; it++) {
+    const u64 v0 = base + (u64)it * kTile + (u64)threadIdx.x * 4;
 #pragma unroll
-  for (int k = 0; k < kItems; k++) {
-    if (keep[k]) {
-      const u64 row = base + (u64)k * kBlock + threadIdx.x;
-      for (u32 c = 0; c < a.n_out_cols; c++) a.out[c][off + pre[k]] = a.in[a.proj[c]][row];
+    for (int r = 0; r < 4; r++) {
+      const bool keep = (bits >> (it * 4 + r)) & 1ull;
+      const unsigned long long m = __ballot(keep);
+      if (keep) {
+        const u64 row = v0 + r - mis;
+        const u64 pos = off + lane_prefix(m);
+        for (u32 c = 0; c < a.n_out_cols; c++) a.out[c][pos] = a.in[a.proj[c]][row];
+      }
+      off += (u32)__popcll(m);
     }
   }
 }
-void launch_filter(const FilterArgs& a, int shape, hipStream_t s) {
-  const dim3 g = grid_for(a.n_in_cap);
-  if (shape == 1) hipLaunchKernelGGL(filter_kernel<1>, g, dim3(kBlock), 0, s, a);
-  else if (shape == 2) hipLaunchKernelGGL(filter_kernel<2>, g, dim3(kBlock), 0, s, a);
-  else hipLaunchKernelGGL(filter_kernel<0>, g, dim3(kBlock), 0, s, a);
+void launch_filter(const FilterArgs& a0, int shape, hipStream_t s) {
+  FilterArgs a = a0;
+  // rows per workgroup: enough workgroups to fill the chip (>= ~1024), few enough reservations
+  u64 iters = (a.n_in_cap + (u64)kTile * 1024 - 1) / ((u64)kTile * 1024);
+  a.iters = (u32)(iters < 1 ? 1 : iters > kFilterMaxIters ? kFilterMaxIters : iters);
+  // 16-byte loads need every column the predicate reads to share one misalignment (slices of one
+  // permutation do; freshly allocated tables are aligned)
+  a.head_skip = 0; a.vec_ok = 0;
+  if (shape != 0) {
+    const uintptr_t p = reinterpret_cast<uintptr_t>(a.in[a.prog.nodes[0].u]);
+    if ((p & 3) == 0) { a.head_skip = (u32)((p >> 2) & 3); a.vec_ok = 1; }
+  }
+  const u64 chunk = (u64)kTile * a.iters;
+  const u64 g = (a.n_in_cap + a.head_skip + chunk - 1) / chunk;
+  const dim3 grid((unsigned)(g ? g : 1));
+  if (shape == 1) hipLaunchKernelGGL(filter_kernel<1>, grid, dim3(kBlock), 0, s, a);
+  else if (shape == 2) hipLaunchKernelGGL(filter_kernel<2>, grid, dim3(kBlock), 0, s, a);
+  else hipLaunchKernelGGL(filter_kernel<0>, grid, dim3(kBlock), 0, s, a);
 }
 
 // --------------------------------------------------------------------------------------------------
@@ -388,15 +455,57 @@ __device__ __forceinline__ u32 ljoin_col(const LdsJoinArgs& a, u32 c, u64 i, u64
   return c < a.n_probe_cols ? a.probe[c][j] : a.build[c - a.n_probe_cols][i];
 }
 
-template <bool WRITE>
-__device__ __forceinline__ u32 lds_probe_row(const LdsJoinArgs& a, const uint2* slots, u64 j, u64 pos) {
+// Join filter, specialised: FS 0 = none, 1 = generic VM, 3 = "window" — the BSBM Q5 shape
+//   EBV(cmp1(ENC_TV(x), ADD|SUB(ENC_TV(y), lit1))) AND EBV(cmp2(ENC_TV(x'), ADD|SUB(ENC_TV(y'), lit2)))
+// evaluated with all typed-value gathers issued back to back (one HBM/L2 latency instead of four).
+__device__ __forceinline__ bool cmp_holds(u8 op, int o) {
+  if (o == ORD_NONE) return false;   // error => null => not `true`
+  return op == RDFGPU_EX_GT ? o > 0 : op == RDFGPU_EX_LT ? o < 0 : op == RDFGPU_EX_GEQ ? o >= 0
+       : op == RDFGPU_EX_LEQ ? o <= 0 : op == RDFGPU_EX_EQ ? o == 0 : o != 0;
+}
+__device__ __forceinline__ Val lit_val(const rdfgpu_expr_node& l) {
+  Val y = val_tv_null(); y.tag = l.tag; y.flags = l.flags; y.aux = l.u; y.lo = l.lo; y.hi = l.hi; return y;
+}
+template <int FS>
+__device__ __forceinline__ bool ljoin_filter(const LdsJoinArgs& a, u64 i, u64 j) {
+  if constexpr (FS == 0) return true;
+  else if constexpr (FS == 3) {
+    const rdfgpu_expr_node* n = a.prog.nodes;
+    const bool same = n[0].u == n[8].u && n[2].u == n[10].u;   // wave-uniform
+    const u32 ix0 = ljoin_col(a, n[0].u, i, j), iy0 = ljoin_col(a, n[2].u, i, j);
+    const u32 ix1 = same ? ix0 : ljoin_col(a, n[8].u, i, j), iy1 = same ? iy0 : ljoin_col(a, n[10].u, i, j);
+    const Val x0 = enc_tv(a.tt, ix0), y0 = enc_tv(a.tt, iy0);
+    const Val x1 = same ? x0 : enc_tv(a.tt, ix1), y1 = same ? y0 : enc_tv(a.tt, iy1);
+    const Val z0 = tv_arith(y0, lit_val(n[4]), n[5].op == RDFGPU_EX_SUB);
+    const Val z1 = tv_arith(y1, lit_val(n[12]), n[13].op == RDFGPU_EX_SUB);
+    return cmp_holds(n[6].op, tv_partial_cmp(x0, z0)) && cmp_holds(n[14].op, tv_partial_cmp(x1, z1));
+  } else {
+    const Val r = eval_program(a.prog, a.tt, [&](u32 col) { return ljoin_col(a, col, i, j); });
+    return r.lo == 1;
+  }
+}
+// Fused FilterExec of the probe child: PFS 0 = none, 1 = col <ID_EQ|ID_NEQ> literal, 2 = generic VM.
+template <int PFS>
+__device__ __forceinline__ bool lprobe_filter(const LdsJoinArgs& a, u64 j) {
+  if constexpr (PFS == 0) return true;
+  else if constexpr (PFS == 1) {
+    const u32 v = a.probe[a.probe_prog.nodes[0].u][j], lit = a.probe_prog.nodes[1].u;
+    if (v == 0 || lit == 0) return false;
+    return (v == lit) == (a.probe_prog.nodes[2].op == RDFGPU_EX_ID_EQ);
+  } else {
+    const Val r = eval_program(a.probe_prog, a.tt, [&](u32 col) { return a.probe[col][j]; });
+    return r.lo == 1;
+  }
+}
+
+// Walks the LDS chain of probe row j.  Pass 1 (WRITE = false) counts the matches and remembers the first
+// two build rows in m0/m1, so the common <= 2-match case never walks (or evaluates its filter) twice.
+template <int FS, int PFS, bool WRITE>
+__device__ __forceinline__ u32 lds_probe_row(const LdsJoinArgs& a, const uint2* slots, u64 j, u64 pos, u32& m0, u32& m1) {
   u32 key[RDFGPU_MAX_KEYS]; bool null_key = false;
   for (u32 q = 0; q < a.n_keys; q++) { key[q] = a.probe[a.probe_keys[q]][j]; null_key = null_key || key[q] == 0; }
   if (null_key) return 0;   // NullEqualsNothing
-  if (a.has_probe_filter) {   // fused FilterExec of the probe child
-    const Val r = eval_program(a.probe_prog, a.tt, [&](u32 col) { return a.probe[col][j]; });
-    if (r.lo != 1) return 0;
-  }
+  if (!WRITE && !lprobe_filter<PFS>(a, j)) return 0;
   u32 c = 0;
   u32 h = hash_keys(key, a.n_keys) & a.tbl_mask;
   for (;;) {
@@ -407,19 +516,23 @@ __device__ __forceinline__ u32 lds_probe_row(const LdsJoinArgs& a, const uint2* 
     bool eq = true;
     for (u32 q = 1; q < a.n_keys; q++) eq = eq && a.build[a.build_keys[q]][s.y] == key[q];
     if (!eq) continue;
-    if (a.has_filter) {
-      const Val r = eval_program(a.prog, a.tt, [&](u32 col) { return ljoin_col(a, col, s.y, j); });
-      if (r.lo != 1) continue;
-    }
+    if (!ljoin_filter<FS>(a, s.y, j)) continue;
     if (WRITE) {
       if (pos + c < a.out_cap) for (u32 oc = 0; oc < a.n_out_cols; oc++) a.out[oc][pos + c] = ljoin_col(a, a.proj[oc], s.y, j);
       if (a.visited) a.visited[s.y] = 1;
+    } else {
+      if (c == 0) m0 = s.y; else if (c == 1) m1 = s.y;
     }
     c++;
   }
   return c;
 }
+__device__ __forceinline__ void ljoin_emit(const LdsJoinArgs& a, u32 i, u64 j, u64 pos) {
+  if (pos < a.out_cap) for (u32 oc = 0; oc < a.n_out_cols; oc++) a.out[oc][pos] = ljoin_col(a, a.proj[oc], i, j);
+  if (a.visited) a.visited[i] = 1;
+}
 
+template <int FS, int PFS>
 __global__ __launch_bounds__(kLdsBlock) void lds_join_kernel(const LdsJoinArgs a) {
   extern __shared__ __align__(16) unsigned char lds_raw[];
   uint2* slots = reinterpret_cast<uint2*>(lds_raw);
@@ -446,11 +559,12 @@ __global__ __launch_bounds__(kLdsBlock) void lds_join_kernel(const LdsJoinArgs a
   const int lane = tid & 63, wave = tid >> 6;
   for (u64 tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const u64 base = tile * kLdsTile;
-    u32 cnt[kLdsItems]; u32 mine = 0;
+    u32 cnt[kLdsItems], m0[kLdsItems], m1[kLdsItems]; u32 mine = 0;
 #pragma unroll
     for (int k = 0; k < kLdsItems; k++) {
       const u64 j = base + (u64)k * kLdsBlock + tid;
-      cnt[k] = j < np ? lds_probe_row<false>(a, slots, j, 0) : 0u;
+      m0[k] = m1[k] = kNil;
+      cnt[k] = j < np ? lds_probe_row<FS, PFS, false>(a, slots, j, 0, m0[k], m1[k]) : 0u;
       mine += cnt[k];
     }
     const u32 incl = wave_incl_scan(mine);
@@ -473,7 +587,8 @@ __global__ __launch_bounds__(kLdsBlock) void lds_join_kernel(const LdsJoinArgs a
     for (int k = 0; k < kLdsItems; k++) {
       if (cnt[k]) {
         const u64 j = base + (u64)k * kLdsBlock + tid;
-        lds_probe_row<true>(a, slots, j, pos);
+        if (cnt[k] <= 2) { ljoin_emit(a, m0[k], j, pos); if (cnt[k] == 2) ljoin_emit(a, m1[k], j, pos + 1); }
+        else { u32 d0, d1; lds_probe_row<FS, PFS, true>(a, slots, j, pos, d0, d1); }
         pos += cnt[k];
       }
     }
@@ -481,18 +596,28 @@ __global__ __launch_bounds__(kLdsBlock) void lds_join_kernel(const LdsJoinArgs a
   }
 }
 
+template <int FS, int PFS>
+static void launch_lds_join_t(const LdsJoinArgs& a, dim3 g, size_t lds, hipStream_t s) {
+  static bool attr_set = false;
+  if (!attr_set) {   // dynamic LDS above 64 KiB has to be opted into, per kernel instance
+    RDFGPU_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lds_join_kernel<FS, PFS>), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((lds_join_kernel<FS, PFS>), g, dim3(kLdsBlock), lds, s, a);
+}
 void launch_lds_join(const LdsJoinArgs& a, hipStream_t s) {
   const u64 n_tiles = (a.n_probe_cap + kLdsTile - 1) / kLdsTile;
   const size_t lds = (size_t)(a.tbl_mask + 1) * sizeof(uint2);
   // enough workgroups to cover all 256 CUs; each builds its LDS copy once and strides over the tiles
   const u64 max_wg = lds > 64 * 1024 ? 256 : lds > 32 * 1024 ? 512 : 1024;
-  const u64 g = n_tiles < max_wg ? (n_tiles ? n_tiles : 1) : max_wg;
-  static bool attr_set = false;
-  if (!attr_set) {   // dynamic LDS above 64 KiB has to be opted into
-    RDFGPU_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lds_join_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
-    attr_set = true;
-  }
-  hipLaunchKernelGGL(lds_join_kernel, dim3((unsigned)g), dim3(kLdsBlock), lds, s, a);
+  const dim3 g((unsigned)(n_tiles < max_wg ? (n_tiles ? n_tiles : 1) : max_wg));
+  const int fs = a.has_filter, pfs = a.has_probe_filter;   // 0 none / 1 VM / 3 window ; 0 none / 1 id-literal / 2 VM
+#define RDFGPU_LJ(F, P) if (fs == F && pfs == P) return launch_lds_join_t<F, P>(a, g, lds, s)
+  RDFGPU_LJ(0, 0); RDFGPU_LJ(0, 1); RDFGPU_LJ(0, 2);
+  RDFGPU_LJ(1, 0); RDFGPU_LJ(1, 1); RDFGPU_LJ(1, 2);
+  RDFGPU_LJ(3, 0); RDFGPU_LJ(3, 1); RDFGPU_LJ(3, 2);
+#undef RDFGPU_LJ
+  fail(RDFGPU_ERR_INVALID, "lds join: bad filter shape %d/%d", fs, pfs);
 }
 
 void launch_join_build(const JoinArgs& a, hipStream_t s) { hipLaunchKernelGGL(join_build_kernel, grid_for(a.n_left_cap), dim3(kBlock), 0, s, a); }

@@ -68,6 +68,22 @@ int detect_shape(const ExprProgram& pr) {
   return 0;
 }
 
+// Join-filter specialisation: 3 = the BSBM Q5 "window" shape
+//   EBV(cmp(ENC_TV(x), ADD|SUB(ENC_TV(y), lit))) AND EBV(cmp(ENC_TV(x'), ADD|SUB(ENC_TV(y'), lit')))
+// (Q5 (Execution Plan).snap:10,12), 1 = generic VM, 0 = no filter.
+int detect_join_filter_shape(const ExprProgram& pr) {
+  if (pr.n == 0) return 0;
+  if (std::getenv("RDFGPU_FORCE_GENERIC_VM")) return 1;
+  const rdfgpu_expr_node* e = pr.nodes;
+  auto half = [&](u32 o) {
+    return e[o].op == RDFGPU_EX_COLUMN && e[o + 1].op == RDFGPU_EX_ENC_TV && e[o + 2].op == RDFGPU_EX_COLUMN &&
+           e[o + 3].op == RDFGPU_EX_ENC_TV && e[o + 4].op == RDFGPU_EX_LIT_TV &&
+           (e[o + 5].op == RDFGPU_EX_ADD || e[o + 5].op == RDFGPU_EX_SUB) && is_cmp(e[o + 6].op) && e[o + 7].op == RDFGPU_EX_EBV;
+  };
+  if (pr.n == 17 && half(0) && half(8) && e[16].op == RDFGPU_EX_AND) return 3;
+  return 1;
+}
+
 void load_program(NodeInfo& nd, const rdfgpu_plan_desc* d, u32 n_cols, const char* what) {
   const rdfgpu_plan_node& r = nd.d;
   nd.prog.n = 0;
@@ -162,6 +178,7 @@ Plan* plan_compile(Store* store, const rdfgpu_plan_desc* d) {
         if (l.width + rr.width > 2u * kMaxCols) fail(RDFGPU_ERR_UNSUPPORTED, "node %u: too many columns", i);
         load_program(nd, d, l.width + rr.width, "join filter");
         load_projection(nd, d, l.width + rr.width, "join");
+        nd.shape = detect_join_filter_shape(nd.prog);
         if (l.width > (u32)kMaxCols || rr.width > (u32)kMaxCols) fail(RDFGPU_ERR_UNSUPPORTED, "node %u: too many columns", i);
         break;
       }
@@ -219,6 +236,12 @@ Plan* plan_compile(Store* store, const rdfgpu_plan_desc* d) {
     }
   }
 
+  for (NodeInfo& nd : plan->nodes) nd.refs = 0;
+  for (const NodeInfo& nd : plan->nodes) {
+    if (nd.d.kind == RDFGPU_NODE_DATA_SOURCE || nd.d.kind == RDFGPU_NODE_TABLE) continue;
+    if (nd.d.left >= 0) plan->nodes[nd.d.left].refs++;
+    if (nd.d.right >= 0 && (nd.d.kind == RDFGPU_NODE_HASH_JOIN || nd.d.kind == RDFGPU_NODE_CROSS_JOIN || nd.d.kind == RDFGPU_NODE_NESTED_LOOP_JOIN)) plan->nodes[nd.d.right].refs++;
+  }
   // per-node byte accounting inputs: distinct columns read, typed gathers per row
   for (NodeInfo& nd : plan->nodes) {
     bool used[2 * kMaxCols] = {};
@@ -455,6 +478,10 @@ DevTable Plan::exec_source(NodeInfo& nd) {
 
 DevTable Plan::exec_filter(NodeInfo& nd) {
   const DevTable in = exec_node((u32)nd.d.left);
+  return apply_filter(nd, in);
+}
+
+DevTable Plan::apply_filter(NodeInfo& nd, const DevTable& in) {
   DevTable t;
   t.n_cols = nd.n_proj;
   if (in.cap == 0) { t.cap = 0; return t; }
@@ -482,9 +509,26 @@ DevTable Plan::exec_filter(NodeInfo& nd) {
 static u32 pow2_at_least(u64 v) { u64 p = 1024; while (p < v && p < (1ull << 31)) p <<= 1; return (u32)p; }
 
 DevTable Plan::exec_join(NodeInfo& nd) {
-  const DevTable L = exec_node((u32)nd.d.left);
-  const DevTable R = exec_node((u32)nd.d.right);
   const bool left_join = nd.d.join_type == RDFGPU_JOIN_LEFT;
+  // Pipeline fusion: a FilterExec child (identity projection, consumed by this join only) is not
+  // materialised when it ends up on the probe side of the LDS join — its predicate runs inside the probe.
+  auto fusable = [&](int32_t ci) {
+    if (nd.d.kind != RDFGPU_NODE_HASH_JOIN || std::getenv("RDFGPU_NO_FILTER_FUSION") || std::getenv("RDFGPU_NO_LDS_JOIN")) return false;
+    const NodeInfo& c = nodes[ci];
+    if (c.d.kind != RDFGPU_NODE_FILTER || c.prog.n == 0 || c.refs != 1 || c.n_proj != nodes[c.d.left].width) return false;
+    for (u32 k = 0; k < c.n_proj; k++) if (c.proj[k] != k) return false;
+    return true;
+  };
+  bool lf = !left_join && fusable(nd.d.left), rf = fusable(nd.d.right);
+  DevTable L = lf ? exec_node((u32)nodes[nd.d.left].d.left) : exec_node((u32)nd.d.left);
+  DevTable R = rf ? exec_node((u32)nodes[nd.d.right].d.left) : exec_node((u32)nd.d.right);
+  if (lf || rf) {
+    const bool build_left = left_join || L.cap <= R.cap;
+    const bool lds = (build_left ? L.cap : R.cap) <= kLdsJoinMaxBuild && L.cap && R.cap;
+    // a fused filter survives only on the probe side of the LDS join; anything else is materialised now
+    if (lf && (!lds || build_left)) { L = apply_filter(nodes[nd.d.left], L); lf = false; }
+    if (rf && (!lds || !build_left)) { R = apply_filter(nodes[nd.d.right], R); rf = false; }
+  }
   DevTable t;
   t.n_cols = nd.n_proj;
 
@@ -513,7 +557,10 @@ DevTable Plan::exec_join(NodeInfo& nd) {
   if (hash && !std::getenv("RDFGPU_NO_LDS_JOIN")) {
     // build on the smaller input (an inner join is symmetric; a left join must build on the preserved side)
     const bool build_left = left_join || L.cap <= R.cap;
-    if ((build_left ? L.cap : R.cap) <= kLdsJoinMaxBuild) return exec_lds_join(nd, L, R, build_left);
+    if ((build_left ? L.cap : R.cap) <= kLdsJoinMaxBuild) {
+      const NodeInfo* pf = lf ? &nodes[nd.d.left] : rf ? &nodes[nd.d.right] : nullptr;
+      return exec_lds_join(nd, L, R, build_left, pf);
+    }
   }
   JoinArgs a{};
   for (u32 c = 0; c < L.n_cols; c++) a.left[c] = L.cols[c];
@@ -583,7 +630,7 @@ DevTable Plan::exec_join(NodeInfo& nd) {
 }
 
 // HashJoinExec whose build side fits one workgroup's LDS: one fused kernel, optimistic output capacity.
-DevTable Plan::exec_lds_join(NodeInfo& nd, const DevTable& L, const DevTable& R, bool build_left) {
+DevTable Plan::exec_lds_join(NodeInfo& nd, const DevTable& L, const DevTable& R, bool build_left, const NodeInfo* probe_filter) {
   const bool left_join = nd.d.join_type == RDFGPU_JOIN_LEFT;
   const DevTable& B = build_left ? L : R;
   const DevTable& P = build_left ? R : L;
@@ -604,8 +651,10 @@ DevTable Plan::exec_lds_join(NodeInfo& nd, const DevTable& L, const DevTable& R,
   u32 slots = 64;
   while (slots < 2 * B.cap) slots <<= 1;
   a.tbl_mask = slots - 1;
-  a.has_filter = nd.prog.n ? 1 : 0;
+  a.has_filter = (u32)nd.shape;   // 0 none / 1 generic VM / 3 window
   a.prog = nd.prog;
+  a.has_probe_filter = probe_filter ? (probe_filter->shape == 1 ? 1u : 2u) : 0u;
+  if (probe_filter) a.probe_prog = probe_filter->prog;
   a.tt = store->typed_table();
   if (left_join) a.visited = scratch<u8>(L.cap);
   u64* n_out = new_counter();
@@ -622,6 +671,7 @@ DevTable Plan::exec_lds_join(NodeInfo& nd, const DevTable& L, const DevTable& R,
     for (u32 k = 0; k < a.n_keys; k++) { pu[a.probe_keys[k]] = true; }
     for (u32 c = 0; c < nd.n_proj; c++) mark(nd.proj[c]);
     for (u32 i = 0; i < nd.prog.n; i++) if (nd.prog.nodes[i].op == RDFGPU_EX_COLUMN) mark(nd.prog.nodes[i].u);
+    if (probe_filter) for (u32 i = 0; i < probe_filter->prog.n; i++) if (probe_filter->prog.nodes[i].op == RDFGPU_EX_COLUMN) pu[probe_filter->prog.nodes[i].u] = true;
     for (u32 k = 0; k < a.n_keys; k++) bu[a.build_keys[k]] = false;
     for (bool b : pu) probe_cols += b;
     for (bool b : bu) build_payload += b;

@@ -29,6 +29,7 @@ struct NodeInfo {
   u32 n_enc_tv = 0;               // ENC_TV gathers per row (algorithmic bytes)
   u32 n_cols_read = 0;            // distinct input columns the kernel has to read
   int source = -1;                // index into Plan::sources
+  u32 refs = 0;                   // how many operators consume this node
 };
 
 struct BoundTable { std::vector<const u32*> cols; u64 n_rows = 0; bool bound = false; };
@@ -88,7 +89,8 @@ struct Plan {
   DevTable exec_source(NodeInfo& nd);
   DevTable exec_filter(NodeInfo& nd);
   DevTable exec_join(NodeInfo& nd);
-  DevTable exec_lds_join(NodeInfo& nd, const DevTable& L, const DevTable& R, bool build_left);
+  DevTable apply_filter(NodeInfo& nd, const DevTable& in);
+  DevTable exec_lds_join(NodeInfo& nd, const DevTable& L, const DevTable& R, bool build_left, const NodeInfo* probe_filter);
   void release_intermediates();
   template <class T> T* scratch(u64 n);
   u64* new_counter();
