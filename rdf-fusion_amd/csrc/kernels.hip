@@ -451,8 +451,8 @@ __device__ __forceinline__ u32 wave_incl_scan(u32 v) {
   return v;
 }
 __device__ __forceinline__ u32 ljoin_col(const LdsJoinArgs& a, u32 c, u64 i, u64 j) {  // column c of [left cols, right cols]
-  if (a.build_is_left) return c < a.n_build_cols ? a.build[c][i] : a.probe[c - a.n_build_cols][j];
-  return c < a.n_probe_cols ? a.probe[c][j] : a.build[c - a.n_probe_cols][i];
+  const bool from_build = (c < a.n_left_cols) == (a.build_is_left != 0);   // wave-uniform
+  return a.cols[c][from_build ? i : j];
 }
 
 // Join filter, specialised: FS 0 = none, 1 = generic VM, 3 = "window" — the BSBM Q5 shape
@@ -463,24 +463,24 @@ __device__ __forceinline__ bool cmp_holds(u8 op, int o) {
   return op == RDFGPU_EX_GT ? o > 0 : op == RDFGPU_EX_LT ? o < 0 : op == RDFGPU_EX_GEQ ? o >= 0
        : op == RDFGPU_EX_LEQ ? o <= 0 : op == RDFGPU_EX_EQ ? o == 0 : o != 0;
 }
-__device__ __forceinline__ Val lit_val(const rdfgpu_expr_node& l) {
-  Val y = val_tv_null(); y.tag = l.tag; y.flags = l.flags; y.aux = l.u; y.lo = l.lo; y.hi = l.hi; return y;
+__device__ __forceinline__ Val lit_val(const TvLiteral& l) {
+  Val y = val_tv_null(); y.tag = l.tag; y.flags = l.flags; y.aux = l.aux; y.lo = l.lo; y.hi = l.hi; return y;
 }
 template <int FS>
 __device__ __forceinline__ bool ljoin_filter(const LdsJoinArgs& a, u64 i, u64 j) {
   if constexpr (FS == 0) return true;
   else if constexpr (FS == 3) {
-    const rdfgpu_expr_node* n = a.prog.nodes;
-    const bool same = n[0].u == n[8].u && n[2].u == n[10].u;   // wave-uniform
-    const u32 ix0 = ljoin_col(a, n[0].u, i, j), iy0 = ljoin_col(a, n[2].u, i, j);
-    const u32 ix1 = same ? ix0 : ljoin_col(a, n[8].u, i, j), iy1 = same ? iy0 : ljoin_col(a, n[10].u, i, j);
+    const WindowFilter& w = a.win;
+    const bool same = w.x0 == w.x1 && w.y0 == w.y1;   // wave-uniform
+    const u32 ix0 = ljoin_col(a, w.x0, i, j), iy0 = ljoin_col(a, w.y0, i, j);
+    const u32 ix1 = same ? ix0 : ljoin_col(a, w.x1, i, j), iy1 = same ? iy0 : ljoin_col(a, w.y1, i, j);
     const Val x0 = enc_tv(a.tt, ix0), y0 = enc_tv(a.tt, iy0);
     const Val x1 = same ? x0 : enc_tv(a.tt, ix1), y1 = same ? y0 : enc_tv(a.tt, iy1);
-    const Val z0 = tv_arith(y0, lit_val(n[4]), n[5].op == RDFGPU_EX_SUB);
-    const Val z1 = tv_arith(y1, lit_val(n[12]), n[13].op == RDFGPU_EX_SUB);
-    return cmp_holds(n[6].op, tv_partial_cmp(x0, z0)) && cmp_holds(n[14].op, tv_partial_cmp(x1, z1));
+    const Val z0 = tv_arith(y0, lit_val(w.l0), w.l0.arith_sub != 0);
+    const Val z1 = tv_arith(y1, lit_val(w.l1), w.l1.arith_sub != 0);
+    return cmp_holds(w.l0.cmp_op, tv_partial_cmp(x0, z0)) && cmp_holds(w.l1.cmp_op, tv_partial_cmp(x1, z1));
   } else {
-    const Val r = eval_program(a.prog, a.tt, [&](u32 col) { return ljoin_col(a, col, i, j); });
+    const Val r = eval_program(*a.prog, a.tt, [&](u32 col) { return ljoin_col(a, col, i, j); });
     return r.lo == 1;
   }
 }
@@ -489,32 +489,49 @@ template <int PFS>
 __device__ __forceinline__ bool lprobe_filter(const LdsJoinArgs& a, u64 j) {
   if constexpr (PFS == 0) return true;
   else if constexpr (PFS == 1) {
-    const u32 v = a.probe[a.probe_prog.nodes[0].u][j], lit = a.probe_prog.nodes[1].u;
+    const u32 v = a.cols[a.pid.col][j], lit = a.pid.lit;
     if (v == 0 || lit == 0) return false;
-    return (v == lit) == (a.probe_prog.nodes[2].op == RDFGPU_EX_ID_EQ);
+    return (v == lit) == (a.pid.is_eq != 0);
   } else {
-    const Val r = eval_program(a.probe_prog, a.tt, [&](u32 col) { return a.probe[col][j]; });
+    const Val r = eval_program(*a.probe_prog, a.tt, [&](u32 col) { return a.cols[a.probe_col_base + col][j]; });
     return r.lo == 1;
   }
 }
 
-// Walks the LDS chain of probe row j.  Pass 1 (WRITE = false) counts the matches and remembers the first
-// two build rows in m0/m1, so the common <= 2-match case never walks (or evaluates its filter) twice.
-template <int FS, int PFS, bool WRITE>
-__device__ __forceinline__ u32 lds_probe_row(const LdsJoinArgs& a, const uint2* slots, u64 j, u64 pos, u32& m0, u32& m1) {
-  u32 key[RDFGPU_MAX_KEYS]; bool null_key = false;
-  for (u32 q = 0; q < a.n_keys; q++) { key[q] = a.probe[a.probe_keys[q]][j]; null_key = null_key || key[q] == 0; }
-  if (null_key) return 0;   // NullEqualsNothing
-  if (!WRITE && !lprobe_filter<PFS>(a, j)) return 0;
+// Static-indexed key handling (runtime n_keys <= 4 without private-memory arrays).
+struct Keys { u32 k[RDFGPU_MAX_KEYS]; };
+__device__ __forceinline__ u32 hash_keys4(const Keys& key, u32 n) {
+  u64 h = 0x9E3779B97F4A7C15ull;
+#pragma unroll
+  for (u32 i = 0; i < RDFGPU_MAX_KEYS; i++) if (i < n) { h ^= key.k[i]; h *= 0xff51afd7ed558ccdull; h ^= h >> 32; }
+  h *= 0xc4ceb9fe1a85ec53ull; h ^= h >> 29;
+  return (u32)h;
+}
+__device__ __forceinline__ bool load_keys(const u32* const* key_cols, u32 n_keys, u64 row, Keys& key) {
+  bool null_key = false;
+#pragma unroll
+  for (u32 q = 0; q < RDFGPU_MAX_KEYS; q++) {
+    key.k[q] = 0;
+    if (q < n_keys) { key.k[q] = key_cols[q][row]; null_key = null_key || key.k[q] == 0; }
+  }
+  return !null_key;   // NullEqualsNothing: a null key never matches
+}
+
+// Walks the LDS chain of probe row j (its keys already in registers).  Pass 1 (WRITE = false) counts the
+// matches and remembers the first two build rows in m0/m1, so the common <= 2-match case never walks
+// (or evaluates its filter) twice.
+template <int FS, bool WRITE>
+__device__ __forceinline__ u32 lds_probe_row(const LdsJoinArgs& a, const uint2* slots, const Keys& key, u64 j, u64 pos, u32& m0, u32& m1) {
   u32 c = 0;
-  u32 h = hash_keys(key, a.n_keys) & a.tbl_mask;
+  u32 h = hash_keys4(key, a.n_keys) & a.tbl_mask;
   for (;;) {
     const uint2 s = slots[h];
     if (s.y == kNil) break;
     h = (h + 1) & a.tbl_mask;
-    if (s.x != key[0]) continue;
+    if (s.x != key.k[0]) continue;
     bool eq = true;
-    for (u32 q = 1; q < a.n_keys; q++) eq = eq && a.build[a.build_keys[q]][s.y] == key[q];
+#pragma unroll
+    for (u32 q = 1; q < RDFGPU_MAX_KEYS; q++) if (q < a.n_keys) eq = eq && a.build_key[q][s.y] == key.k[q];
     if (!eq) continue;
     if (!ljoin_filter<FS>(a, s.y, j)) continue;
     if (WRITE) {
@@ -532,39 +549,46 @@ __device__ __forceinline__ void ljoin_emit(const LdsJoinArgs& a, u32 i, u64 j, u
   if (a.visited) a.visited[i] = 1;
 }
 
-template <int FS, int PFS>
+template <int FS, int PFS, int ITEMS>
 __global__ __launch_bounds__(kLdsBlock) void lds_join_kernel(const LdsJoinArgs a) {
   extern __shared__ __align__(16) unsigned char lds_raw[];
   uint2* slots = reinterpret_cast<uint2*>(lds_raw);
   __shared__ u32 wave_tot[kLdsBlock / 64];
   __shared__ u64 tile_base;
+  constexpr int kTileRows = kLdsBlock * ITEMS;
   const u32 tid = threadIdx.x;
   for (u32 s = tid; s <= a.tbl_mask; s += kLdsBlock) slots[s] = make_uint2(0u, kNil);
   __syncthreads();
   const u64 nb = live_rows(a.n_build_dev, a.n_build_cap);
   for (u64 i = tid; i < nb; i += kLdsBlock) {
-    u32 key[RDFGPU_MAX_KEYS]; bool null_key = false;
-    for (u32 q = 0; q < a.n_keys; q++) { key[q] = a.build[a.build_keys[q]][i]; null_key = null_key || key[q] == 0; }
-    if (null_key) continue;
-    u32 h = hash_keys(key, a.n_keys) & a.tbl_mask;
+    Keys key;
+    if (!load_keys(a.build_key, a.n_keys, i, key)) continue;
+    u32 h = hash_keys4(key, a.n_keys) & a.tbl_mask;
     for (;;) {
-      if (atomicCAS(&slots[h].y, kNil, (u32)i) == kNil) { slots[h].x = key[0]; break; }
+      if (atomicCAS(&slots[h].y, kNil, (u32)i) == kNil) { slots[h].x = key.k[0]; break; }
       h = (h + 1) & a.tbl_mask;
     }
   }
   __syncthreads();
 
   const u64 np = live_rows(a.n_probe_dev, a.n_probe_cap);
-  const u64 n_tiles = (np + kLdsTile - 1) / kLdsTile;
+  const u64 n_tiles = (np + kTileRows - 1) / kTileRows;
   const int lane = tid & 63, wave = tid >> 6;
   for (u64 tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-    const u64 base = tile * kLdsTile;
-    u32 cnt[kLdsItems], m0[kLdsItems], m1[kLdsItems]; u32 mine = 0;
+    const u64 base = tile * kTileRows;
+    // all of this lane's probe keys first: ITEMS independent coalesced loads in flight together
+    Keys key[ITEMS]; bool live[ITEMS];
 #pragma unroll
-    for (int k = 0; k < kLdsItems; k++) {
+    for (int k = 0; k < ITEMS; k++) {
       const u64 j = base + (u64)k * kLdsBlock + tid;
-      m0[k] = m1[k] = kNil;
-      cnt[k] = j < np ? lds_probe_row<FS, PFS, false>(a, slots, j, 0, m0[k], m1[k]) : 0u;
+      live[k] = j < np && load_keys(a.probe_key, a.n_keys, j, key[k]);
+    }
+    u32 cnt[ITEMS], m0[ITEMS], m1[ITEMS]; u32 mine = 0;
+#pragma unroll
+    for (int k = 0; k < ITEMS; k++) {
+      const u64 j = base + (u64)k * kLdsBlock + tid;
+      m0[k] = m1[k] = kNil; cnt[k] = 0;
+      if (live[k] && lprobe_filter<PFS>(a, j)) cnt[k] = lds_probe_row<FS, false>(a, slots, key[k], j, 0, m0[k], m1[k]);
       mine += cnt[k];
     }
     const u32 incl = wave_incl_scan(mine);
@@ -584,11 +608,11 @@ __global__ __launch_bounds__(kLdsBlock) void lds_join_kernel(const LdsJoinArgs a
     u64 pos = tile_base + (incl - mine);
     for (int w = 0; w < wave; w++) pos += wave_tot[w];
 #pragma unroll
-    for (int k = 0; k < kLdsItems; k++) {
+    for (int k = 0; k < ITEMS; k++) {
       if (cnt[k]) {
         const u64 j = base + (u64)k * kLdsBlock + tid;
         if (cnt[k] <= 2) { ljoin_emit(a, m0[k], j, pos); if (cnt[k] == 2) ljoin_emit(a, m1[k], j, pos + 1); }
-        else { u32 d0, d1; lds_probe_row<FS, PFS, true>(a, slots, j, pos, d0, d1); }
+        else { u32 d0, d1; lds_probe_row<FS, true>(a, slots, key[k], j, pos, d0, d1); }
         pos += cnt[k];
       }
     }
@@ -596,26 +620,29 @@ __global__ __launch_bounds__(kLdsBlock) void lds_join_kernel(const LdsJoinArgs a
   }
 }
 
-template <int FS, int PFS>
+template <int FS, int PFS, int ITEMS>
 static void launch_lds_join_t(const LdsJoinArgs& a, dim3 g, size_t lds, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {   // dynamic LDS above 64 KiB has to be opted into, per kernel instance
-    RDFGPU_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lds_join_kernel<FS, PFS>), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
+    RDFGPU_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lds_join_kernel<FS, PFS, ITEMS>), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
     attr_set = true;
   }
-  hipLaunchKernelGGL((lds_join_kernel<FS, PFS>), g, dim3(kLdsBlock), lds, s, a);
+  hipLaunchKernelGGL((lds_join_kernel<FS, PFS, ITEMS>), g, dim3(kLdsBlock), lds, s, a);
 }
 void launch_lds_join(const LdsJoinArgs& a, hipStream_t s) {
-  const u64 n_tiles = (a.n_probe_cap + kLdsTile - 1) / kLdsTile;
   const size_t lds = (size_t)(a.tbl_mask + 1) * sizeof(uint2);
   // enough workgroups to cover all 256 CUs; each builds its LDS copy once and strides over the tiles
   const u64 max_wg = lds > 64 * 1024 ? 256 : lds > 32 * 1024 ? 512 : 1024;
+  // small probe sides: one row per lane (more, shorter workgroups) instead of four
+  const bool wide = (a.n_probe_cap + kLdsTile - 1) / kLdsTile >= 512;
+  const u64 rows = wide ? kLdsTile : kLdsBlock;
+  const u64 n_tiles = (a.n_probe_cap + rows - 1) / rows;
   const dim3 g((unsigned)(n_tiles < max_wg ? (n_tiles ? n_tiles : 1) : max_wg));
   const int fs = a.has_filter, pfs = a.has_probe_filter;   // 0 none / 1 VM / 3 window ; 0 none / 1 id-literal / 2 VM
-#define RDFGPU_LJ(F, P) if (fs == F && pfs == P) return launch_lds_join_t<F, P>(a, g, lds, s)
-  RDFGPU_LJ(0, 0); RDFGPU_LJ(0, 1); RDFGPU_LJ(0, 2);
-  RDFGPU_LJ(1, 0); RDFGPU_LJ(1, 1); RDFGPU_LJ(1, 2);
-  RDFGPU_LJ(3, 0); RDFGPU_LJ(3, 1); RDFGPU_LJ(3, 2);
+#define RDFGPU_LJ(F, P) if (fs == F && pfs == P) { if (wide) return launch_lds_join_t<F, P, kLdsItems>(a, g, lds, s); return launch_lds_join_t<F, P, 1>(a, g, lds, s); }
+  RDFGPU_LJ(0, 0) RDFGPU_LJ(0, 1) RDFGPU_LJ(0, 2)
+  RDFGPU_LJ(1, 0) RDFGPU_LJ(1, 1) RDFGPU_LJ(1, 2)
+  RDFGPU_LJ(3, 0) RDFGPU_LJ(3, 1) RDFGPU_LJ(3, 2)
 #undef RDFGPU_LJ
   fail(RDFGPU_ERR_INVALID, "lds join: bad filter shape %d/%d", fs, pfs);
 }

@@ -99,15 +99,26 @@ void launch_join_left_unmatched(const JoinArgs& a, hipStream_t s);
 void launch_nlj_count(const JoinArgs& a, hipStream_t s);
 void launch_nlj_write(const JoinArgs& a, hipStream_t s);
 
+// Parameters of the specialised predicate shapes.
+struct TvLiteral { int64_t lo, hi; u32 aux; u8 tag, flags, arith_sub, cmp_op; };
+struct WindowFilter {   // EBV(cmp0(ENC_TV(x0), y0 +/- lit0)) AND EBV(cmp1(ENC_TV(x1), y1 +/- lit1))
+  u32 x0, y0, x1, y1;   // column indices in [left cols, right cols]
+  TvLiteral l0, l1;
+};
+struct IdFilter { u32 col, lit, is_eq; };   // col <ID_EQ | ID_NEQ> object-id literal
+
 // ---- K4+K5 fused: LDS-staged hash join for build sides that fit one workgroup's LDS ----
 constexpr u32 kLdsJoinMaxBuild = 8192;   // rows; 16384 slots x 8 B = 128 KiB of the CU's 160 KiB
 struct LdsJoinArgs {
-  const u32* build[kMaxCols]; const u32* probe[kMaxCols];
+  const u32* cols[2 * kMaxCols];   // the operator's [left cols, right cols] schema, one pointer per column
+  u32 n_left_cols;
+  u32 build_is_left;               // 1: build = left input; 0: the engine swapped sides (inner joins only)
   u32* out[kMaxCols];
-  u32 n_build_cols, n_probe_cols, n_out_cols;
-  u32 proj[kMaxCols];       // into the operator's [left cols, right cols] schema
-  u32 build_is_left;        // 1: build = left input; 0: the engine swapped sides (inner joins only)
-  u32 n_keys; u32 build_keys[RDFGPU_MAX_KEYS]; u32 probe_keys[RDFGPU_MAX_KEYS];
+  u32 n_out_cols;
+  u32 proj[kMaxCols];              // into [left cols, right cols]
+  u32 n_keys;
+  const u32* build_key[RDFGPU_MAX_KEYS];   // key columns, resolved to pointers on the host
+  const u32* probe_key[RDFGPU_MAX_KEYS];
   const u64* n_build_dev; u64 n_build_cap;
   const u64* n_probe_dev; u64 n_probe_cap;
   u32 tbl_mask;             // LDS slots - 1 (power of two >= 2 x build rows)
@@ -115,10 +126,15 @@ struct LdsJoinArgs {
   u64 out_cap;              // rows the out columns can hold (optimistic)
   u32* overflow;            // set when the matches did not fit
   u8* visited;              // left join: per build row
-  u32 has_filter, has_probe_filter;
+  u32 has_filter, has_probe_filter;   // join filter: 0 none / 1 VM / 3 window ; probe filter: 0 none / 1 id-literal / 2 VM
   TypedTable tt;
-  ExprProgram prog;         // join filter over [left cols, right cols]
-  ExprProgram probe_prog;   // fused FilterExec of the probe child, over the probe columns
+  // Generic programs live in device memory (a 2.5 KB by-value kernarg block made the compiler copy the
+  // whole argument struct to scratch); the specialised shapes get their few parameters inline.
+  const ExprProgram* prog;        // join filter over [left cols, right cols] (VM)
+  const ExprProgram* probe_prog;  // fused FilterExec of the probe child, over the probe side's columns (VM)
+  u32 probe_col_base;             // first column of the probe side inside cols[]
+  WindowFilter win;               // has_filter == 3
+  IdFilter pid;                   // has_probe_filter == 1; pid.col indexes cols[] directly
 };
 void launch_lds_join(const LdsJoinArgs& a, hipStream_t s);
 

@@ -334,6 +334,14 @@ template <class T> T* Plan::scratch(u64 n) {
   metrics.device_bytes += (n ? n : 1) * sizeof(T);
   return (T*)p;
 }
+// Generic (VM) programs of the LDS join live in device memory; staged through the context's pinned slots.
+const ExprProgram* Plan::upload_program(const ExprProgram& p) {
+  if (progs_used >= ExecContext::kProgSlots) fail(RDFGPU_ERR_UNSUPPORTED, "plan needs more than %u device expression programs", ExecContext::kProgSlots);
+  const u32 slot = progs_used++;
+  ctx->progs_host[slot] = p;
+  RDFGPU_HIP(hipMemcpyAsync(ctx->progs_dev + slot, ctx->progs_host + slot, sizeof(ExprProgram), hipMemcpyHostToDevice, stream));
+  return ctx->progs_dev + slot;
+}
 u64* Plan::new_counter() {
   if (counters_used >= 256) fail(RDFGPU_ERR_UNSUPPORTED, "plan needs more than 256 cardinality counters");
   return counters + counters_used++;
@@ -353,6 +361,7 @@ void Plan::execute() {
   release_intermediates();
   metrics = rdfgpu_metrics{};
   counters_used = 0;
+  progs_used = 0;
   events_used = 2;   // events 0/1 bracket the whole execute
   pending.clear();
   host_valid = false; cursor = 0; executed = false;
@@ -637,24 +646,40 @@ DevTable Plan::exec_lds_join(NodeInfo& nd, const DevTable& L, const DevTable& R,
   DevTable t;
   t.n_cols = nd.n_proj;
   LdsJoinArgs a{};
-  for (u32 c = 0; c < B.n_cols; c++) a.build[c] = B.cols[c];
-  for (u32 c = 0; c < P.n_cols; c++) a.probe[c] = P.cols[c];
-  a.n_build_cols = B.n_cols; a.n_probe_cols = P.n_cols; a.n_out_cols = nd.n_proj;
+  for (u32 c = 0; c < L.n_cols; c++) a.cols[c] = L.cols[c];
+  for (u32 c = 0; c < R.n_cols; c++) a.cols[L.n_cols + c] = R.cols[c];
+  a.n_left_cols = L.n_cols; a.n_out_cols = nd.n_proj;
   for (u32 c = 0; c < nd.n_proj; c++) a.proj[c] = nd.proj[c];
   a.build_is_left = build_left ? 1 : 0;
   a.n_keys = nd.d.n_keys;
+  u32 build_keys[RDFGPU_MAX_KEYS] = {}, probe_keys[RDFGPU_MAX_KEYS] = {};
   for (u32 k = 0; k < a.n_keys; k++) {
-    a.build_keys[k] = build_left ? nd.d.left_keys[k] : nd.d.right_keys[k];
-    a.probe_keys[k] = build_left ? nd.d.right_keys[k] : nd.d.left_keys[k];
+    build_keys[k] = build_left ? nd.d.left_keys[k] : nd.d.right_keys[k];
+    probe_keys[k] = build_left ? nd.d.right_keys[k] : nd.d.left_keys[k];
+    a.build_key[k] = B.cols[build_keys[k]];
+    a.probe_key[k] = P.cols[probe_keys[k]];
   }
   a.n_build_dev = B.n_dev; a.n_build_cap = B.cap; a.n_probe_dev = P.n_dev; a.n_probe_cap = P.cap;
   u32 slots = 64;
   while (slots < 2 * B.cap) slots <<= 1;
   a.tbl_mask = slots - 1;
+  a.probe_col_base = build_left ? L.n_cols : 0;
   a.has_filter = (u32)nd.shape;   // 0 none / 1 generic VM / 3 window
-  a.prog = nd.prog;
+  if (nd.shape == 1) a.prog = upload_program(nd.prog);
+  if (nd.shape == 3) {
+    const rdfgpu_expr_node* e = nd.prog.nodes;
+    auto lit = [&](u32 o) { TvLiteral l{}; l.lo = e[o + 4].lo; l.hi = e[o + 4].hi; l.aux = e[o + 4].u; l.tag = e[o + 4].tag; l.flags = e[o + 4].flags;
+                            l.arith_sub = e[o + 5].op == RDFGPU_EX_SUB; l.cmp_op = e[o + 6].op; return l; };
+    a.win.x0 = e[0].u; a.win.y0 = e[2].u; a.win.x1 = e[8].u; a.win.y1 = e[10].u;
+    a.win.l0 = lit(0); a.win.l1 = lit(8);
+  }
   a.has_probe_filter = probe_filter ? (probe_filter->shape == 1 ? 1u : 2u) : 0u;
-  if (probe_filter) a.probe_prog = probe_filter->prog;
+  if (probe_filter) {
+    if (probe_filter->shape == 1) {
+      const rdfgpu_expr_node* e = probe_filter->prog.nodes;
+      a.pid.col = a.probe_col_base + e[0].u; a.pid.lit = e[1].u; a.pid.is_eq = e[2].op == RDFGPU_EX_ID_EQ;
+    } else a.probe_prog = upload_program(probe_filter->prog);
+  }
   a.tt = store->typed_table();
   if (left_join) a.visited = scratch<u8>(L.cap);
   u64* n_out = new_counter();
@@ -668,11 +693,11 @@ DevTable Plan::exec_lds_join(NodeInfo& nd, const DevTable& L, const DevTable& R,
     bool pu[kMaxCols] = {}, bu[kMaxCols] = {};
     const u32 nl = L.n_cols;
     auto mark = [&](u32 c) { const bool from_left = c < nl; const u32 local = from_left ? c : c - nl; ((from_left == build_left) ? bu : pu)[local] = true; };
-    for (u32 k = 0; k < a.n_keys; k++) { pu[a.probe_keys[k]] = true; }
+    for (u32 k = 0; k < a.n_keys; k++) { pu[probe_keys[k]] = true; }
     for (u32 c = 0; c < nd.n_proj; c++) mark(nd.proj[c]);
     for (u32 i = 0; i < nd.prog.n; i++) if (nd.prog.nodes[i].op == RDFGPU_EX_COLUMN) mark(nd.prog.nodes[i].u);
     if (probe_filter) for (u32 i = 0; i < probe_filter->prog.n; i++) if (probe_filter->prog.nodes[i].op == RDFGPU_EX_COLUMN) pu[probe_filter->prog.nodes[i].u] = true;
-    for (u32 k = 0; k < a.n_keys; k++) bu[a.build_keys[k]] = false;
+    for (u32 k = 0; k < a.n_keys; k++) bu[build_keys[k]] = false;
     for (bool b : pu) probe_cols += b;
     for (bool b : bu) build_payload += b;
   }

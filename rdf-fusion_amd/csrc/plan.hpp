@@ -71,6 +71,7 @@ struct Plan {
   std::vector<void*> allocs;      // pool blocks owned by the current result / intermediates
   u64* counters = nullptr;        // device u64 slots for operator output counts
   u32 counters_used = 0;
+  u32 progs_used = 0;
   DevTable result; u64 result_rows = 0; bool executed = false;
   rdfgpu_metrics metrics{};
   bool timing = false;
@@ -94,6 +95,7 @@ struct Plan {
   void release_intermediates();
   template <class T> T* scratch(u64 n);
   u64* new_counter();
+  const ExprProgram* upload_program(const ExprProgram& p);
   u64 read_u64(const u64* dev);
   // brackets one launch with HIP events when timing is on
   template <class F>

@@ -99,6 +99,8 @@ ExecContext::~ExecContext() {
   for (hipEvent_t e : events) (void)hipEventDestroy(e);
   if (counters) (void)hipFree(counters);
   if (counters_host) (void)hipHostFree(counters_host);
+  if (progs_dev) (void)hipFree(progs_dev);
+  if (progs_host) (void)hipHostFree(progs_host);
   if (jobs_dev) (void)hipFree(jobs_dev);
   if (lohi_dev) (void)hipFree(lohi_dev);
   if (jobs_host) (void)hipHostFree(jobs_host);
@@ -117,6 +119,8 @@ ExecContext* Store::acquire_context(u32 n_sources) {
     RDFGPU_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     RDFGPU_HIP(hipMalloc((void**)&c->counters, 256 * sizeof(u64)));
     RDFGPU_HIP(hipHostMalloc((void**)&c->counters_host, 256 * sizeof(u64), hipHostMallocDefault));
+    RDFGPU_HIP(hipMalloc((void**)&c->progs_dev, ExecContext::kProgSlots * sizeof(ExprProgram)));
+    RDFGPU_HIP(hipHostMalloc((void**)&c->progs_host, ExecContext::kProgSlots * sizeof(ExprProgram), hipHostMallocDefault));
   }
   const u32 need = n_sources ? n_sources : 1;
   if (c->job_cap < need) {

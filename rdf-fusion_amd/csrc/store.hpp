@@ -39,6 +39,8 @@ struct ExecContext {
   u64* counters_host = nullptr; // pinned mirror
   void* jobs_dev = nullptr; u64* lohi_dev = nullptr; u32 job_cap = 0;
   void* jobs_host = nullptr; u64* lohi_host = nullptr;   // pinned staging
+  static constexpr u32 kProgSlots = 16;
+  ExprProgram* progs_dev = nullptr; ExprProgram* progs_host = nullptr;   // VM programs of fused kernels
   hipEvent_t event(u32 i);
   ~ExecContext();
 };
