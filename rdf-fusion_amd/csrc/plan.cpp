@@ -236,11 +236,22 @@ Plan* plan_compile(Store* store, const rdfgpu_plan_desc* d) {
     }
   }
 
+  // consumers per node, counted over the operators reachable from the root only (a rewritten-away
+  // CrossJoinExec must not keep its former inputs "shared")
   for (NodeInfo& nd : plan->nodes) nd.refs = 0;
-  for (const NodeInfo& nd : plan->nodes) {
-    if (nd.d.kind == RDFGPU_NODE_DATA_SOURCE || nd.d.kind == RDFGPU_NODE_TABLE) continue;
-    if (nd.d.left >= 0) plan->nodes[nd.d.left].refs++;
-    if (nd.d.right >= 0 && (nd.d.kind == RDFGPU_NODE_HASH_JOIN || nd.d.kind == RDFGPU_NODE_CROSS_JOIN || nd.d.kind == RDFGPU_NODE_NESTED_LOOP_JOIN)) plan->nodes[nd.d.right].refs++;
+  {
+    std::vector<u32> stack{plan->root};
+    std::vector<bool> seen(plan->nodes.size(), false);
+    while (!stack.empty()) {
+      const u32 i = stack.back(); stack.pop_back();
+      if (seen[i]) continue;
+      seen[i] = true;
+      const NodeInfo& nd = plan->nodes[i];
+      if (nd.d.kind == RDFGPU_NODE_DATA_SOURCE || nd.d.kind == RDFGPU_NODE_TABLE) continue;
+      const bool binary = nd.d.kind == RDFGPU_NODE_HASH_JOIN || nd.d.kind == RDFGPU_NODE_CROSS_JOIN || nd.d.kind == RDFGPU_NODE_NESTED_LOOP_JOIN;
+      if (nd.d.left >= 0) { plan->nodes[nd.d.left].refs++; stack.push_back((u32)nd.d.left); }
+      if (binary && nd.d.right >= 0) { plan->nodes[nd.d.right].refs++; stack.push_back((u32)nd.d.right); }
+    }
   }
   // per-node byte accounting inputs: distinct columns read, typed gathers per row
   for (NodeInfo& nd : plan->nodes) {

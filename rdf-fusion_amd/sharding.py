@@ -92,19 +92,21 @@ def unpack_records(gathered):
     return out
 
 
-def run_q5_batch_sharded(ds, products, run_const, run_local, all_gather):
+def run_q5_batch_sharded(ds, products, run_const, run_local, all_gather, pmap=None):
     """One step of the sharded Q5 batch.
 
     run_const(desc) -> 1-column numpy result of a tiny constant-subject plan on this rank
     run_local(desc, [feats, o1, o2]) -> number of bindings the local plan produced on this rank
     all_gather(int32 array [Q, RECORD]) -> int32 array [world, Q, RECORD]
+    pmap(fn, items) -> list: optional parallel map (host threads; every plan owns its own HIP stream)
     Returns the number of bindings this rank produced."""
+    pmap = pmap or (lambda fn, items: [fn(i) for i in items])
     recs = np.zeros((len(products), RECORD), dtype=np.int32)
-    for i, x in enumerate(products):
-        f, a, b = [run_const(d) for d in q5_const_plans(ds, x)]
+
+    def phase_a(i):
+        f, a, b = [run_const(d) for d in q5_const_plans(ds, products[i])]
         recs[i] = pack_record(f, a, b)
+    pmap(phase_a, range(len(products)))
     gathered = all_gather(recs)
-    rows = 0
-    for x, (f, a, b) in zip(products, unpack_records(gathered)):
-        rows += run_local(q5_local_plan(ds, x), [f, a, b])
-    return rows
+    tables = unpack_records(gathered)
+    return sum(pmap(lambda i: run_local(q5_local_plan(ds, products[i]), list(tables[i])), range(len(products))))
