@@ -159,6 +159,12 @@ __device__ __forceinline__ bool filter_pred_value(const FilterArgs& a, u32 v) {
   } else {                     // EBV(cmp(ENC_TV(col), typed literal)) — the BSBM Q1 numeric FILTER
     const Val x = enc_tv(a.tt, v);
     const rdfgpu_expr_node& l = a.prog.nodes[2];
+    if (x.tag == RDFGPU_TV_INTEGER && l.tag == RDFGPU_TV_INTEGER) {   // xsd:integer vs xsd:integer: plain i64 compare
+      const u8 op = a.prog.nodes[3].op;
+      const int64_t p = x.lo, q = l.lo;
+      return op == RDFGPU_EX_GT ? p > q : op == RDFGPU_EX_LT ? p < q : op == RDFGPU_EX_GEQ ? p >= q
+           : op == RDFGPU_EX_LEQ ? p <= q : op == RDFGPU_EX_EQ ? p == q : p != q;
+    }
     Val y = val_tv_null(); y.tag = l.tag; y.flags = l.flags; y.aux = l.u; y.lo = l.lo; y.hi = l.hi;
     const int o = tv_partial_cmp(x, y);
     if (o == ORD_NONE) return false;
@@ -188,6 +194,7 @@ __global__ __launch_bounds__(kBlock) void filter_kernel(const FilterArgs a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const u32* pcol = (SHAPE != 0) ? a.in[a.prog.nodes[0].u] : nullptr;
   unsigned long long bits = 0;
+#pragma unroll 2
   for (u32 it = 0; it < a.iters; it++) {
     const u64 v0 = base + (u64)it * kTile + (u64)threadIdx.x * 4;
     if (v0 >= nv) break;
@@ -228,16 +235,30 @@ __global__ __launch_bounds__(kBlock) void filter_kernel(const FilterArgs a) {
   if (wsum == 0) return;                            // wave-uniform
   for (u32 it = 0; it < a.iters; it++) {
     const u64 v0 = base + (u64)it * kTile + (u64)threadIdx.x * 4;
+    const u32 nib = (u32)(bits >> (it * 4)) & 15u;
+    if (__ballot(nib != 0) == 0) continue;          // wave-uniform: nothing survived this round
+    u64 pos[4];
 #pragma unroll
     for (int r = 0; r < 4; r++) {
-      const bool keep = (bits >> (it * 4 + r)) & 1ull;
+      const bool keep = (nib >> r) & 1u;
       const unsigned long long m = __ballot(keep);
-      if (keep) {
-        const u64 row = v0 + r - mis;
-        const u64 pos = off + lane_prefix(m);
-        for (u32 c = 0; c < a.n_out_cols; c++) a.out[c][pos] = a.in[a.proj[c]][row];
-      }
+      pos[r] = off + lane_prefix(m);
       off += (u32)__popcll(m);
+    }
+    if (nib == 0) continue;
+    for (u32 c = 0; c < a.n_out_cols; c++) {
+      const u32* src = a.in[a.proj[c]];
+      u32 val[4];
+      if (a.vec_proj_ok && v0 >= mis && v0 + 4 <= nv) {   // one aligned 16-byte load per column and round
+        const uint4 q = *reinterpret_cast<const uint4*>(src + (v0 - mis));
+        val[0] = q.x; val[1] = q.y; val[2] = q.z; val[3] = q.w;
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; r++) val[r] = ((nib >> r) & 1u) ? src[v0 + r - mis] : 0u;
+      }
+      u32* dst = a.out[c];
+#pragma unroll
+      for (int r = 0; r < 4; r++) if ((nib >> r) & 1u) dst[pos[r]] = val[r];
     }
   }
 }
@@ -252,6 +273,11 @@ void launch_filter(const FilterArgs& a0, int shape, hipStream_t s) {
   if (shape != 0) {
     const uintptr_t p = reinterpret_cast<uintptr_t>(a.in[a.prog.nodes[0].u]);
     if ((p & 3) == 0) { a.head_skip = (u32)((p >> 2) & 3); a.vec_ok = 1; }
+  }
+  a.vec_proj_ok = 1;
+  for (u32 c = 0; c < a.n_out_cols; c++) {
+    const uintptr_t p = reinterpret_cast<uintptr_t>(a.in[a.proj[c]]);
+    if ((p & 3) != 0 || ((p >> 2) & 3) != a.head_skip) a.vec_proj_ok = 0;
   }
   const u64 chunk = (u64)kTile * a.iters;
   const u64 g = (a.n_in_cap + a.head_skip + chunk - 1) / chunk;

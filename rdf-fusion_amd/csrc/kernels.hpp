@@ -53,7 +53,7 @@ struct FilterArgs {
   u32 proj[kMaxCols];
   const u64* n_in_dev; u64 n_in_cap;
   u64* n_out_dev;       // zeroed before launch
-  u32 iters, head_skip, vec_ok;   // set by launch_filter: rounds per workgroup, alignment head, 16-B loads allowed
+  u32 iters, head_skip, vec_ok, vec_proj_ok;   // set by launch_filter: rounds per workgroup, alignment head, 16-B loads allowed
   TypedTable tt;
   ExprProgram prog;
 };

@@ -1,0 +1,108 @@
+"""The N > 1 path on CPU: gloo ranks, triples sharded by hash(subject), the constant-subject bindings
+all-gathered, the rest of Q5 local (rdf-fusion_amd/sharding.py).  The executor here is the CPU oracle
+(the HIP library cannot run without a GPU); what is under test is the sharding + exchange logic: the
+union of the ranks' bindings must equal the unsharded answer."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PRODUCTS = (3, 77, 401, 599)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
+    import torch.distributed as dist
+    from rdf_fusion_amd import bsbm, sharding
+    from oracle import oracle as orc
+    import kat_util as ku
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ds = bsbm.generate(600)
+        g, s, p, o = sharding.shard_dataset(ds, rank, world)
+        st = orc.OracleStore()
+        st.extend(g, s, p, o)
+        st.set_typed_values(ds.typed_values)
+        products = [ds.product(i) for i in PRODUCTS]
+        rows = []
+
+        def run_const(desc):
+            cols, n, _ = st.execute(desc)
+            return cols[0]
+
+        def run_local(desc, tables):
+            if any(len(t) == 0 for t in tables):
+                return 0
+            cols, n, _ = st.execute(desc, tables=[[t] for t in tables])
+            rows.append(ku.multiset(cols, n))
+            return n
+
+        def all_gather(recs):
+            mine = torch.from_numpy(recs)
+            out = [torch.empty_like(mine) for _ in range(world)]
+            dist.all_gather(out, mine)
+            return torch.stack(out).numpy()
+
+        n = sharding.run_q5_batch_sharded(ds, products, run_const, run_local, all_gather)
+        mine = np.concatenate(rows) if rows else np.zeros((0, 2), np.uint32)
+        q.put((rank, n, mine))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_q5_equals_unsharded(world):
+    import torch.multiprocessing as mp
+    from rdf_fusion_amd import bsbm, sharding
+    from oracle import oracle as orc
+    import kat_util as ku
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    ds = bsbm.generate(600)
+    st = orc.OracleStore()
+    st.extend(ds.g, ds.s, ds.p, ds.o)
+    st.set_typed_values(ds.typed_values)
+    expected = []
+    for i in PRODUCTS:
+        cols, n, _ = st.execute(bsbm.q5_plan(ds, ds.product(i)))
+        expected.append(ku.multiset(cols, n))
+    expected = np.concatenate(expected)
+    expected = ku.multiset(list(expected.T))
+    got = np.concatenate([r[2] for r in results])
+    got = ku.multiset(list(got.T))
+    assert sum(r[1] for r in results) == len(expected) > 0
+    np.testing.assert_array_equal(got, expected)
+    # shards are disjoint and cover the dataset
+    sizes = [len(sharding.shard_dataset(ds, r, world)[0]) for r in range(world)]
+    assert sum(sizes) == ds.n_triples and min(sizes) > 0.5 * ds.n_triples / world
+
+
+def test_exchange_record_roundtrip():
+    from rdf_fusion_amd import sharding
+    rec0 = sharding.pack_record([], [], [])
+    rec1 = sharding.pack_record([5, 9, 4000000000], [77], [88])
+    out = sharding.unpack_records(np.stack([np.stack([rec0, rec1]), np.stack([rec1, rec0])]))
+    assert out[0][0].tolist() == [5, 9, 4000000000] and out[0][1].tolist() == [77] and out[0][2].tolist() == [88]
+    assert out[1][0].tolist() == [5, 9, 4000000000]
