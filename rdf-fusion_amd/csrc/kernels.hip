@@ -564,7 +564,8 @@ __device__ __forceinline__ u32 lds_probe_row(const LdsJoinArgs& a, const uint2* 
       if (pos + c < a.out_cap) for (u32 oc = 0; oc < a.n_out_cols; oc++) a.out[oc][pos + c] = ljoin_col(a, a.proj[oc], s.y, j);
       if (a.visited) a.visited[s.y] = 1;
     } else {
-      if (c == 0) m0 = s.y; else if (c == 1) m1 = s.y;
+      m0 = c == 0 ? s.y : m0;   // value selects, not pointer selects: the latter force m0/m1 into scratch
+      m1 = c == 1 ? s.y : m1;
     }
     c++;
   }
