@@ -252,7 +252,7 @@ int rdfgpu_plan_kernel_stats(rdfgpu_plan* plan, rdfgpu_kernel_stat* out, uint32_
   for (int k = 0; k < KC__N; k++) {
     const KernelStat& s = p->kstats[k];
     if (!s.launches) continue;
-    if (w < cap) { out[w].kernel = kKernelNames[k]; out[w].launches = s.launches; out[w].reserved = 0; out[w].total_ms = s.ms; out[w].algorithmic_bytes = s.bytes; out[w].rows_in = s.rows; }
+    if (w < cap) { out[w].kernel = kernel_class_name(k); out[w].launches = s.launches; out[w].reserved = 0; out[w].total_ms = s.ms; out[w].algorithmic_bytes = s.bytes; out[w].rows_in = s.rows; }
     w++;
   }
   *n = w < cap ? w : cap;

@@ -656,12 +656,13 @@ static void launch_lds_join_t(const LdsJoinArgs& a, dim3 g, size_t lds, hipStrea
   }
   hipLaunchKernelGGL((lds_join_kernel<FS, PFS, ITEMS>), g, dim3(kLdsBlock), lds, s, a);
 }
+bool lds_join_is_wide(u64 n_probe_cap) { return (n_probe_cap + kLdsTile - 1) / kLdsTile >= 512; }
 void launch_lds_join(const LdsJoinArgs& a, hipStream_t s) {
   const size_t lds = (size_t)(a.tbl_mask + 1) * sizeof(uint2);
   // enough workgroups to cover all 256 CUs; each builds its LDS copy once and strides over the tiles
   const u64 max_wg = lds > 64 * 1024 ? 256 : lds > 32 * 1024 ? 512 : 1024;
   // small probe sides: one row per lane (more, shorter workgroups) instead of four
-  const bool wide = (a.n_probe_cap + kLdsTile - 1) / kLdsTile >= 512;
+  const bool wide = lds_join_is_wide(a.n_probe_cap);
   const u64 rows = wide ? kLdsTile : kLdsBlock;
   const u64 n_tiles = (a.n_probe_cap + rows - 1) / rows;
   const dim3 g((unsigned)(n_tiles < max_wg ? (n_tiles ? n_tiles : 1) : max_wg));

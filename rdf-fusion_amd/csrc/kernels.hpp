@@ -137,6 +137,7 @@ struct LdsJoinArgs {
   IdFilter pid;                   // has_probe_filter == 1; pid.col indexes cols[] directly
 };
 void launch_lds_join(const LdsJoinArgs& a, hipStream_t s);
+bool lds_join_is_wide(u64 n_probe_cap);   // true: the 4-rows-per-lane instantiation is launched, false: 1 row per lane
 
 // ---- utilities ----
 void launch_fill_u32(u32* p, u32 v, u64 n, hipStream_t s);

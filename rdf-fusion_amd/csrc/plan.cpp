@@ -290,12 +290,24 @@ Plan::~Plan() {
   if (store && ctx) store->release_context(ctx);
 }
 
-const char* const kKernelNames[KC__N] = {
-    "rdfgpu::locate_kernel", "rdfgpu::scan_count_kernel", "rdfgpu::scan_write_kernel",
-    "void rdfgpu::filter_kernel<1>", "void rdfgpu::filter_kernel<2>", "void rdfgpu::filter_kernel<0>",
-    "rdfgpu::cross_kernel", "rdfgpu::join_build_kernel", "void rdfgpu::join_probe_kernel<false>",
-    "void rdfgpu::join_probe_kernel<true>", "rdfgpu::join_left_unmatched_kernel", "void rdfgpu::nlj_kernel<false>",
-    "void rdfgpu::nlj_kernel<true>", "rocprim device scan", "rdfgpu::lds_join_kernel"};
+// Names as rocprofv3 --kernel-trace prints them (prefix up to the argument list).
+const char* kernel_class_name(int kc) {
+  static const char* const fixed[KC_LDS_JOIN0] = {
+      "rdfgpu::locate_kernel", "rdfgpu::scan_count_kernel", "rdfgpu::scan_write_kernel",
+      "void rdfgpu::filter_kernel<1>", "void rdfgpu::filter_kernel<2>", "void rdfgpu::filter_kernel<0>",
+      "rdfgpu::cross_kernel", "rdfgpu::join_build_kernel", "void rdfgpu::join_probe_kernel<false>",
+      "void rdfgpu::join_probe_kernel<true>", "rdfgpu::join_left_unmatched_kernel", "void rdfgpu::nlj_kernel<false>",
+      "void rdfgpu::nlj_kernel<true>", "rocprim device scan"};
+  if (kc < KC_LDS_JOIN0) return fixed[kc];
+  static std::string names[18];
+  static std::once_flag once;
+  std::call_once(once, [] {
+    const int fs[3] = {0, 1, 3};
+    for (int f = 0; f < 3; f++) for (int p = 0; p < 3; p++) for (int w = 0; w < 2; w++)
+      names[(f * 3 + p) * 2 + w] = "void rdfgpu::lds_join_kernel<" + std::to_string(fs[f]) + ", " + std::to_string(p) + ", " + (w == 0 ? "4" : "1") + ">";
+  });
+  return names[kc - KC_LDS_JOIN0].c_str();
+}
 
 template <class F>
 void Plan::timed(int kc, u64 fixed_bytes, u64 rows_cap, const u64* rows_dev, u64 bytes_per_row,
@@ -721,7 +733,7 @@ DevTable Plan::exec_lds_join(NodeInfo& nd, const DevTable& L, const DevTable& R,
     a.out_cap = out_cap;
     for (u32 c = 0; c < nd.n_proj; c++) { a.out[c] = scratch<u32>(out_cap + tail); t.cols[c] = a.out[c]; }
     if (left_join) RDFGPU_HIP(hipMemsetAsync(a.visited, 0, L.cap, stream));
-    timed(KC_LDS_JOIN, fixed, P.cap, P.n_dev, 4ull * probe_cols + 8, n_out, 0, 4ull * nd.n_proj, [&] { launch_lds_join(a, stream); });
+    timed(lds_join_class(a.has_filter, a.has_probe_filter, lds_join_is_wide(P.cap)), fixed, P.cap, P.n_dev, 4ull * probe_cols + 8, n_out, 0, 4ull * nd.n_proj, [&] { launch_lds_join(a, stream); });
     const u32 i0 = (u32)(n_out - counters);
     RDFGPU_HIP(hipMemcpyAsync(ctx->counters_host + i0, counters + i0, 2 * sizeof(u64), hipMemcpyDeviceToHost, stream));
     RDFGPU_HIP(hipStreamSynchronize(stream)); metrics.host_syncs++;
