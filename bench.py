@@ -93,11 +93,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    # rehearsal knob: RDFGPU_BENCH_REHEARSE=1 runs every rank on GPU 0 with the gloo backend (1-GPU boxes)
+    rehearse = os.environ.get("RDFGPU_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    xdev = "cpu" if rehearse else "cuda"   # where the exchanged tensors live
 
     def barrier():
         if dist is not None:
@@ -192,7 +200,7 @@ def main():
                 return n
 
             def all_gather(recs):
-                mine = torch.from_numpy(recs).cuda()
+                mine = torch.from_numpy(recs).to(xdev)
                 out = torch.empty((world,) + tuple(mine.shape), dtype=mine.dtype, device=mine.device)
                 dist.all_gather_into_tensor(out, mine)
                 return out.cpu().numpy()
@@ -214,7 +222,7 @@ def main():
 
     total_rows = local_rows
     if dist is not None:
-        t = torch.tensor([elapsed, float(local_rows)], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed, float(local_rows)], dtype=torch.float64, device=xdev)
         tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = t.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
         elapsed = float(tmax[0].item()); total_rows = int(tsum[1].item())
