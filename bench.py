@@ -201,9 +201,10 @@ def main():
 
             def all_gather(recs):
                 mine = torch.from_numpy(recs).to(xdev)
-                out = torch.empty((world,) + tuple(mine.shape), dtype=mine.dtype, device=mine.device)
+                # concatenated along dim 0 (the layout every backend accepts), then viewed as [world, Q, RECORD]
+                out = torch.empty((world * mine.shape[0], mine.shape[1]), dtype=mine.dtype, device=mine.device)
                 dist.all_gather_into_tensor(out, mine)
-                return out.cpu().numpy()
+                return out.cpu().numpy().reshape(world, mine.shape[0], mine.shape[1])
 
             rows = sharding.run_q5_batch_sharded(ds, batch, run_const, run_local, all_gather, pmap)
         return rows
