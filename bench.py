@@ -4,16 +4,22 @@
 Contract: `python bench.py --gpus N --steps K --warmup W`; for N > 1 the driver launches one rank
 per GPU with torch.distributed.run.  Rank 0 prints ONE JSON line.
 
-A step = one batch of `--queries` BSBM Explore Q5 instances (distinct %Product% constants), each
-planned exactly as the reference plans it (bench/tests/plans/snapshots/*Q5 (Execution Plan).snap) and
-run through the C ABI over a synthetic BSBM-shaped store of `--products` products (285 000 products
-= 98 M triples, "BSBM-100M") whose three sorted permutations and typed-value table are already resident
-in HBM when the timed region starts.  value = solution bindings (rows leaving the top join, before
+Workload (BASELINE.json configs[2]/[3]): a synthetic BSBM-shaped store of `--products` products
+(285 000 products = 98 M triples, "BSBM-100M"); its three sorted permutations and the typed-value
+table are resident in HBM before the timed region starts.
+
+A step = ONE BATCH of `--queries` BSBM Explore Q5 instances (distinct %Product% constants) pushed
+through the operator pipeline.  Default: the batch runs as one operator tree (`bsbm.q5_batch_plan`: the
+reference's operators — HashJoinExec / FilterExec over the same seven triple patterns — with the
+per-instance constant carried as a column, so every pattern partition is streamed once per batch;
+results per instance are identical to the reference's per-query plan, tests/test_gpu_parity.py).
+`--per-instance` runs the reference's per-query plan (Q5 (Execution Plan).snap) once per instance from
+`--threads` host threads instead.  value = solution bindings (rows leaving the top join, before
 DISTINCT / ORDER BY / LIMIT) per second over all ranks.
 
-N > 1: triples are sharded by hash(subject) over the ranks (strong scaling: the dataset is fixed); the
-constant-subject patterns' bindings are all-gathered over RCCL, everything else is local
-(rdf-fusion_amd/sharding.py).
+N > 1 (strong scaling, the dataset is fixed): triples are sharded by hash(subject); each rank evaluates
+the batch's constant-subject patterns on its shard, the bindings are exchanged with ONE all-gather per
+table and step (counts + padded rows = all-gatherv) over RCCL, everything else is local.
 """
 import argparse
 import json
@@ -74,17 +80,19 @@ def scan_roofline(rf, device, log2_rows=26, threshold=1000, reps=10):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--products", type=int, default=285_000, help="BSBM scale (285000 products = ~100 M triples)")
-    ap.add_argument("--queries", type=int, default=16, help="Q5 instances per step")
-    ap.add_argument("--threads", type=int, default=4, help="host threads submitting queries (each plan owns a HIP stream)")
+    ap.add_argument("--queries", type=int, default=256, help="Q5 instances per step (the batch)")
+    ap.add_argument("--per-instance", action="store_true", help="one reference plan per instance instead of one batched tree")
+    ap.add_argument("--threads", type=int, default=4, help="--per-instance: host threads submitting queries")
     ap.add_argument("--cpu-sample", type=int, default=4, help="Q5 instances timed on the CPU oracle (rank 0, N=1)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-scan", action="store_true", help="skip the scaled scan+FILTER roofline measurement")
     ap.add_argument("--scan-log2-rows", type=int, default=26)
     args = ap.parse_args()
 
+    import threading
     import torch
     import rdf_fusion_amd as rf
     from rdf_fusion_amd import bsbm, sharding
@@ -125,99 +133,120 @@ def main():
 
     rng = np.random.default_rng(12345)
     n_batches = args.steps + args.warmup
-    products = [ds.product(i) for i in rng.choice(ds.n_products, size=n_batches * args.queries, replace=False)]
+    Q = args.queries
+    products = np.array([ds.product(i) for i in rng.choice(ds.n_products, size=min(ds.n_products, n_batches * Q), replace=False)], dtype=np.uint32)
+    batches = [products[(i * Q) % len(products):(i * Q) % len(products) + Q] for i in range(n_batches)]
+    batches = [b if len(b) == Q else products[:Q] for b in batches]
 
     kstats = {}
+    lock = threading.Lock()
 
     def account(plan):
-        for name, launches, ms, nbytes, rows in plan.kernel_stats():
-            k = kstats.setdefault(name, [0, 0.0, 0, 0])
-            k[0] += launches; k[1] += ms; k[2] += nbytes; k[3] += rows
+        with lock:
+            for name, launches, ms, nbytes, rows in plan.kernel_stats():
+                k = kstats.setdefault(name, [0, 0.0, 0, 0])
+                k[0] += launches; k[1] += ms; k[2] += nbytes; k[3] += rows
+
+    def dev_table(cols):
+        """numpy u32 columns -> one device tensor + per-column pointers"""
+        n = len(cols[0])
+        flat = np.ascontiguousarray(np.stack([np.asarray(c, dtype=np.uint32) for c in cols]) if n else np.zeros((len(cols), 0), np.uint32))
+        t = torch.from_numpy(flat.view(np.int32)).cuda()
+        return t, [t.data_ptr() + 4 * n * k for k in range(len(cols))], n
 
     lat_ms = []
 
-    def run_plan_count(desc, tables=None, timing=True):
-        plan = store.plan(desc)
-        keep = []
-        if tables is not None:
-            for slot, t in enumerate(tables):
-                dt = torch.from_numpy(np.ascontiguousarray(t, dtype=np.uint32).view(np.int32)).cuda()
-                keep.append(dt)
-                plan.bind_table(slot, [dt.data_ptr()], len(t))
-        if timing:
-            plan.enable_kernel_timing(True)
-        plan.execute()
-        n, _ = plan.result_info()
-        if timing:
-            with lock:
-                account(plan)
-        return plan, n
-
-    # The operator trees are described once, outside the timed region: building the ctypes description
-    # is the Python stand-in for DataFusion's planner handing the subtree over.  What is timed per query:
-    # rdfgpu_plan_compile (index choice, join reordering, validation) + execute + the result count.
-    descs = {x: bsbm.q5_plan(ds, x) for x in products} if world == 1 else {}
-    pool = None
-    if args.threads > 1:
+    # ------------------------------------------------------------------ the step
+    if args.per_instance:
+        assert world == 1, "--per-instance is a single-GPU mode"
+        # Plans are described once, outside the timed region (the ctypes description is the Python stand-in
+        # for DataFusion handing the subtree over); timed per query: rdfgpu_plan_compile + execute + count.
+        descs = {int(x): bsbm.q5_plan(ds, int(x)) for x in np.unique(np.concatenate(batches))}
         from concurrent.futures import ThreadPoolExecutor
-        pool = ThreadPoolExecutor(args.threads)
-    import threading
-    lock = threading.Lock()
+        pool = ThreadPoolExecutor(args.threads) if args.threads > 1 else None
 
-    def pmap(fn, items):
-        return list(pool.map(fn, items)) if pool is not None else [fn(i) for i in items]
+        def one(x, timing):
+            t1 = time.perf_counter()
+            plan = store.plan(descs[int(x)])
+            if timing:
+                plan.enable_kernel_timing(True)
+            plan.execute()
+            n, _ = plan.result_info()
+            dt = (time.perf_counter() - t1) * 1e3
+            with lock:
+                lat_ms.append(dt)
+            if timing:
+                account(plan)
+            plan.close()
+            return n
 
-    def step(batch, timing):
-        rows = 0
-        if world == 1:
-            def one(x):
-                t1 = time.perf_counter()
-                plan = store.plan(descs[x])
+        def step(batch, timing):
+            f = lambda x: one(x, timing)
+            return sum(pool.map(f, batch)) if pool else sum(f(x) for x in batch)
+    elif world == 1:
+        plan = store.plan(bsbm.q5_batch_plan(ds))           # compiled once; only the bound PARAMS change
+
+        def step(batch, timing):
+            inst = np.arange(1, len(batch) + 1, dtype=np.uint32)   # instance tags are 1-based (0 = null)
+            t, ptrs, n = dev_table([inst, batch])
+            plan.bind_table(0, ptrs, n)
+            plan.enable_kernel_timing(timing)
+            plan.execute()
+            rows, _ = plan.result_info()
+            if timing:
+                account(plan)
+            return rows
+    else:
+        plans_a = [store.plan(d) for d in bsbm.q5_batch_const_plans(ds)]
+        plan_b = store.plan(bsbm.q5_batch_plan(ds, tables=True))
+        caps = [Q * 32, Q * 2, Q * 2]                        # rows per rank and table (fan-out U{9..28}; 1 value)
+
+        def exchange(cols, cap):
+            """all-gatherv of one (inst, X, v) table: [count, 3*cap padded u32] per rank, one collective"""
+            n = len(cols[0])
+            assert n <= cap, (n, cap)
+            buf = np.zeros(1 + 3 * cap, dtype=np.int32)
+            buf[0] = n
+            for k in range(3):
+                buf[1 + k * cap:1 + k * cap + n] = cols[k].view(np.int32)
+            mine = torch.from_numpy(buf).to(xdev)
+            out = torch.empty(world * len(buf), dtype=mine.dtype, device=mine.device)
+            dist.all_gather_into_tensor(out, mine)
+            allb = out.cpu().numpy().reshape(world, len(buf))
+            parts = [[allb[r, 1 + k * cap:1 + k * cap + allb[r, 0]].view(np.uint32) for r in range(world)] for k in range(3)]
+            return [np.concatenate(pk) for pk in parts]
+
+        def step(batch, timing):
+            inst = np.arange(1, len(batch) + 1, dtype=np.uint32)
+            t, ptrs, n = dev_table([inst, batch])
+            tables = []
+            for pa, cap in zip(plans_a, caps):
+                pa.bind_table(0, ptrs, n)
+                pa.enable_kernel_timing(timing)
+                pa.execute()
                 if timing:
-                    plan.enable_kernel_timing(True)
-                plan.execute()
-                n, _ = plan.result_info()
-                dt = (time.perf_counter() - t1) * 1e3
-                with lock:
-                    lat_ms.append(dt)
-                    if timing:
-                        account(plan)
-                plan.close()
-                return n
-            rows = sum(pmap(one, batch))
-        else:
-            def run_const(desc):
-                plan, _ = run_plan_count(desc, timing=timing)
-                out = plan.fetch()[0]
-                plan.close()
-                return out
+                    account(pa)
+                tables.append(exchange(pa.fetch(), cap))
+            keep = []
+            for slot, cols in enumerate(tables):
+                tt, pp, nn = dev_table(cols)
+                keep.append(tt)
+                plan_b.bind_table(slot, pp, nn)
+            plan_b.enable_kernel_timing(timing)
+            plan_b.execute()
+            rows, _ = plan_b.result_info()
+            if timing:
+                account(plan_b)
+            return rows
 
-            def run_local(desc, tables):
-                if any(len(t) == 0 for t in tables):
-                    return 0
-                plan, n = run_plan_count(desc, tables, timing=timing)
-                plan.close()
-                return n
-
-            def all_gather(recs):
-                mine = torch.from_numpy(recs).to(xdev)
-                # concatenated along dim 0 (the layout every backend accepts), then viewed as [world, Q, RECORD]
-                out = torch.empty((world * mine.shape[0], mine.shape[1]), dtype=mine.dtype, device=mine.device)
-                dist.all_gather_into_tensor(out, mine)
-                return out.cpu().numpy().reshape(world, mine.shape[0], mine.shape[1])
-
-            rows = sharding.run_q5_batch_sharded(ds, batch, run_const, run_local, all_gather, pmap)
-        return rows
-
-    batches = [products[i * args.queries:(i + 1) * args.queries] for i in range(n_batches)]
     for b in batches[:args.warmup]:
-        step(b, timing=False)
+        step(b, False)
     kstats.clear(); lat_ms.clear()
     barrier()
     t0 = time.perf_counter()
     local_rows = 0
     for b in batches[args.warmup:]:
-        local_rows += step(b, timing=True)
+        local_rows += step(b, True)
     barrier()
     elapsed = time.perf_counter() - t0
 
@@ -237,11 +266,24 @@ def main():
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                     "launches": launches, "avg_us": round(ms * 1e3 / max(1, launches), 2),
                     "algorithmic_bytes_per_launch": int(nbytes / max(1, launches))}
-    kernel_table = {k: {"launches": v[0], "total_ms": round(v[1], 3), "algorithmic_GBps": round(v[2] / (v[1] * 1e-3) / 1e9, 1) if v[1] > 0 else None}
+    kernel_table = {k: {"launches": v[0], "total_ms": round(v[1], 3), "avg_us": round(v[1] * 1e3 / max(1, v[0]), 1),
+                        "algorithmic_GBps": round(v[2] / (v[1] * 1e-3) / 1e9, 1) if v[1] > 0 else None}
                     for k, v in sorted(kstats.items(), key=lambda kv: -kv[1][1])}
 
-    # ------------------------------------------------------------------ CPU baseline (oracle = restated reference), rank 0, N=1
+    # ------------------------------------------------------------------ single-instance latency + CPU baseline, rank 0, N=1
     cpu = None
+    single = None
+    if rank == 0 and world == 1:
+        sample = [int(x) for x in products[:max(8, args.cpu_sample)]]
+        lat = []
+        for x in sample:                                   # the reference's per-query plan, one stream
+            d = bsbm.q5_plan(ds, x)
+            t1 = time.perf_counter()
+            pl = store.plan(d).execute()
+            pl.result_info()
+            lat.append((time.perf_counter() - t1) * 1e3)
+            pl.close()
+        single = round(float(np.median(lat)), 3)
     if rank == 0 and world == 1 and not args.no_cpu and args.cpu_sample > 0:
         from oracle import oracle as orc
         sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -250,26 +292,34 @@ def main():
         for comp in (0, 1, 2):   # adopt the device-built permutations: no second 100 M-row sort on the host
             os_.adopt_sorted(comp, store.read_index(comp))
         os_.set_typed_values(ds.typed_values)
-        sample = products[:args.cpu_sample]
-        cpu_rows, t_cpu = 0, 0.0
-        for x in sample:
-            desc = bsbm.q5_plan(ds, x)
+        sample = [int(x) for x in products[:args.cpu_sample]]
+        cpu_rows, t_cpu, expected = 0, 0.0, []
+        for i, x in enumerate(sample):
+            desc = bsbm.q5_plan(ds, x)                     # the reference's per-query plan on the CPU
             t1 = time.perf_counter()
             cols, n, _ = os_.execute(desc)
             t_cpu += time.perf_counter() - t1
             cpu_rows += n
-            plan, n_gpu = run_plan_count(desc, timing=False)   # full-size parity on the sampled instances
-            assert n_gpu == n, (n_gpu, n)
-            np.testing.assert_array_equal(ku.multiset(plan.fetch(), n), ku.multiset(cols, n))
-            plan.close()
+            pl = store.plan(desc).execute()                # full-size parity, per-instance path
+            np.testing.assert_array_equal(ku.multiset(pl.fetch(), n), ku.multiset(cols, n))
+            pl.close()
+            expected.append(np.stack([np.full(n, i + 1, np.uint32), cols[0], cols[1]], axis=1))
+        # full-size parity, batched path: the same instances as one batch
+        pb = store.plan(bsbm.q5_batch_plan(ds))
+        tt, pp, nn = dev_table([np.arange(1, len(sample) + 1, dtype=np.uint32), np.array(sample, dtype=np.uint32)])
+        pb.bind_table(0, pp, nn)
+        got = pb.execute().fetch()
+        np.testing.assert_array_equal(ku.multiset(got), ku.multiset(list(np.concatenate(expected).T)))
+        pb.close()
         cpu = {"value": round(cpu_rows / t_cpu, 2) if t_cpu > 0 else None, "unit": "bindings/s", "cores": 1, "kind": "port",
-               "sample": f"{len(sample)} Q5 instances of this workload ({cpu_rows} bindings, {t_cpu:.1f} s on one host core); "
-                         "C restatement of the reference's operators (oracle/rdf_oracle.c), single thread like the "
-                         "reference's default target_partitions=1; GPU results on these instances compared multiset-equal",
+               "sample": f"{len(sample)} Q5 instances of this workload ({cpu_rows} bindings, {t_cpu:.1f} s on one host core), each run "
+                         "as the reference's per-query plan by the C restatement of the reference's operators "
+                         "(oracle/rdf_oracle.c), single thread like the reference's default target_partitions=1; the GPU's "
+                         "per-instance and batched results on these instances were compared multiset-equal",
                "queries_per_s": round(len(sample) / t_cpu, 3) if t_cpu > 0 else None}
 
     if rank == 0:
-        n_q = args.steps * args.queries
+        n_q = args.steps * Q
         out = {
             "metric": "solution bindings/sec + achieved HBM GB/s, BSBM Q5 at 1/2/4/8 GPUs",
             "value": round(total_rows / elapsed, 2),
@@ -282,9 +332,13 @@ def main():
             "dtype": "u32 ids / i64 typed values",
             "data": "synthetic",
             "config": {"workload": f"BSBM-shaped store, {args.products} products ({ds.n_triples} triples), Explore Q5 "
-                                   f"(7 triple patterns, 3 hash joins + 3 cross joins + 4 filters), {args.queries} instances/step",
-                       "triples_per_gpu": n_local, "sharding": "hash(subject) mod N" if world > 1 else "none",
-                       "queries_per_s": round(n_q / elapsed, 2), "bindings": total_rows, "host_threads": args.threads,
+                                   f"(7 triple patterns -> scans, hash joins, FILTERs), {Q} instances per step, "
+                                   + ("one reference plan per instance" if args.per_instance else "batched into one operator tree (shared scans)"),
+                       "mode": "per-instance" if args.per_instance else "batched",
+                       "triples_per_gpu": n_local, "sharding": "hash(subject) mod N, all-gatherv of constant-pattern bindings" if world > 1 else "none",
+                       "queries_per_s": round(n_q / elapsed, 2), "bindings": total_rows,
+                       "host_threads": args.threads if args.per_instance else 1,
+                       "single_instance_latency_ms": single,
                        "median_query_latency_ms": round(float(np.median(lat_ms)), 3) if lat_ms else None,
                        "load_seconds": round(load_s, 1)},
             "roofline": roofline,

@@ -213,6 +213,58 @@ def q5_plan(ds, product_id, w1=120, w2=170):
     return pb.build(node)
 
 
+def _window(sim, orig, w):
+    """EBV(LT(ENC_TV(sim), ADD(ENC_TV(orig), 9:w))) AND EBV(GT(ENC_TV(sim), SUB(ENC_TV(orig), 9:w)))"""
+    return AND(EBV(LT(ENC_TV(col(sim)), ADD(ENC_TV(col(orig)), integer(w)))),
+               EBV(GT(ENC_TV(col(sim)), SUB(ENC_TV(col(orig)), integer(w)))))
+
+
+def q5_batch_const_plans(ds):
+    """Phase A of a batched Q5: the constant-subject patterns of ALL instances of a batch at once.
+    Table 0 = PARAMS(inst, X): one row per query instance (inst = position in the batch, X = %Product%).
+    Each plan joins PARAMS with the pattern's (unbound-subject) scan on X = ?s, which is what B separate
+    `<X> p ?v` scans return, tagged with the instance:  (inst, X, v)."""
+    pr = ds.pred
+    out = []
+    for pname in ("bsbm:productFeature", "bsbm:productPropertyNumeric1", "bsbm:productPropertyNumeric2"):
+        pb = PlanBuilder()
+        params = pb.table(0, 2)
+        scan = pb.data_source(quad_pattern("s", pr[pname], "v"))          # (s, v)
+        out.append(pb.build(pb.hash_join(params, scan, on=[(1, 0)], projection=[0, 1, 3])))
+    return out
+
+
+def q5_batch_plan(ds, w1=120, w2=170, tables=None):
+    """BSBM Q5 for a BATCH of instances in one operator tree (shared scans: every triple-pattern partition
+    is streamed once per batch instead of once per query).  Same operators as q5_plan; the per-instance
+    constant becomes a column: tables F(inst, X, prodFeature), O1(inst, X, origProperty1), O2(inst, X,
+    origProperty2) are either bound (slots 0,1,2 — the graph-sharded case, after the all-gather) or, when
+    `tables` is None, computed in-plan from PARAMS(inst, X) bound at slot 0.
+    `product != X` is applied once, where the instance meets the product (all later joins are on product).
+    Output: (inst, product, productLabel) — per instance exactly q5_plan's bindings."""
+    pr = ds.pred
+    pb = PlanBuilder()
+    if tables is None:
+        params = pb.table(0, 2)
+
+        def const(pname):
+            scan = pb.data_source(quad_pattern("s", pr[pname], "v"))
+            return pb.hash_join(params, scan, on=[(1, 0)], projection=[0, 1, 3])
+        F, O1, O2 = const("bsbm:productFeature"), const("bsbm:productPropertyNumeric1"), const("bsbm:productPropertyNumeric2")
+    else:
+        F, O1, O2 = pb.table(0, 3), pb.table(1, 3), pb.table(2, 3)
+    pf = pb.data_source(quad_pattern("product", pr["bsbm:productFeature"], "prodFeature"))      # (product, prodFeature)
+    # (inst, X, f) JOIN (product, f) ON f, product != X   ->  (inst, X, product)
+    j1a = pb.hash_join(F, pf, on=[(2, 1)], filter=ID_NEQ(col(3), col(1)), projection=[0, 1, 3])
+    label = pb.data_source(quad_pattern("product", pr["rdfs:label"], "productLabel"))           # (product, label)
+    node = pb.hash_join(j1a, label, on=[(2, 0)], projection=[0, 1, 2, 4])                       # (inst, X, product, label)
+    for k, w, O in ((1, w1, O1), (2, w2, O2)):
+        withorig = pb.hash_join(node, O, on=[(0, 0)], projection=[0, 1, 2, 3, 6])               # + origPropertyK
+        sim = pb.data_source(quad_pattern("product", pr[f"bsbm:productPropertyNumeric{k}"], f"simProperty{k}"))
+        node = pb.hash_join(withorig, sim, on=[(2, 0)], filter=_window(6, 4, w), projection=[0, 1, 2, 3])
+    return pb.build(pb.projection(node, [0, 2, 3]))
+
+
 def q1_plan(ds, type_id, feature1, feature2, threshold):
     """BSBM Explore Q1: four chained single-key hash joins on ?product and the numeric FILTER
     (Q1 (Execution Plan).snap:10-19).  Output: (product, label)."""

@@ -495,7 +495,11 @@ __device__ __forceinline__ Val lit_val(const TvLiteral& l) {
 template <int FS>
 __device__ __forceinline__ bool ljoin_filter(const LdsJoinArgs& a, u64 i, u64 j) {
   if constexpr (FS == 0) return true;
-  else if constexpr (FS == 3) {
+  else if constexpr (FS == 2) {   // column <ID_EQ | ID_NEQ> column (e.g. `product != X` with the instance's X as a column)
+    const u32 va = ljoin_col(a, a.idp.a, i, j), vb = ljoin_col(a, a.idp.b, i, j);
+    if (va == 0 || vb == 0) return false;   // null => not `true`
+    return (va == vb) == (a.idp.is_eq != 0);
+  } else if constexpr (FS == 3) {
     const WindowFilter& w = a.win;
     const bool same = w.x0 == w.x1 && w.y0 == w.y1;   // wave-uniform
     const u32 ix0 = ljoin_col(a, w.x0, i, j), iy0 = ljoin_col(a, w.y0, i, j);
@@ -670,6 +674,7 @@ void launch_lds_join(const LdsJoinArgs& a, hipStream_t s) {
 #define RDFGPU_LJ(F, P) if (fs == F && pfs == P) { if (wide) return launch_lds_join_t<F, P, kLdsItems>(a, g, lds, s); return launch_lds_join_t<F, P, 1>(a, g, lds, s); }
   RDFGPU_LJ(0, 0) RDFGPU_LJ(0, 1) RDFGPU_LJ(0, 2)
   RDFGPU_LJ(1, 0) RDFGPU_LJ(1, 1) RDFGPU_LJ(1, 2)
+  RDFGPU_LJ(2, 0) RDFGPU_LJ(2, 1) RDFGPU_LJ(2, 2)
   RDFGPU_LJ(3, 0) RDFGPU_LJ(3, 1) RDFGPU_LJ(3, 2)
 #undef RDFGPU_LJ
   fail(RDFGPU_ERR_INVALID, "lds join: bad filter shape %d/%d", fs, pfs);

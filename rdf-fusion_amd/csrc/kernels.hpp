@@ -106,6 +106,7 @@ struct WindowFilter {   // EBV(cmp0(ENC_TV(x0), y0 +/- lit0)) AND EBV(cmp1(ENC_T
   TvLiteral l0, l1;
 };
 struct IdFilter { u32 col, lit, is_eq; };   // col <ID_EQ | ID_NEQ> object-id literal
+struct IdPairFilter { u32 a, b, is_eq; };   // col a <ID_EQ | ID_NEQ> col b
 
 // ---- K4+K5 fused: LDS-staged hash join for build sides that fit one workgroup's LDS ----
 constexpr u32 kLdsJoinMaxBuild = 8192;   // rows; 16384 slots x 8 B = 128 KiB of the CU's 160 KiB
@@ -134,6 +135,7 @@ struct LdsJoinArgs {
   const ExprProgram* probe_prog;  // fused FilterExec of the probe child, over the probe side's columns (VM)
   u32 probe_col_base;             // first column of the probe side inside cols[]
   WindowFilter win;               // has_filter == 3
+  IdPairFilter idp;               // has_filter == 2
   IdFilter pid;                   // has_probe_filter == 1; pid.col indexes cols[] directly
 };
 void launch_lds_join(const LdsJoinArgs& a, hipStream_t s);

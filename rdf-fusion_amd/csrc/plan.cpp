@@ -81,6 +81,8 @@ int detect_join_filter_shape(const ExprProgram& pr) {
            (e[o + 5].op == RDFGPU_EX_ADD || e[o + 5].op == RDFGPU_EX_SUB) && is_cmp(e[o + 6].op) && e[o + 7].op == RDFGPU_EX_EBV;
   };
   if (pr.n == 17 && half(0) && half(8) && e[16].op == RDFGPU_EX_AND) return 3;
+  // 2 = column <ID_EQ | ID_NEQ> column
+  if (pr.n == 3 && e[0].op == RDFGPU_EX_COLUMN && e[1].op == RDFGPU_EX_COLUMN && (e[2].op == RDFGPU_EX_ID_EQ || e[2].op == RDFGPU_EX_ID_NEQ)) return 2;
   return 1;
 }
 
@@ -299,12 +301,11 @@ const char* kernel_class_name(int kc) {
       "void rdfgpu::join_probe_kernel<true>", "rdfgpu::join_left_unmatched_kernel", "void rdfgpu::nlj_kernel<false>",
       "void rdfgpu::nlj_kernel<true>", "rocprim device scan"};
   if (kc < KC_LDS_JOIN0) return fixed[kc];
-  static std::string names[18];
+  static std::string names[24];
   static std::once_flag once;
   std::call_once(once, [] {
-    const int fs[3] = {0, 1, 3};
-    for (int f = 0; f < 3; f++) for (int p = 0; p < 3; p++) for (int w = 0; w < 2; w++)
-      names[(f * 3 + p) * 2 + w] = "void rdfgpu::lds_join_kernel<" + std::to_string(fs[f]) + ", " + std::to_string(p) + ", " + (w == 0 ? "4" : "1") + ">";
+    for (int f = 0; f < 4; f++) for (int p = 0; p < 3; p++) for (int w = 0; w < 2; w++)
+      names[(f * 3 + p) * 2 + w] = "void rdfgpu::lds_join_kernel<" + std::to_string(f) + ", " + std::to_string(p) + ", " + (w == 0 ? "4" : "1") + ">";
   });
   return names[kc - KC_LDS_JOIN0].c_str();
 }
@@ -689,6 +690,7 @@ DevTable Plan::exec_lds_join(NodeInfo& nd, const DevTable& L, const DevTable& R,
   a.probe_col_base = build_left ? L.n_cols : 0;
   a.has_filter = (u32)nd.shape;   // 0 none / 1 generic VM / 3 window
   if (nd.shape == 1) a.prog = upload_program(nd.prog);
+  if (nd.shape == 2) { a.idp.a = nd.prog.nodes[0].u; a.idp.b = nd.prog.nodes[1].u; a.idp.is_eq = nd.prog.nodes[2].op == RDFGPU_EX_ID_EQ; }
   if (nd.shape == 3) {
     const rdfgpu_expr_node* e = nd.prog.nodes;
     auto lit = [&](u32 o) { TvLiteral l{}; l.lo = e[o + 4].lo; l.hi = e[o + 4].hi; l.aux = e[o + 4].u; l.tag = e[o + 4].tag; l.flags = e[o + 4].flags;

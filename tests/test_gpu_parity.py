@@ -390,6 +390,35 @@ def test_bsbm_q1_matches_oracle(bsbm_stores):
         run_both(gs, os_, bsbm.q1_scan_filter_plan(ds, thr))
 
 
+@pytest.mark.parametrize("batch", [1, 24, 400])
+def test_bsbm_q5_batched_equals_per_instance(bsbm_stores, torch_cuda, batch):
+    """A batch of Q5 instances as ONE operator tree (shared scans, the constant as a column) must give,
+    per instance, exactly the bindings of the per-instance reference plan."""
+    ds, gs, os_ = bsbm_stores
+    rng = np.random.default_rng(batch)
+    prods = [ds.product(i) for i in rng.choice(ds.n_products, batch, replace=False)]
+    params = [np.arange(1, batch + 1, dtype=np.uint32), np.array(prods, dtype=np.uint32)]   # inst tags are 1-based: 0 is null
+    keep, ptrs = table_on_device(torch_cuda, params)
+    plan, got = run_both(gs, os_, bsbm.q5_batch_plan(ds), gpu_tables=[(ptrs, batch)], cpu_tables=[params])
+    expected = []
+    for i, x in enumerate(prods[:40]):      # per-instance reference plans (oracle) for a sample of the batch
+        c, m, _ = os_.execute(bsbm.q5_plan(ds, x))
+        expected.append(np.stack([np.full(m, i + 1, np.uint32), c[0], c[1]], axis=1))
+    expected = np.concatenate(expected)
+    sel = got[0] <= min(batch, 40)
+    np.testing.assert_array_equal(ku.multiset([g[sel] for g in got]), ku.multiset(list(expected.T)))
+    # graph-sharded form: phase A (constant patterns of the whole batch) then phase B over bound tables
+    tabs = []
+    for d in bsbm.q5_batch_const_plans(ds):
+        p = gs.plan(d)
+        p.bind_table(0, ptrs, batch)
+        tabs.append(p.execute().fetch())
+    keeps = [table_on_device(torch_cuda, t) for t in tabs]
+    plan_b, got_b = run_both(gs, os_, bsbm.q5_batch_plan(ds, tables=True),
+                             gpu_tables=[(k[1], len(t[0])) for k, t in zip(keeps, tabs)], cpu_tables=tabs)
+    np.testing.assert_array_equal(ku.multiset(got_b), ku.multiset(got))
+
+
 def test_generic_vm_equals_specialised_kernels(bsbm_stores, monkeypatch):
     ds, gs, os_ = bsbm_stores
     desc = bsbm.q5_plan(ds, ds.product(17))
