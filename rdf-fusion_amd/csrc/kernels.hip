@@ -580,27 +580,53 @@ __device__ __forceinline__ void ljoin_emit(const LdsJoinArgs& a, u32 i, u64 j, u
   if (a.visited) a.visited[i] = 1;
 }
 
-template <int FS, int PFS, int ITEMS>
-__global__ __launch_bounds__(kLdsBlock) void lds_join_kernel(const LdsJoinArgs a) {
-  extern __shared__ __align__(16) unsigned char lds_raw[];
-  uint2* slots = reinterpret_cast<uint2*>(lds_raw);
-  __shared__ u32 wave_tot[kLdsBlock / 64];
-  __shared__ u64 tile_base;
-  constexpr int kTileRows = kLdsBlock * ITEMS;
-  const u32 tid = threadIdx.x;
-  for (u32 s = tid; s <= a.tbl_mask; s += kLdsBlock) slots[s] = make_uint2(0u, kNil);
-  __syncthreads();
+// Build sides above the LDS limit: the same {key0,row} open-addressing table, but ONE copy in HBM (8 B per
+// slot, load <= 0.5; a 285 k-row build = 8 MiB, i.e. L2 / Infinity-Cache resident), filled by this kernel.
+// The probe is lds_join_kernel<.., GLOBAL = true>: identical code, the slot reads go to L2 instead of LDS.
+__global__ __launch_bounds__(kBlock) void gjoin_build_kernel(const LdsJoinArgs a) {
   const u64 nb = live_rows(a.n_build_dev, a.n_build_cap);
-  for (u64 i = tid; i < nb; i += kLdsBlock) {
+  const u64 base = (u64)blockIdx.x * kTile;
+#pragma unroll
+  for (int k = 0; k < kItems; k++) {
+    const u64 i = base + (u64)k * kBlock + threadIdx.x;
+    if (i >= nb) break;
     Keys key;
     if (!load_keys(a.build_key, a.n_keys, i, key)) continue;
     u32 h = hash_keys4(key, a.n_keys) & a.tbl_mask;
     for (;;) {
-      if (atomicCAS(&slots[h].y, kNil, (u32)i) == kNil) { slots[h].x = key.k[0]; break; }
+      if (atomicCAS(&a.gslots[h].y, kNil, (u32)i) == kNil) { a.gslots[h].x = key.k[0]; break; }
       h = (h + 1) & a.tbl_mask;
     }
   }
-  __syncthreads();
+}
+void launch_gjoin_build(const LdsJoinArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(gjoin_build_kernel, grid_for(a.n_build_cap), dim3(kBlock), 0, s, a);
+}
+
+template <int FS, int PFS, int ITEMS, bool GLOBAL>
+__global__ __launch_bounds__(kLdsBlock) void lds_join_kernel(const LdsJoinArgs a) {
+  extern __shared__ __align__(16) unsigned char lds_raw[];
+  const uint2* slots = GLOBAL ? a.gslots : reinterpret_cast<const uint2*>(lds_raw);
+  __shared__ u32 wave_tot[kLdsBlock / 64];
+  __shared__ u64 tile_base;
+  constexpr int kTileRows = kLdsBlock * ITEMS;
+  const u32 tid = threadIdx.x;
+  if constexpr (!GLOBAL) {
+    uint2* lslots = reinterpret_cast<uint2*>(lds_raw);
+    for (u32 s = tid; s <= a.tbl_mask; s += kLdsBlock) lslots[s] = make_uint2(0u, kNil);
+    __syncthreads();
+    const u64 nb = live_rows(a.n_build_dev, a.n_build_cap);
+    for (u64 i = tid; i < nb; i += kLdsBlock) {
+      Keys key;
+      if (!load_keys(a.build_key, a.n_keys, i, key)) continue;
+      u32 h = hash_keys4(key, a.n_keys) & a.tbl_mask;
+      for (;;) {
+        if (atomicCAS(&lslots[h].y, kNil, (u32)i) == kNil) { lslots[h].x = key.k[0]; break; }
+        h = (h + 1) & a.tbl_mask;
+      }
+    }
+    __syncthreads();
+  }
 
   const u64 np = live_rows(a.n_probe_dev, a.n_probe_cap);
   const u64 n_tiles = (np + kTileRows - 1) / kTileRows;
@@ -651,27 +677,30 @@ __global__ __launch_bounds__(kLdsBlock) void lds_join_kernel(const LdsJoinArgs a
   }
 }
 
-template <int FS, int PFS, int ITEMS>
+template <int FS, int PFS, int ITEMS, bool GLOBAL>
 static void launch_lds_join_t(const LdsJoinArgs& a, dim3 g, size_t lds, hipStream_t s) {
   static bool attr_set = false;
-  if (!attr_set) {   // dynamic LDS above 64 KiB has to be opted into, per kernel instance
-    RDFGPU_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lds_join_kernel<FS, PFS, ITEMS>), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
+  if (!attr_set && !GLOBAL) {   // dynamic LDS above 64 KiB has to be opted into, per kernel instance
+    RDFGPU_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lds_join_kernel<FS, PFS, ITEMS, GLOBAL>), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
     attr_set = true;
   }
-  hipLaunchKernelGGL((lds_join_kernel<FS, PFS, ITEMS>), g, dim3(kLdsBlock), lds, s, a);
+  hipLaunchKernelGGL((lds_join_kernel<FS, PFS, ITEMS, GLOBAL>), g, dim3(kLdsBlock), GLOBAL ? 0 : lds, s, a);
 }
 bool lds_join_is_wide(u64 n_probe_cap) { return (n_probe_cap + kLdsTile - 1) / kLdsTile >= 512; }
 void launch_lds_join(const LdsJoinArgs& a, hipStream_t s) {
-  const size_t lds = (size_t)(a.tbl_mask + 1) * sizeof(uint2);
+  const bool global = a.gslots != nullptr;
+  const size_t lds = global ? 0 : (size_t)(a.tbl_mask + 1) * sizeof(uint2);
   // enough workgroups to cover all 256 CUs; each builds its LDS copy once and strides over the tiles
-  const u64 max_wg = lds > 64 * 1024 ? 256 : lds > 32 * 1024 ? 512 : 1024;
+  const u64 max_wg = global ? 2048 : lds > 64 * 1024 ? 256 : lds > 32 * 1024 ? 512 : 1024;
   // small probe sides: one row per lane (more, shorter workgroups) instead of four
   const bool wide = lds_join_is_wide(a.n_probe_cap);
   const u64 rows = wide ? kLdsTile : kLdsBlock;
   const u64 n_tiles = (a.n_probe_cap + rows - 1) / rows;
   const dim3 g((unsigned)(n_tiles < max_wg ? (n_tiles ? n_tiles : 1) : max_wg));
-  const int fs = a.has_filter, pfs = a.has_probe_filter;   // 0 none / 1 VM / 3 window ; 0 none / 1 id-literal / 2 VM
-#define RDFGPU_LJ(F, P) if (fs == F && pfs == P) { if (wide) return launch_lds_join_t<F, P, kLdsItems>(a, g, lds, s); return launch_lds_join_t<F, P, 1>(a, g, lds, s); }
+  const int fs = a.has_filter, pfs = a.has_probe_filter;   // 0 none / 1 VM / 2 col-col / 3 window ; 0 none / 1 id-literal / 2 VM
+#define RDFGPU_LJ(F, P) if (fs == F && pfs == P) { \
+    if (global) { if (wide) return launch_lds_join_t<F, P, kLdsItems, true>(a, g, lds, s); return launch_lds_join_t<F, P, 1, true>(a, g, lds, s); } \
+    if (wide) return launch_lds_join_t<F, P, kLdsItems, false>(a, g, lds, s); return launch_lds_join_t<F, P, 1, false>(a, g, lds, s); }
   RDFGPU_LJ(0, 0) RDFGPU_LJ(0, 1) RDFGPU_LJ(0, 2)
   RDFGPU_LJ(1, 0) RDFGPU_LJ(1, 1) RDFGPU_LJ(1, 2)
   RDFGPU_LJ(2, 0) RDFGPU_LJ(2, 1) RDFGPU_LJ(2, 2)

@@ -122,7 +122,8 @@ struct LdsJoinArgs {
   const u32* probe_key[RDFGPU_MAX_KEYS];
   const u64* n_build_dev; u64 n_build_cap;
   const u64* n_probe_dev; u64 n_probe_cap;
-  u32 tbl_mask;             // LDS slots - 1 (power of two >= 2 x build rows)
+  u32 tbl_mask;             // table slots - 1 (power of two >= 2 x build rows)
+  uint2* gslots;            // null: the table lives in LDS (one copy per workgroup); else ONE {key0,row} table in HBM
   u64* n_out_dev;           // exact number of matches (zeroed before launch)
   u64 out_cap;              // rows the out columns can hold (optimistic)
   u32* overflow;            // set when the matches did not fit
@@ -139,6 +140,7 @@ struct LdsJoinArgs {
   IdFilter pid;                   // has_probe_filter == 1; pid.col indexes cols[] directly
 };
 void launch_lds_join(const LdsJoinArgs& a, hipStream_t s);
+void launch_gjoin_build(const LdsJoinArgs& a, hipStream_t s);   // fills a.gslots (memset to 0xFF first)
 bool lds_join_is_wide(u64 n_probe_cap);   // true: the 4-rows-per-lane instantiation is launched, false: 1 row per lane
 
 // ---- utilities ----

@@ -299,13 +299,14 @@ const char* kernel_class_name(int kc) {
       "void rdfgpu::filter_kernel<1>", "void rdfgpu::filter_kernel<2>", "void rdfgpu::filter_kernel<0>",
       "rdfgpu::cross_kernel", "rdfgpu::join_build_kernel", "void rdfgpu::join_probe_kernel<false>",
       "void rdfgpu::join_probe_kernel<true>", "rdfgpu::join_left_unmatched_kernel", "void rdfgpu::nlj_kernel<false>",
-      "void rdfgpu::nlj_kernel<true>", "rocprim device scan"};
+      "void rdfgpu::nlj_kernel<true>", "rocprim device scan", "rdfgpu::gjoin_build_kernel"};
   if (kc < KC_LDS_JOIN0) return fixed[kc];
-  static std::string names[24];
+  static std::string names[48];
   static std::once_flag once;
   std::call_once(once, [] {
-    for (int f = 0; f < 4; f++) for (int p = 0; p < 3; p++) for (int w = 0; w < 2; w++)
-      names[(f * 3 + p) * 2 + w] = "void rdfgpu::lds_join_kernel<" + std::to_string(f) + ", " + std::to_string(p) + ", " + (w == 0 ? "4" : "1") + ">";
+    for (int f = 0; f < 4; f++) for (int p = 0; p < 3; p++) for (int w = 0; w < 2; w++) for (int g = 0; g < 2; g++)
+      names[((f * 3 + p) * 2 + w) * 2 + g] = "void rdfgpu::lds_join_kernel<" + std::to_string(f) + ", " + std::to_string(p) + ", " +
+                                             (w == 0 ? "4" : "1") + ", " + (g ? "true" : "false") + ">";
   });
   return names[kc - KC_LDS_JOIN0].c_str();
 }
@@ -557,7 +558,7 @@ DevTable Plan::exec_join(NodeInfo& nd) {
   DevTable R = rf ? exec_node((u32)nodes[nd.d.right].d.left) : exec_node((u32)nd.d.right);
   if (lf || rf) {
     const bool build_left = left_join || L.cap <= R.cap;
-    const bool lds = (build_left ? L.cap : R.cap) <= kLdsJoinMaxBuild && L.cap && R.cap;
+    const bool lds = ((build_left ? L.cap : R.cap) <= kLdsJoinMaxBuild || !std::getenv("RDFGPU_NO_GLOBAL_TABLE_JOIN")) && L.cap && R.cap;
     // a fused filter survives only on the probe side of the LDS join; anything else is materialised now
     if (lf && (!lds || build_left)) { L = apply_filter(nodes[nd.d.left], L); lf = false; }
     if (rf && (!lds || !build_left)) { R = apply_filter(nodes[nd.d.right], R); rf = false; }
@@ -590,7 +591,7 @@ DevTable Plan::exec_join(NodeInfo& nd) {
   if (hash && !std::getenv("RDFGPU_NO_LDS_JOIN")) {
     // build on the smaller input (an inner join is symmetric; a left join must build on the preserved side)
     const bool build_left = left_join || L.cap <= R.cap;
-    if ((build_left ? L.cap : R.cap) <= kLdsJoinMaxBuild) {
+    if ((build_left ? L.cap : R.cap) <= kLdsJoinMaxBuild || !std::getenv("RDFGPU_NO_GLOBAL_TABLE_JOIN")) {
       const NodeInfo* pf = lf ? &nodes[nd.d.left] : rf ? &nodes[nd.d.right] : nullptr;
       return exec_lds_join(nd, L, R, build_left, pf);
     }
@@ -684,9 +685,15 @@ DevTable Plan::exec_lds_join(NodeInfo& nd, const DevTable& L, const DevTable& R,
     a.probe_key[k] = P.cols[probe_keys[k]];
   }
   a.n_build_dev = B.n_dev; a.n_build_cap = B.cap; a.n_probe_dev = P.n_dev; a.n_probe_cap = P.cap;
+  if (B.cap >= (1ull << 30)) fail(RDFGPU_ERR_UNSUPPORTED, "build side of %llu rows", (unsigned long long)B.cap);
   u32 slots = 64;
   while (slots < 2 * B.cap) slots <<= 1;
   a.tbl_mask = slots - 1;
+  const bool global_table = B.cap > kLdsJoinMaxBuild;   // one {key0,row} table in HBM instead of a copy per workgroup in LDS
+  if (global_table) {
+    a.gslots = scratch<uint2>(slots);
+    RDFGPU_HIP(hipMemsetAsync(a.gslots, 0xFF, (size_t)slots * sizeof(uint2), stream));
+  }
   a.probe_col_base = build_left ? L.n_cols : 0;
   a.has_filter = (u32)nd.shape;   // 0 none / 1 generic VM / 3 window
   if (nd.shape == 1) a.prog = upload_program(nd.prog);
@@ -729,13 +736,15 @@ DevTable Plan::exec_lds_join(NodeInfo& nd, const DevTable& L, const DevTable& R,
   // SURVEY §8d hash join: 4(k+p_b)N_b + 8N_b + 4(k+p_p)N_p + 8N_p + 4 c_o N_o  (the 8-byte slot lives in LDS here)
   const u64 fixed = (4ull * (a.n_keys + build_payload) + 8) * B.cap;
 
+  if (global_table)   // build pass: keys read + one 8-byte slot written per build row
+    timed(KC_GJOIN_BUILD, 0, B.cap, B.n_dev, 4ull * a.n_keys + 8, nullptr, 0, 0, [&] { launch_gjoin_build(a, stream); });
   u64 out_cap = P.cap < 1024 ? 1024 : P.cap;   // optimistic: at most one match per probe row on average
   u64 total = 0;
   for (int attempt = 0; attempt < 2; attempt++) {
     a.out_cap = out_cap;
     for (u32 c = 0; c < nd.n_proj; c++) { a.out[c] = scratch<u32>(out_cap + tail); t.cols[c] = a.out[c]; }
     if (left_join) RDFGPU_HIP(hipMemsetAsync(a.visited, 0, L.cap, stream));
-    timed(lds_join_class(a.has_filter, a.has_probe_filter, lds_join_is_wide(P.cap)), fixed, P.cap, P.n_dev, 4ull * probe_cols + 8, n_out, 0, 4ull * nd.n_proj, [&] { launch_lds_join(a, stream); });
+    timed(lds_join_class(a.has_filter, a.has_probe_filter, lds_join_is_wide(P.cap), global_table), global_table ? 0 : fixed, P.cap, P.n_dev, 4ull * probe_cols + 8, n_out, 0, 4ull * nd.n_proj, [&] { launch_lds_join(a, stream); });
     const u32 i0 = (u32)(n_out - counters);
     RDFGPU_HIP(hipMemcpyAsync(ctx->counters_host + i0, counters + i0, 2 * sizeof(u64), hipMemcpyDeviceToHost, stream));
     RDFGPU_HIP(hipStreamSynchronize(stream)); metrics.host_syncs++;

@@ -38,11 +38,12 @@ struct BoundTable { std::vector<const u32*> cols; u64 n_rows = 0; bool bound = f
 enum KernelClass {
   KC_LOCATE, KC_SCAN_COUNT, KC_SCAN_WRITE, KC_FILTER_ID, KC_FILTER_TV, KC_FILTER_VM, KC_CROSS, KC_JOIN_BUILD,
   KC_JOIN_COUNT, KC_JOIN_WRITE, KC_LEFT_TAIL, KC_NLJ_COUNT, KC_NLJ_WRITE, KC_DEVICE_SCAN,
-  KC_LDS_JOIN0,                      // 24 instantiations: lds_join_kernel<FS in {0,1,2,3}, PFS in {0,1,2}, ITEMS in {4,1}>
-  KC__N = KC_LDS_JOIN0 + 24
+  KC_GJOIN_BUILD,
+  KC_LDS_JOIN0,                      // 48 instantiations: lds_join_kernel<FS in {0..3}, PFS in {0,1,2}, ITEMS in {4,1}, GLOBAL>
+  KC__N = KC_LDS_JOIN0 + 48
 };
 const char* kernel_class_name(int kc);
-inline int lds_join_class(u32 fs, u32 pfs, bool wide) { return KC_LDS_JOIN0 + (int)((fs * 3 + pfs) * 2 + (wide ? 0 : 1)); }
+inline int lds_join_class(u32 fs, u32 pfs, bool wide, bool global) { return KC_LDS_JOIN0 + (int)(((fs * 3 + pfs) * 2 + (wide ? 0 : 1)) * 2 + (global ? 1 : 0)); }
 
 struct KernelStat { u32 launches = 0; double ms = 0; u64 bytes = 0; u64 rows = 0; };
 
