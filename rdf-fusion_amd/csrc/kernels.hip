@@ -448,6 +448,7 @@ __global__ __launch_bounds__(kBlock) void join_left_unmatched_kernel(const JoinA
   for (int k = 0; k < kItems; k++) {
     if (keep[k]) {
       const u64 i = base + (u64)k * kBlock + threadIdx.x;
+      if (a.matched_total && off + pre[k] >= a.matched_total) continue;   // speculative sizing: never write past the block
       for (u32 oc = 0; oc < a.n_out_cols; oc++) {
         const u32 p = a.proj[oc];
         a.out[oc][off + pre[k]] = p < a.n_left_cols ? a.left[p][i] : 0u;

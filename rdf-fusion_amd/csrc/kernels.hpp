@@ -86,7 +86,7 @@ struct JoinArgs {
   u32* counts;                  // per probe row match count / inclusive offsets [n_right_cap]
   u8* visited;                  // left join: per build row
   u64* n_out_dev;               // left join: final count
-  u64 matched_total;            // write pass (left join): rows produced by matches
+  u64 matched_total;            // left-join tail: capacity of the out columns (0 = unchecked)
   u32 has_filter;
   TypedTable tt;
   ExprProgram prog;

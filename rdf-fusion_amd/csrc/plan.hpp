@@ -30,7 +30,9 @@ struct NodeInfo {
   u32 n_cols_read = 0;            // distinct input columns the kernel has to read
   int source = -1;                // index into Plan::sources
   u32 refs = 0;                   // how many operators consume this node
+  u64 last_rows = 0; bool has_last = false;   // output cardinality of the previous execution (speculative sizing)
 };
+struct SpecCheck { NodeInfo* node; u32 counter; bool left_join; };   // counter = n_out slot, counter+1 = overflow flag
 
 struct BoundTable { std::vector<const u32*> cols; u64 n_rows = 0; bool bound = false; };
 
@@ -79,6 +81,9 @@ struct Plan {
   DevTable result; u64 result_rows = 0; bool executed = false;
   rdfgpu_metrics metrics{};
   bool timing = false;
+  u64 located_version = ~0ull;    // store version the cached scan ranges belong to
+  bool allow_speculation = true, speculative = false;
+  std::vector<SpecCheck> spec_checks;
   std::vector<PendingLaunch> pending;
   u32 events_used = 0;
   KernelStat kstats[KC__N];

@@ -152,6 +152,7 @@ Store::~Store() {
 void Store::clear() {
   std::unique_lock<std::shared_mutex> lock(mu);
   activate();
+  version++;
   for (auto& ix : idx) { for (auto& c : ix.col) { if (c) RDFGPU_HIP(hipFree(c)); c = nullptr; } ix.n = 0; }
 }
 
@@ -195,6 +196,7 @@ u64 Store::extend_device(const u32* g, const u32* s_, const u32* p, const u32* o
   std::unique_lock<std::shared_mutex> lock(mu);
   activate();
   if (n == 0) return 0;
+  version++;
   const u32* in[4] = {g, s_, p, o};
   hipStream_t s = stream;
   u64 inserted = 0;
@@ -254,6 +256,7 @@ u64 Store::remove_host(const u32* g, const u32* s_, const u32* p, const u32* o, 
   std::unique_lock<std::shared_mutex> lock(mu);
   activate();
   if (n == 0 || idx[0].n == 0) return 0;
+  version++;
   hipStream_t s = stream;
   const u32* h[4] = {g, s_, p, o};
   u64 removed = 0;

@@ -2,6 +2,7 @@
 // Replaces MemQuadStorage / IndexPermutations<MemQuadIndex> / MemIndexData
 // (lib/storage/src/memory/storage/mem_storage.rs:22-102, quad_index_data.rs:57-64).
 #pragma once
+#include <atomic>
 #include <map>
 #include <mutex>
 #include <shared_mutex>
@@ -60,6 +61,7 @@ struct Store {
   DevicePool pool;
   hipStream_t stream = nullptr;  // load-path stream
   std::shared_mutex mu;   // readers = running plans (a snapshot), writers = extend / remove / clear
+  std::atomic<u64> version{0};   // bumped by every extend / remove / clear: cached scan ranges of plans are keyed on it
   std::mutex ctx_mu;
   std::vector<ExecContext*> free_ctx;
   ExecContext* acquire_context(u32 n_sources);

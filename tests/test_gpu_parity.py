@@ -436,7 +436,39 @@ def test_plan_is_reexecutable_and_sees_updates(bsbm_stores):
     b = ku.multiset(plan.execute().fetch())
     np.testing.assert_array_equal(a, b)
     m = plan.metrics()
-    assert m.output_rows == len(a) and m.kernels_launched >= 2 and m.elapsed_compute_ms > 0
+    assert m.output_rows == len(a) and m.kernels_launched >= 1 and m.elapsed_compute_ms > 0
+
+
+def test_reexecution_is_speculative_but_exact(torch_cuda):
+    """A re-executed plan reuses its located ranges and sizes join outputs from the previous run without
+    waiting; when the guess is wrong (the batch grows 20x) or the store changes, results must still be exact."""
+    ds = bsbm.generate(800)
+    gs, os_ = both_stores((ds.g, ds.s, ds.p, ds.o), typed=ds.typed_values)
+    desc = bsbm.q5_batch_plan(ds)
+    plan = gs.plan(desc)
+    rng = np.random.default_rng(9)
+    syncs = []
+    for batch in (8, 8, 8, 160, 160, 3):
+        prods = np.array([ds.product(i) for i in rng.choice(ds.n_products, batch, replace=False)], dtype=np.uint32)
+        params = [np.arange(1, batch + 1, dtype=np.uint32), prods]
+        keep, ptrs = table_on_device(torch_cuda, params)
+        plan.bind_table(0, ptrs, batch)
+        got = plan.execute().fetch()
+        exp, n_exp, _ = os_.execute(desc, [params])
+        np.testing.assert_array_equal(ku.multiset(got), ku.multiset(exp, n_exp))
+        syncs.append(plan.metrics().host_syncs)
+    assert syncs[1] < syncs[0] and syncs[2] == syncs[1]          # steady state: no per-join waits
+    # the store changes under the compiled plan: ranges are re-located, results follow the data
+    x = ds.product(5)
+    extra = (np.zeros(3, np.uint32), np.full(3, x, np.uint32), np.full(3, ds.pred["bsbm:productFeature"], np.uint32),
+             (ds.feature_base + np.array([1, 2, 3])).astype(np.uint32))
+    assert gs.extend(*extra) == os_.extend(*extra)
+    params = [np.array([1], np.uint32), np.array([x], np.uint32)]
+    keep, ptrs = table_on_device(torch_cuda, params)
+    plan.bind_table(0, ptrs, 1)
+    got = plan.execute().fetch()
+    exp, n_exp, _ = os_.execute(desc, [params])
+    np.testing.assert_array_equal(ku.multiset(got), ku.multiset(exp, n_exp))
 
 
 def test_invalid_plans_are_rejected():
