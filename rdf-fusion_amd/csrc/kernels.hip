@@ -634,20 +634,27 @@ __global__ __launch_bounds__(kLdsBlock) void lds_join_kernel(const LdsJoinArgs a
   const int lane = tid & 63, wave = tid >> 6;
   for (u64 tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const u64 base = tile * kTileRows;
-    // all of this lane's probe keys first: ITEMS independent coalesced loads in flight together
-    Keys key[ITEMS]; bool live[ITEMS];
-#pragma unroll
-    for (int k = 0; k < ITEMS; k++) {
-      const u64 j = base + (u64)k * kLdsBlock + tid;
-      live[k] = j < np && load_keys(a.probe_key, a.n_keys, j, key[k]);
-    }
+    // Pass 1, in groups of up to 4 rows per lane: the group's probe keys are loaded first (independent
+    // coalesced loads in flight together), then each row walks its chain.  Only (count, first two matches)
+    // survive the pass — 3 registers per row — so a lane can own 16 rows (8192-row tiles: one output
+    // reservation per 8192 rows; same-address atomics retire at only ~88 per microsecond).
+    constexpr int kGroup = ITEMS < 4 ? ITEMS : 4;
     u32 cnt[ITEMS], m0[ITEMS], m1[ITEMS]; u32 mine = 0;
 #pragma unroll
-    for (int k = 0; k < ITEMS; k++) {
-      const u64 j = base + (u64)k * kLdsBlock + tid;
-      m0[k] = m1[k] = kNil; cnt[k] = 0;
-      if (live[k] && lprobe_filter<PFS>(a, j)) cnt[k] = lds_probe_row<FS, false>(a, slots, key[k], j, 0, m0[k], m1[k]);
-      mine += cnt[k];
+    for (int g0 = 0; g0 < ITEMS; g0 += kGroup) {
+      Keys key[kGroup]; bool live[kGroup];
+#pragma unroll
+      for (int k = 0; k < kGroup; k++) {
+        const u64 j = base + (u64)(g0 + k) * kLdsBlock + tid;
+        live[k] = j < np && load_keys(a.probe_key, a.n_keys, j, key[k]);
+      }
+#pragma unroll
+      for (int k = 0; k < kGroup; k++) {
+        const u64 j = base + (u64)(g0 + k) * kLdsBlock + tid;
+        m0[g0 + k] = m1[g0 + k] = kNil; cnt[g0 + k] = 0;
+        if (live[k] && lprobe_filter<PFS>(a, j)) cnt[g0 + k] = lds_probe_row<FS, false>(a, slots, key[k], j, 0, m0[g0 + k], m1[g0 + k]);
+        mine += cnt[g0 + k];
+      }
     }
     const u32 incl = wave_incl_scan(mine);
     if (lane == 63) wave_tot[wave] = incl;
@@ -670,7 +677,7 @@ __global__ __launch_bounds__(kLdsBlock) void lds_join_kernel(const LdsJoinArgs a
       if (cnt[k]) {
         const u64 j = base + (u64)k * kLdsBlock + tid;
         if (cnt[k] <= 2) { ljoin_emit(a, m0[k], j, pos); if (cnt[k] == 2) ljoin_emit(a, m1[k], j, pos + 1); }
-        else { u32 d0, d1; lds_probe_row<FS, true>(a, slots, key[k], j, pos, d0, d1); }
+        else { Keys key; load_keys(a.probe_key, a.n_keys, j, key); u32 d0, d1; lds_probe_row<FS, true>(a, slots, key, j, pos, d0, d1); }
         pos += cnt[k];
       }
     }
@@ -687,26 +694,33 @@ static void launch_lds_join_t(const LdsJoinArgs& a, dim3 g, size_t lds, hipStrea
   }
   hipLaunchKernelGGL((lds_join_kernel<FS, PFS, ITEMS, GLOBAL>), g, dim3(kLdsBlock), GLOBAL ? 0 : lds, s, a);
 }
-bool lds_join_is_wide(u64 n_probe_cap) { return (n_probe_cap + kLdsTile - 1) / kLdsTile >= 512; }
+// Rows per lane and tile: 16 for multi-million-row probes (few output reservations), 4 for LDS tables over
+// ~1 M-row probes (amortises the per-workgroup LDS build), else 1 (many short workgroups; an HBM table has
+// no per-workgroup build to amortise and its probes are latency chains that want parallelism).
+int lds_join_items(u64 n_probe_cap, bool global) {
+  if (n_probe_cap >= (4ull << 20)) return 16;
+  if (!global && n_probe_cap >= (1ull << 20)) return 4;
+  return 1;
+}
 void launch_lds_join(const LdsJoinArgs& a, hipStream_t s) {
   const bool global = a.gslots != nullptr;
   const size_t lds = global ? 0 : (size_t)(a.tbl_mask + 1) * sizeof(uint2);
   // enough workgroups to cover all 256 CUs; each builds its LDS copy once and strides over the tiles
-  const u64 max_wg = global ? 2048 : lds > 64 * 1024 ? 256 : lds > 32 * 1024 ? 512 : 1024;
-  // small probe sides: one row per lane (more, shorter workgroups) instead of four
-  const bool wide = lds_join_is_wide(a.n_probe_cap);
-  const u64 rows = wide ? kLdsTile : kLdsBlock;
+  const u64 max_wg = global ? 4096 : lds > 64 * 1024 ? 256 : lds > 32 * 1024 ? 512 : 1024;
+  const int items = lds_join_items(a.n_probe_cap, global);
+  const u64 rows = (u64)kLdsBlock * items;
   const u64 n_tiles = (a.n_probe_cap + rows - 1) / rows;
   const dim3 g((unsigned)(n_tiles < max_wg ? (n_tiles ? n_tiles : 1) : max_wg));
   const int fs = a.has_filter, pfs = a.has_probe_filter;   // 0 none / 1 VM / 2 col-col / 3 window ; 0 none / 1 id-literal / 2 VM
-#define RDFGPU_LJ(F, P) if (fs == F && pfs == P) { \
-    if (global) { if (wide) return launch_lds_join_t<F, P, kLdsItems, true>(a, g, lds, s); return launch_lds_join_t<F, P, 1, true>(a, g, lds, s); } \
-    if (wide) return launch_lds_join_t<F, P, kLdsItems, false>(a, g, lds, s); return launch_lds_join_t<F, P, 1, false>(a, g, lds, s); }
+#define RDFGPU_LJI(F, P, G) { if (items == 16) return launch_lds_join_t<F, P, 16, G>(a, g, lds, s); \
+                              if (items == 4) return launch_lds_join_t<F, P, 4, G>(a, g, lds, s); return launch_lds_join_t<F, P, 1, G>(a, g, lds, s); }
+#define RDFGPU_LJ(F, P) if (fs == F && pfs == P) { if (global) RDFGPU_LJI(F, P, true) else RDFGPU_LJI(F, P, false) }
   RDFGPU_LJ(0, 0) RDFGPU_LJ(0, 1) RDFGPU_LJ(0, 2)
   RDFGPU_LJ(1, 0) RDFGPU_LJ(1, 1) RDFGPU_LJ(1, 2)
   RDFGPU_LJ(2, 0) RDFGPU_LJ(2, 1) RDFGPU_LJ(2, 2)
   RDFGPU_LJ(3, 0) RDFGPU_LJ(3, 1) RDFGPU_LJ(3, 2)
 #undef RDFGPU_LJ
+#undef RDFGPU_LJI
   fail(RDFGPU_ERR_INVALID, "lds join: bad filter shape %d/%d", fs, pfs);
 }
 

@@ -16,6 +16,7 @@ struct DevTable {
   const u32* cols[kMaxCols] = {};
   u64 cap = 0;
   const u64* n_dev = nullptr;
+  u64 stable_id = 0;   // non-zero: a pure slice of the store (same rows on every execution until the store changes)
 };
 
 // ---- K1: range locate on a sorted permutation (prune_relevant_row_groups, quad_index_data.rs:155-284) ----
@@ -141,7 +142,7 @@ struct LdsJoinArgs {
 };
 void launch_lds_join(const LdsJoinArgs& a, hipStream_t s);
 void launch_gjoin_build(const LdsJoinArgs& a, hipStream_t s);   // fills a.gslots (memset to 0xFF first)
-bool lds_join_is_wide(u64 n_probe_cap);   // true: the 4-rows-per-lane instantiation is launched, false: 1 row per lane
+int lds_join_items(u64 n_probe_cap, bool global);   // rows per lane of the instantiation that will be launched: 16 / 4 / 1
 
 // ---- utilities ----
 void launch_fill_u32(u32* p, u32 v, u64 n, hipStream_t s);
