@@ -470,7 +470,6 @@ __global__ __launch_bounds__(kBlock) void join_left_unmatched_kernel(const JoinA
 // --------------------------------------------------------------------------------------------------
 constexpr int kLdsBlock = 512;
 constexpr int kLdsItems = 4;
-constexpr int kLdsTile = kLdsBlock * kLdsItems;
 
 __device__ __forceinline__ u32 wave_incl_scan(u32 v) {
 #pragma unroll
@@ -632,6 +631,64 @@ __global__ __launch_bounds__(kLdsBlock) void lds_join_kernel(const LdsJoinArgs a
   const u64 np = live_rows(a.n_probe_dev, a.n_probe_cap);
   const u64 n_tiles = (np + kTileRows - 1) / kTileRows;
   const int lane = tid & 63, wave = tid >> 6;
+
+  if (n_tiles > gridDim.x) {
+    // Several tiles per workgroup (multi-million-row probes): ONE output reservation per workgroup instead of
+    // one per tile.  Same-address returning atomics retire at only ~88 per microsecond on this chip, so 2 600
+    // per-tile reservations cost ~30 us of a 45 us kernel.  Pass 1 only counts this lane's matches over all
+    // of the workgroup's tiles; pass 2 re-reads the keys (L2 / Infinity Cache) and re-walks the table, writing
+    // each lane's matches contiguously.
+    u32 mine = 0;
+    for (u64 tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+      const u64 base = tile * kTileRows;
+      Keys key[ITEMS]; bool live[ITEMS];
+#pragma unroll
+      for (int k = 0; k < ITEMS; k++) {
+        const u64 j = base + (u64)k * kLdsBlock + tid;
+        live[k] = j < np && load_keys(a.probe_key, a.n_keys, j, key[k]);
+      }
+#pragma unroll
+      for (int k = 0; k < ITEMS; k++) {
+        const u64 j = base + (u64)k * kLdsBlock + tid;
+        u32 d0 = kNil, d1 = kNil;
+        if (live[k] && lprobe_filter<PFS>(a, j)) mine += lds_probe_row<FS, false>(a, slots, key[k], j, 0, d0, d1);
+      }
+    }
+    const u32 incl = wave_incl_scan(mine);
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    if (tid == 0) {
+      u32 t = 0;
+      for (int w = 0; w < kLdsBlock / 64; w++) t += wave_tot[w];
+      u64 b = 0;
+      if (t) {
+        b = atomicAdd((unsigned long long*)a.n_out_dev, (unsigned long long)t);
+        if (b + t > a.out_cap) *a.overflow = 1u;
+      }
+      tile_base = b;
+    }
+    __syncthreads();
+    u64 pos = tile_base + (incl - mine);
+    for (int w = 0; w < wave; w++) pos += wave_tot[w];
+    if (mine == 0) return;
+    for (u64 tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+      const u64 base = tile * kTileRows;
+      Keys key[ITEMS]; bool live[ITEMS];
+#pragma unroll
+      for (int k = 0; k < ITEMS; k++) {
+        const u64 j = base + (u64)k * kLdsBlock + tid;
+        live[k] = j < np && load_keys(a.probe_key, a.n_keys, j, key[k]);
+      }
+#pragma unroll
+      for (int k = 0; k < ITEMS; k++) {
+        const u64 j = base + (u64)k * kLdsBlock + tid;
+        u32 d0 = kNil, d1 = kNil;
+        if (live[k] && lprobe_filter<PFS>(a, j)) pos += lds_probe_row<FS, true>(a, slots, key[k], j, pos, d0, d1);
+      }
+    }
+    return;
+  }
+
   for (u64 tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const u64 base = tile * kTileRows;
     // Pass 1, in groups of up to 4 rows per lane: the group's probe keys are loaded first (independent
@@ -694,11 +751,11 @@ static void launch_lds_join_t(const LdsJoinArgs& a, dim3 g, size_t lds, hipStrea
   }
   hipLaunchKernelGGL((lds_join_kernel<FS, PFS, ITEMS, GLOBAL>), g, dim3(kLdsBlock), GLOBAL ? 0 : lds, s, a);
 }
-// Rows per lane and tile: 16 for multi-million-row probes (few output reservations), 4 for LDS tables over
-// ~1 M-row probes (amortises the per-workgroup LDS build), else 1 (many short workgroups; an HBM table has
-// no per-workgroup build to amortise and its probes are latency chains that want parallelism).
+// Rows per lane and tile: 4 for multi-million-row probes and for LDS tables over ~1 M-row probes (amortises
+// the per-workgroup LDS build), else 1 (many short workgroups; an HBM table has no per-workgroup build to
+// amortise and its probes are latency chains that want parallelism).
 int lds_join_items(u64 n_probe_cap, bool global) {
-  if (n_probe_cap >= (4ull << 20)) return 16;
+  if (n_probe_cap >= (4ull << 20)) return 4;
   if (!global && n_probe_cap >= (1ull << 20)) return 4;
   return 1;
 }
@@ -712,8 +769,7 @@ void launch_lds_join(const LdsJoinArgs& a, hipStream_t s) {
   const u64 n_tiles = (a.n_probe_cap + rows - 1) / rows;
   const dim3 g((unsigned)(n_tiles < max_wg ? (n_tiles ? n_tiles : 1) : max_wg));
   const int fs = a.has_filter, pfs = a.has_probe_filter;   // 0 none / 1 VM / 2 col-col / 3 window ; 0 none / 1 id-literal / 2 VM
-#define RDFGPU_LJI(F, P, G) { if (items == 16) return launch_lds_join_t<F, P, 16, G>(a, g, lds, s); \
-                              if (items == 4) return launch_lds_join_t<F, P, 4, G>(a, g, lds, s); return launch_lds_join_t<F, P, 1, G>(a, g, lds, s); }
+#define RDFGPU_LJI(F, P, G) { if (items == 4) return launch_lds_join_t<F, P, 4, G>(a, g, lds, s); return launch_lds_join_t<F, P, 1, G>(a, g, lds, s); }
 #define RDFGPU_LJ(F, P) if (fs == F && pfs == P) { if (global) RDFGPU_LJI(F, P, true) else RDFGPU_LJI(F, P, false) }
   RDFGPU_LJ(0, 0) RDFGPU_LJ(0, 1) RDFGPU_LJ(0, 2)
   RDFGPU_LJ(1, 0) RDFGPU_LJ(1, 1) RDFGPU_LJ(1, 2)
