@@ -763,7 +763,11 @@ void launch_lds_join(const LdsJoinArgs& a, hipStream_t s) {
   const bool global = a.gslots != nullptr;
   const size_t lds = global ? 0 : (size_t)(a.tbl_mask + 1) * sizeof(uint2);
   // enough workgroups to cover all 256 CUs; each builds its LDS copy once and strides over the tiles
-  const u64 max_wg = global ? 4096 : lds > 64 * 1024 ? 256 : lds > 32 * 1024 ? 512 : 1024;
+  static const u64 wg_cap = [] { const char* e = std::getenv("RDFGPU_JOIN_MAX_WG"); return e ? std::strtoull(e, nullptr, 10) : 0ull; }();
+  // HBM table: no per-workgroup build, so one tile per workgroup and let the hardware overlap them.  LDS
+  // table: the build is repeated per workgroup, so cap the grid by what that costs (tiny tables: no cap).
+  u64 max_wg = global ? (1ull << 22) : lds > 64 * 1024 ? 256 : lds > 32 * 1024 ? 512 : lds > 2 * 1024 ? 1024 : (1ull << 22);
+  if (wg_cap) max_wg = wg_cap;
   const int items = lds_join_items(a.n_probe_cap, global);
   const u64 rows = (u64)kLdsBlock * items;
   const u64 n_tiles = (a.n_probe_cap + rows - 1) / rows;

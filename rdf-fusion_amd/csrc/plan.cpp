@@ -714,7 +714,10 @@ DevTable Plan::exec_lds_join(NodeInfo& nd, const DevTable& L, const DevTable& R,
   u32 slots = 64;
   while (slots < 2 * B.cap) slots <<= 1;
   a.tbl_mask = slots - 1;
-  const bool global_table = B.cap > kLdsJoinMaxBuild;   // one {key0,row} table in HBM instead of a copy per workgroup in LDS
+  // LDS copy per workgroup vs ONE table in HBM/L2: the LDS form pays the build once per workgroup and, above
+  // ~16 KiB of table, costs occupancy (a 128 KiB table = one workgroup per CU = latency-bound probes).
+  static const u64 lds_limit = [] { const char* e = std::getenv("RDFGPU_LDS_MAX_BUILD"); const u64 v = e ? std::strtoull(e, nullptr, 10) : 1024; return v > kLdsJoinMaxBuild ? (u64)kLdsJoinMaxBuild : v; }();
+  const bool global_table = B.cap > lds_limit;
   // The HBM table of a build side that is a pure slice of the store (a param-free scan: label, simProperty…)
   // is the same on every execution of this plan until the store changes: it is built once and kept.
   bool table_ready = false;
