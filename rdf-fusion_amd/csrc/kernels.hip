@@ -632,63 +632,6 @@ __global__ __launch_bounds__(kLdsBlock) void lds_join_kernel(const LdsJoinArgs a
   const u64 n_tiles = (np + kTileRows - 1) / kTileRows;
   const int lane = tid & 63, wave = tid >> 6;
 
-  if (n_tiles > gridDim.x) {
-    // Several tiles per workgroup (multi-million-row probes): ONE output reservation per workgroup instead of
-    // one per tile.  Same-address returning atomics retire at only ~88 per microsecond on this chip, so 2 600
-    // per-tile reservations cost ~30 us of a 45 us kernel.  Pass 1 only counts this lane's matches over all
-    // of the workgroup's tiles; pass 2 re-reads the keys (L2 / Infinity Cache) and re-walks the table, writing
-    // each lane's matches contiguously.
-    u32 mine = 0;
-    for (u64 tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-      const u64 base = tile * kTileRows;
-      Keys key[ITEMS]; bool live[ITEMS];
-#pragma unroll
-      for (int k = 0; k < ITEMS; k++) {
-        const u64 j = base + (u64)k * kLdsBlock + tid;
-        live[k] = j < np && load_keys(a.probe_key, a.n_keys, j, key[k]);
-      }
-#pragma unroll
-      for (int k = 0; k < ITEMS; k++) {
-        const u64 j = base + (u64)k * kLdsBlock + tid;
-        u32 d0 = kNil, d1 = kNil;
-        if (live[k] && lprobe_filter<PFS>(a, j)) mine += lds_probe_row<FS, false>(a, slots, key[k], j, 0, d0, d1);
-      }
-    }
-    const u32 incl = wave_incl_scan(mine);
-    if (lane == 63) wave_tot[wave] = incl;
-    __syncthreads();
-    if (tid == 0) {
-      u32 t = 0;
-      for (int w = 0; w < kLdsBlock / 64; w++) t += wave_tot[w];
-      u64 b = 0;
-      if (t) {
-        b = atomicAdd((unsigned long long*)a.n_out_dev, (unsigned long long)t);
-        if (b + t > a.out_cap) *a.overflow = 1u;
-      }
-      tile_base = b;
-    }
-    __syncthreads();
-    u64 pos = tile_base + (incl - mine);
-    for (int w = 0; w < wave; w++) pos += wave_tot[w];
-    if (mine == 0) return;
-    for (u64 tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-      const u64 base = tile * kTileRows;
-      Keys key[ITEMS]; bool live[ITEMS];
-#pragma unroll
-      for (int k = 0; k < ITEMS; k++) {
-        const u64 j = base + (u64)k * kLdsBlock + tid;
-        live[k] = j < np && load_keys(a.probe_key, a.n_keys, j, key[k]);
-      }
-#pragma unroll
-      for (int k = 0; k < ITEMS; k++) {
-        const u64 j = base + (u64)k * kLdsBlock + tid;
-        u32 d0 = kNil, d1 = kNil;
-        if (live[k] && lprobe_filter<PFS>(a, j)) pos += lds_probe_row<FS, true>(a, slots, key[k], j, pos, d0, d1);
-      }
-    }
-    return;
-  }
-
   for (u64 tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const u64 base = tile * kTileRows;
     // Pass 1, in groups of up to 4 rows per lane: the group's probe keys are loaded first (independent
@@ -766,7 +709,7 @@ void launch_lds_join(const LdsJoinArgs& a, hipStream_t s) {
   static const u64 wg_cap = [] { const char* e = std::getenv("RDFGPU_JOIN_MAX_WG"); return e ? std::strtoull(e, nullptr, 10) : 0ull; }();
   // HBM table: no per-workgroup build, so one tile per workgroup and let the hardware overlap them.  LDS
   // table: the build is repeated per workgroup, so cap the grid by what that costs (tiny tables: no cap).
-  u64 max_wg = global ? (1ull << 22) : lds > 64 * 1024 ? 256 : lds > 32 * 1024 ? 512 : lds > 2 * 1024 ? 1024 : (1ull << 22);
+  u64 max_wg = global ? (1ull << 22) : lds > 64 * 1024 ? 256 : lds > 32 * 1024 ? 512 : 1024;
   if (wg_cap) max_wg = wg_cap;
   const int items = lds_join_items(a.n_probe_cap, global);
   const u64 rows = (u64)kLdsBlock * items;
