@@ -460,16 +460,14 @@ __global__ __launch_bounds__(kBlock) void join_left_unmatched_kernel(const JoinA
 // --------------------------------------------------------------------------------------------------
 // K4+K5 fused, LDS-staged: the whole build side (<= 8192 rows) lives in ONE LDS open-addressing table
 // per workgroup ({key0, row} slots, linear probing, load factor <= 0.5), built once per workgroup from
-// L2 and then probed by that workgroup's share of the probe side, 2048 rows per tile.
-// Variable-cardinality output without a count pass over HBM: pass 1 counts each lane's matches out of
-// LDS, a wave64 shuffle scan + one LDS exchange give every lane its offset, ONE atomicAdd per tile
-// reserves the output range, pass 2 re-walks LDS and writes.  The total is always exact; if it exceeds
-// the optimistic capacity the host re-runs with the exact size.
+// L2 and then probed by that workgroup's share of the probe side, 512 x ITEMS rows per tile.
+// Variable-cardinality output without a count pass over HBM: matches are compacted into wave-private
+// LDS queues and leave in reserved, consecutive output ranges (see the kernel).  The total is always
+// exact; if it exceeds the optimistic capacity the host re-runs with the exact size.
 // This is the path every BSBM Q1/Q5 join takes after the engine's join reordering (build = the
 // smaller input, cross products decomposed): J2/J3 build ~2 k rows and probe 285 k.
 // --------------------------------------------------------------------------------------------------
 constexpr int kLdsBlock = 512;
-constexpr int kLdsItems = 4;
 
 __device__ __forceinline__ u32 wave_incl_scan(u32 v) {
 #pragma unroll
@@ -506,6 +504,16 @@ __device__ __forceinline__ bool ljoin_filter(const LdsJoinArgs& a, u64 i, u64 j)
     const u32 ix1 = same ? ix0 : ljoin_col(a, w.x1, i, j), iy1 = same ? iy0 : ljoin_col(a, w.y1, i, j);
     const Val x0 = enc_tv(a.tt, ix0), y0 = enc_tv(a.tt, iy0);
     const Val x1 = same ? x0 : enc_tv(a.tt, ix1), y1 = same ? y0 : enc_tv(a.tt, iy1);
+    if (x0.tag == RDFGPU_TV_INTEGER && y0.tag == RDFGPU_TV_INTEGER && x1.tag == RDFGPU_TV_INTEGER && y1.tag == RDFGPU_TV_INTEGER &&
+        w.l0.tag == RDFGPU_TV_INTEGER && w.l1.tag == RDFGPU_TV_INTEGER) {
+      // all xsd:integer (the BSBM numeric properties): checked i64 arithmetic and compares, none of the promotion
+      // machinery below (which the compiler otherwise evaluates for every row: ~1000 VALU ops)
+      long long z0, z1;
+      const bool o0 = w.l0.arith_sub ? __builtin_sub_overflow((long long)y0.lo, (long long)w.l0.lo, &z0) : __builtin_add_overflow((long long)y0.lo, (long long)w.l0.lo, &z0);
+      const bool o1 = w.l1.arith_sub ? __builtin_sub_overflow((long long)y1.lo, (long long)w.l1.lo, &z1) : __builtin_add_overflow((long long)y1.lo, (long long)w.l1.lo, &z1);
+      if (o0 || o1) return false;   // overflow => error => null => not `true`
+      return cmp_holds(w.l0.cmp_op, x0.lo < z0 ? -1 : x0.lo > z0) && cmp_holds(w.l1.cmp_op, x1.lo < z1 ? -1 : x1.lo > z1);
+    }
     const Val z0 = tv_arith(y0, lit_val(w.l0), w.l0.arith_sub != 0);
     const Val z1 = tv_arith(y1, lit_val(w.l1), w.l1.arith_sub != 0);
     return cmp_holds(w.l0.cmp_op, tv_partial_cmp(x0, z0)) && cmp_holds(w.l1.cmp_op, tv_partial_cmp(x1, z1));
@@ -530,12 +538,12 @@ __device__ __forceinline__ bool lprobe_filter(const LdsJoinArgs& a, u64 j) {
 
 // Static-indexed key handling (runtime n_keys <= 4 without private-memory arrays).
 struct Keys { u32 k[RDFGPU_MAX_KEYS]; };
-__device__ __forceinline__ u32 hash_keys4(const Keys& key, u32 n) {
-  u64 h = 0x9E3779B97F4A7C15ull;
+__device__ __forceinline__ u32 hash_keys4(const Keys& key, u32 n) {   // 32-bit multiply/xorshift mix: 64-bit multiplies are 4 quarter-rate ops each
+  u32 h = 0x9E3779B9u;
 #pragma unroll
-  for (u32 i = 0; i < RDFGPU_MAX_KEYS; i++) if (i < n) { h ^= key.k[i]; h *= 0xff51afd7ed558ccdull; h ^= h >> 32; }
-  h *= 0xc4ceb9fe1a85ec53ull; h ^= h >> 29;
-  return (u32)h;
+  for (u32 i = 0; i < RDFGPU_MAX_KEYS; i++) if (i < n) { h = (h ^ key.k[i]) * 0x85EBCA6Bu; h ^= h >> 15; }
+  h *= 0xC2B2AE35u; h ^= h >> 16;
+  return h;
 }
 __device__ __forceinline__ bool load_keys(const u32* const* key_cols, u32 n_keys, u64 row, Keys& key) {
   bool null_key = false;
@@ -547,37 +555,8 @@ __device__ __forceinline__ bool load_keys(const u32* const* key_cols, u32 n_keys
   return !null_key;   // NullEqualsNothing: a null key never matches
 }
 
-// Walks the LDS chain of probe row j (its keys already in registers).  Pass 1 (WRITE = false) counts the
-// matches and remembers the first two build rows in m0/m1, so the common <= 2-match case never walks
-// (or evaluates its filter) twice.
-template <int FS, bool WRITE>
-__device__ __forceinline__ u32 lds_probe_row(const LdsJoinArgs& a, const uint2* slots, const Keys& key, u64 j, u64 pos, u32& m0, u32& m1) {
-  u32 c = 0;
-  u32 h = hash_keys4(key, a.n_keys) & a.tbl_mask;
-  for (;;) {
-    const uint2 s = slots[h];
-    if (s.y == kNil) break;
-    h = (h + 1) & a.tbl_mask;
-    if (s.x != key.k[0]) continue;
-    bool eq = true;
-#pragma unroll
-    for (u32 q = 1; q < RDFGPU_MAX_KEYS; q++) if (q < a.n_keys) eq = eq && a.build_key[q][s.y] == key.k[q];
-    if (!eq) continue;
-    if (!ljoin_filter<FS>(a, s.y, j)) continue;
-    if (WRITE) {
-      if (pos + c < a.out_cap) for (u32 oc = 0; oc < a.n_out_cols; oc++) a.out[oc][pos + c] = ljoin_col(a, a.proj[oc], s.y, j);
-      if (a.visited) a.visited[s.y] = 1;
-    } else {
-      m0 = c == 0 ? s.y : m0;   // value selects, not pointer selects: the latter force m0/m1 into scratch
-      m1 = c == 1 ? s.y : m1;
-    }
-    c++;
-  }
-  return c;
-}
 __device__ __forceinline__ void ljoin_emit(const LdsJoinArgs& a, u32 i, u64 j, u64 pos) {
   if (pos < a.out_cap) for (u32 oc = 0; oc < a.n_out_cols; oc++) a.out[oc][pos] = ljoin_col(a, a.proj[oc], i, j);
-  if (a.visited) a.visited[i] = 1;
 }
 
 // Build sides above the LDS limit: the same {key0,row} open-addressing table, but ONE copy in HBM (8 B per
@@ -603,12 +582,22 @@ void launch_gjoin_build(const LdsJoinArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(gjoin_build_kernel, grid_for(a.n_build_cap), dim3(kBlock), 0, s, a);
 }
 
+// Probe side.  Every wave owns a private LDS queue of (build row, probe row) matches: lanes walk their
+// chains, a ballot + mbcnt compacts the wave's new matches into the queue, and the probe loop has NO
+// workgroup barrier and NO global atomic.  A queue that would overflow is flushed by its wave alone (one
+// atomicAdd reserves the output range for <= 256 rows, the 64 lanes then write consecutive output rows);
+// what is left at the end is flushed by the whole workgroup with ONE reservation.  Sparse joins (BSBM:
+// a handful of matches per thousand probe rows) therefore pay one same-address atomic per workgroup
+// instead of one per tile, and output rows are written coalesced from the queue.
+constexpr u32 kWaveQ = 256;   // queue entries per wave (8 waves x 2 KiB)
+
 template <int FS, int PFS, int ITEMS, bool GLOBAL>
 __global__ __launch_bounds__(kLdsBlock) void lds_join_kernel(const LdsJoinArgs a) {
   extern __shared__ __align__(16) unsigned char lds_raw[];
   const uint2* slots = GLOBAL ? a.gslots : reinterpret_cast<const uint2*>(lds_raw);
+  __shared__ uint2 wave_queue[kLdsBlock / 64][kWaveQ];
   __shared__ u32 wave_tot[kLdsBlock / 64];
-  __shared__ u64 tile_base;
+  __shared__ u64 wg_base;
   constexpr int kTileRows = kLdsBlock * ITEMS;
   const u32 tid = threadIdx.x;
   if constexpr (!GLOBAL) {
@@ -630,66 +619,101 @@ __global__ __launch_bounds__(kLdsBlock) void lds_join_kernel(const LdsJoinArgs a
 
   const u64 np = live_rows(a.n_probe_dev, a.n_probe_cap);
   const u64 n_tiles = (np + kTileRows - 1) / kTileRows;
-  const int lane = tid & 63, wave = tid >> 6;
+  const u32 lane = tid & 63, wave = tid >> 6;
+  uint2* wq = wave_queue[wave];
+  u32 qn = 0;   // entries in this wave's queue (wave-uniform)
+
+  auto drain = [&](u64 base) {   // the wave writes its queue to output rows base .. base + qn
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    for (u32 e = lane; e < qn; e += 64) {
+      const uint2 m = wq[e];
+      ljoin_emit(a, m.x, m.y, base + e);
+      if (a.visited) a.visited[m.x] = 1;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    qn = 0;
+  };
 
   for (u64 tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const u64 base = tile * kTileRows;
-    // Pass 1, in groups of up to 4 rows per lane: the group's probe keys are loaded first (independent
-    // coalesced loads in flight together), then each row walks its chain.  Only (count, first two matches)
-    // survive the pass — 3 registers per row — so a lane can own 16 rows (8192-row tiles: one output
-    // reservation per 8192 rows; same-address atomics retire at only ~88 per microsecond).
-    constexpr int kGroup = ITEMS < 4 ? ITEMS : 4;
-    u32 cnt[ITEMS], m0[ITEMS], m1[ITEMS]; u32 mine = 0;
-#pragma unroll
-    for (int g0 = 0; g0 < ITEMS; g0 += kGroup) {
-      Keys key[kGroup]; bool live[kGroup];
-#pragma unroll
-      for (int k = 0; k < kGroup; k++) {
-        const u64 j = base + (u64)(g0 + k) * kLdsBlock + tid;
-        live[k] = j < np && load_keys(a.probe_key, a.n_keys, j, key[k]);
-      }
-#pragma unroll
-      for (int k = 0; k < kGroup; k++) {
-        const u64 j = base + (u64)(g0 + k) * kLdsBlock + tid;
-        m0[g0 + k] = m1[g0 + k] = kNil; cnt[g0 + k] = 0;
-        if (live[k] && lprobe_filter<PFS>(a, j)) cnt[g0 + k] = lds_probe_row<FS, false>(a, slots, key[k], j, 0, m0[g0 + k], m1[g0 + k]);
-        mine += cnt[g0 + k];
-      }
-    }
-    const u32 incl = wave_incl_scan(mine);
-    if (lane == 63) wave_tot[wave] = incl;
-    __syncthreads();
-    if (tid == 0) {
-      u32 t = 0;
-      for (int w = 0; w < kLdsBlock / 64; w++) t += wave_tot[w];
-      u64 b = 0;
-      if (t) {
-        b = atomicAdd((unsigned long long*)a.n_out_dev, (unsigned long long)t);
-        if (b + t > a.out_cap) *a.overflow = 1u;
-      }
-      tile_base = b;
-    }
-    __syncthreads();
-    u64 pos = tile_base + (incl - mine);
-    for (int w = 0; w < wave; w++) pos += wave_tot[w];
+    // the tile's probe keys first (independent coalesced loads in flight together), then the first table
+    // slot of every row, then the chain walks
+    Keys key[ITEMS]; bool live[ITEMS]; u32 h[ITEMS]; uint2 s[ITEMS];
 #pragma unroll
     for (int k = 0; k < ITEMS; k++) {
-      if (cnt[k]) {
-        const u64 j = base + (u64)k * kLdsBlock + tid;
-        if (cnt[k] <= 2) { ljoin_emit(a, m0[k], j, pos); if (cnt[k] == 2) ljoin_emit(a, m1[k], j, pos + 1); }
-        else { Keys key; load_keys(a.probe_key, a.n_keys, j, key); u32 d0, d1; lds_probe_row<FS, true>(a, slots, key, j, pos, d0, d1); }
-        pos += cnt[k];
+      const u64 j = base + (u64)k * kLdsBlock + tid;
+      live[k] = j < np && load_keys(a.probe_key, a.n_keys, j, key[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < ITEMS; k++) {
+      const u64 j = base + (u64)k * kLdsBlock + tid;
+      live[k] = live[k] && lprobe_filter<PFS>(a, j);
+      h[k] = hash_keys4(key[k], a.n_keys) & a.tbl_mask;
+      s[k] = make_uint2(0u, kNil);
+      if (live[k]) s[k] = slots[h[k]];
+    }
+#pragma unroll
+    for (int k = 0; k < ITEMS; k++) {
+      const u64 j = base + (u64)k * kLdsBlock + tid;
+      bool walking = live[k];
+      for (;;) {
+        u32 hit = kNil;   // this lane's next match, if any
+        while (walking) {
+          if (s[k].y == kNil) { walking = false; break; }
+          const uint2 c = s[k];
+          h[k] = (h[k] + 1) & a.tbl_mask;
+          s[k] = slots[h[k]];   // issued before the candidate is examined
+          if (c.x != key[k].k[0]) continue;
+          bool eq = true;
+#pragma unroll
+          for (u32 q = 1; q < RDFGPU_MAX_KEYS; q++) if (q < a.n_keys) eq = eq && a.build_key[q][c.y] == key[k].k[q];
+          if (!eq) continue;
+          if (!ljoin_filter<FS>(a, c.y, j)) continue;
+          hit = c.y;
+          break;
+        }
+        const unsigned long long found = __ballot(hit != kNil);
+        if (found == 0) break;
+        const u32 n_found = (u32)__popcll(found);
+        if (qn + n_found > kWaveQ) {   // wave-uniform: flush this wave's queue on its own
+          unsigned long long b = 0;
+          if (lane == 0) {
+            b = atomicAdd((unsigned long long*)a.n_out_dev, (unsigned long long)qn);
+            if (b + qn > a.out_cap) *a.overflow = 1u;
+          }
+          b = __shfl(b, 0, 64);
+          drain(b);
+        }
+        if (hit != kNil) wq[qn + __builtin_amdgcn_mbcnt_hi((u32)(found >> 32), __builtin_amdgcn_mbcnt_lo((u32)found, 0u))] = make_uint2(hit, (u32)j);
+        qn += n_found;
       }
     }
-    __syncthreads();   // wave_tot / tile_base are reused by the next tile
   }
+
+  // what is still queued leaves with one reservation for the whole workgroup
+  if (lane == 0) wave_tot[wave] = qn;
+  __syncthreads();
+  if (tid == 0) {
+    u32 t = 0;
+    for (int w = 0; w < kLdsBlock / 64; w++) t += wave_tot[w];
+    u64 b = 0;
+    if (t) {
+      b = atomicAdd((unsigned long long*)a.n_out_dev, (unsigned long long)t);
+      if (b + t > a.out_cap) *a.overflow = 1u;
+    }
+    wg_base = b;
+  }
+  __syncthreads();
+  u64 out_base = wg_base;
+  for (u32 w = 0; w < wave; w++) out_base += wave_tot[w];
+  drain(out_base);
 }
 
 template <int FS, int PFS, int ITEMS, bool GLOBAL>
 static void launch_lds_join_t(const LdsJoinArgs& a, dim3 g, size_t lds, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set && !GLOBAL) {   // dynamic LDS above 64 KiB has to be opted into, per kernel instance
-    RDFGPU_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lds_join_kernel<FS, PFS, ITEMS, GLOBAL>), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
+    RDFGPU_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lds_join_kernel<FS, PFS, ITEMS, GLOBAL>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     attr_set = true;
   }
   hipLaunchKernelGGL((lds_join_kernel<FS, PFS, ITEMS, GLOBAL>), g, dim3(kLdsBlock), GLOBAL ? 0 : lds, s, a);

@@ -713,11 +713,15 @@ DevTable Plan::exec_lds_join(NodeInfo& nd, const DevTable& L, const DevTable& R,
   if (B.cap >= (1ull << 30)) fail(RDFGPU_ERR_UNSUPPORTED, "build side of %llu rows", (unsigned long long)B.cap);
   u32 slots = 64;
   while (slots < 2 * B.cap) slots <<= 1;
-  a.tbl_mask = slots - 1;
   // LDS copy per workgroup vs ONE table in HBM/L2: the LDS form pays the build once per workgroup and, above
   // ~16 KiB of table, costs occupancy (a 128 KiB table = one workgroup per CU = latency-bound probes).
   static const u64 lds_limit = [] { const char* e = std::getenv("RDFGPU_LDS_MAX_BUILD"); const u64 v = e ? std::strtoull(e, nullptr, 10) : 1024; return v > kLdsJoinMaxBuild ? (u64)kLdsJoinMaxBuild : v; }();
   const bool global_table = B.cap > lds_limit;
+  // Every lane of a wave waits for the longest chain among its 64 probes, so short chains matter more than a
+  // small table: LDS tables get load <= 0.25 and at least 2048 slots (16 KiB), HBM tables under 1 MiB load <= 0.125.
+  if (!global_table) { while ((slots < 4 * B.cap || slots < 2048) && slots < 2 * kLdsJoinMaxBuild) slots <<= 1; }
+  else { while (slots < 8 * B.cap && (u64)slots * sizeof(uint2) < (1u << 20)) slots <<= 1; }
+  a.tbl_mask = slots - 1;
   // The HBM table of a build side that is a pure slice of the store (a param-free scan: label, simProperty…)
   // is the same on every execution of this plan until the store changes: it is built once and kept.
   bool table_ready = false;
