@@ -241,7 +241,9 @@ def q5_batch_plan(ds, w1=120, w2=170, tables=None):
     origProperty2) are either bound (slots 0,1,2 — the graph-sharded case, after the all-gather) or, when
     `tables` is None, computed in-plan from PARAMS(inst, X) bound at slot 0.
     `product != X` is applied once, where the instance meets the product (all later joins are on product).
-    Output: (inst, product, productLabel) — per instance exactly q5_plan's bindings."""
+    Inner joins commute, so the batch is free to order them by cost: constants first, then the candidate
+    join, then the two selective numeric windows, and the 1:1 label lookup last.
+    Output: (inst, product, productLabel) — per instance exactly q5_plan's bindings (as a multiset)."""
     pr = ds.pred
     pb = PlanBuilder()
     if tables is None:
@@ -253,16 +255,18 @@ def q5_batch_plan(ds, w1=120, w2=170, tables=None):
         F, O1, O2 = const("bsbm:productFeature"), const("bsbm:productPropertyNumeric1"), const("bsbm:productPropertyNumeric2")
     else:
         F, O1, O2 = pb.table(0, 3), pb.table(1, 3), pb.table(2, 3)
+    # the instance's constants meet first (B x ~19 rows): (inst, X, f) JOIN O1 JOIN O2 ON inst -> (inst, X, f, orig1, orig2)
+    c = pb.hash_join(F, O1, on=[(0, 0)], projection=[0, 1, 2, 5])
+    c = pb.hash_join(c, O2, on=[(0, 0)], projection=[0, 1, 2, 3, 6])
     pf = pb.data_source(quad_pattern("product", pr["bsbm:productFeature"], "prodFeature"))      # (product, prodFeature)
-    # (inst, X, f) JOIN (product, f) ON f, product != X   ->  (inst, X, product)
-    j1a = pb.hash_join(F, pf, on=[(2, 1)], filter=ID_NEQ(col(3), col(1)), projection=[0, 1, 3])
-    label = pb.data_source(quad_pattern("product", pr["rdfs:label"], "productLabel"))           # (product, label)
-    node = pb.hash_join(j1a, label, on=[(2, 0)], projection=[0, 1, 2, 4])                       # (inst, X, product, label)
-    for k, w, O in ((1, w1, O1), (2, w2, O2)):
-        withorig = pb.hash_join(node, O, on=[(0, 0)], projection=[0, 1, 2, 3, 6])               # + origPropertyK
+    # candidates: JOIN (product, f) ON f, product != X   ->  (inst, product, orig1, orig2)
+    node = pb.hash_join(c, pf, on=[(2, 1)], filter=ID_NEQ(col(5), col(1)), projection=[0, 5, 3, 4])
+    # the two numeric windows cut the candidates down before anything else is looked up
+    for k, w, orig in ((1, w1, 2), (2, w2, 3)):
         sim = pb.data_source(quad_pattern("product", pr[f"bsbm:productPropertyNumeric{k}"], f"simProperty{k}"))
-        node = pb.hash_join(withorig, sim, on=[(2, 0)], filter=_window(6, 4, w), projection=[0, 1, 2, 3])
-    return pb.build(pb.projection(node, [0, 2, 3]))
+        node = pb.hash_join(node, sim, on=[(1, 0)], filter=_window(5, orig, w), projection=[0, 1, 2, 3])
+    label = pb.data_source(quad_pattern("product", pr["rdfs:label"], "productLabel"))           # (product, label)
+    return pb.build(pb.hash_join(node, label, on=[(1, 0)], projection=[0, 1, 5]))                # (inst, product, label)
 
 
 def q1_plan(ds, type_id, feature1, feature2, threshold):

@@ -125,8 +125,11 @@ struct LdsJoinArgs {
   const u64* n_probe_dev; u64 n_probe_cap;
   u32 tbl_mask;             // table slots - 1 (power of two >= 2 x build rows)
   uint2* gslots;            // null: the table lives in LDS (one copy per workgroup); else ONE {key0,row} table in HBM
+  const u32* direct;        // non-null: direct-address table in HBM instead (single unique dense key): row = direct[key - direct_min]
+  u32 direct_min, direct_n;
   u64* n_out_dev;           // exact number of matches (zeroed before launch)
   u64 out_cap;              // rows the out columns can hold (optimistic)
+  u32 wave_q;               // entries of each wave's LDS candidate queue (>= 64; 8 queues x 8 B x wave_q of LDS)
   u32* overflow;            // set when the matches did not fit
   u8* visited;              // left join: per build row
   u32 has_filter, has_probe_filter;   // join filter: 0 none / 1 VM / 3 window ; probe filter: 0 none / 1 id-literal / 2 VM
@@ -142,7 +145,11 @@ struct LdsJoinArgs {
 };
 void launch_lds_join(const LdsJoinArgs& a, hipStream_t s);
 void launch_gjoin_build(const LdsJoinArgs& a, hipStream_t s);   // fills a.gslots (memset to 0xFF first)
-int lds_join_items(u64 n_probe_cap, bool global);   // rows per lane of the instantiation that will be launched: 16 / 4 / 1
+int lds_join_items(u64 n_probe_cap, bool global);   // rows per lane of the instantiation that will be launched: 4 / 1
+enum { kJoinTableLds = 0, kJoinTableHash = 1, kJoinTableDirect = 2 };   // lds_join_kernel's MODE
+int lds_join_mode(const LdsJoinArgs& a);
+void launch_minmax_u32(const u32* col, u64 n, u32* out_dev /* {min, max}: preset to {~0, 0} */, hipStream_t s);   // nulls (0) skipped
+void launch_gdirect_build(const u32* keys, u64 n, u32* direct /* 0xFF-filled */, u32 kmin, u32 kn, u32* dup_dev, hipStream_t s);
 
 // ---- utilities ----
 void launch_fill_u32(u32* p, u32 v, u64 n, hipStream_t s);

@@ -289,7 +289,7 @@ Plan::~Plan() {
   if (stream) (void)hipStreamSynchronize(stream);
   release_intermediates();
   if (pool_dev) (void)hipFree(pool_dev);
-  for (NodeInfo& nd : nodes) if (nd.cached_slots) (void)hipFree(nd.cached_slots);
+  for (NodeInfo& nd : nodes) { if (nd.cached_slots) (void)hipFree(nd.cached_slots); if (nd.cached_direct) (void)hipFree(nd.cached_direct); }
   if (store && ctx) store->release_context(ctx);
 }
 
@@ -300,15 +300,16 @@ const char* kernel_class_name(int kc) {
       "void rdfgpu::filter_kernel<1>", "void rdfgpu::filter_kernel<2>", "void rdfgpu::filter_kernel<0>",
       "rdfgpu::cross_kernel", "rdfgpu::join_build_kernel", "void rdfgpu::join_probe_kernel<false>",
       "void rdfgpu::join_probe_kernel<true>", "rdfgpu::join_left_unmatched_kernel", "void rdfgpu::nlj_kernel<false>",
-      "void rdfgpu::nlj_kernel<true>", "rocprim device scan", "rdfgpu::gjoin_build_kernel"};
+      "void rdfgpu::nlj_kernel<true>", "rocprim device scan", "rdfgpu::gjoin_build_kernel", "rdfgpu::gdirect_build_kernel",
+      "rdfgpu::minmax_u32_kernel"};
   if (kc < KC_LDS_JOIN0) return fixed[kc];
   static std::string names[72];
   static std::once_flag once;
   std::call_once(once, [] {
-    const char* items[3] = {"16", "4", "1"};
-    for (int f = 0; f < 4; f++) for (int p = 0; p < 3; p++) for (int w = 0; w < 3; w++) for (int g = 0; g < 2; g++)
-      names[((f * 3 + p) * 3 + w) * 2 + g] = "void rdfgpu::lds_join_kernel<" + std::to_string(f) + ", " + std::to_string(p) + ", " +
-                                             items[w] + ", " + (g ? "true" : "false") + ">";
+    const char* items[2] = {"4", "1"};
+    for (int f = 0; f < 4; f++) for (int p = 0; p < 3; p++) for (int w = 0; w < 2; w++) for (int m = 0; m < 3; m++)
+      names[((f * 3 + p) * 2 + w) * 3 + m] = "void rdfgpu::lds_join_kernel<" + std::to_string(f) + ", " + std::to_string(p) + ", " +
+                                             items[w] + ", " + std::to_string(m) + ">";
   });
   return names[kc - KC_LDS_JOIN0].c_str();
 }
@@ -728,18 +729,62 @@ DevTable Plan::exec_lds_join(NodeInfo& nd, const DevTable& L, const DevTable& R,
   if (global_table) {
     const bool cacheable = B.stable_id != 0 && B.n_dev == nullptr && !std::getenv("RDFGPU_NO_TABLE_CACHE");
     if (cacheable) {
-      if (nd.cached_slots && nd.cached_version == store->version.load() && nd.cached_mask == a.tbl_mask && nd.cached_stable_id == B.stable_id) {
+      const u64 ver = store->version.load();
+      if (nd.cached_version != ver || nd.cached_stable_id != B.stable_id) {   // new build side: forget what was cached
+        if (nd.cached_direct) { RDFGPU_HIP(hipFree(nd.cached_direct)); nd.cached_direct = nullptr; }
+        nd.cached_direct_tried = false;
+        nd.cached_version = ver; nd.cached_stable_id = B.stable_id; nd.cached_mask = 0;   // mask 0: hash table not built
+      }
+      // Direct addressing first (one single key, unique and dense): decided once per build side; costs two small
+      // kernels and two host syncs at that time, nothing afterwards.
+      if (!nd.cached_direct_tried && a.n_keys == 1 && !std::getenv("RDFGPU_NO_DIRECT_TABLE")) {
+        nd.cached_direct_tried = true;
+        u32* mm = reinterpret_cast<u32*>(new_counter());   // {min, max}; the next counter slot holds the duplicate flag
+        u32* dup = reinterpret_cast<u32*>(new_counter());
+        const u32 init[2] = {0xFFFFFFFFu, 0u};
+        RDFGPU_HIP(hipMemcpyAsync(mm, init, sizeof(init), hipMemcpyHostToDevice, stream));
+        timed(KC_MINMAX, 4ull * B.cap, 0, nullptr, 0, nullptr, 0, 0, [&] { launch_minmax_u32(a.build_key[0], B.cap, mm, stream); });
+        u32 got[2];
+        RDFGPU_HIP(hipMemcpyAsync(got, mm, sizeof(got), hipMemcpyDeviceToHost, stream));
+        RDFGPU_HIP(hipStreamSynchronize(stream)); metrics.host_syncs++;
+        if (got[0] <= got[1] && (u64)(got[1] - got[0]) + 1 <= 4 * B.cap + 1024) {
+          const u32 kn = got[1] - got[0] + 1;
+          RDFGPU_HIP(hipMalloc((void**)&nd.cached_direct, (size_t)kn * sizeof(u32)));
+          RDFGPU_HIP(hipMemsetAsync(nd.cached_direct, 0xFF, (size_t)kn * sizeof(u32), stream));
+          timed(KC_GDIRECT_BUILD, 0, B.cap, nullptr, 8, nullptr, 0, 0, [&] { launch_gdirect_build(a.build_key[0], B.cap, nd.cached_direct, got[0], kn, dup, stream); });
+          u32 is_dup = 0;
+          RDFGPU_HIP(hipMemcpyAsync(&is_dup, dup, sizeof(u32), hipMemcpyDeviceToHost, stream));
+          RDFGPU_HIP(hipStreamSynchronize(stream)); metrics.host_syncs++;
+          if (is_dup) { RDFGPU_HIP(hipFree(nd.cached_direct)); nd.cached_direct = nullptr; }
+          else { nd.cached_direct_min = got[0]; nd.cached_direct_n = kn; }
+        }
+      }
+      if (nd.cached_direct) {
+        a.direct = nd.cached_direct; a.direct_min = nd.cached_direct_min; a.direct_n = nd.cached_direct_n;
         table_ready = true;
       } else {
-        if (nd.cached_slots && nd.cached_mask != a.tbl_mask) { RDFGPU_HIP(hipFree(nd.cached_slots)); nd.cached_slots = nullptr; }
-        if (!nd.cached_slots) RDFGPU_HIP(hipMalloc((void**)&nd.cached_slots, (size_t)slots * sizeof(uint2)));
-        nd.cached_version = store->version.load(); nd.cached_mask = a.tbl_mask; nd.cached_stable_id = B.stable_id;
+        if (nd.cached_slots && nd.cached_mask == a.tbl_mask) table_ready = true;
+        else {
+          if (nd.cached_slots) { RDFGPU_HIP(hipFree(nd.cached_slots)); nd.cached_slots = nullptr; }
+          RDFGPU_HIP(hipMalloc((void**)&nd.cached_slots, (size_t)slots * sizeof(uint2)));
+          nd.cached_mask = a.tbl_mask;
+        }
+        a.gslots = nd.cached_slots;
       }
-      a.gslots = nd.cached_slots;
     } else {
       a.gslots = scratch<uint2>(slots);
     }
     if (!table_ready) RDFGPU_HIP(hipMemsetAsync(a.gslots, 0xFF, (size_t)slots * sizeof(uint2), stream));
+  }
+  if (P.cap >= (1ull << 32)) fail(RDFGPU_ERR_UNSUPPORTED, "probe side of %llu rows", (unsigned long long)P.cap);
+  {
+    // Candidate queue per wave: one output reservation (a same-address atomic, ~88 per microsecond chip-wide) per
+    // queue-full of matches, so joins expected to be dense get 1024-entry queues (64 KiB of LDS per workgroup),
+    // sparse ones 256 (16 KiB, no occupancy cost).  "Expected" = the previous execution's cardinality if known.
+    static const u32 q_env = [] { const char* e = std::getenv("RDFGPU_JOIN_WAVE_Q"); return e ? (u32)std::strtoul(e, nullptr, 10) : 0u; }();
+    const u64 expect = nd.has_last ? nd.last_rows : P.cap;
+    const bool dense = expect * 8 >= P.cap && (global_table || (size_t)slots * sizeof(uint2) <= 64 * 1024);
+    a.wave_q = q_env ? q_env : dense ? 1024u : 256u;
   }
   a.probe_col_base = build_left ? L.n_cols : 0;
   a.has_filter = (u32)nd.shape;   // 0 none / 1 generic VM / 3 window
@@ -794,7 +839,7 @@ DevTable Plan::exec_lds_join(NodeInfo& nd, const DevTable& L, const DevTable& R,
     a.out_cap = spec_cap;
     for (u32 c = 0; c < nd.n_proj; c++) { a.out[c] = scratch<u32>(spec_cap + tail); t.cols[c] = a.out[c]; }
     if (left_join) RDFGPU_HIP(hipMemsetAsync(a.visited, 0, L.cap, stream));
-    timed(lds_join_class(a.has_filter, a.has_probe_filter, lds_join_items(P.cap, global_table), global_table), global_table ? 0 : fixed, P.cap, P.n_dev,
+    timed(lds_join_class(a.has_filter, a.has_probe_filter, lds_join_items(P.cap, global_table), lds_join_mode(a)), global_table ? 0 : fixed, P.cap, P.n_dev,
           4ull * probe_cols + 8, n_out, 0, 4ull * nd.n_proj, [&] { launch_lds_join(a, stream); });
     spec_checks.push_back({&nd, (u32)(n_out - counters), left_join});
     t.cap = spec_cap + tail; t.n_dev = n_out;
@@ -815,7 +860,7 @@ DevTable Plan::exec_lds_join(NodeInfo& nd, const DevTable& L, const DevTable& R,
     a.out_cap = out_cap;
     for (u32 c = 0; c < nd.n_proj; c++) { a.out[c] = scratch<u32>(out_cap + tail); t.cols[c] = a.out[c]; }
     if (left_join) RDFGPU_HIP(hipMemsetAsync(a.visited, 0, L.cap, stream));
-    timed(lds_join_class(a.has_filter, a.has_probe_filter, lds_join_items(P.cap, global_table), global_table), global_table ? 0 : fixed, P.cap, P.n_dev, 4ull * probe_cols + 8, n_out, 0, 4ull * nd.n_proj, [&] { launch_lds_join(a, stream); });
+    timed(lds_join_class(a.has_filter, a.has_probe_filter, lds_join_items(P.cap, global_table), lds_join_mode(a)), global_table ? 0 : fixed, P.cap, P.n_dev, 4ull * probe_cols + 8, n_out, 0, 4ull * nd.n_proj, [&] { launch_lds_join(a, stream); });
     const u32 i0 = (u32)(n_out - counters);
     RDFGPU_HIP(hipMemcpyAsync(ctx->counters_host + i0, counters + i0, 2 * sizeof(u64), hipMemcpyDeviceToHost, stream));
     RDFGPU_HIP(hipStreamSynchronize(stream)); metrics.host_syncs++;

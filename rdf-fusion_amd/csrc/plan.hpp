@@ -33,6 +33,8 @@ struct NodeInfo {
   u64 last_rows = 0; bool has_last = false;   // output cardinality of the previous execution (speculative sizing)
   // HBM join table kept across executions when the build side is a pure slice of the store
   uint2* cached_slots = nullptr; u64 cached_version = ~0ull, cached_stable_id = 0; u32 cached_mask = 0;
+  u32* cached_direct = nullptr; u32 cached_direct_min = 0, cached_direct_n = 0;   // direct-address form (unique dense single key)
+  bool cached_direct_tried = false;   // for (cached_version, cached_stable_id): direct addressing was attempted
 };
 struct SpecCheck { NodeInfo* node; u32 counter; bool left_join; };   // counter = n_out slot, counter+1 = overflow flag
 
@@ -43,12 +45,13 @@ enum KernelClass {
   KC_LOCATE, KC_SCAN_COUNT, KC_SCAN_WRITE, KC_FILTER_ID, KC_FILTER_TV, KC_FILTER_VM, KC_CROSS, KC_JOIN_BUILD,
   KC_JOIN_COUNT, KC_JOIN_WRITE, KC_LEFT_TAIL, KC_NLJ_COUNT, KC_NLJ_WRITE, KC_DEVICE_SCAN,
   KC_GJOIN_BUILD,
-  KC_LDS_JOIN0,                      // 72 instantiations: lds_join_kernel<FS in {0..3}, PFS in {0,1,2}, ITEMS in {16,4,1}, GLOBAL>
+  KC_GDIRECT_BUILD, KC_MINMAX,
+  KC_LDS_JOIN0,                      // 72 instantiations: lds_join_kernel<FS in {0..3}, PFS in {0,1,2}, ITEMS in {4,1}, MODE in {0,1,2}>
   KC__N = KC_LDS_JOIN0 + 72
 };
 const char* kernel_class_name(int kc);
-inline int lds_join_class(u32 fs, u32 pfs, int items, bool global) {
-  return KC_LDS_JOIN0 + (int)(((fs * 3 + pfs) * 3 + (items == 16 ? 0 : items == 4 ? 1 : 2)) * 2 + (global ? 1 : 0));
+inline int lds_join_class(u32 fs, u32 pfs, int items, int mode) {
+  return KC_LDS_JOIN0 + (int)(((fs * 3 + pfs) * 2 + (items == 4 ? 0 : 1)) * 3) + mode;
 }
 
 struct KernelStat { u32 launches = 0; double ms = 0; u64 bytes = 0; u64 rows = 0; };
