@@ -555,9 +555,6 @@ __device__ __forceinline__ bool load_keys(const u32* const* key_cols, u32 n_keys
   return !null_key;   // NullEqualsNothing: a null key never matches
 }
 
-__device__ __forceinline__ void ljoin_emit(const LdsJoinArgs& a, u32 i, u64 j, u64 pos) {
-  if (pos < a.out_cap) for (u32 oc = 0; oc < a.n_out_cols; oc++) a.out[oc][pos] = ljoin_col(a, a.proj[oc], i, j);
-}
 
 // Build sides above the LDS limit: the same {key0,row} open-addressing table, but ONE copy in HBM (8 B per
 // slot, load <= 0.5; a 285 k-row build = 8 MiB, i.e. L2 / Infinity-Cache resident), filled by this kernel.
@@ -633,11 +630,19 @@ __global__ __launch_bounds__(kLdsBlock) void lds_join_kernel(const LdsJoinArgs a
   u32 qn = 0;   // candidates in this wave's queue (wave-uniform)
 
   auto write_out = [&](u64 base) {   // queue entries -> consecutive output rows base .. base + qn
-    for (u32 e = lane; e < qn; e += 64) {
-      const uint2 m = wq[e];
-      ljoin_emit(a, m.x, m.y, base + e);
-      if (a.visited) a.visited[m.x] = 1;
+    // column by column: the column's pointers are fetched (scalar loads) once per call, not once per entry
+    for (u32 oc = 0; oc < a.n_out_cols; oc++) {
+      const u32 c = a.proj[oc];
+      const bool from_build = (c < a.n_left_cols) == (a.build_is_left != 0);
+      const u32* src = a.cols[c];
+      u32* dst = a.out[oc];
+      for (u32 e = lane; e < qn; e += 64) {
+        const uint2 m = wq[e];
+        const u64 pos = base + e;
+        if (pos < a.out_cap) dst[pos] = src[from_build ? m.x : m.y];
+      }
     }
+    if (a.visited) for (u32 e = lane; e < qn; e += 64) a.visited[wq[e].x] = 1;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   };
 

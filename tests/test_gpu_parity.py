@@ -417,6 +417,13 @@ def test_bsbm_q5_batched_equals_per_instance(bsbm_stores, torch_cuda, batch):
     plan_b, got_b = run_both(gs, os_, bsbm.q5_batch_plan(ds, tables=True),
                              gpu_tables=[(k[1], len(t[0])) for k, t in zip(keeps, tabs)], cpu_tables=tabs)
     np.testing.assert_array_equal(ku.multiset(got_b), ku.multiset(got))
+    # the multi-GPU exchange binds fixed-size, zero-padded buffers: a padding row has inst = 0 = null and must never join
+    padded = [[np.concatenate([c, np.zeros(37, np.uint32)]) for c in t] for t in tabs]
+    keeps_p = [table_on_device(torch_cuda, t) for t in padded]
+    for slot, (k, t) in enumerate(zip(keeps_p, padded)):
+        plan_b.bind_table(slot, k[1], len(t[0]))
+    got_p = plan_b.execute().fetch()
+    np.testing.assert_array_equal(ku.multiset(got_p), ku.multiset(got))
 
 
 def test_generic_vm_equals_specialised_kernels(bsbm_stores, monkeypatch):
