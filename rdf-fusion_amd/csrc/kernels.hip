@@ -630,16 +630,27 @@ __global__ __launch_bounds__(kLdsBlock) void lds_join_kernel(const LdsJoinArgs a
   u32 qn = 0;   // candidates in this wave's queue (wave-uniform)
 
   auto write_out = [&](u64 base) {   // queue entries -> consecutive output rows base .. base + qn
-    // column by column: the column's pointers are fetched (scalar loads) once per call, not once per entry
-    for (u32 oc = 0; oc < a.n_out_cols; oc++) {
-      const u32 c = a.proj[oc];
-      const bool from_build = (c < a.n_left_cols) == (a.build_is_left != 0);
-      const u32* src = a.cols[c];
-      u32* dst = a.out[oc];
+    // four columns at a time: their pointers are fetched (scalar loads) once per call, and a lane has four
+    // independent gathers in flight per entry instead of one load -> store chain per column
+    for (u32 oc0 = 0; oc0 < a.n_out_cols; oc0 += 4) {
+      const u32* src[4]; u32* dst[4]; bool from_build[4], on[4];
+#pragma unroll
+      for (u32 u = 0; u < 4; u++) {
+        on[u] = oc0 + u < a.n_out_cols;
+        const u32 oc = on[u] ? oc0 + u : oc0;
+        const u32 c = a.proj[oc];
+        from_build[u] = (c < a.n_left_cols) == (a.build_is_left != 0);
+        src[u] = a.cols[c]; dst[u] = a.out[oc];
+      }
       for (u32 e = lane; e < qn; e += 64) {
         const uint2 m = wq[e];
         const u64 pos = base + e;
-        if (pos < a.out_cap) dst[pos] = src[from_build ? m.x : m.y];
+        if (pos >= a.out_cap) continue;
+        u32 v[4];
+#pragma unroll
+        for (u32 u = 0; u < 4; u++) if (on[u]) v[u] = src[u][from_build[u] ? m.x : m.y];
+#pragma unroll
+        for (u32 u = 0; u < 4; u++) if (on[u]) dst[u][pos] = v[u];
       }
     }
     if (a.visited) for (u32 e = lane; e < qn; e += 64) a.visited[wq[e].x] = 1;

@@ -778,13 +778,19 @@ DevTable Plan::exec_lds_join(NodeInfo& nd, const DevTable& L, const DevTable& R,
   }
   if (P.cap >= (1ull << 32)) fail(RDFGPU_ERR_UNSUPPORTED, "probe side of %llu rows", (unsigned long long)P.cap);
   {
-    // Candidate queue per wave: one output reservation (a same-address atomic, ~88 per microsecond chip-wide) per
-    // queue-full of matches, so joins expected to be dense get 1024-entry queues (64 KiB of LDS per workgroup),
-    // sparse ones 256 (16 KiB, no occupancy cost).  "Expected" = the previous execution's cardinality if known.
+    // Candidate queue per wave: a full queue costs one output reservation (a same-address atomic, ~88 per
+    // microsecond chip-wide), an oversized one costs occupancy (8 queues x 8 B x entries of LDS per workgroup).
+    // Sized from the matches a wave can expect out of one tile (64 x rows-per-lane probe rows), which is what a
+    // workgroup of an HBM-table join sees in its whole life; "expected" = the previous execution's cardinality
+    // when known, else one match per probe row.  A direct-address table has at most one match per row.
     static const u32 q_env = [] { const char* e = std::getenv("RDFGPU_JOIN_WAVE_Q"); return e ? (u32)std::strtoul(e, nullptr, 10) : 0u; }();
+    const u64 per_tile = 64ull * (u64)lds_join_items(P.cap, global_table);
     const u64 expect = nd.has_last ? nd.last_rows : P.cap;
-    const bool dense = expect * 8 >= P.cap && (global_table || (size_t)slots * sizeof(uint2) <= 64 * 1024);
-    a.wave_q = q_env ? q_env : dense ? 1024u : 256u;
+    u64 want = a.direct ? per_tile : (expect * per_tile * 3 / 2) / (P.cap ? P.cap : 1);
+    u32 q = 256;
+    while (q < want && q < 1024) q <<= 1;
+    if (!global_table && (size_t)slots * sizeof(uint2) > 64 * 1024) q = 256;
+    a.wave_q = q_env ? q_env : q;
   }
   a.probe_col_base = build_left ? L.n_cols : 0;
   a.has_filter = (u32)nd.shape;   // 0 none / 1 generic VM / 3 window
