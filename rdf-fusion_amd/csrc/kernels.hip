@@ -490,37 +490,54 @@ __device__ __forceinline__ bool cmp_holds(u8 op, int o) {
 __device__ __forceinline__ Val lit_val(const TvLiteral& l) {
   Val y = val_tv_null(); y.tag = l.tag; y.flags = l.flags; y.aux = l.aux; y.lo = l.lo; y.hi = l.hi; return y;
 }
+// The filter comes in two halves.  ljoin_filter_fast decides the cheap, common cases in a handful of ops and is
+// what the resolve phase runs four-wide; whatever it cannot decide (undecided = true) goes to ljoin_filter_slow,
+// the full reference semantics, of which the kernel holds ONE copy run one candidate at a time — so the promotion
+// machinery (i128 decimals, float/double casts) costs neither registers nor instruction cache on the fast path.
 template <int FS>
-__device__ __forceinline__ bool ljoin_filter(const LdsJoinArgs& a, u64 i, u64 j) {
+__device__ __forceinline__ bool ljoin_filter_fast(const LdsJoinArgs& a, u32 i, u32 j, bool& undecided) {
+  undecided = false;
   if constexpr (FS == 0) return true;
   else if constexpr (FS == 2) {   // column <ID_EQ | ID_NEQ> column (e.g. `product != X` with the instance's X as a column)
     const u32 va = ljoin_col(a, a.idp.a, i, j), vb = ljoin_col(a, a.idp.b, i, j);
     if (va == 0 || vb == 0) return false;   // null => not `true`
     return (va == vb) == (a.idp.is_eq != 0);
   } else if constexpr (FS == 3) {
+    // all four operands and both literals xsd:integer (the BSBM numeric properties): checked i64 arithmetic
     const WindowFilter& w = a.win;
     const bool same = w.x0 == w.x1 && w.y0 == w.y1;   // wave-uniform
     const u32 ix0 = ljoin_col(a, w.x0, i, j), iy0 = ljoin_col(a, w.y0, i, j);
     const u32 ix1 = same ? ix0 : ljoin_col(a, w.x1, i, j), iy1 = same ? iy0 : ljoin_col(a, w.y1, i, j);
-    const Val x0 = enc_tv(a.tt, ix0), y0 = enc_tv(a.tt, iy0);
-    const Val x1 = same ? x0 : enc_tv(a.tt, ix1), y1 = same ? y0 : enc_tv(a.tt, iy1);
-    if (x0.tag == RDFGPU_TV_INTEGER && y0.tag == RDFGPU_TV_INTEGER && x1.tag == RDFGPU_TV_INTEGER && y1.tag == RDFGPU_TV_INTEGER &&
-        w.l0.tag == RDFGPU_TV_INTEGER && w.l1.tag == RDFGPU_TV_INTEGER) {
-      // all xsd:integer (the BSBM numeric properties): checked i64 arithmetic and compares, none of the promotion
-      // machinery below (which the compiler otherwise evaluates for every row: ~1000 VALU ops)
-      long long z0, z1;
-      const bool o0 = w.l0.arith_sub ? __builtin_sub_overflow((long long)y0.lo, (long long)w.l0.lo, &z0) : __builtin_add_overflow((long long)y0.lo, (long long)w.l0.lo, &z0);
-      const bool o1 = w.l1.arith_sub ? __builtin_sub_overflow((long long)y1.lo, (long long)w.l1.lo, &z1) : __builtin_add_overflow((long long)y1.lo, (long long)w.l1.lo, &z1);
-      if (o0 || o1) return false;   // overflow => error => null => not `true`
-      return cmp_holds(w.l0.cmp_op, x0.lo < z0 ? -1 : x0.lo > z0) && cmp_holds(w.l1.cmp_op, x1.lo < z1 ? -1 : x1.lo > z1);
-    }
+    const u64 n_ids = a.tt.n_ids;
+    const bool valid = ix0 && iy0 && ix1 && iy1 && ix0 < n_ids && iy0 < n_ids && ix1 < n_ids && iy1 < n_ids;
+    if (!valid) { undecided = true; return false; }
+    const int4* tv = reinterpret_cast<const int4*>(a.tt.tv);
+    const int4 rx0 = tv[ix0], ry0 = tv[iy0];
+    const int4 rx1 = same ? rx0 : tv[ix1], ry1 = same ? ry0 : tv[iy1];
+    const u32 tags = ((u32)rx0.w & 0xff) | (((u32)ry0.w & 0xff) << 8) | (((u32)rx1.w & 0xff) << 16) | (((u32)ry1.w & 0xff) << 24);
+    if (tags != RDFGPU_TV_INTEGER * 0x01010101u || w.l0.tag != RDFGPU_TV_INTEGER || w.l1.tag != RDFGPU_TV_INTEGER) { undecided = true; return false; }
+    auto i64 = [](const int4& r) { return (long long)(((u64)(u32)r.y << 32) | (u32)r.x); };
+    long long z0, z1;
+    const bool o0 = w.l0.arith_sub ? __builtin_sub_overflow(i64(ry0), (long long)w.l0.lo, &z0) : __builtin_add_overflow(i64(ry0), (long long)w.l0.lo, &z0);
+    const bool o1 = w.l1.arith_sub ? __builtin_sub_overflow(i64(ry1), (long long)w.l1.lo, &z1) : __builtin_add_overflow(i64(ry1), (long long)w.l1.lo, &z1);
+    if (o0 || o1) return false;   // overflow => error => null => not `true`
+    const long long p0 = i64(rx0), p1 = i64(rx1);
+    return cmp_holds(w.l0.cmp_op, p0 < z0 ? -1 : p0 > z0) && cmp_holds(w.l1.cmp_op, p1 < z1 ? -1 : p1 > z1);
+  } else { undecided = true; return false; }
+}
+template <int FS>
+__device__ __forceinline__ bool ljoin_filter_slow(const LdsJoinArgs& a, u32 i, u32 j) {
+  if constexpr (FS == 3) {
+    const WindowFilter& w = a.win;
+    const Val x0 = enc_tv(a.tt, ljoin_col(a, w.x0, i, j)), y0 = enc_tv(a.tt, ljoin_col(a, w.y0, i, j));
+    const Val x1 = enc_tv(a.tt, ljoin_col(a, w.x1, i, j)), y1 = enc_tv(a.tt, ljoin_col(a, w.y1, i, j));
     const Val z0 = tv_arith(y0, lit_val(w.l0), w.l0.arith_sub != 0);
     const Val z1 = tv_arith(y1, lit_val(w.l1), w.l1.arith_sub != 0);
     return cmp_holds(w.l0.cmp_op, tv_partial_cmp(x0, z0)) && cmp_holds(w.l1.cmp_op, tv_partial_cmp(x1, z1));
-  } else {
+  } else if constexpr (FS == 1) {
     const Val r = eval_program(*a.prog, a.tt, [&](u32 col) { return ljoin_col(a, col, i, j); });
     return r.lo == 1;
-  }
+  } else return false;   // FS 0 / 2 are always decided by the fast half
 }
 // Fused FilterExec of the probe child: PFS 0 = none, 1 = col <ID_EQ|ID_NEQ> literal, 2 = generic VM.
 template <int PFS>
@@ -597,13 +614,17 @@ template <int FS, int PFS, int ITEMS, int MODE>
 __global__ __launch_bounds__(kLdsBlock) void lds_join_kernel(const LdsJoinArgs a) {
   constexpr bool GLOBAL = MODE != kJoinTableLds;      // the table lives in HBM / L2
   constexpr bool DIRECT = MODE == kJoinTableDirect;   // direct-address table: row = direct[key - direct_min]
+  constexpr bool CSR = MODE == kJoinTableCsr;         // rows of key k: csr_rows[csr_off[k - min] .. csr_off[k - min + 1])
   extern __shared__ __align__(16) unsigned char lds_raw[];
   // dynamic LDS: [hash table (LDS variant only)] [8 wave queues]
   const uint2* slots = GLOBAL ? a.gslots : reinterpret_cast<const uint2*>(lds_raw);
   uint2* queues = reinterpret_cast<uint2*>(lds_raw) + (GLOBAL ? 0u : a.tbl_mask + 1u);
   __shared__ u32 wave_tot[kLdsBlock / 64];
   __shared__ u64 wg_base;
-  constexpr int kTileRows = kLdsBlock * ITEMS;
+  // CSR mode may give every probe row 2^rl lanes (they take the row's matches round-robin), so that a small probe
+  // side with a large fan-out still fills the chip; all other modes have rl = 0.
+  const u32 rl = CSR ? a.row_lanes_log2 : 0u;
+  const u32 kTileRows = (u32)(kLdsBlock * ITEMS) >> rl;
   const u32 tid = threadIdx.x;
   if constexpr (!GLOBAL) {
     uint2* lslots = reinterpret_cast<uint2*>(lds_raw);
@@ -670,17 +691,21 @@ __global__ __launch_bounds__(kLdsBlock) void lds_join_kernel(const LdsJoinArgs a
         // the tile's probe keys first (independent coalesced loads in flight together), then the first table slot of every row
 #pragma unroll
         for (int k = 0; k < ITEMS; k++) {
-          const u64 j = base + (u64)k * kLdsBlock + tid;
+          const u64 j = base + (((u32)k * kLdsBlock + tid) >> rl);
           walking[k] = j < np && load_keys(a.probe_key, a.n_keys, j, key[k]);
         }
 #pragma unroll
         for (int k = 0; k < ITEMS; k++) {
-          const u64 j = base + (u64)k * kLdsBlock + tid;
+          const u64 j = base + (((u32)k * kLdsBlock + tid) >> rl);
           walking[k] = walking[k] && lprobe_filter<PFS>(a, j);
           s[k] = make_uint2(0u, kNil);
           if constexpr (DIRECT) {   // unique dense keys: the one candidate is a single 4-byte load, no chain
             h[k] = key[k].k[0] - a.direct_min;
             if (walking[k] && h[k] < a.direct_n) s[k].y = a.direct[h[k]];
+          } else if constexpr (CSR) {   // dense keys with duplicates: s = [cursor, end) into the key's row list
+            h[k] = key[k].k[0] - a.direct_min;
+            s[k] = make_uint2(0u, 0u);
+            if (walking[k] && h[k] < a.direct_n) { s[k].x = a.csr_off[h[k]] + (tid & ((1u << rl) - 1u)); s[k].y = a.csr_off[h[k] + 1]; }
           } else {
             h[k] = hash_keys4(key[k], a.n_keys) & a.tbl_mask;
             if (walking[k]) s[k] = slots[h[k]];
@@ -691,12 +716,17 @@ __global__ __launch_bounds__(kLdsBlock) void lds_join_kernel(const LdsJoinArgs a
       }
 #pragma unroll
       for (int k = 0; k < ITEMS; k++) {
-        const u32 j = (u32)(tile * kTileRows + (u64)k * kLdsBlock + tid);
+        const u32 j = (u32)(tile * kTileRows + (((u32)k * kLdsBlock + tid) >> rl));
         while (!full) {
           u32 hit = pend[k];   // a candidate that did not fit before the last resolve, else the lane's next key-equal build row
           pend[k] = kNil;
           if constexpr (DIRECT) {
             if (walking[k]) { hit = s[k].y; walking[k] = false; }
+          } else if constexpr (CSR) {
+            if (hit == kNil && walking[k]) {
+              if (s[k].x < s[k].y) { hit = a.csr_rows ? a.csr_rows[s[k].x] : s[k].x; s[k].x += 1u << rl; }
+              else walking[k] = false;
+            }
           } else if (hit == kNil) {
             while (walking[k]) {
               if (s[k].y == kNil) { walking[k] = false; break; }
@@ -734,8 +764,28 @@ __global__ __launch_bounds__(kLdsBlock) void lds_join_kernel(const LdsJoinArgs a
           ok[u] = e < qn; m[u] = make_uint2(0u, 0u);
           if (ok[u]) m[u] = wq[e];
         }
+        bool slow[kResolveUnroll];
 #pragma unroll
-        for (int u = 0; u < kResolveUnroll; u++) if (ok[u]) ok[u] = ljoin_filter<FS>(a, m[u].x, m[u].y);
+        for (int u = 0; u < kResolveUnroll; u++) {
+          slow[u] = false;
+          if (ok[u]) ok[u] = ljoin_filter_fast<FS>(a, m[u].x, m[u].y, slow[u]);
+        }
+        if constexpr (FS == 1 || FS == 3) {
+          for (;;) {   // the undecided candidates, one per lane and round, through the single copy of the full semantics
+            int pick = -1;
+#pragma unroll
+            for (int u = kResolveUnroll - 1; u >= 0; u--) pick = slow[u] ? u : pick;
+            if (!__any(pick >= 0)) break;
+            if (pick >= 0) {
+              uint2 mm = m[0];
+#pragma unroll
+              for (int u = 1; u < kResolveUnroll; u++) mm = pick == u ? m[u] : mm;   // value selects keep m[] in registers
+              const bool r = ljoin_filter_slow<FS>(a, mm.x, mm.y);
+#pragma unroll
+              for (int u = 0; u < kResolveUnroll; u++) { ok[u] = pick == u ? r : ok[u]; slow[u] = pick == u ? false : slow[u]; }
+            }
+          }
+        }
 #pragma unroll
         for (int u = 0; u < kResolveUnroll; u++) {   // every read of this round is done: writing below g0 + 256 is safe
           const unsigned long long mask = __ballot(ok[u]);
@@ -793,27 +843,29 @@ int lds_join_items(u64 n_probe_cap, bool global) {
   static const u64 min_lds = [] { const char* e = std::getenv("RDFGPU_JOIN_ITEMS4_MIN_LDS"); return e ? std::strtoull(e, nullptr, 10) : (1ull << 20); }();
   return n_probe_cap >= (global ? min_global : min_lds) ? 4 : 1;
 }
-int lds_join_mode(const LdsJoinArgs& a) { return a.direct ? kJoinTableDirect : a.gslots ? kJoinTableHash : kJoinTableLds; }
+int lds_join_mode(const LdsJoinArgs& a) { return a.csr_off ? kJoinTableCsr : a.direct ? kJoinTableDirect : a.gslots ? kJoinTableHash : kJoinTableLds; }
 void launch_lds_join(const LdsJoinArgs& a, hipStream_t s) {
   const int mode = lds_join_mode(a);
   const bool global = mode != kJoinTableLds;
   const size_t tbl_lds = global ? 0 : (size_t)(a.tbl_mask + 1) * sizeof(uint2);
   const size_t lds = tbl_lds + (size_t)(kLdsBlock / 64) * a.wave_q * sizeof(uint2);
   if (a.wave_q < 64 || lds > 152 * 1024) fail(RDFGPU_ERR_INVALID, "lds join: %zu bytes of LDS", lds);
-  if (mode == kJoinTableDirect && a.n_keys != 1) fail(RDFGPU_ERR_INVALID, "direct-address join table needs exactly one key");
+  if ((mode == kJoinTableDirect || mode == kJoinTableCsr) && a.n_keys != 1) fail(RDFGPU_ERR_INVALID, "dense join table needs exactly one key");
+  const u32 rl = mode == kJoinTableCsr ? a.row_lanes_log2 : 0u;
+  if (rl > 6) fail(RDFGPU_ERR_INVALID, "lds join: %u lanes per row", 1u << rl);
   // enough workgroups to cover all 256 CUs; each builds its LDS copy once and strides over the tiles
   static const u64 wg_cap = [] { const char* e = std::getenv("RDFGPU_JOIN_MAX_WG"); return e ? std::strtoull(e, nullptr, 10) : 0ull; }();
   // HBM table: no per-workgroup build, so one tile per workgroup and let the hardware overlap them.  LDS
   // table: the build is repeated per workgroup, so cap the grid by what that costs (tiny tables: no cap).
   u64 max_wg = global ? (1ull << 22) : tbl_lds > 64 * 1024 ? 256 : tbl_lds > 32 * 1024 ? 512 : 1024;
   if (wg_cap) max_wg = wg_cap;
-  const int items = lds_join_items(a.n_probe_cap, global);
-  const u64 rows = (u64)kLdsBlock * items;
+  const int items = lds_join_items(a.n_probe_cap << rl, global);
+  const u64 rows = ((u64)kLdsBlock * items) >> rl;
   const u64 n_tiles = (a.n_probe_cap + rows - 1) / rows;
   const dim3 g((unsigned)(n_tiles < max_wg ? (n_tiles ? n_tiles : 1) : max_wg));
   const int fs = a.has_filter, pfs = a.has_probe_filter;   // 0 none / 1 VM / 2 col-col / 3 window ; 0 none / 1 id-literal / 2 VM
 #define RDFGPU_LJI(F, P, M) { if (items == 4) return launch_lds_join_t<F, P, 4, M>(a, g, lds, s); return launch_lds_join_t<F, P, 1, M>(a, g, lds, s); }
-#define RDFGPU_LJ(F, P) if (fs == F && pfs == P) { if (mode == kJoinTableDirect) RDFGPU_LJI(F, P, kJoinTableDirect) else if (mode == kJoinTableHash) RDFGPU_LJI(F, P, kJoinTableHash) else RDFGPU_LJI(F, P, kJoinTableLds) }
+#define RDFGPU_LJ(F, P) if (fs == F && pfs == P) { if (mode == kJoinTableCsr) RDFGPU_LJI(F, P, kJoinTableCsr) else if (mode == kJoinTableDirect) RDFGPU_LJI(F, P, kJoinTableDirect) else if (mode == kJoinTableHash) RDFGPU_LJI(F, P, kJoinTableHash) else RDFGPU_LJI(F, P, kJoinTableLds) }
   RDFGPU_LJ(0, 0) RDFGPU_LJ(0, 1) RDFGPU_LJ(0, 2)
   RDFGPU_LJ(1, 0) RDFGPU_LJ(1, 1) RDFGPU_LJ(1, 2)
   RDFGPU_LJ(2, 0) RDFGPU_LJ(2, 1) RDFGPU_LJ(2, 2)
@@ -854,6 +906,36 @@ __global__ __launch_bounds__(kBlock) void gdirect_build_kernel(const u32* keys, 
 void launch_gdirect_build(const u32* keys, u64 n, u32* direct, u32 kmin, u32 kn, u32* dup_dev, hipStream_t s) {
   const u64 g = (n + kBlock - 1) / kBlock;
   hipLaunchKernelGGL(gdirect_build_kernel, dim3((unsigned)(g ? g : 1)), dim3(kBlock), 0, s, keys, n, direct, kmin, kn, dup_dev);
+}
+
+// CSR form of the same idea for dense keys WITH duplicates (`?product bsbm:productFeature ?f` keyed by either end):
+// off[k - min] .. off[k - min + 1] delimit the rows of key k inside rows[] (row ids grouped by key, by a counting
+// sort: histogram -> exclusive scan -> scatter).  When the column is already sorted by the key (a GPOS slice keyed
+// by its object), rows[] is the identity and is not materialised: the store's own permutation IS the join index.
+__global__ __launch_bounds__(kBlock) void csr_hist_kernel(const u32* keys, u64 n, u32 kmin, u32 kn, u32* counts, u32* unsorted) {
+  const u64 i = (u64)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const u32 k = keys[i];
+  if (k == 0 || (i > 0 && keys[i - 1] > k)) *unsorted = 1u;   // identity rows[] needs sorted, null-free keys
+  if (k == 0) return;
+  const u32 d = k - kmin;
+  if (d < kn) atomicAdd(&counts[d], 1u);
+}
+__global__ __launch_bounds__(kBlock) void csr_scatter_kernel(const u32* keys, u64 n, u32 kmin, u32 kn, u32* cursor, u32* rows) {
+  const u64 i = (u64)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const u32 k = keys[i];
+  if (k == 0) return;
+  const u32 d = k - kmin;
+  if (d < kn) rows[atomicAdd(&cursor[d], 1u)] = (u32)i;
+}
+void launch_csr_hist(const u32* keys, u64 n, u32 kmin, u32 kn, u32* counts, u32* unsorted_dev, hipStream_t s) {
+  const u64 g = (n + kBlock - 1) / kBlock;
+  hipLaunchKernelGGL(csr_hist_kernel, dim3((unsigned)(g ? g : 1)), dim3(kBlock), 0, s, keys, n, kmin, kn, counts, unsorted_dev);
+}
+void launch_csr_scatter(const u32* keys, u64 n, u32 kmin, u32 kn, u32* cursor, u32* rows, hipStream_t s) {
+  const u64 g = (n + kBlock - 1) / kBlock;
+  hipLaunchKernelGGL(csr_scatter_kernel, dim3((unsigned)(g ? g : 1)), dim3(kBlock), 0, s, keys, n, kmin, kn, cursor, rows);
 }
 
 void launch_join_build(const JoinArgs& a, hipStream_t s) { hipLaunchKernelGGL(join_build_kernel, grid_for(a.n_left_cap), dim3(kBlock), 0, s, a); }

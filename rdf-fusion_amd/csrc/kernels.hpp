@@ -127,6 +127,9 @@ struct LdsJoinArgs {
   uint2* gslots;            // null: the table lives in LDS (one copy per workgroup); else ONE {key0,row} table in HBM
   const u32* direct;        // non-null: direct-address table in HBM instead (single unique dense key): row = direct[key - direct_min]
   u32 direct_min, direct_n;
+  const u32* csr_off;       // non-null: CSR table instead (single dense key, duplicates allowed): direct_n + 1 offsets into csr_rows
+  const u32* csr_rows;      // row ids grouped by key; null = identity (the build column is sorted by the key)
+  u32 row_lanes_log2;       // CSR: lanes sharing one probe row (its matches are dealt round-robin)
   u64* n_out_dev;           // exact number of matches (zeroed before launch)
   u64 out_cap;              // rows the out columns can hold (optimistic)
   u32 wave_q;               // entries of each wave's LDS candidate queue (>= 64; 8 queues x 8 B x wave_q of LDS)
@@ -146,9 +149,11 @@ struct LdsJoinArgs {
 void launch_lds_join(const LdsJoinArgs& a, hipStream_t s);
 void launch_gjoin_build(const LdsJoinArgs& a, hipStream_t s);   // fills a.gslots (memset to 0xFF first)
 int lds_join_items(u64 n_probe_cap, bool global);   // rows per lane of the instantiation that will be launched: 4 / 1
-enum { kJoinTableLds = 0, kJoinTableHash = 1, kJoinTableDirect = 2 };   // lds_join_kernel's MODE
+enum { kJoinTableLds = 0, kJoinTableHash = 1, kJoinTableDirect = 2, kJoinTableCsr = 3 };   // lds_join_kernel's MODE
 int lds_join_mode(const LdsJoinArgs& a);
 void launch_minmax_u32(const u32* col, u64 n, u32* out_dev /* {min, max}: preset to {~0, 0} */, hipStream_t s);   // nulls (0) skipped
+void launch_csr_hist(const u32* keys, u64 n, u32 kmin, u32 kn, u32* counts /* zeroed, kn + 1 */, u32* unsorted_dev, hipStream_t s);
+void launch_csr_scatter(const u32* keys, u64 n, u32 kmin, u32 kn, u32* cursor /* copy of the offsets */, u32* rows, hipStream_t s);
 void launch_gdirect_build(const u32* keys, u64 n, u32* direct /* 0xFF-filled */, u32 kmin, u32 kn, u32* dup_dev, hipStream_t s);
 
 // ---- utilities ----

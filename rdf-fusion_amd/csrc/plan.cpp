@@ -289,7 +289,12 @@ Plan::~Plan() {
   if (stream) (void)hipStreamSynchronize(stream);
   release_intermediates();
   if (pool_dev) (void)hipFree(pool_dev);
-  for (NodeInfo& nd : nodes) { if (nd.cached_slots) (void)hipFree(nd.cached_slots); if (nd.cached_direct) (void)hipFree(nd.cached_direct); }
+  for (NodeInfo& nd : nodes) {
+    if (nd.cached_slots) (void)hipFree(nd.cached_slots);
+    if (nd.cached_direct) (void)hipFree(nd.cached_direct);
+    if (nd.cached_csr_off) (void)hipFree(nd.cached_csr_off);
+    if (nd.cached_csr_rows) (void)hipFree(nd.cached_csr_rows);
+  }
   if (store && ctx) store->release_context(ctx);
 }
 
@@ -301,14 +306,14 @@ const char* kernel_class_name(int kc) {
       "rdfgpu::cross_kernel", "rdfgpu::join_build_kernel", "void rdfgpu::join_probe_kernel<false>",
       "void rdfgpu::join_probe_kernel<true>", "rdfgpu::join_left_unmatched_kernel", "void rdfgpu::nlj_kernel<false>",
       "void rdfgpu::nlj_kernel<true>", "rocprim device scan", "rdfgpu::gjoin_build_kernel", "rdfgpu::gdirect_build_kernel",
-      "rdfgpu::minmax_u32_kernel"};
+      "rdfgpu::minmax_u32_kernel", "rdfgpu::csr_hist_kernel", "rdfgpu::csr_scatter_kernel"};
   if (kc < KC_LDS_JOIN0) return fixed[kc];
-  static std::string names[72];
+  static std::string names[96];
   static std::once_flag once;
   std::call_once(once, [] {
     const char* items[2] = {"4", "1"};
-    for (int f = 0; f < 4; f++) for (int p = 0; p < 3; p++) for (int w = 0; w < 2; w++) for (int m = 0; m < 3; m++)
-      names[((f * 3 + p) * 2 + w) * 3 + m] = "void rdfgpu::lds_join_kernel<" + std::to_string(f) + ", " + std::to_string(p) + ", " +
+    for (int f = 0; f < 4; f++) for (int p = 0; p < 3; p++) for (int w = 0; w < 2; w++) for (int m = 0; m < 4; m++)
+      names[((f * 3 + p) * 2 + w) * 4 + m] = "void rdfgpu::lds_join_kernel<" + std::to_string(f) + ", " + std::to_string(p) + ", " +
                                              items[w] + ", " + std::to_string(m) + ">";
   });
   return names[kc - KC_LDS_JOIN0].c_str();
@@ -568,6 +573,27 @@ DevTable Plan::apply_filter(NodeInfo& nd, const DevTable& in) {
 
 static u32 pow2_at_least(u64 v) { u64 p = 1024; while (p < v && p < (1ull << 31)) p <<= 1; return (u32)p; }
 
+// Which input the hash join builds on.  A left join must build on the preserved (left) side.  An inner join builds
+// on the smaller input — unless exactly one input is a pure slice of the store (the same rows on every execution
+// until the store changes) and the other one is no larger: the slice's join table (direct-address / CSR / hash) is
+// built once and cached on the node, so building there costs nothing per execution and the probe is the SMALL side
+// (an index nested-loop join against the store's own permutation: `PARAMS JOIN (?s p ?o)` touches |PARAMS| rows,
+// not the 5 M-row predicate partition).
+bool Plan::choose_build_left(const NodeInfo& nd, const DevTable& L, const DevTable& R, bool left_join, bool lf, bool rf) const {
+  if (left_join) return true;
+  const bool smaller_left = L.cap <= R.cap;
+  if (nd.d.kind != RDFGPU_NODE_HASH_JOIN || nd.d.n_keys != 1 || std::getenv("RDFGPU_NO_TABLE_CACHE") || std::getenv("RDFGPU_NO_INDEX_JOIN")) return smaller_left;
+  const bool ls = L.stable_id != 0 && L.n_dev == nullptr && !lf, rs = R.stable_id != 0 && R.n_dev == nullptr && !rf;
+  if (ls == rs) return smaller_left;
+  const DevTable& S = ls ? L : R; const DevTable& O = ls ? R : L;
+  if (O.cap > S.cap) return smaller_left;                   // the slice is already the smaller side
+  // not dense (known from an earlier attempt on this very slice): a cached HASH table of the slice still wins when the
+  // other side is much smaller, and stays within a sane footprint (16 B per slot, load <= 0.5)
+  const bool known_not_dense = nd.dense_failed && nd.cached_stable_id == S.stable_id && nd.cached_version == store->version.load();
+  if (known_not_dense && (O.cap * 8 > S.cap || S.cap > (64ull << 20))) return smaller_left;
+  return ls;
+}
+
 DevTable Plan::exec_join(NodeInfo& nd) {
   const bool left_join = nd.d.join_type == RDFGPU_JOIN_LEFT;
   // Pipeline fusion: a FilterExec child (identity projection, consumed by this join only) is not
@@ -583,7 +609,7 @@ DevTable Plan::exec_join(NodeInfo& nd) {
   DevTable L = lf ? exec_node((u32)nodes[nd.d.left].d.left) : exec_node((u32)nd.d.left);
   DevTable R = rf ? exec_node((u32)nodes[nd.d.right].d.left) : exec_node((u32)nd.d.right);
   if (lf || rf) {
-    const bool build_left = left_join || L.cap <= R.cap;
+    const bool build_left = choose_build_left(nd, L, R, left_join, lf, rf);
     const bool lds = ((build_left ? L.cap : R.cap) <= kLdsJoinMaxBuild || !std::getenv("RDFGPU_NO_GLOBAL_TABLE_JOIN")) && L.cap && R.cap;
     // a fused filter survives only on the probe side of the LDS join; anything else is materialised now
     if (lf && (!lds || build_left)) { L = apply_filter(nodes[nd.d.left], L); lf = false; }
@@ -615,8 +641,7 @@ DevTable Plan::exec_join(NodeInfo& nd) {
   if (L.cap == 0 || (R.cap == 0 && !left_join)) { t.cap = 0; return t; }
   const bool hash = nd.d.kind == RDFGPU_NODE_HASH_JOIN;
   if (hash && !std::getenv("RDFGPU_NO_LDS_JOIN")) {
-    // build on the smaller input (an inner join is symmetric; a left join must build on the preserved side)
-    const bool build_left = left_join || L.cap <= R.cap;
+    const bool build_left = choose_build_left(nd, L, R, left_join, lf, rf);
     if ((build_left ? L.cap : R.cap) <= kLdsJoinMaxBuild || !std::getenv("RDFGPU_NO_GLOBAL_TABLE_JOIN")) {
       const NodeInfo* pf = lf ? &nodes[nd.d.left] : rf ? &nodes[nd.d.right] : nullptr;
       return exec_lds_join(nd, L, R, build_left, pf);
@@ -732,34 +757,63 @@ DevTable Plan::exec_lds_join(NodeInfo& nd, const DevTable& L, const DevTable& R,
       const u64 ver = store->version.load();
       if (nd.cached_version != ver || nd.cached_stable_id != B.stable_id) {   // new build side: forget what was cached
         if (nd.cached_direct) { RDFGPU_HIP(hipFree(nd.cached_direct)); nd.cached_direct = nullptr; }
-        nd.cached_direct_tried = false;
+        if (nd.cached_csr_off) { RDFGPU_HIP(hipFree(nd.cached_csr_off)); nd.cached_csr_off = nullptr; }
+        if (nd.cached_csr_rows) { RDFGPU_HIP(hipFree(nd.cached_csr_rows)); nd.cached_csr_rows = nullptr; }
+        nd.cached_direct_tried = false; nd.dense_failed = false;
         nd.cached_version = ver; nd.cached_stable_id = B.stable_id; nd.cached_mask = 0;   // mask 0: hash table not built
       }
-      // Direct addressing first (one single key, unique and dense): decided once per build side; costs two small
-      // kernels and two host syncs at that time, nothing afterwards.
+      // Dense forms first (one single key over a dense id range): direct-address if the keys are unique, CSR if not.
+      // Decided once per build side; costs a few small kernels and host syncs at that time, nothing afterwards.
       if (!nd.cached_direct_tried && a.n_keys == 1 && !std::getenv("RDFGPU_NO_DIRECT_TABLE")) {
         nd.cached_direct_tried = true;
-        u32* mm = reinterpret_cast<u32*>(new_counter());   // {min, max}; the next counter slot holds the duplicate flag
-        u32* dup = reinterpret_cast<u32*>(new_counter());
+        u32* mm = reinterpret_cast<u32*>(new_counter());     // {min, max}
+        u32* flags = reinterpret_cast<u32*>(new_counter());  // {duplicate seen, unsorted seen}
         const u32 init[2] = {0xFFFFFFFFu, 0u};
         RDFGPU_HIP(hipMemcpyAsync(mm, init, sizeof(init), hipMemcpyHostToDevice, stream));
         timed(KC_MINMAX, 4ull * B.cap, 0, nullptr, 0, nullptr, 0, 0, [&] { launch_minmax_u32(a.build_key[0], B.cap, mm, stream); });
         u32 got[2];
         RDFGPU_HIP(hipMemcpyAsync(got, mm, sizeof(got), hipMemcpyDeviceToHost, stream));
         RDFGPU_HIP(hipStreamSynchronize(stream)); metrics.host_syncs++;
-        if (got[0] <= got[1] && (u64)(got[1] - got[0]) + 1 <= 4 * B.cap + 1024) {
-          const u32 kn = got[1] - got[0] + 1;
+        const bool dense = got[0] <= got[1] && (u64)(got[1] - got[0]) + 1 <= 4 * B.cap + 1024;
+        if (!dense) nd.dense_failed = true;
+        else {
+          const u32 kmin = got[0], kn = got[1] - got[0] + 1;
           RDFGPU_HIP(hipMalloc((void**)&nd.cached_direct, (size_t)kn * sizeof(u32)));
           RDFGPU_HIP(hipMemsetAsync(nd.cached_direct, 0xFF, (size_t)kn * sizeof(u32), stream));
-          timed(KC_GDIRECT_BUILD, 0, B.cap, nullptr, 8, nullptr, 0, 0, [&] { launch_gdirect_build(a.build_key[0], B.cap, nd.cached_direct, got[0], kn, dup, stream); });
+          timed(KC_GDIRECT_BUILD, 0, B.cap, nullptr, 8, nullptr, 0, 0, [&] { launch_gdirect_build(a.build_key[0], B.cap, nd.cached_direct, kmin, kn, flags, stream); });
           u32 is_dup = 0;
-          RDFGPU_HIP(hipMemcpyAsync(&is_dup, dup, sizeof(u32), hipMemcpyDeviceToHost, stream));
+          RDFGPU_HIP(hipMemcpyAsync(&is_dup, flags, sizeof(u32), hipMemcpyDeviceToHost, stream));
           RDFGPU_HIP(hipStreamSynchronize(stream)); metrics.host_syncs++;
-          if (is_dup) { RDFGPU_HIP(hipFree(nd.cached_direct)); nd.cached_direct = nullptr; }
-          else { nd.cached_direct_min = got[0]; nd.cached_direct_n = kn; }
+          nd.cached_direct_min = kmin; nd.cached_direct_n = kn;
+          if (is_dup) {   // duplicates: counting sort into CSR (offsets + row ids grouped by key)
+            RDFGPU_HIP(hipFree(nd.cached_direct)); nd.cached_direct = nullptr;
+            RDFGPU_HIP(hipMalloc((void**)&nd.cached_csr_off, ((size_t)kn + 1) * sizeof(u32)));
+            u32* counts = scratch<u32>((u64)kn + 1);
+            RDFGPU_HIP(hipMemsetAsync(counts, 0, ((size_t)kn + 1) * sizeof(u32), stream));
+            timed(KC_CSR_HIST, 0, B.cap, nullptr, 8, nullptr, 0, 0, [&] { launch_csr_hist(a.build_key[0], B.cap, kmin, kn, counts, flags + 1, stream); });
+            const size_t tb = scan_temp_bytes((u64)kn + 1);
+            void* temp = scratch<unsigned char>(tb);
+            exclusive_scan_u32(counts, nd.cached_csr_off, (u64)kn + 1, temp, tb, stream);
+            u32 unsorted = 0;
+            RDFGPU_HIP(hipMemcpyAsync(&unsorted, flags + 1, sizeof(u32), hipMemcpyDeviceToHost, stream));
+            RDFGPU_HIP(hipStreamSynchronize(stream)); metrics.host_syncs++;
+            if (unsorted) {   // else the slice is sorted by the key: rows[] is the identity and is never materialised
+              RDFGPU_HIP(hipMalloc((void**)&nd.cached_csr_rows, (size_t)B.cap * sizeof(u32)));
+              RDFGPU_HIP(hipMemcpyAsync(counts, nd.cached_csr_off, (size_t)kn * sizeof(u32), hipMemcpyDeviceToDevice, stream));   // cursors
+              timed(KC_CSR_SCATTER, 0, B.cap, nullptr, 12, nullptr, 0, 0, [&] { launch_csr_scatter(a.build_key[0], B.cap, kmin, kn, counts, nd.cached_csr_rows, stream); });
+            }
+          }
         }
       }
-      if (nd.cached_direct) {
+      if (nd.cached_csr_off) {
+        a.csr_off = nd.cached_csr_off; a.csr_rows = nd.cached_csr_rows; a.direct_min = nd.cached_direct_min; a.direct_n = nd.cached_direct_n;
+        // lanes per probe row: a small probe side with a large fan-out is spread over the chip
+        const u64 fan = nd.has_last ? nd.last_rows / (P.cap ? P.cap : 1) : 1;
+        u32 rl = 0;
+        while (rl < 6 && (2ull << rl) <= fan && (P.cap << (rl + 1)) <= (1ull << 21)) rl++;
+        a.row_lanes_log2 = rl;
+        table_ready = true;
+      } else if (nd.cached_direct) {
         a.direct = nd.cached_direct; a.direct_min = nd.cached_direct_min; a.direct_n = nd.cached_direct_n;
         table_ready = true;
       } else {
@@ -784,7 +838,7 @@ DevTable Plan::exec_lds_join(NodeInfo& nd, const DevTable& L, const DevTable& R,
     // workgroup of an HBM-table join sees in its whole life; "expected" = the previous execution's cardinality
     // when known, else one match per probe row.  A direct-address table has at most one match per row.
     static const u32 q_env = [] { const char* e = std::getenv("RDFGPU_JOIN_WAVE_Q"); return e ? (u32)std::strtoul(e, nullptr, 10) : 0u; }();
-    const u64 per_tile = 64ull * (u64)lds_join_items(P.cap, global_table);
+    const u64 per_tile = 64ull * (u64)lds_join_items(P.cap << a.row_lanes_log2, global_table);
     const u64 expect = nd.has_last ? nd.last_rows : P.cap;
     u64 want = a.direct ? per_tile : (expect * per_tile * 3 / 2) / (P.cap ? P.cap : 1);
     u32 q = 256;
@@ -845,7 +899,7 @@ DevTable Plan::exec_lds_join(NodeInfo& nd, const DevTable& L, const DevTable& R,
     a.out_cap = spec_cap;
     for (u32 c = 0; c < nd.n_proj; c++) { a.out[c] = scratch<u32>(spec_cap + tail); t.cols[c] = a.out[c]; }
     if (left_join) RDFGPU_HIP(hipMemsetAsync(a.visited, 0, L.cap, stream));
-    timed(lds_join_class(a.has_filter, a.has_probe_filter, lds_join_items(P.cap, global_table), lds_join_mode(a)), global_table ? 0 : fixed, P.cap, P.n_dev,
+    timed(lds_join_class(a.has_filter, a.has_probe_filter, lds_join_items(P.cap << a.row_lanes_log2, global_table), lds_join_mode(a)), global_table ? 0 : fixed, P.cap, P.n_dev,
           4ull * probe_cols + 8, n_out, 0, 4ull * nd.n_proj, [&] { launch_lds_join(a, stream); });
     spec_checks.push_back({&nd, (u32)(n_out - counters), left_join});
     t.cap = spec_cap + tail; t.n_dev = n_out;
@@ -866,7 +920,7 @@ DevTable Plan::exec_lds_join(NodeInfo& nd, const DevTable& L, const DevTable& R,
     a.out_cap = out_cap;
     for (u32 c = 0; c < nd.n_proj; c++) { a.out[c] = scratch<u32>(out_cap + tail); t.cols[c] = a.out[c]; }
     if (left_join) RDFGPU_HIP(hipMemsetAsync(a.visited, 0, L.cap, stream));
-    timed(lds_join_class(a.has_filter, a.has_probe_filter, lds_join_items(P.cap, global_table), lds_join_mode(a)), global_table ? 0 : fixed, P.cap, P.n_dev, 4ull * probe_cols + 8, n_out, 0, 4ull * nd.n_proj, [&] { launch_lds_join(a, stream); });
+    timed(lds_join_class(a.has_filter, a.has_probe_filter, lds_join_items(P.cap << a.row_lanes_log2, global_table), lds_join_mode(a)), global_table ? 0 : fixed, P.cap, P.n_dev, 4ull * probe_cols + 8, n_out, 0, 4ull * nd.n_proj, [&] { launch_lds_join(a, stream); });
     const u32 i0 = (u32)(n_out - counters);
     RDFGPU_HIP(hipMemcpyAsync(ctx->counters_host + i0, counters + i0, 2 * sizeof(u64), hipMemcpyDeviceToHost, stream));
     RDFGPU_HIP(hipStreamSynchronize(stream)); metrics.host_syncs++;

@@ -34,7 +34,9 @@ struct NodeInfo {
   // HBM join table kept across executions when the build side is a pure slice of the store
   uint2* cached_slots = nullptr; u64 cached_version = ~0ull, cached_stable_id = 0; u32 cached_mask = 0;
   u32* cached_direct = nullptr; u32 cached_direct_min = 0, cached_direct_n = 0;   // direct-address form (unique dense single key)
-  bool cached_direct_tried = false;   // for (cached_version, cached_stable_id): direct addressing was attempted
+  u32* cached_csr_off = nullptr; u32* cached_csr_rows = nullptr;                   // CSR form (dense single key with duplicates)
+  bool cached_direct_tried = false;   // for (cached_version, cached_stable_id): the dense forms were attempted
+  bool dense_failed = false;          // ... and neither applies (keys not dense): only a hash table can be cached
 };
 struct SpecCheck { NodeInfo* node; u32 counter; bool left_join; };   // counter = n_out slot, counter+1 = overflow flag
 
@@ -45,13 +47,13 @@ enum KernelClass {
   KC_LOCATE, KC_SCAN_COUNT, KC_SCAN_WRITE, KC_FILTER_ID, KC_FILTER_TV, KC_FILTER_VM, KC_CROSS, KC_JOIN_BUILD,
   KC_JOIN_COUNT, KC_JOIN_WRITE, KC_LEFT_TAIL, KC_NLJ_COUNT, KC_NLJ_WRITE, KC_DEVICE_SCAN,
   KC_GJOIN_BUILD,
-  KC_GDIRECT_BUILD, KC_MINMAX,
-  KC_LDS_JOIN0,                      // 72 instantiations: lds_join_kernel<FS in {0..3}, PFS in {0,1,2}, ITEMS in {4,1}, MODE in {0,1,2}>
-  KC__N = KC_LDS_JOIN0 + 72
+  KC_GDIRECT_BUILD, KC_MINMAX, KC_CSR_HIST, KC_CSR_SCATTER,
+  KC_LDS_JOIN0,                      // 96 instantiations: lds_join_kernel<FS in {0..3}, PFS in {0,1,2}, ITEMS in {4,1}, MODE in {0,1,2,3}>
+  KC__N = KC_LDS_JOIN0 + 96
 };
 const char* kernel_class_name(int kc);
 inline int lds_join_class(u32 fs, u32 pfs, int items, int mode) {
-  return KC_LDS_JOIN0 + (int)(((fs * 3 + pfs) * 2 + (items == 4 ? 0 : 1)) * 3) + mode;
+  return KC_LDS_JOIN0 + (int)(((fs * 3 + pfs) * 2 + (items == 4 ? 0 : 1)) * 4) + mode;
 }
 
 struct KernelStat { u32 launches = 0; double ms = 0; u64 bytes = 0; u64 rows = 0; };
@@ -108,6 +110,7 @@ struct Plan {
   DevTable exec_join(NodeInfo& nd);
   DevTable apply_filter(NodeInfo& nd, const DevTable& in);
   DevTable exec_lds_join(NodeInfo& nd, const DevTable& L, const DevTable& R, bool build_left, const NodeInfo* probe_filter);
+  bool choose_build_left(const NodeInfo& nd, const DevTable& L, const DevTable& R, bool left_join, bool lf, bool rf) const;
   void release_intermediates();
   template <class T> T* scratch(u64 n);
   u64* new_counter();
