@@ -426,6 +426,57 @@ def test_bsbm_q5_batched_equals_per_instance(bsbm_stores, torch_cuda, batch):
     np.testing.assert_array_equal(ku.multiset(got_p), ku.multiset(got))
 
 
+@pytest.mark.parametrize("shape", ["unique_dense", "dup_sorted", "dup_scattered", "sparse"])
+@pytest.mark.parametrize("n_tab", [1, 700, 40_000])
+def test_index_join_against_store_slice(torch_cuda, shape, n_tab):
+    """TABLE JOIN (?s <p> ?o) with the engine building on the store slice (cached direct-address / CSR / hash
+    table) and probing with the table — every table mode, keyed by either end of the pattern, with a residual
+    filter, null keys in the table, keys outside the slice, and re-execution from the cache."""
+    rng = np.random.default_rng(len(shape) * 100_003 + n_tab)
+    n_sub = 6000
+    pred, other_pred = 5, 6
+    sub = 1000 + (np.arange(n_sub) if shape != "sparse" else np.sort(rng.choice(10_000_000, n_sub, replace=False)))
+    if shape == "unique_dense":      # one object per subject: keyed by ?s the keys are unique and dense -> direct
+        s_col, o_col = sub, 50_000 + rng.integers(0, 300, n_sub)
+    else:                            # ~8 objects per subject: duplicates -> CSR (dense) or hash (sparse)
+        s_col = np.repeat(sub, 8)
+        o_col = 50_000 + rng.integers(0, 300, len(s_col))
+    quads = (np.zeros(len(s_col) + 50, np.uint32),
+             np.concatenate([s_col, 1000 + rng.integers(0, n_sub, 50)]).astype(np.uint32),
+             np.concatenate([np.full(len(s_col), pred), np.full(50, other_pred)]).astype(np.uint32),
+             np.concatenate([o_col, 50_000 + rng.integers(0, 300, 50)]).astype(np.uint32))
+    gs, os_ = both_stores(quads)
+    # "dup_sorted": key = ?o of the GPOS slice (sorted by the key); the others: key = ?s (scattered inside the slice)
+    key_is_object = shape == "dup_sorted"
+    key_pool = np.unique(o_col if key_is_object else s_col)
+    keys = rng.choice(np.concatenate([key_pool, key_pool[:3] + 9_999_999]), n_tab).astype(np.uint32)
+    keys[rng.random(n_tab) < 0.05] = 0                                    # null keys never join
+    tab = [rng.integers(1, 9, n_tab).astype(np.uint32), keys, rng.integers(50_000, 50_300, n_tab).astype(np.uint32)]
+    keep, ptrs = table_on_device(torch_cuda, tab)
+    k_scan = 1 if key_is_object else 0
+    for mk in (None, ID_NEQ, ID_EQ):
+        pb = PlanBuilder()
+        t = pb.table(0, 3)
+        scan = pb.data_source(quad_pattern("s", pred, "o"))               # (s, o) at columns 3, 4
+        flt = None if mk is None else mk(col(2), col(4))
+        desc = pb.build(pb.hash_join(t, scan, on=[(1, k_scan)], filter=flt, projection=[0, 1, 3, 4, 2]))
+        plan, got = run_both(gs, os_, desc, gpu_tables=[(ptrs, n_tab)], cpu_tables=[tab])
+        plan.enable_kernel_timing(True)
+        again = plan.execute().fetch()                                    # second run: cached table, speculative sizes
+        np.testing.assert_array_equal(ku.multiset(again), ku.multiset(got))
+        if n_tab == 700:   # the table mode is the last template argument of the kernel name: 2 direct, 3 CSR, 1 hash
+            mode = {"unique_dense": "2", "dup_sorted": "3", "dup_scattered": "3", "sparse": "1"}[shape]
+            joins = [k[0] for k in plan.kernel_stats() if "lds_join_kernel" in k[0]]
+            assert joins and all(k.rstrip(">").split(", ")[-1] == mode for k in joins), (shape, joins)
+        # and with the inputs swapped (the slice as the plan's left child: (s, o) at 0, 1; the table at 2, 3, 4)
+        pb = PlanBuilder()
+        scan = pb.data_source(quad_pattern("s", pred, "o"))
+        t = pb.table(0, 3)
+        flt = None if mk is None else mk(col(4), col(1))
+        run_both(gs, os_, pb.build(pb.hash_join(scan, t, on=[(k_scan, 1)], filter=flt, projection=[2, 3, 0, 1])),
+                 gpu_tables=[(ptrs, n_tab)], cpu_tables=[tab])
+
+
 def test_generic_vm_equals_specialised_kernels(bsbm_stores, monkeypatch):
     ds, gs, os_ = bsbm_stores
     desc = bsbm.q5_plan(ds, ds.product(17))
