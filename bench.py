@@ -77,6 +77,22 @@ def scan_roofline(rf, device, log2_rows=26, threshold=1000, reps=10):
             "frac": round(gbs / HBM_PEAK_GBS, 4), "frac_of_measured_copy_ceiling": round(gbs / 6290.0, 4)}
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of THIS command (FETCH_SIZE and
+    WRITE_SIZE in separate runs, gfx950 corrections applied by profiles/summarize.py) — counters cannot be read
+    from inside the benchmark process, so the newest summary under profiles/ is quoted, with its file name."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_fetch_write_per_kernel.json")))
+    for f in reversed(files):
+        try:
+            e = json.load(open(f)).get(kernel)
+        except (OSError, ValueError):
+            continue
+        if e and "hbm_bytes_per_launch" in e:
+            return int(e["hbm_bytes_per_launch"]), os.path.relpath(f, ROOT)
+    return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -272,8 +288,9 @@ def main():
     if kstats:
         name, (launches, ms, nbytes, rows) = max(kstats.items(), key=lambda kv: kv[1][1])
         achieved = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        traffic, traffic_src = pmc_traffic(name)
         roofline = {"bound": "hbm", "kernel": name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                     "launches": launches, "avg_us": round(ms * 1e3 / max(1, launches), 2),
                     "algorithmic_bytes_per_launch": int(nbytes / max(1, launches))}
     kernel_table = {k: {"launches": v[0], "total_ms": round(v[1], 3), "avg_us": round(v[1] * 1e3 / max(1, v[0]), 1),

@@ -174,12 +174,46 @@ find_range_cases = [  # D:1202-1250 ; None = null
     dict(values=[10, 20, 30], value=50, result=["After"]),
 ]
 
+# Checked arithmetic and casts of the xsd value types (inputs and expected results of the reference's in-file
+# tests).  Sources: M = lib/model/src/xsd/.  Values: ["int", v] i32, ["integer", v] i64, ["decimal", raw] with
+# raw = value * 10^18 as a decimal string (i128: decimal.rs:9-29, STEP = raw 1), ["double", v].
+I32_MIN, I32_MAX = -(1 << 31), (1 << 31) - 1
+I64_MIN, I64_MAX = -(1 << 63), (1 << 63) - 1
+I128_MIN, I128_MAX = -(1 << 127), (1 << 127) - 1
+dec = lambda raw: ["decimal", str(raw)]
+numeric_arith_cases = [
+    dict(src="M/integer.rs:420-423", op="add", a=["integer", I64_MIN], b=["integer", 1], expect=["integer", I64_MIN + 1]),
+    dict(src="M/integer.rs:420-423", op="add", a=["integer", I64_MAX], b=["integer", 1], expect="error"),
+    dict(src="M/integer.rs:426-429", op="sub", a=["integer", I64_MIN], b=["integer", 1], expect="error"),
+    dict(src="M/integer.rs:426-429", op="sub", a=["integer", I64_MAX], b=["integer", 1], expect=["integer", I64_MAX - 1]),
+    dict(src="M/int.rs:369-372", op="add", a=["int", I32_MIN], b=["int", 1], expect=["int", I32_MIN + 1]),
+    dict(src="M/int.rs:369-372", op="add", a=["int", I32_MAX], b=["int", 1], expect="error"),
+    dict(src="M/int.rs:375-378", op="sub", a=["int", I32_MIN], b=["int", 1], expect="error"),
+    dict(src="M/int.rs:375-378", op="sub", a=["int", I32_MAX], b=["int", 1], expect=["int", I32_MAX - 1]),
+    dict(src="M/decimal.rs:755-762", op="add", a=dec(I128_MIN), b=dec(1), expect=dec(I128_MIN + 1)),
+    dict(src="M/decimal.rs:755-762", op="add", a=dec(I128_MAX), b=dec(1), expect="error"),
+    dict(src="M/decimal.rs:755-762", op="add", a=dec(I128_MAX), b=dec(I128_MIN), expect=dec(-1)),
+    dict(src="M/decimal.rs:765-768", op="sub", a=dec(I128_MIN), b=dec(1), expect="error"),
+    dict(src="M/decimal.rs:765-768", op="sub", a=dec(I128_MAX), b=dec(1), expect=dec(I128_MAX - 1)),
+]
+E18 = 10 ** 18
+decimal_to_double_cases = [  # M/decimal.rs:1097-1117 (Double::from(Decimal)); tol = the test's own bound, 0 = assert_eq
+    dict(raw=str(0), value=0.0, tol=0.0),
+    dict(raw=str(1 * E18), value=1.0, tol=0.0),
+    dict(raw=str(10 * E18), value=10.0, tol=0.0),
+    dict(raw=str(E18 // 10), value=0.1, tol=1.1920928955078125e-07),
+    # the reference asserts |x - v| < 1; doubles are 32768 apart at 1.7e20, so that is x == v
+    dict(raw=str(I128_MAX), value=1.7014118346046924e20, tol=0.0),
+    dict(raw=str(I128_MIN), value=-1.7014118346046924e20, tol=0.0),
+]
+
 out = dict(
     _about="Known-answer vectors transcribed from the reference's unit tests (see make_reference_kats.py).",
     scan=scan_cases, remove=remove_cases, store=store_cases, predicate_and=predicate_and_cases,
     index_choice=index_choice_cases, score_order=score_order_cases, pushdown=pushdown_cases,
     pushdown_display=pushdown_display_cases, rowgroups=rowgroup_cases, dedupe=dedupe_cases,
-    prune=prune_cases, find_range=find_range_cases)
+    prune=prune_cases, find_range=find_range_cases, numeric_arith=numeric_arith_cases,
+    decimal_to_double=decimal_to_double_cases)
 
 if __name__ == "__main__":
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "reference_kats.json")

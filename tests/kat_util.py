@@ -67,3 +67,35 @@ def multiset(cols, n_rows=None):
         return m
     order = np.lexsort(tuple(m[:, k] for k in reversed(range(m.shape[1]))))
     return m[order]
+
+
+def kat_literal(v):
+    """["int"|"integer"|"decimal"|"double", value] of reference_kats.json -> a typed-value literal expression"""
+    from rdf_fusion_amd.plan import int32, integer, decimal, double
+    kind, val = v
+    return {"int": int32, "integer": integer, "decimal": lambda r: decimal(int(r)), "double": double}[kind](int(val) if kind != "double" else val)
+
+
+def numeric_kat_plans(kats):
+    """(name, plan description over a bound 1-row table, expected row count) for every numeric KAT: the row
+    survives iff the reference's assertion holds.  An error is the SPARQL error value: `x = x` is then not true."""
+    from rdf_fusion_amd.plan import PlanBuilder, ADD, SUB, EQ, EBV, LT, GT, AND, ENC_TV, col, double  # noqa: F401
+    out = []
+    for c in kats["numeric_arith"]:
+        f = ADD if c["op"] == "add" else SUB
+        z = f(kat_literal(c["a"]), kat_literal(c["b"]))
+        pb = PlanBuilder()
+        if c["expect"] == "error":
+            expr, n = EBV(EQ(z, z)), 0
+        else:
+            expr, n = EBV(EQ(z, kat_literal(c["expect"]))), 1
+        out.append((f'{c["src"]} {c["op"]} {c["a"]} {c["b"]}', pb.build(pb.filter(pb.table(0, 1), expr)), n))
+    for c in kats["decimal_to_double"]:
+        x = kat_literal(["decimal", c["raw"]])
+        pb = PlanBuilder()
+        if c["tol"] == 0.0:
+            expr = EBV(EQ(x, double(c["value"])))            # decimal vs double compares as doubles (numeric.rs:127-201)
+        else:
+            expr = AND(EBV(LT(x, double(c["value"] + c["tol"]))), EBV(GT(x, double(c["value"] - c["tol"]))))
+        out.append((f'decimal->double {c["raw"]}', pb.build(pb.filter(pb.table(0, 1), expr)), 1))
+    return out

@@ -137,6 +137,17 @@ def test_reference_prune_kats_as_located_ranges(kats):
             assert plan.metrics().input_rows == kept or plan.selected_index(node) != abi.GSPO, case["src"]
 
 
+def test_reference_numeric_kats(kats, torch_cuda):
+    """checked add/sub at the type bounds and Decimal -> Double (the reference's xsd in-file tests), on the device"""
+    gs = rf.GpuQuadStore()
+    one = [np.array([7], dtype=np.uint32)]
+    keep, ptrs = table_on_device(torch_cuda, one)
+    for name, desc, n_expected in ku.numeric_kat_plans(kats):
+        plan = gs.plan(desc)
+        plan.bind_table(0, ptrs, 1)
+        assert plan.execute().result_info()[0] == n_expected, name
+
+
 # ---------------------------------------------------------------------------------------------------
 # index build, random scans
 # ---------------------------------------------------------------------------------------------------

@@ -144,3 +144,12 @@ def test_find_range_kats(kats):
             assert (lo, hi) == (exp[1], exp[2]), case
         if exp[0] == "NotContained":
             assert lo == exp[1], case
+
+
+def test_numeric_kats(kats):
+    """checked add/sub at the type bounds and Decimal -> Double (the reference's xsd in-file tests)"""
+    os_ = orc.OracleStore()
+    one = [np.array([7], dtype=np.uint32)]
+    for name, desc, n_expected in ku.numeric_kat_plans(kats):
+        _, n, _ = os_.execute(desc, [one])
+        assert n == n_expected, name

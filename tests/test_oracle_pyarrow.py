@@ -1,0 +1,84 @@
+"""Independent columnar-CPU cross-check of the oracle's join / filter operators: pyarrow's
+Acero hash join and compute kernels on the same u32 tables.  pyarrow is NOT the reference — the reference's
+HashJoinExec is DataFusion 52, absent here — but it implements the same SQL join semantics the reference relies on
+(null keys never match = NullEqualsNothing; a left join keeps unmatched left rows with null right columns), so an
+oracle that agrees with it on random multisets is not agreeing with itself only.  CPU only, no GPU."""
+import numpy as np
+import pytest
+
+pa = pytest.importorskip("pyarrow")
+import pyarrow.compute as pc  # noqa: E402
+
+from rdf_fusion_amd import abi  # noqa: E402
+from rdf_fusion_amd.engine import TV_DTYPE  # noqa: E402
+from rdf_fusion_amd.plan import PlanBuilder, col, integer, ENC_TV, GT, LT, GEQ, LEQ, EBV, ID_NEQ  # noqa: E402
+from oracle import oracle as orc  # noqa: E402
+import kat_util as ku  # noqa: E402
+
+
+def rand_table(rng, n, ncols, n_ids, null_frac=0.1):
+    cols = [rng.integers(1, n_ids, n).astype(np.uint32) for _ in range(ncols)]
+    for c in cols:
+        c[rng.random(n) < null_frac] = 0
+    return cols
+
+
+def to_arrow(cols, prefix):
+    """0 is the null id (quad_index_data.rs:438-440): becomes an Arrow null"""
+    return pa.table({f"{prefix}{k}": pa.array(c, type=pa.uint32(), mask=(c == 0)) for k, c in enumerate(cols)})
+
+
+def from_arrow(tbl, names):
+    return [np.asarray(tbl[n].fill_null(0).to_numpy(zero_copy_only=False), dtype=np.uint32) for n in names]
+
+
+@pytest.mark.parametrize("nl,nr,n_ids", [(0, 10, 5), (10, 0, 5), (1, 1, 2), (300, 500, 20), (5000, 20_000, 400), (40_000, 3_000, 1500)])
+@pytest.mark.parametrize("join_type", ["inner", "left outer"])
+def test_hash_join_agrees_with_acero(nl, nr, n_ids, join_type):
+    rng = np.random.default_rng(nl * 7 + nr)
+    L, R = rand_table(rng, nl, 3, n_ids), rand_table(rng, nr, 2, n_ids)
+    os_ = orc.OracleStore()
+    for on in ([(0, 0)], [(0, 0), (1, 1)], [(1, 0)]):
+        pb = PlanBuilder()
+        jt = abi.JOIN_INNER if join_type == "inner" else abi.JOIN_LEFT
+        desc = pb.build(pb.hash_join(pb.table(0, 3), pb.table(1, 2), on=on, join_type=jt))
+        got, n, _ = os_.execute(desc, [L, R])
+        exp = to_arrow(L, "l").join(to_arrow(R, "r"), keys=[f"l{a}" for a, _ in on], right_keys=[f"r{b}" for _, b in on],
+                                    join_type=join_type, coalesce_keys=False)
+        exp_cols = from_arrow(exp, ["l0", "l1", "l2", "r0", "r1"])
+        assert n == exp.num_rows
+        np.testing.assert_array_equal(ku.multiset(got, n), ku.multiset(exp_cols, exp.num_rows))
+
+
+def test_join_with_id_filter_agrees_with_acero():
+    """inner join + residual `l0 != r1` (the Q5 `product != X` shape): Acero join then compute filter"""
+    rng = np.random.default_rng(11)
+    L, R = rand_table(rng, 4000, 3, 300, null_frac=0.05), rand_table(rng, 6000, 2, 300, null_frac=0.05)
+    pb = PlanBuilder()
+    desc = pb.build(pb.hash_join(pb.table(0, 3), pb.table(1, 2), on=[(1, 0)], filter=ID_NEQ(col(0), col(4)), projection=[0, 4, 2]))
+    got, n, _ = orc.OracleStore().execute(desc, [L, R])
+    j = to_arrow(L, "l").join(to_arrow(R, "r"), keys=["l1"], right_keys=["r0"], join_type="inner", coalesce_keys=False)
+    keep = pc.fill_null(pc.not_equal(j["l0"], j["r1"]), False)       # a null operand => not `true` => dropped
+    j = j.filter(keep)
+    np.testing.assert_array_equal(ku.multiset(got, n), ku.multiset(from_arrow(j, ["l0", "r1", "l2"]), j.num_rows))
+
+
+@pytest.mark.parametrize("op,pc_op", [(GT, pc.greater), (LT, pc.less), (GEQ, pc.greater_equal), (LEQ, pc.less_equal)])
+def test_integer_filter_agrees_with_arrow_compute(op, pc_op):
+    """EBV(op(ENC_TV(col), literal)) over xsd:integer ids (the BSBM Q1 FILTER) vs an Arrow compare on the decoded values"""
+    rng = np.random.default_rng(5)
+    n_ids = 3000
+    tv = np.zeros(n_ids, dtype=TV_DTYPE)
+    values = rng.integers(-1000, 1000, n_ids)
+    tv["tag"][1:] = abi.TV_INTEGER
+    tv["lo"][1:] = values[1:]
+    os_ = orc.OracleStore()
+    os_.set_typed_values(tv)
+    ids = rng.integers(0, n_ids, 50_000).astype(np.uint32)            # 0 = null => dropped
+    payload = rng.integers(1, 1 << 30, len(ids)).astype(np.uint32)
+    pb = PlanBuilder()
+    desc = pb.build(pb.filter(pb.table(0, 2), EBV(op(ENC_TV(col(0)), integer(17))), projection=[1, 0]))
+    got, n, _ = os_.execute(desc, [[ids, payload]])
+    vals = pa.array(values[ids], type=pa.int64(), mask=(ids == 0))
+    keep = np.asarray(pc.fill_null(pc_op(vals, 17), False))
+    np.testing.assert_array_equal(ku.multiset(got, n), ku.multiset([payload[keep], ids[keep]]))
