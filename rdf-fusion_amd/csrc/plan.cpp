@@ -289,12 +289,7 @@ Plan::~Plan() {
   if (stream) (void)hipStreamSynchronize(stream);
   release_intermediates();
   if (pool_dev) (void)hipFree(pool_dev);
-  for (NodeInfo& nd : nodes) {
-    if (nd.cached_slots) (void)hipFree(nd.cached_slots);
-    if (nd.cached_direct) (void)hipFree(nd.cached_direct);
-    if (nd.cached_csr_off) (void)hipFree(nd.cached_csr_off);
-    if (nd.cached_csr_rows) (void)hipFree(nd.cached_csr_rows);
-  }
+
   if (store && ctx) store->release_context(ctx);
 }
 
@@ -584,14 +579,19 @@ bool Plan::choose_build_left(const NodeInfo& nd, const DevTable& L, const DevTab
   const bool smaller_left = L.cap <= R.cap;
   if (nd.d.kind != RDFGPU_NODE_HASH_JOIN || nd.d.n_keys != 1 || std::getenv("RDFGPU_NO_TABLE_CACHE") || std::getenv("RDFGPU_NO_INDEX_JOIN")) return smaller_left;
   const bool ls = L.stable_id != 0 && L.n_dev == nullptr && !lf, rs = R.stable_id != 0 && R.n_dev == nullptr && !rf;
-  if (ls == rs) return smaller_left;
-  const DevTable& S = ls ? L : R; const DevTable& O = ls ? R : L;
+  if (!ls && !rs) return smaller_left;
+  // candidate: build on the slice (the larger one when both inputs are slices), probe with the other input
+  const bool slice_left = ls && rs ? !smaller_left : ls;
+  const DevTable& S = slice_left ? L : R; const DevTable& O = slice_left ? R : L;
   if (O.cap > S.cap) return smaller_left;                   // the slice is already the smaller side
-  // not dense (known from an earlier attempt on this very slice): a cached HASH table of the slice still wins when the
-  // other side is much smaller, and stays within a sane footprint (16 B per slot, load <= 0.5)
-  const bool known_not_dense = nd.dense_failed && nd.cached_stable_id == S.stable_id && nd.cached_version == store->version.load();
-  if (known_not_dense && (O.cap * 8 > S.cap || S.cap > (64ull << 20))) return smaller_left;
-  return ls;
+  if (ls && rs && O.cap * 8 > S.cap) return smaller_left;   // two slices of similar size: nothing to gain
+  if (S.cap <= 1024) return smaller_left;                   // LDS-table territory
+  // keys known not to be dense (from an earlier attempt on this very slice): a cached HASH table of the slice still
+  // wins when the other side is much smaller, and stays within a sane footprint (16 B per row at load 0.5)
+  SliceKey sk; sk.n_keys = 1; sk.rows = S.cap; sk.key[0] = S.cols[slice_left ? nd.d.left_keys[0] : nd.d.right_keys[0]];
+  const SliceTable* st = store->find_slice_table(sk);
+  if (st && st->dense_failed && (O.cap * 8 > S.cap || S.cap > (64ull << 20))) return smaller_left;
+  return slice_left;
 }
 
 DevTable Plan::exec_join(NodeInfo& nd) {
@@ -748,24 +748,19 @@ DevTable Plan::exec_lds_join(NodeInfo& nd, const DevTable& L, const DevTable& R,
   if (!global_table) { while ((slots < 4 * B.cap || slots < 2048) && slots < 2 * kLdsJoinMaxBuild) slots <<= 1; }
   else { while (slots < 8 * B.cap && (u64)slots * sizeof(uint2) < (1u << 20)) slots <<= 1; }
   a.tbl_mask = slots - 1;
-  // The HBM table of a build side that is a pure slice of the store (a param-free scan: label, simProperty…)
-  // is the same on every execution of this plan until the store changes: it is built once and kept.
-  bool table_ready = false;
+  // The HBM table of a build side that is a pure slice of the store (a param-free scan: label, simProperty…) is the
+  // same for every plan until the store changes: it is built once per store version and kept on the store.
+  bool build_now = false;
   if (global_table) {
     const bool cacheable = B.stable_id != 0 && B.n_dev == nullptr && !std::getenv("RDFGPU_NO_TABLE_CACHE");
     if (cacheable) {
-      const u64 ver = store->version.load();
-      if (nd.cached_version != ver || nd.cached_stable_id != B.stable_id) {   // new build side: forget what was cached
-        if (nd.cached_direct) { RDFGPU_HIP(hipFree(nd.cached_direct)); nd.cached_direct = nullptr; }
-        if (nd.cached_csr_off) { RDFGPU_HIP(hipFree(nd.cached_csr_off)); nd.cached_csr_off = nullptr; }
-        if (nd.cached_csr_rows) { RDFGPU_HIP(hipFree(nd.cached_csr_rows)); nd.cached_csr_rows = nullptr; }
-        nd.cached_direct_tried = false; nd.dense_failed = false;
-        nd.cached_version = ver; nd.cached_stable_id = B.stable_id; nd.cached_mask = 0;   // mask 0: hash table not built
-      }
+      SliceKey sk; sk.n_keys = a.n_keys; sk.rows = B.cap;
+      for (u32 k = 0; k < a.n_keys; k++) sk.key[k] = a.build_key[k];
+      SliceTable* st = store->slice_table(sk);
+      std::unique_lock<std::mutex> building(store->slice_build_mu);
       // Dense forms first (one single key over a dense id range): direct-address if the keys are unique, CSR if not.
-      // Decided once per build side; costs a few small kernels and host syncs at that time, nothing afterwards.
-      if (!nd.cached_direct_tried && a.n_keys == 1 && !std::getenv("RDFGPU_NO_DIRECT_TABLE")) {
-        nd.cached_direct_tried = true;
+      // Decided once per slice; costs a few small kernels and host syncs at that time, nothing afterwards.
+      if (!st->dense_tried && a.n_keys == 1 && !std::getenv("RDFGPU_NO_DIRECT_TABLE")) {
         u32* mm = reinterpret_cast<u32*>(new_counter());     // {min, max}
         u32* flags = reinterpret_cast<u32*>(new_counter());  // {duplicate seen, unsorted seen}
         const u32 init[2] = {0xFFFFFFFFu, 0u};
@@ -775,60 +770,69 @@ DevTable Plan::exec_lds_join(NodeInfo& nd, const DevTable& L, const DevTable& R,
         RDFGPU_HIP(hipMemcpyAsync(got, mm, sizeof(got), hipMemcpyDeviceToHost, stream));
         RDFGPU_HIP(hipStreamSynchronize(stream)); metrics.host_syncs++;
         const bool dense = got[0] <= got[1] && (u64)(got[1] - got[0]) + 1 <= 4 * B.cap + 1024;
-        if (!dense) nd.dense_failed = true;
+        if (!dense) st->dense_failed = true;
         else {
           const u32 kmin = got[0], kn = got[1] - got[0] + 1;
-          RDFGPU_HIP(hipMalloc((void**)&nd.cached_direct, (size_t)kn * sizeof(u32)));
-          RDFGPU_HIP(hipMemsetAsync(nd.cached_direct, 0xFF, (size_t)kn * sizeof(u32), stream));
-          timed(KC_GDIRECT_BUILD, 0, B.cap, nullptr, 8, nullptr, 0, 0, [&] { launch_gdirect_build(a.build_key[0], B.cap, nd.cached_direct, kmin, kn, flags, stream); });
+          u32* direct = nullptr;
+          RDFGPU_HIP(hipMalloc((void**)&direct, (size_t)kn * sizeof(u32)));
+          RDFGPU_HIP(hipMemsetAsync(direct, 0xFF, (size_t)kn * sizeof(u32), stream));
+          timed(KC_GDIRECT_BUILD, 0, B.cap, nullptr, 8, nullptr, 0, 0, [&] { launch_gdirect_build(a.build_key[0], B.cap, direct, kmin, kn, flags, stream); });
           u32 is_dup = 0;
           RDFGPU_HIP(hipMemcpyAsync(&is_dup, flags, sizeof(u32), hipMemcpyDeviceToHost, stream));
           RDFGPU_HIP(hipStreamSynchronize(stream)); metrics.host_syncs++;
-          nd.cached_direct_min = kmin; nd.cached_direct_n = kn;
-          if (is_dup) {   // duplicates: counting sort into CSR (offsets + row ids grouped by key)
-            RDFGPU_HIP(hipFree(nd.cached_direct)); nd.cached_direct = nullptr;
-            RDFGPU_HIP(hipMalloc((void**)&nd.cached_csr_off, ((size_t)kn + 1) * sizeof(u32)));
+          st->kmin = kmin; st->kn = kn;
+          if (!is_dup) st->direct = direct;
+          else {   // duplicates: counting sort into CSR (offsets + row ids grouped by key)
+            RDFGPU_HIP(hipFree(direct));
+            u32* off = nullptr; u32* rows = nullptr;
+            RDFGPU_HIP(hipMalloc((void**)&off, ((size_t)kn + 1) * sizeof(u32)));
             u32* counts = scratch<u32>((u64)kn + 1);
             RDFGPU_HIP(hipMemsetAsync(counts, 0, ((size_t)kn + 1) * sizeof(u32), stream));
             timed(KC_CSR_HIST, 0, B.cap, nullptr, 8, nullptr, 0, 0, [&] { launch_csr_hist(a.build_key[0], B.cap, kmin, kn, counts, flags + 1, stream); });
             const size_t tb = scan_temp_bytes((u64)kn + 1);
             void* temp = scratch<unsigned char>(tb);
-            exclusive_scan_u32(counts, nd.cached_csr_off, (u64)kn + 1, temp, tb, stream);
+            exclusive_scan_u32(counts, off, (u64)kn + 1, temp, tb, stream);
             u32 unsorted = 0;
             RDFGPU_HIP(hipMemcpyAsync(&unsorted, flags + 1, sizeof(u32), hipMemcpyDeviceToHost, stream));
             RDFGPU_HIP(hipStreamSynchronize(stream)); metrics.host_syncs++;
             if (unsorted) {   // else the slice is sorted by the key: rows[] is the identity and is never materialised
-              RDFGPU_HIP(hipMalloc((void**)&nd.cached_csr_rows, (size_t)B.cap * sizeof(u32)));
-              RDFGPU_HIP(hipMemcpyAsync(counts, nd.cached_csr_off, (size_t)kn * sizeof(u32), hipMemcpyDeviceToDevice, stream));   // cursors
-              timed(KC_CSR_SCATTER, 0, B.cap, nullptr, 12, nullptr, 0, 0, [&] { launch_csr_scatter(a.build_key[0], B.cap, kmin, kn, counts, nd.cached_csr_rows, stream); });
+              RDFGPU_HIP(hipMalloc((void**)&rows, (size_t)B.cap * sizeof(u32)));
+              RDFGPU_HIP(hipMemcpyAsync(counts, off, (size_t)kn * sizeof(u32), hipMemcpyDeviceToDevice, stream));   // cursors
+              timed(KC_CSR_SCATTER, 0, B.cap, nullptr, 12, nullptr, 0, 0, [&] { launch_csr_scatter(a.build_key[0], B.cap, kmin, kn, counts, rows, stream); });
+              RDFGPU_HIP(hipStreamSynchronize(stream)); metrics.host_syncs++;   // complete before other plans may see it
             }
+            st->csr_rows = rows; st->csr_off = off;
           }
         }
+        st->dense_tried = true;
       }
-      if (nd.cached_csr_off) {
-        a.csr_off = nd.cached_csr_off; a.csr_rows = nd.cached_csr_rows; a.direct_min = nd.cached_direct_min; a.direct_n = nd.cached_direct_n;
+      if (st->csr_off) {
+        a.csr_off = st->csr_off; a.csr_rows = st->csr_rows; a.direct_min = st->kmin; a.direct_n = st->kn;
         // lanes per probe row: a small probe side with a large fan-out is spread over the chip
         const u64 fan = nd.has_last ? nd.last_rows / (P.cap ? P.cap : 1) : 1;
         u32 rl = 0;
         while (rl < 6 && (2ull << rl) <= fan && (P.cap << (rl + 1)) <= (1ull << 21)) rl++;
         a.row_lanes_log2 = rl;
-        table_ready = true;
-      } else if (nd.cached_direct) {
-        a.direct = nd.cached_direct; a.direct_min = nd.cached_direct_min; a.direct_n = nd.cached_direct_n;
-        table_ready = true;
+      } else if (st->direct) {
+        a.direct = st->direct; a.direct_min = st->kmin; a.direct_n = st->kn;
       } else {
-        if (nd.cached_slots && nd.cached_mask == a.tbl_mask) table_ready = true;
-        else {
-          if (nd.cached_slots) { RDFGPU_HIP(hipFree(nd.cached_slots)); nd.cached_slots = nullptr; }
-          RDFGPU_HIP(hipMalloc((void**)&nd.cached_slots, (size_t)slots * sizeof(uint2)));
-          nd.cached_mask = a.tbl_mask;
-        }
-        a.gslots = nd.cached_slots;
+        if (!st->slots || st->mask != a.tbl_mask) {   // build the hash form now, under the lock, and publish it only when complete
+          if (st->slots) { RDFGPU_HIP(hipFree(st->slots)); st->slots = nullptr; }
+          void* mem = nullptr;
+          RDFGPU_HIP(hipMalloc(&mem, (size_t)slots * sizeof(uint2)));
+          a.gslots = static_cast<uint2*>(mem);
+          RDFGPU_HIP(hipMemsetAsync(a.gslots, 0xFF, (size_t)slots * sizeof(uint2), stream));
+          timed(KC_GJOIN_BUILD, 0, B.cap, B.n_dev, 4ull * a.n_keys + 8, nullptr, 0, 0, [&] { launch_gjoin_build(a, stream); });
+          RDFGPU_HIP(hipStreamSynchronize(stream)); metrics.host_syncs++;
+          st->slots = mem; st->mask = a.tbl_mask;
+          }
+        a.gslots = static_cast<uint2*>(st->slots);
       }
     } else {
       a.gslots = scratch<uint2>(slots);
+      build_now = true;
+      RDFGPU_HIP(hipMemsetAsync(a.gslots, 0xFF, (size_t)slots * sizeof(uint2), stream));
     }
-    if (!table_ready) RDFGPU_HIP(hipMemsetAsync(a.gslots, 0xFF, (size_t)slots * sizeof(uint2), stream));
   }
   if (P.cap >= (1ull << 32)) fail(RDFGPU_ERR_UNSUPPORTED, "probe side of %llu rows", (unsigned long long)P.cap);
   {
@@ -888,7 +892,7 @@ DevTable Plan::exec_lds_join(NodeInfo& nd, const DevTable& L, const DevTable& R,
   // SURVEY §8d hash join: 4(k+p_b)N_b + 8N_b + 4(k+p_p)N_p + 8N_p + 4 c_o N_o  (the 8-byte slot lives in LDS here)
   const u64 fixed = (4ull * (a.n_keys + build_payload) + 8) * B.cap;
 
-  if (global_table && !table_ready)   // build pass: keys read + one 8-byte slot written per build row
+  if (build_now)   // build pass: keys read + one 8-byte slot written per build row
     timed(KC_GJOIN_BUILD, 0, B.cap, B.n_dev, 4ull * a.n_keys + 8, nullptr, 0, 0, [&] { launch_gjoin_build(a, stream); });
   // Speculative mode (re-execution of a plan whose previous run is known): the output is sized from the
   // previous cardinality of this operator and NOTHING is waited for — the exact count stays on the device,

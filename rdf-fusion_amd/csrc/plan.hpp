@@ -31,12 +31,6 @@ struct NodeInfo {
   int source = -1;                // index into Plan::sources
   u32 refs = 0;                   // how many operators consume this node
   u64 last_rows = 0; bool has_last = false;   // output cardinality of the previous execution (speculative sizing)
-  // HBM join table kept across executions when the build side is a pure slice of the store
-  uint2* cached_slots = nullptr; u64 cached_version = ~0ull, cached_stable_id = 0; u32 cached_mask = 0;
-  u32* cached_direct = nullptr; u32 cached_direct_min = 0, cached_direct_n = 0;   // direct-address form (unique dense single key)
-  u32* cached_csr_off = nullptr; u32* cached_csr_rows = nullptr;                   // CSR form (dense single key with duplicates)
-  bool cached_direct_tried = false;   // for (cached_version, cached_stable_id): the dense forms were attempted
-  bool dense_failed = false;          // ... and neither applies (keys not dense): only a hash table can be cached
 };
 struct SpecCheck { NodeInfo* node; u32 counter; bool left_join; };   // counter = n_out slot, counter+1 = overflow flag
 

@@ -140,8 +140,30 @@ void Store::release_context(ExecContext* c) {
   free_ctx.push_back(c);
 }
 
+SliceTable* Store::slice_table(const SliceKey& k) {
+  std::lock_guard<std::mutex> lock(slice_mu);
+  return &slice_tables[k];   // std::map nodes never move
+}
+const SliceTable* Store::find_slice_table(const SliceKey& k) {
+  std::lock_guard<std::mutex> lock(slice_mu);
+  auto it = slice_tables.find(k);
+  return it == slice_tables.end() ? nullptr : &it->second;
+}
+void Store::drop_slice_tables() {
+  std::lock_guard<std::mutex> lock(slice_mu);
+  for (auto& kv : slice_tables) {
+    SliceTable& t = kv.second;
+    if (t.direct) (void)hipFree(t.direct);
+    if (t.csr_off) (void)hipFree(t.csr_off);
+    if (t.csr_rows) (void)hipFree(t.csr_rows);
+    if (t.slots) (void)hipFree(t.slots);
+  }
+  slice_tables.clear();
+}
+
 Store::~Store() {
   (void)hipSetDevice(device);
+  drop_slice_tables();
   for (ExecContext* c : free_ctx) delete c;
   for (auto& ix : idx) for (auto& c : ix.col) if (c) (void)hipFree(c);
   if (tv) (void)hipFree(tv);
@@ -153,6 +175,7 @@ void Store::clear() {
   std::unique_lock<std::shared_mutex> lock(mu);
   activate();
   version++;
+  drop_slice_tables();
   for (auto& ix : idx) { for (auto& c : ix.col) { if (c) RDFGPU_HIP(hipFree(c)); c = nullptr; } ix.n = 0; }
 }
 
@@ -197,6 +220,7 @@ u64 Store::extend_device(const u32* g, const u32* s_, const u32* p, const u32* o
   activate();
   if (n == 0) return 0;
   version++;
+  drop_slice_tables();
   const u32* in[4] = {g, s_, p, o};
   hipStream_t s = stream;
   u64 inserted = 0;
@@ -257,6 +281,7 @@ u64 Store::remove_host(const u32* g, const u32* s_, const u32* p, const u32* o, 
   activate();
   if (n == 0 || idx[0].n == 0) return 0;
   version++;
+  drop_slice_tables();
   hipStream_t s = stream;
   const u32* h[4] = {g, s_, p, o};
   u64 removed = 0;

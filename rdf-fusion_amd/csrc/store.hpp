@@ -51,6 +51,26 @@ struct Permutation {
   u64 n = 0;
 };
 
+// Join table of one key-column slice of the store (a param-free triple-pattern scan joined on `n_keys` of its
+// columns).  The slice is the same on every execution of every plan until the store changes, so its table is built
+// once per store version and shared by all plans (kept here, not on a plan node: DataFusion compiles a fresh plan per
+// query).  Forms: direct-address (single unique dense key), CSR (single dense key with duplicates), else hash.
+struct SliceTable {
+  bool dense_tried = false, dense_failed = false;
+  u32* direct = nullptr; u32 kmin = 0, kn = 0;      // row = direct[key - kmin]
+  u32* csr_off = nullptr; u32* csr_rows = nullptr;  // rows of key k: csr_rows[csr_off[k - kmin] .. csr_off[k - kmin + 1]); null rows = identity
+  void* slots = nullptr; u32 mask = 0;              // {key0,row} open-addressing table (uint2[mask + 1])
+};
+struct SliceKey {
+  const u32* key[RDFGPU_MAX_KEYS] = {}; u32 n_keys = 0; u64 rows = 0;
+  bool operator<(const SliceKey& o) const {
+    if (n_keys != o.n_keys) return n_keys < o.n_keys;
+    if (rows != o.rows) return rows < o.rows;
+    for (u32 i = 0; i < RDFGPU_MAX_KEYS; i++) if (key[i] != o.key[i]) return key[i] < o.key[i];
+    return false;
+  }
+};
+
 struct Store {
   int device = 0;
   u32 batch_size = 8192;
@@ -62,6 +82,13 @@ struct Store {
   hipStream_t stream = nullptr;  // load-path stream
   std::shared_mutex mu;   // readers = running plans (a snapshot), writers = extend / remove / clear
   std::atomic<u64> version{0};   // bumped by every extend / remove / clear: cached scan ranges of plans are keyed on it
+  // slice join tables: looked up under slice_mu; a table is built (and its stream synchronised) with slice_build_mu
+  // held, so concurrent plans never see a half-built one.  Dropped by every mutation (which holds `mu` exclusively).
+  std::mutex slice_mu, slice_build_mu;
+  std::map<SliceKey, SliceTable> slice_tables;
+  SliceTable* slice_table(const SliceKey& k);
+  const SliceTable* find_slice_table(const SliceKey& k);
+  void drop_slice_tables();
   std::mutex ctx_mu;
   std::vector<ExecContext*> free_ctx;
   ExecContext* acquire_context(u32 n_sources);
