@@ -165,6 +165,16 @@ int rdfgpu_store_set_typed_values(rdfgpu_store* store, const rdfgpu_typed_value*
                                   uint64_t n_ids, const int64_t* decimals, uint64_t n_decimals);
 
 /*
+ * Installs the lexical forms of the string-valued object ids in HBM (the part of the reference's
+ * MemObjectIdMapping dictionary that string builtins read: object_id_mapping.rs:48-59, 262-276).
+ * The UTF-8 lexical form of object id i is heap[offsets[i] .. offsets[i + 1]); offsets has
+ * n_ids + 1 entries; only ids whose typed value has tag RDFGPU_TV_STRING are ever read.
+ * Needed by RDFGPU_EX_REGEX; a plan using it on a store without strings fails to compile.
+ */
+int rdfgpu_store_set_strings(rdfgpu_store* store, const uint64_t* offsets, uint64_t n_ids,
+                             const uint8_t* heap, uint64_t heap_bytes);
+
+/*
  * Test / debug access to a sorted permutation (MemIndexData, quad_index_data.rs:57-64):
  * copies up to `cap` rows of index `components` (RDFGPU_GSPO..) into four host columns,
  * in index order (e.g. g,p,o,s for GPOS).  `*n` receives the index length.
@@ -224,6 +234,11 @@ enum {
   RDFGPU_EX_BOOL_AS_TV = 20,  /* BOOL -> TV   BOOLEAN_AS_TERM (expr_builder.rs:694-698)                        */
   RDFGPU_EX_LIT_BOOL = 21,    /* -> BOOL      literal true (u=1) / false (u=0) / null (u=2)                    */
   RDFGPU_EX_NEQ = 22,         /* TV TV -> TV  NOT(EQ) kept as one op for convenience                            */
+  RDFGPU_EX_REGEX = 23,       /* TV -> TV(boolean|null)  REGEX(value, <constant pattern>[, <constant flags>]),
+                                 scalar/strings/regex.rs:47-141; `u` indexes rdfgpu_plan_desc.regexes.  The value
+                                 must come from ENC_TV of a column; simple / language strings match, anything else is
+                                 the error value.  Patterns that are not plan constants (regex_variable.rq) and
+                                 syntax outside csrc/regex_compile.hpp's subset are RDFGPU_ERR_UNSUPPORTED.        */
   RDFGPU_EX__COUNT
 };
 
@@ -270,6 +285,13 @@ typedef struct rdfgpu_plan_node {
   uint32_t table_cols;                    /* TABLE: number of columns                     */
 } rdfgpu_plan_node;
 
+typedef struct rdfgpu_regex {             /* one constant REGEX pattern of the plan (UTF-8, not NUL-terminated) */
+  const char* pattern;
+  const char* flags;                      /* SPARQL flags: any of s m i x q (regex.rs:107-141); may be NULL    */
+  uint32_t pattern_len;
+  uint32_t flags_len;
+} rdfgpu_regex;
+
 typedef struct rdfgpu_plan_desc {
   const rdfgpu_plan_node* nodes;
   uint32_t n_nodes;
@@ -279,6 +301,9 @@ typedef struct rdfgpu_plan_desc {
   const uint32_t* pool;                   /* IN-set ids and projection lists              */
   uint32_t n_pool;
   uint32_t flags;                         /* RDFGPU_PLAN_*                                */
+  const rdfgpu_regex* regexes;            /* patterns referenced by RDFGPU_EX_REGEX nodes */
+  uint32_t n_regexes;
+  uint32_t reserved;
 } rdfgpu_plan_desc;
 #define RDFGPU_PLAN_ALLOW_OPAQUE 1u
 
@@ -386,6 +411,14 @@ int rdfgpu_predicate_and(const rdfgpu_predicate* lhs, const rdfgpu_predicate* rh
  */
 enum { RDFGPU_OP_EQ = 0, RDFGPU_OP_GT = 1, RDFGPU_OP_GTEQ = 2, RDFGPU_OP_LT = 3, RDFGPU_OP_LTEQ = 4 };
 int rdfgpu_pushdown_to_scan_predicate(uint32_t op, uint32_t value, rdfgpu_predicate* out);
+
+/*
+ * compile_pattern (scalar/strings/regex.rs:107-141) for the device: checks that a REGEX pattern / flags pair is inside
+ * the supported subset (csrc/regex_compile.hpp) without touching a device.  Returns RDFGPU_OK and the number of
+ * automaton positions in *positions (0 for a pattern that can only yield the error value: an invalid flag), or
+ * RDFGPU_ERR_UNSUPPORTED with the reason in rdfgpu_last_error() — exactly what rdfgpu_plan_compile would answer.
+ */
+int rdfgpu_regex_check(const char* pattern, uint32_t pattern_len, const char* flags, uint32_t flags_len, uint32_t* positions);
 
 #ifdef __cplusplus
 }

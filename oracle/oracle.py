@@ -59,6 +59,9 @@ def lib():
         l.orc_store_adopt_sorted.argtypes = [vp, C.c_uint32, vp, vp, vp, vp, C.c_uint64]
         l.orc_store_read_index.argtypes = [vp, C.c_uint32, vp, vp, vp, vp, C.c_uint64, u64p]
         l.orc_store_set_typed_values.argtypes = [vp, vp, C.c_uint64, vp, C.c_uint64]
+        l.orc_store_set_strings.argtypes = [vp, vp, C.c_uint64, vp, C.c_uint64]
+        l.orc_regex_is_match.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]
+        l.orc_regex_is_match.restype = C.c_int
         l.orc_store_set_faithful_decode.argtypes = [vp, C.c_int]
         l.orc_scan_score.restype = C.c_uint64
         l.orc_scan_score.argtypes = [C.POINTER(abi.ScanInstruction)]
@@ -90,6 +93,13 @@ def _err():
 def _u32(a):
     a = np.ascontiguousarray(a, dtype=np.uint32)
     return a, a.ctypes.data_as(C.c_void_p)
+
+
+def regex_is_match(pattern, flags, subject):
+    """REGEX restatement (regex_oracle.c): True / False, or None for the error value."""
+    p, f, s = (x.encode("utf-8") if isinstance(x, str) else bytes(x) for x in (pattern, flags, subject))
+    r = lib().orc_regex_is_match(p, len(p), f, len(f), s, len(s))
+    return None if r < 0 else bool(r)
 
 
 def find_range_between(values, lo, hi):
@@ -161,6 +171,12 @@ class OracleStore:
         self._l.orc_store_read_index(self._h, components, *[c.ctypes.data_as(C.c_void_p) for c in cols],
                                      n.value, C.byref(n))
         return cols
+
+    def set_strings(self, offsets, heap):
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        heap = np.frombuffer(bytes(heap), dtype=np.uint8) if not isinstance(heap, np.ndarray) else np.ascontiguousarray(heap, dtype=np.uint8)
+        self._l.orc_store_set_strings(self._h, offsets.ctypes.data_as(C.c_void_p), len(offsets) - 1,
+                                      heap.ctypes.data_as(C.c_void_p), len(heap))
 
     def set_typed_values(self, values, decimals=None):
         values = np.ascontiguousarray(values)

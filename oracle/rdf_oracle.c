@@ -49,7 +49,11 @@ struct orc_store {
   i128* dec; u64 n_dec;
   int faithful_decode;
   u32* hm_keys; u32* hm_vals; u64 hm_cap; /* id -> id hash map for faithful decode */
+  u64* str_off; unsigned char* heap; u64 n_str_ids; /* lexical forms of string ids (object_id_mapping.rs:48-59) */
 };
+
+/* REGEX patterns of the plan being executed (rdfgpu_plan_desc.regexes) */
+static __thread const rdfgpu_regex* g_regexes; static __thread u32 g_n_regexes;
 
 orc_store* orc_store_new(u32 batch_size) {
   orc_store* s = (orc_store*)calloc(1, sizeof *s);
@@ -164,6 +168,15 @@ void orc_store_set_typed_values(orc_store* s, const rdfgpu_typed_value* values, 
     while (s->hm_keys[h] != 0xffffffffu) h = (h + 1) & (cap - 1);
     s->hm_keys[h] = (u32)id; s->hm_vals[h] = (u32)id;
   }
+}
+
+void orc_store_set_strings(orc_store* s, const u64* offsets, u64 n_ids, const unsigned char* heap, u64 heap_bytes) {
+  free(s->str_off); free(s->heap);
+  s->str_off = (u64*)malloc((n_ids + 1) * sizeof(u64));
+  memcpy(s->str_off, offsets, (n_ids + 1) * sizeof(u64));
+  s->heap = (unsigned char*)malloc(heap_bytes ? heap_bytes : 1);
+  memcpy(s->heap, heap, heap_bytes);
+  s->n_str_ids = n_ids;
 }
 
 /* ------------------------------------------------------------------------------------ */
@@ -474,7 +487,7 @@ static val enc_tv(const orc_store* s, u32 id) {
     slot = s->hm_vals[h];
   }
   const rdfgpu_typed_value* t = &s->tv[slot];
-  v.tag = t->tag; v.flags = t->flags; v.aux = t->aux; v.lo = t->lo;
+  v.tag = t->tag; v.flags = t->flags; v.aux = t->aux; v.lo = t->lo; v.id = id;
   if (t->tag == RDFGPU_TV_DECIMAL) { if ((u64)t->lo >= s->n_dec) return tv_null(); v.dec = s->dec[t->lo]; }
   return v;
 }
@@ -621,6 +634,17 @@ static int eval_prog(const orc_store* s, const rdfgpu_expr_node* p, u32 n, const
       case RDFGPU_EX_ADD: case RDFGPU_EX_SUB: {
         if (sp < 2 || st[sp - 1].kind != 1 || st[sp - 2].kind != 1) FAIL("arithmetic needs two typed values");
         val b = st[--sp], a = st[--sp]; v = tv_arith(&a, &b, e->op == RDFGPU_EX_SUB); break; }
+      case RDFGPU_EX_REGEX: {   /* regex.rs:47-141: simple / language strings are searched, anything else is an error */
+        if (sp < 1 || st[sp - 1].kind != 1) FAIL("REGEX needs a typed value");
+        if (e->u >= g_n_regexes) FAIL("REGEX pattern %u out of range", e->u);
+        val a = st[--sp];
+        v = tv_null();
+        if (a.tag != RDFGPU_TV_STRING || a.id == 0 || a.id >= s->n_str_ids) break;
+        const rdfgpu_regex* rx = &g_regexes[e->u];
+        int m = orc_regex_is_match(rx->pattern, rx->pattern_len, rx->flags ? rx->flags : "", rx->flags ? rx->flags_len : 0,
+                                   s->heap + s->str_off[a.id], (size_t)(s->str_off[a.id + 1] - s->str_off[a.id]));
+        if (m >= 0) v = tv_bool(m);
+        break; }
       case RDFGPU_EX_EBV: if (sp < 1 || st[sp - 1].kind != 1) FAIL("EBV needs a typed value"); { val a = st[--sp]; v.kind = 2; v.b = tv_ebv(&a); } break;
       case RDFGPU_EX_ID_EQ: case RDFGPU_EX_ID_NEQ: {
         if (sp < 2 || st[sp - 1].kind != 0 || st[sp - 2].kind != 0) FAIL("id comparison needs two ids");
@@ -827,6 +851,7 @@ static int exec_node(const pctx* c, u32 idx, orc_table* out) {
 int orc_plan_execute(const orc_store* s, const rdfgpu_plan_desc* desc, const orc_bound_table* tables, u32 n_tables, orc_table* out, rdfgpu_metrics* metrics) {
   if (metrics) memset(metrics, 0, sizeof *metrics);
   pctx c = {s, desc, tables, n_tables, metrics};
+  g_regexes = desc->regexes; g_n_regexes = desc->n_regexes;
   if (exec_node(&c, desc->root, out)) return -1;
   if (metrics) metrics->output_rows = out->n_rows;
   return 0;

@@ -43,6 +43,10 @@ int orc_store_adopt_sorted(orc_store* s, uint32_t components, const uint32_t* c0
                            const uint32_t* c2, const uint32_t* c3, uint64_t n);
 int orc_store_read_index(const orc_store* s, uint32_t components, uint32_t* c0, uint32_t* c1,
                          uint32_t* c2, uint32_t* c3, uint64_t cap, uint64_t* n);
+/* lexical forms of string ids: heap[offsets[i] .. offsets[i+1]) (rdfgpu_store_set_strings) */
+void orc_store_set_strings(orc_store* s, const uint64_t* offsets, uint64_t n_ids, const unsigned char* heap, uint64_t heap_bytes);
+/* SPARQL REGEX (regex.rs:47-141), regex_oracle.c: 1 match / 0 no match / -1 error value */
+int orc_regex_is_match(const char* pattern, size_t pattern_len, const char* flags, size_t flags_len, const unsigned char* subject, size_t subject_len);
 void orc_store_set_typed_values(orc_store* s, const rdfgpu_typed_value* values, uint64_t n_ids,
                                 const int64_t* decimals, uint64_t n_decimals);
 /* 0 = array lookup for ENC_TV (default), 1 = hash-map lookup per row like the reference's DashMap */

@@ -1,0 +1,373 @@
+/* regex_oracle.c — CPU restatement of SPARQL REGEX for the ORACLE (test infrastructure only; nothing under
+ * rdf-fusion_amd/ links or calls this).
+ *
+ * Follows lib/functions/src/scalar/strings/regex.rs:47-141: `compile_pattern` (flags s m i x q; `q` escapes the
+ * pattern; an unknown flag or an invalid pattern is the error value) and `Regex::is_match` = unanchored search.
+ * The `regex` crate itself (1.12.2, Cargo.lock:3834-3835) is a third-party dependency absent from /root/reference;
+ * this restates its documented syntax for the subset the device supports and a little more (anchors anywhere):
+ *   literals, `.`, `[...]`, `( )`, `(?: )`, `(?P<n> )`, `|`, `* + ? {m} {m,} {m,n}` (+ lazy suffix), `^ $ \A \z`,
+ *   escaped punctuation, `\n \r \t \f \v \a \xHH`.
+ * Deliberately a DIFFERENT algorithm from the device's bit-parallel Glushkov automaton over bytes: a Thompson
+ * program (char / split / jmp / assert / match) run by a Pike VM over decoded CODE POINTS, so UTF-8 expansion,
+ * follow-set or anchoring mistakes on the device side do not cancel out.  tests/ cross-check both against Python's
+ * `re` as a third opinion.
+ * Returns: 1 match, 0 no match, -1 = the error value (bad flag / unsupported or invalid pattern).
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+enum { I_CHAR, I_SPLIT, I_JMP, I_MATCH, I_BOL, I_EOL, I_BOT, I_EOT };
+typedef struct {
+  int op;
+  int x, y;            /* SPLIT: both targets; JMP: x */
+  uint64_t ascii[2];   /* CHAR: members among U+0000..U+007F */
+  uint32_t extra[2];   /* CHAR: up to two non-ASCII members (case folds) */
+  int n_extra;
+  int neg;             /* CHAR: negated set */
+  int any_non_ascii;   /* CHAR: (non-negated) also every code point >= 0x80 */
+} inst;
+
+typedef struct {
+  const unsigned char* p; size_t n, i;
+  int f_i, f_s, f_m, f_x;
+  inst* prog; int n_inst, cap;
+  int bad;
+} rx;
+
+static int emit(rx* r, int op) {
+  if (r->n_inst == r->cap) { r->cap = r->cap ? 2 * r->cap : 64; r->prog = (inst*)realloc(r->prog, (size_t)r->cap * sizeof(inst)); }
+  memset(&r->prog[r->n_inst], 0, sizeof(inst));
+  r->prog[r->n_inst].op = op;
+  return r->n_inst++;
+}
+static void set_add(inst* c, unsigned ch) { c->ascii[ch >> 6] |= 1ull << (ch & 63); }
+static int set_has(const inst* c, unsigned ch) { return (int)((c->ascii[ch >> 6] >> (ch & 63)) & 1); }
+static void fold(rx* r, inst* c) {   /* `i`: simple case folding of ASCII letters + the two non-ASCII partners */
+  if (!r->f_i) return;
+  for (unsigned ch = 'a'; ch <= 'z'; ch++) if (set_has(c, ch) || set_has(c, ch - 32)) { set_add(c, ch); set_add(c, ch - 32); }
+  if (set_has(c, 'k')) c->extra[c->n_extra++] = 0x212A;   /* KELVIN SIGN */
+  if (set_has(c, 's')) c->extra[c->n_extra++] = 0x017F;   /* LATIN SMALL LETTER LONG S */
+}
+static void skip_x(rx* r) {
+  if (!r->f_x) return;
+  for (;;) {
+    while (r->i < r->n && strchr(" \t\n\r\f\v", r->p[r->i])) r->i++;
+    if (r->i < r->n && r->p[r->i] == '#') { while (r->i < r->n && r->p[r->i] != '\n') r->i++; continue; }
+    break;
+  }
+}
+static int decode(const unsigned char* s, size_t n, size_t* i, uint32_t* cp) {
+  unsigned c = s[*i];
+  int len = c < 0x80 ? 1 : (c >> 5) == 6 ? 2 : (c >> 4) == 14 ? 3 : (c >> 3) == 30 ? 4 : 0;
+  if (!len || *i + (size_t)len > n) return -1;
+  uint32_t v = len == 1 ? c : len == 2 ? (c & 0x1F) : len == 3 ? (c & 0x0F) : (c & 0x07);
+  for (int k = 1; k < len; k++) { if ((s[*i + k] & 0xC0) != 0x80) return -1; v = (v << 6) | (s[*i + k] & 0x3F); }
+  *i += (size_t)len; *cp = v;
+  return 0;
+}
+static int escape(rx* r, unsigned* out) {   /* after '\\' */
+  if (r->i >= r->n) return -1;
+  unsigned e = r->p[r->i++];
+  switch (e) {
+    case 'n': *out = '\n'; return 0; case 'r': *out = '\r'; return 0; case 't': *out = '\t'; return 0;
+    case 'f': *out = '\f'; return 0; case 'v': *out = '\v'; return 0; case 'a': *out = 7; return 0;
+    case 'x': {
+      if (r->i + 2 > r->n) return -1;
+      unsigned v = 0;
+      for (int k = 0; k < 2; k++) {
+        unsigned h = r->p[r->i++];
+        int d = h >= '0' && h <= '9' ? (int)(h - '0') : h >= 'a' && h <= 'f' ? (int)(h - 'a' + 10) : h >= 'A' && h <= 'F' ? (int)(h - 'A' + 10) : -1;
+        if (d < 0) return -1;
+        v = v * 16 + (unsigned)d;
+      }
+      if (v >= 0x80) return -1;
+      *out = v; return 0;
+    }
+    default:
+      /* regex-syntax is_escapeable_character: any ASCII character that is not a letter, a digit, '<' or '>' */
+      if (e < 0x80 && e != '<' && e != '>' && !(e >= '0' && e <= '9') && !((e | 32) >= 'a' && (e | 32) <= 'z')) { *out = e; return 0; }
+      return -1;   /* \d \w \s \b \p{..}: not restated */
+  }
+}
+
+/* Fragments: the parser emits code for a sub-expression into [start, n_inst) and every fragment falls through at its
+ * end, so concatenation is emission order; repetition and alternation copy / patch with relative fix-ups. */
+static int parse_alt(rx* r);
+
+static void shift_targets(rx* r, int from, int by, int lo) {   /* instructions moved up by `by`: fix absolute targets >= lo */
+  for (int k = from; k < r->n_inst; k++) {
+    inst* in = &r->prog[k];
+    if (in->op == I_SPLIT) { if (in->x >= lo) in->x += by; if (in->y >= lo) in->y += by; }
+    else if (in->op == I_JMP) { if (in->x >= lo) in->x += by; }
+  }
+}
+static void insert_at(rx* r, int at, int op) {   /* open a slot at `at` */
+  emit(r, op);
+  memmove(&r->prog[at + 1], &r->prog[at], (size_t)(r->n_inst - 1 - at) * sizeof(inst));
+  memset(&r->prog[at], 0, sizeof(inst));
+  r->prog[at].op = op;
+  shift_targets(r, at + 1, 1, at);
+}
+static void copy_frag(rx* r, int start, int end) {   /* append a copy of [start, end) */
+  const int delta = r->n_inst - start;
+  for (int k = start; k < end; k++) {
+    int id = emit(r, 0);
+    r->prog[id] = r->prog[k];
+    inst* in = &r->prog[id];
+    if (in->op == I_SPLIT) { in->x += delta; in->y += delta; }
+    else if (in->op == I_JMP) in->x += delta;
+  }
+}
+
+static int parse_class(rx* r) {
+  int id = emit(r, I_CHAR);
+  inst c = r->prog[id];
+  if (r->i < r->n && r->p[r->i] == '^') { c.neg = 1; r->i++; }
+  int first = 1;
+  for (;;) {
+    if (r->i >= r->n) return -1;
+    unsigned ch = r->p[r->i];
+    if (ch == ']' && !first) { r->i++; break; }
+    first = 0;
+    if (ch == '[' || ch >= 0x80) return -1;
+    if ((ch == '&' || ch == '~') && r->i + 1 < r->n && r->p[r->i + 1] == ch) return -1;
+    r->i++;
+    if (ch == '\\' && escape(r, &ch)) return -1;
+    unsigned hi = ch;
+    if (r->i + 1 < r->n && r->p[r->i] == '-' && r->p[r->i + 1] != ']') {
+      if (r->p[r->i + 1] == '-') return -1;
+      r->i++;
+      hi = r->p[r->i++];
+      if (hi >= 0x80 || hi == '[') return -1;
+      if (hi == '\\' && escape(r, &hi)) return -1;
+      if (hi < ch) return -1;
+    }
+    for (unsigned k = ch; k <= hi; k++) set_add(&c, k);
+  }
+  fold(r, &c);
+  r->prog[id] = c;
+  return 0;
+}
+
+static int parse_atom(rx* r) {
+  unsigned ch = r->p[r->i];
+  if (ch == '(') {
+    r->i++;
+    if (r->i < r->n && r->p[r->i] == '?') {
+      if (r->i + 1 < r->n && r->p[r->i + 1] == ':') r->i += 2;
+      else if (r->i + 1 < r->n && (r->p[r->i + 1] == 'P' || r->p[r->i + 1] == '<')) {
+        r->i += r->p[r->i + 1] == 'P' ? 2 : 1;
+        if (r->i >= r->n || r->p[r->i] != '<') return -1;
+        while (r->i < r->n && r->p[r->i] != '>') r->i++;
+        if (r->i >= r->n) return -1;
+        r->i++;
+      } else return -1;
+    }
+    if (parse_alt(r)) return -1;
+    if (r->i >= r->n || r->p[r->i] != ')') return -1;
+    r->i++;
+    return 0;
+  }
+  if (ch == '[') { r->i++; return parse_class(r); }
+  if (ch == '.') {
+    r->i++;
+    int id = emit(r, I_CHAR);
+    inst* c = &r->prog[id];
+    c->neg = 1;                         /* everything ... */
+    if (!r->f_s) set_add(c, '\n');      /* ... except a line feed */
+    return 0;
+  }
+  if (ch == '^') { r->i++; emit(r, r->f_m ? I_BOL : I_BOT); return 0; }
+  if (ch == '$') { r->i++; emit(r, r->f_m ? I_EOL : I_EOT); return 0; }
+  if (ch == '\\') {
+    r->i++;
+    if (r->i < r->n && r->p[r->i] == 'A') { r->i++; emit(r, I_BOT); return 0; }
+    if (r->i < r->n && r->p[r->i] == 'z') { r->i++; emit(r, I_EOT); return 0; }
+    unsigned b;
+    if (escape(r, &b)) return -1;
+    int id = emit(r, I_CHAR);
+    set_add(&r->prog[id], b);
+    fold(r, &r->prog[id]);
+    return 0;
+  }
+  if (ch == '*' || ch == '+' || ch == '?' || ch == '{' || ch == ')' || ch == '|') return -1;
+  uint32_t cp;
+  if (decode(r->p, r->n, &r->i, &cp)) return -1;
+  int id = emit(r, I_CHAR);
+  if (cp < 0x80) { set_add(&r->prog[id], cp); fold(r, &r->prog[id]); }
+  else { if (r->f_i) return -1; r->prog[id].extra[0] = cp; r->prog[id].n_extra = 1; }
+  return 0;
+}
+
+static int is_assert(const rx* r, int start) { return r->n_inst == start + 1 && r->prog[start].op >= I_BOL; }
+
+static void wrap_star(rx* r, int start) {   /* L1: split L2, L3; L2: e; jmp L1; L3: */
+  insert_at(r, start, I_SPLIT);
+  int j = emit(r, I_JMP);
+  r->prog[j].x = start;
+  r->prog[start].x = start + 1; r->prog[start].y = r->n_inst;
+}
+static void wrap_opt(rx* r, int start) {    /* split L1, L2; L1: e; L2: */
+  insert_at(r, start, I_SPLIT);
+  r->prog[start].x = start + 1; r->prog[start].y = r->n_inst;
+}
+static int parse_uint(rx* r, unsigned* v) {
+  if (r->i >= r->n || r->p[r->i] < '0' || r->p[r->i] > '9') return -1;
+  *v = 0;
+  while (r->i < r->n && r->p[r->i] >= '0' && r->p[r->i] <= '9') { *v = *v * 10 + (r->p[r->i] - '0'); if (*v > 1000) return -2; r->i++; }
+  return 0;
+}
+static int parse_repeat(rx* r) {
+  int start = r->n_inst;
+  if (parse_atom(r)) return -1;
+  for (;;) {
+    skip_x(r);
+    if (r->i >= r->n) break;
+    unsigned ch = r->p[r->i];
+    if (ch != '*' && ch != '+' && ch != '?' && ch != '{') break;
+    if (is_assert(r, start)) return -1;
+    if (ch == '{') {
+      r->i++;
+      unsigned lo = 0, hi = 0; int open = 0;
+      if (parse_uint(r, &lo)) return -1;
+      if (r->i < r->n && r->p[r->i] == ',') { r->i++; int e = parse_uint(r, &hi); if (e == -2) return -1; if (e) open = 1; }
+      else hi = lo;
+      if (r->i >= r->n || r->p[r->i] != '}') return -1;
+      r->i++;
+      if (!open && hi < lo) return -1;
+      if (lo + (open ? 1 : hi - lo) > 64) return -1;
+      /* e{lo,hi} = e x lo, then (e)? x (hi - lo)   |   e{lo,} = e x lo, then e* */
+      const int end = r->n_inst, len = end - start;
+      inst* body = (inst*)malloc((size_t)(len ? len : 1) * sizeof(inst));
+      memcpy(body, &r->prog[start], (size_t)len * sizeof(inst));
+      r->n_inst = start;                                 /* re-emit from scratch */
+      const unsigned copies = lo + (open ? 1 : hi - lo);
+      for (unsigned k = 0; k < copies; k++) {
+        const int at = r->n_inst;
+        for (int q = 0; q < len; q++) {
+          int id = emit(r, 0);
+          r->prog[id] = body[q];
+          inst* in = &r->prog[id];
+          if (in->op == I_SPLIT) { in->x += at - start; in->y += at - start; }
+          else if (in->op == I_JMP) in->x += at - start;
+        }
+        if (k >= lo) { if (open) wrap_star(r, at); else wrap_opt(r, at); }
+      }
+      free(body);
+    } else {
+      r->i++;
+      if (ch == '*') wrap_star(r, start);
+      else if (ch == '?') wrap_opt(r, start);
+      else {   /* e+ = e e* */
+        const int end = r->n_inst;
+        copy_frag(r, start, end);
+        wrap_star(r, end);
+      }
+    }
+    if (r->i < r->n && r->p[r->i] == '?') r->i++;   /* lazy: same language */
+  }
+  return 0;
+}
+static int parse_cat(rx* r) {
+  for (;;) {
+    skip_x(r);
+    if (r->i >= r->n || r->p[r->i] == '|' || r->p[r->i] == ')') return 0;
+    if (parse_repeat(r)) return -1;
+  }
+}
+static int parse_alt(rx* r) {   /* split L1, L2; L1: a; jmp END; L2: b ... */
+  int start = r->n_inst;
+  if (parse_cat(r)) return -1;
+  int jumps[256], n_j = 0;
+  skip_x(r);
+  while (r->i < r->n && r->p[r->i] == '|') {
+    r->i++;
+    insert_at(r, start, I_SPLIT);
+    for (int k = 0; k < n_j; k++) if (jumps[k] >= start) jumps[k]++;   /* jmp slots behind the insertion moved up by one */
+    if (n_j == 255) return -1;
+    jumps[n_j++] = emit(r, I_JMP);
+    r->prog[start].x = start + 1; r->prog[start].y = r->n_inst;
+    start = r->n_inst;
+    if (parse_cat(r)) return -1;
+    skip_x(r);
+  }
+  for (int k = 0; k < n_j; k++) r->prog[jumps[k]].x = r->n_inst;
+  return 0;
+}
+
+/* ---- Pike VM over code points ---- */
+typedef struct { int* pc; int n; } tlist;
+static void add_thread(const rx* r, tlist* l, int* mark, int gen, int pc, const uint32_t* s, size_t i, size_t len) {
+  if (mark[pc] == gen) return;
+  mark[pc] = gen;
+  const inst* in = &r->prog[pc];
+  switch (in->op) {
+    case I_JMP: add_thread(r, l, mark, gen, in->x, s, i, len); break;
+    case I_SPLIT: add_thread(r, l, mark, gen, in->x, s, i, len); add_thread(r, l, mark, gen, in->y, s, i, len); break;
+    case I_BOT: if (i == 0) add_thread(r, l, mark, gen, pc + 1, s, i, len); break;
+    case I_EOT: if (i == len) add_thread(r, l, mark, gen, pc + 1, s, i, len); break;
+    case I_BOL: if (i == 0 || s[i - 1] == '\n') add_thread(r, l, mark, gen, pc + 1, s, i, len); break;
+    case I_EOL: if (i == len || s[i] == '\n') add_thread(r, l, mark, gen, pc + 1, s, i, len); break;
+    default: l->pc[l->n++] = pc;
+  }
+}
+static int char_ok(const inst* in, uint32_t cp) {
+  int member = 0;
+  if (cp < 0x80) member = set_has(in, cp);
+  else { for (int k = 0; k < in->n_extra; k++) member = member || in->extra[k] == cp; if (in->any_non_ascii) member = 1; }
+  return in->neg ? !member : member;
+}
+
+int orc_regex_is_match(const char* pattern, size_t pattern_len, const char* flags, size_t flags_len, const unsigned char* subject, size_t subject_len) {
+  rx r; memset(&r, 0, sizeof r);
+  int q = 0;
+  for (size_t k = 0; k < flags_len; k++) {
+    switch (flags[k]) {
+      case 's': r.f_s = 1; break; case 'm': r.f_m = 1; break; case 'i': r.f_i = 1; break; case 'x': r.f_x = 1; break; case 'q': q = 1; break;
+      default: return -1;   /* regex.rs:137 */
+    }
+  }
+  r.p = (const unsigned char*)pattern; r.n = pattern_len;
+  int bad = 0;
+  if (q) {   /* regex::escape: every character stands for itself */
+    if (r.f_x) bad = 1;   /* `x` would still strip the whitespace that escape() leaves alone: outside the restated subset */
+    while (!bad && r.i < r.n) {
+      uint32_t cp;
+      if (decode(r.p, r.n, &r.i, &cp)) { bad = 1; break; }
+      int id = emit(&r, I_CHAR);
+      if (cp < 0x80) { set_add(&r.prog[id], cp); fold(&r, &r.prog[id]); }
+      else { if (r.f_i) { bad = 1; break; } r.prog[id].extra[0] = cp; r.prog[id].n_extra = 1; }
+    }
+  } else {
+    if (parse_alt(&r) || r.i != r.n) bad = 1;
+  }
+  if (bad) { free(r.prog); return -1; }
+  emit(&r, I_MATCH);
+
+  uint32_t* cps = (uint32_t*)malloc((subject_len + 1) * sizeof(uint32_t));
+  size_t len = 0, at = 0;
+  while (at < subject_len) { if (decode(subject, subject_len, &at, &cps[len])) { free(cps); free(r.prog); return -1; } len++; }
+
+  /* raw = successor pcs of the previous character; clist = their epsilon closure at this position */
+  int* raw = (int*)malloc((size_t)r.n_inst * sizeof(int)); int n_raw = 0;
+  int* next_raw = (int*)malloc((size_t)r.n_inst * sizeof(int));
+  tlist clist = {(int*)malloc((size_t)r.n_inst * sizeof(int)), 0};
+  int* mark = (int*)calloc((size_t)r.n_inst, sizeof(int));
+  int gen = 0, matched = 0;
+  for (size_t i = 0; i <= len && !matched; i++) {
+    gen++;
+    clist.n = 0;
+    for (int k = 0; k < n_raw; k++) add_thread(&r, &clist, mark, gen, raw[k], cps, i, len);
+    add_thread(&r, &clist, mark, gen, 0, cps, i, len);   /* unanchored search: a match may start here */
+    int n_next = 0;
+    for (int k = 0; k < clist.n; k++) {
+      const inst* in = &r.prog[clist.pc[k]];
+      if (in->op == I_MATCH) { matched = 1; break; }
+      if (i < len && char_ok(in, cps[i])) next_raw[n_next++] = clist.pc[k] + 1;
+    }
+    int* t = raw; raw = next_raw; next_raw = t; n_raw = n_next;
+  }
+  free(raw); free(next_raw); free(clist.pc); free(mark); free(cps); free(r.prog);
+  return matched;
+}

@@ -27,7 +27,7 @@ TVF_EMPTY_STRING = 1
 # expression ops
 (EX_COLUMN, EX_LIT_ID, EX_LIT_TV, EX_ENC_TV, EX_GT, EX_LT, EX_GEQ, EX_LEQ, EX_EQ, EX_ADD, EX_SUB,
  EX_EBV, EX_ID_EQ, EX_ID_NEQ, EX_AND, EX_OR, EX_NOT, EX_IS_COMPATIBLE, EX_BOUND, EX_BOOL_AS_TV,
- EX_LIT_BOOL, EX_NEQ) = range(1, 23)
+ EX_LIT_BOOL, EX_NEQ, EX_REGEX) = range(1, 24)
 
 # plan nodes
 (NODE_DATA_SOURCE, NODE_FILTER, NODE_HASH_JOIN, NODE_CROSS_JOIN, NODE_NESTED_LOOP_JOIN,
@@ -68,10 +68,15 @@ class PlanNode(C.Structure):
                 ("n_proj", C.c_uint32), ("table_slot", C.c_uint32), ("table_cols", C.c_uint32)]
 
 
+class Regex(C.Structure):
+    _fields_ = [("pattern", C.c_char_p), ("flags", C.c_char_p), ("pattern_len", C.c_uint32), ("flags_len", C.c_uint32)]
+
+
 class PlanDesc(C.Structure):
     _fields_ = [("nodes", C.POINTER(PlanNode)), ("n_nodes", C.c_uint32), ("root", C.c_uint32),
                 ("exprs", C.POINTER(ExprNode)), ("n_exprs", C.c_uint32),
-                ("pool", C.POINTER(C.c_uint32)), ("n_pool", C.c_uint32), ("flags", C.c_uint32)]
+                ("pool", C.POINTER(C.c_uint32)), ("n_pool", C.c_uint32), ("flags", C.c_uint32),
+                ("regexes", C.POINTER(Regex)), ("n_regexes", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class Metrics(C.Structure):
@@ -119,12 +124,12 @@ assert C.sizeof(ExprNode) == 24
 EXPORTED_SYMBOLS = [
     "rdfgpu_last_error", "rdfgpu_abi_version",
     "rdfgpu_store_create", "rdfgpu_store_destroy", "rdfgpu_store_extend", "rdfgpu_store_extend_device",
-    "rdfgpu_store_remove", "rdfgpu_store_clear", "rdfgpu_store_len", "rdfgpu_store_set_typed_values",
+    "rdfgpu_store_remove", "rdfgpu_store_clear", "rdfgpu_store_len", "rdfgpu_store_set_typed_values", "rdfgpu_store_set_strings",
     "rdfgpu_store_read_index",
     "rdfgpu_plan_compile", "rdfgpu_plan_destroy", "rdfgpu_plan_bind_table", "rdfgpu_plan_execute",
     "rdfgpu_plan_result_info", "rdfgpu_plan_result_device", "rdfgpu_plan_fetch", "rdfgpu_plan_next",
     "rdfgpu_plan_rewind", "rdfgpu_plan_metrics", "rdfgpu_plan_selected_index", "rdfgpu_plan_stream",
     "rdfgpu_plan_enable_kernel_timing", "rdfgpu_plan_kernel_stats",
     "rdfgpu_scan_score", "rdfgpu_choose_index", "rdfgpu_predicate_and",
-    "rdfgpu_pushdown_to_scan_predicate",
+    "rdfgpu_pushdown_to_scan_predicate", "rdfgpu_regex_check",
 ]

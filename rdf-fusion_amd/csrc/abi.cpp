@@ -5,6 +5,7 @@
 
 #include "host_logic.hpp"
 #include "plan.hpp"
+#include "regex_compile.hpp"
 #include "store.hpp"
 
 namespace rdfgpu {
@@ -68,6 +69,13 @@ int rdfgpu_store_len(const rdfgpu_store* store, uint64_t* out) {
   *out = S(store)->idx[0].n;
   ABI_END
 }
+int rdfgpu_store_set_strings(rdfgpu_store* store, const uint64_t* offsets, uint64_t n_ids, const uint8_t* heap, uint64_t heap_bytes) {
+  ABI_BEGIN
+  if (!store) fail(RDFGPU_ERR_INVALID, "null store");
+  S(store)->set_strings(offsets, n_ids, heap, heap_bytes);
+  ABI_END
+}
+
 int rdfgpu_store_set_typed_values(rdfgpu_store* store, const rdfgpu_typed_value* values, uint64_t n_ids, const int64_t* decimals, uint64_t n_decimals) {
   ABI_BEGIN
   if ((n_ids && !values) || (n_decimals && !decimals)) fail(RDFGPU_ERR_INVALID, "null typed-value table");
@@ -310,6 +318,16 @@ int rdfgpu_pushdown_to_scan_predicate(uint32_t op, uint32_t value, rdfgpu_predic
     out->pred = r.kind; out->from = r.from; out->to = r.to;
     if (r.kind == RDFGPU_PRED_IN) { out->from = out->to = r.ids[0]; out->n_ids = 1; }
     return 1;
+  } catch (const Error& e) { set_last_error(e.what()); return e.status; }
+}
+
+int rdfgpu_regex_check(const char* pattern, uint32_t pattern_len, const char* flags, uint32_t flags_len, uint32_t* positions) {
+  try {
+    RegexProg prog; std::string why;
+    if (regex_compile(pattern ? pattern : "", pattern_len, flags ? flags : "", flags ? flags_len : 0, prog, why) != REGEX_OK)
+      fail(RDFGPU_ERR_UNSUPPORTED, "REGEX pattern: %s", why.c_str());
+    if (positions) *positions = prog.n_pos;
+    return RDFGPU_OK;
   } catch (const Error& e) { set_last_error(e.what()); return e.status; }
 }
 

@@ -14,6 +14,7 @@
 #include <stdint.h>
 
 #include "../../include/rdfgpu.h"
+#include "regex_prog.hpp"
 
 namespace rdfgpu {
 
@@ -24,6 +25,7 @@ struct ExprProgram {
   uint32_t n;
   uint32_t pad;
   rdfgpu_expr_node nodes[kMaxExpr];
+  const RegexProg* regex;        // the plan's compiled REGEX patterns (device memory), indexed by REGEX nodes' `u`
 };
 
 struct TypedTable {
@@ -31,6 +33,9 @@ struct TypedTable {
   uint64_t n_ids;
   const int64_t* dec;            // (lo, hi) pairs of i128 decimals
   uint64_t n_dec;
+  const uint64_t* str_off;       // lexical form of string id i: heap[str_off[i] .. str_off[i + 1]) (null: not installed)
+  const uint8_t* heap;
+  uint64_t n_str_ids;
 };
 
 // Value kinds on the evaluation stack.
@@ -63,6 +68,7 @@ __device__ __forceinline__ Val enc_tv(const TypedTable& t, uint32_t id) {
   v.aux = (uint32_t)raw.z;
   v.tag = (uint8_t)((uint32_t)raw.w & 0xff);
   v.flags = (uint8_t)(((uint32_t)raw.w >> 8) & 0xff);
+  if (v.tag == RDFGPU_TV_STRING) v.hi = id;   // string builtins find the lexical form through the id
   if (v.tag == RDFGPU_TV_DECIMAL) {
     if ((uint64_t)v.lo >= t.n_dec) return val_tv_null();
     const int64_t* d = t.dec + 2 * v.lo;
@@ -217,6 +223,31 @@ __device__ __forceinline__ uint32_t tv_ebv(const Val& v) {
   }
 }
 
+// REGEX, scalar/strings/regex.rs:47-141: unanchored search (`Regex::is_match`) by simulating the pattern's position
+// automaton with ONE u64 of state per row: next = (U follow[s] for s in cur  |  first if a match may start here)
+// & byte_mask[byte].  Simple and language-tagged strings match; every other kind is the error value.
+__device__ __forceinline__ Val tv_regex(const RegexProg& p, const TypedTable& t, const Val& v) {
+  if (v.tag != RDFGPU_TV_STRING || p.always_error || t.str_off == nullptr) return val_tv_null();
+  const uint64_t id = (uint64_t)v.hi;
+  if (id == 0 || id >= t.n_str_ids) return val_tv_null();   // a string literal of the plan has no lexical form on the device
+  const uint64_t b0 = t.str_off[id], len = t.str_off[id + 1] - b0;
+  const uint8_t* s = t.heap + b0;
+  auto start_ok = [&](uint64_t i) { return !p.anchor_start || i == 0 || (p.ml_start && s[i - 1] == '\n'); };
+  auto end_ok = [&](uint64_t i) { return !p.anchor_end || i == len || (p.ml_end && s[i] == '\n'); };
+  if (p.nullable) {
+    if (!p.anchor_start && !p.anchor_end) return val_tv_bool(true);
+    for (uint64_t i = 0; i <= len; i++) if (start_ok(i) && end_ok(i)) return val_tv_bool(true);
+  }
+  uint64_t cur = 0;
+  for (uint64_t i = 0; i < len; i++) {
+    uint64_t nxt = start_ok(i) ? p.first : 0;
+    for (uint64_t c = cur; c; c &= c - 1) nxt |= p.follow[__builtin_ctzll(c)];
+    cur = nxt & p.byte_mask[s[i]];
+    if ((cur & p.last) && end_ok(i + 1)) return val_tv_bool(true);
+  }
+  return val_tv_bool(false);
+}
+
 // Evaluates `prog` for one row.  `col(c)` returns the u32 value of input column c.  The program was
 // type-checked on the host (plan compile), so the stack discipline is not re-checked here.
 // Returns the final value (BOOL for predicates).
@@ -242,6 +273,7 @@ __device__ __forceinline__ Val eval_program(const ExprProgram& prog, const Typed
         v = val_tv_bool(r); break; }
       case RDFGPU_EX_ADD: case RDFGPU_EX_SUB: { const Val b = st[--sp]; const Val a = st[--sp]; v = tv_arith(a, b, e.op == RDFGPU_EX_SUB); break; }
       case RDFGPU_EX_EBV: v = val_bool(tv_ebv(st[--sp])); break;
+      case RDFGPU_EX_REGEX: v = tv_regex(prog.regex[e.u], tt, st[--sp]); break;
       case RDFGPU_EX_ID_EQ: case RDFGPU_EX_ID_NEQ: {
         const uint32_t b = (uint32_t)st[--sp].lo, a = (uint32_t)st[--sp].lo;
         v = val_bool((a == 0 || b == 0) ? 2u : (uint32_t)((a == b) == (e.op == RDFGPU_EX_ID_EQ))); break; }

@@ -15,6 +15,8 @@
 #include <mutex>
 #include <shared_mutex>
 
+#include "regex_compile.hpp"
+
 namespace rdfgpu {
 
 // ------------------------------------------------------------------------------------------------
@@ -27,7 +29,7 @@ bool is_cmp(u8 op) {
 }
 
 // Type-checks a postfix program against `n_cols` input columns; returns the kind it leaves.
-u32 check_program(const rdfgpu_expr_node* p, u32 n, u32 n_cols) {
+u32 check_program(const rdfgpu_expr_node* p, u32 n, u32 n_cols, u32 n_regexes = 0) {
   if (n > (u32)kMaxExpr) fail(RDFGPU_ERR_UNSUPPORTED, "expression has %u nodes (max %d)", n, kMaxExpr);
   u32 st[kMaxStack]; int sp = 0;
   auto pop = [&](u32 kind, const char* what) {
@@ -46,6 +48,11 @@ u32 check_program(const rdfgpu_expr_node* p, u32 n, u32 n_cols) {
       case RDFGPU_EX_GT: case RDFGPU_EX_LT: case RDFGPU_EX_GEQ: case RDFGPU_EX_LEQ: case RDFGPU_EX_EQ: case RDFGPU_EX_NEQ:
       case RDFGPU_EX_ADD: case RDFGPU_EX_SUB: pop(VK_TV, "binary typed op"); pop(VK_TV, "binary typed op"); out = VK_TV; break;
       case RDFGPU_EX_EBV: pop(VK_TV, "EBV"); out = VK_BOOL; break;
+      case RDFGPU_EX_REGEX:
+        if (e.u >= n_regexes) fail(RDFGPU_ERR_INVALID, "expression: REGEX pattern %u out of range (%u patterns)", e.u, n_regexes);
+        // the lexical form lives in HBM under the value's object id: the operand has to be ENC_TV(column)
+        if (i < 2 || p[i - 1].op != RDFGPU_EX_ENC_TV || p[i - 2].op != RDFGPU_EX_COLUMN) fail(RDFGPU_ERR_UNSUPPORTED, "REGEX over anything but ENC_TV(column)");
+        pop(VK_TV, "REGEX"); out = VK_TV; break;
       case RDFGPU_EX_ID_EQ: case RDFGPU_EX_ID_NEQ: case RDFGPU_EX_IS_COMPATIBLE: pop(VK_ID, "id comparison"); pop(VK_ID, "id comparison"); out = VK_BOOL; break;
       case RDFGPU_EX_AND: case RDFGPU_EX_OR: pop(VK_BOOL, "AND/OR"); pop(VK_BOOL, "AND/OR"); out = VK_BOOL; break;
       case RDFGPU_EX_NOT: pop(VK_BOOL, "NOT"); out = VK_BOOL; break;
@@ -86,14 +93,15 @@ int detect_join_filter_shape(const ExprProgram& pr) {
   return 1;
 }
 
-void load_program(NodeInfo& nd, const rdfgpu_plan_desc* d, u32 n_cols, const char* what) {
+void load_program(NodeInfo& nd, const rdfgpu_plan_desc* d, u32 n_cols, const char* what, const RegexProg* regex_dev) {
   const rdfgpu_plan_node& r = nd.d;
   nd.prog.n = 0;
   if (r.expr_len == 0) return;
   if ((u64)r.expr_off + r.expr_len > d->n_exprs) fail(RDFGPU_ERR_INVALID, "%s: expression outside the expression array", what);
-  if (check_program(d->exprs + r.expr_off, r.expr_len, n_cols) != VK_BOOL) fail(RDFGPU_ERR_INVALID, "%s: predicate does not yield a boolean", what);
+  if (check_program(d->exprs + r.expr_off, r.expr_len, n_cols, d->n_regexes) != VK_BOOL) fail(RDFGPU_ERR_INVALID, "%s: predicate does not yield a boolean", what);
   nd.prog.n = r.expr_len;
   std::memcpy(nd.prog.nodes, d->exprs + r.expr_off, r.expr_len * sizeof(rdfgpu_expr_node));
+  nd.prog.regex = regex_dev;
 }
 
 void load_projection(NodeInfo& nd, const rdfgpu_plan_desc* d, u32 full, const char* what) {
@@ -125,6 +133,20 @@ Plan* plan_compile(Store* store, const rdfgpu_plan_desc* d) {
   plan->root = d->root;
   plan->nodes.resize(d->n_nodes);
   std::vector<u32> scan_ids;  // sorted IN sets of all sources, uploaded once
+  if (d->n_regexes) {   // REGEX patterns are plan constants: compiled here, simulated per row on the device
+    if (!d->regexes) fail(RDFGPU_ERR_INVALID, "plan_compile: %u regexes but no table", d->n_regexes);
+    if (!store->str_off) fail(RDFGPU_ERR_INVALID, "plan uses REGEX but the store has no strings (rdfgpu_store_set_strings)");
+    std::vector<RegexProg> progs(d->n_regexes);
+    for (u32 r = 0; r < d->n_regexes; r++) {
+      const rdfgpu_regex& rx = d->regexes[r];
+      std::string why;
+      if (regex_compile(rx.pattern ? rx.pattern : "", rx.pattern_len, rx.flags ? rx.flags : "", rx.flags ? rx.flags_len : 0, progs[r], why) != REGEX_OK)
+        fail(RDFGPU_ERR_UNSUPPORTED, "REGEX pattern %u: %s", r, why.c_str());
+    }
+    store->activate();
+    RDFGPU_HIP(hipMalloc((void**)&plan->regex_dev, progs.size() * sizeof(RegexProg)));
+    RDFGPU_HIP(hipMemcpy(plan->regex_dev, progs.data(), progs.size() * sizeof(RegexProg), hipMemcpyHostToDevice));
+  }
 
   for (u32 i = 0; i < d->n_nodes; i++) {
     NodeInfo& nd = plan->nodes[i];
@@ -157,7 +179,7 @@ Plan* plan_compile(Store* store, const rdfgpu_plan_desc* d) {
       }
       case RDFGPU_NODE_FILTER: {
         const NodeInfo& c = child(r.left, "input");
-        load_program(nd, d, c.width, "FilterExec");
+        load_program(nd, d, c.width, "FilterExec", plan->regex_dev);
         load_projection(nd, d, c.width, "FilterExec");
         nd.shape = detect_shape(nd.prog);
         break;
@@ -178,7 +200,7 @@ Plan* plan_compile(Store* store, const rdfgpu_plan_desc* d) {
         }
         if (r.kind == RDFGPU_NODE_CROSS_JOIN && (r.expr_len || r.join_type != RDFGPU_JOIN_INNER)) fail(RDFGPU_ERR_INVALID, "node %u: CrossJoinExec takes no filter / join type", i);
         if (l.width + rr.width > 2u * kMaxCols) fail(RDFGPU_ERR_UNSUPPORTED, "node %u: too many columns", i);
-        load_program(nd, d, l.width + rr.width, "join filter");
+        load_program(nd, d, l.width + rr.width, "join filter", plan->regex_dev);
         load_projection(nd, d, l.width + rr.width, "join");
         nd.shape = detect_join_filter_shape(nd.prog);
         if (l.width > (u32)kMaxCols || rr.width > (u32)kMaxCols) fail(RDFGPU_ERR_UNSUPPORTED, "node %u: too many columns", i);
@@ -289,6 +311,7 @@ Plan::~Plan() {
   if (stream) (void)hipStreamSynchronize(stream);
   release_intermediates();
   if (pool_dev) (void)hipFree(pool_dev);
+  if (regex_dev) (void)hipFree(regex_dev);
 
   if (store && ctx) store->release_context(ctx);
 }

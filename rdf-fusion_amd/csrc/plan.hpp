@@ -71,6 +71,7 @@ struct Plan {
   std::vector<SourceInfo> sources;
   std::vector<u32> pool;          // IN-set ids of residual predicates (host copy)
   u32* pool_dev = nullptr;        // same, on device
+  RegexProg* regex_dev = nullptr; // compiled REGEX patterns of the plan (device)
   u32 root = 0;
   ExecContext* ctx = nullptr;     // stream, events, counters (pooled per store)
   hipStream_t stream = nullptr;

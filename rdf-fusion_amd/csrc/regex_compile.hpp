@@ -1,0 +1,377 @@
+// regex_compile.hpp — host-side compiler of SPARQL REGEX patterns into a bit-parallel position automaton
+// (Glushkov construction, <= 64 byte positions) that the device simulates per row with one u64 of state.
+//
+// Replaces `compile_pattern` + `Regex::is_match` (lib/functions/src/scalar/strings/regex.rs:47-141; the `regex`
+// crate 1.12, Cargo.lock:3834-3835).  is_match is an unanchored search, so greedy / lazy makes no difference and
+// no captures are needed.  Supported syntax — everything else is reported as UNSUPPORTED at plan compile, never
+// answered differently from the crate:
+//   literals (any UTF-8), `.`, `[...]` / `[^...]` with ASCII members and ranges, `( )`, `(?: )`, `(?P<n> )`, `|`,
+//   `* + ? {m} {m,} {m,n}` (+ lazy suffix), escaped punctuation, `\n \r \t \f \v \xHH`, a leading `^` / `\A` and a
+//   trailing `$` / `\z` of a pattern without top-level alternation;
+//   flags: `i` (ASCII letters, incl. the two non-ASCII simple folds K <-> U+212A and s <-> U+017F), `s`, `m`, `x`, `q`.
+// Not supported: `\d \w \s \b` and `\p{..}` (Unicode tables), class set operations, inline flags, non-ASCII class
+// members, non-ASCII letters under `i`, anchors elsewhere, > 64 positions.
+#pragma once
+#include <cstdint>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "regex_prog.hpp"
+
+namespace rdfgpu {
+
+namespace regex_detail {
+
+struct ByteSet {
+  uint64_t w[4] = {0, 0, 0, 0};
+  void add(unsigned b) { w[b >> 6] |= 1ull << (b & 63); }
+  void add_range(unsigned a, unsigned b) { for (unsigned c = a; c <= b; c++) add(c); }
+  bool has(unsigned b) const { return (w[b >> 6] >> (b & 63)) & 1; }
+};
+
+enum Kind { EMPTY, LEAF, CAT, ALT, STAR, PLUS, OPT, A_START, A_END };
+struct Node {
+  Kind kind = EMPTY;
+  ByteSet set;
+  std::vector<std::shared_ptr<Node>> kids;
+};
+using NodeP = std::shared_ptr<Node>;
+inline NodeP mk(Kind k) { auto n = std::make_shared<Node>(); n->kind = k; return n; }
+inline NodeP leaf(const ByteSet& s) { auto n = mk(LEAF); n->set = s; return n; }
+inline NodeP leaf_range(unsigned a, unsigned b) { ByteSet s; s.add_range(a, b); return leaf(s); }
+inline NodeP cat(std::vector<NodeP> k) { if (k.empty()) return mk(EMPTY); if (k.size() == 1) return k[0]; auto n = mk(CAT); n->kids = std::move(k); return n; }
+inline NodeP alt(std::vector<NodeP> k) { if (k.size() == 1) return k[0]; auto n = mk(ALT); n->kids = std::move(k); return n; }
+inline NodeP un(Kind k, NodeP a) { auto n = mk(k); n->kids.push_back(std::move(a)); return n; }
+
+// any non-ASCII Unicode scalar as UTF-8 (loose on surrogates / overlongs: the subject strings are valid UTF-8)
+inline NodeP non_ascii_char() {
+  return alt({cat({leaf_range(0xC2, 0xDF), leaf_range(0x80, 0xBF)}),
+              cat({leaf_range(0xE0, 0xEF), leaf_range(0x80, 0xBF), leaf_range(0x80, 0xBF)}),
+              cat({leaf_range(0xF0, 0xF4), leaf_range(0x80, 0xBF), leaf_range(0x80, 0xBF), leaf_range(0x80, 0xBF)})});
+}
+inline NodeP bytes_seq(const unsigned char* b, size_t n) {
+  std::vector<NodeP> k;
+  for (size_t i = 0; i < n; i++) { ByteSet s; s.add(b[i]); k.push_back(leaf(s)); }
+  return cat(std::move(k));
+}
+
+struct Parser {
+  const unsigned char* p; size_t n, i = 0;
+  bool f_i = false, f_s = false, f_x = false;
+  std::string err;
+  bool fail(const char* m) { if (err.empty()) err = m; return false; }
+  bool eof() const { return i >= n; }
+
+  void skip_x() {   // `x`: whitespace and #-comments are ignored outside classes
+    if (!f_x) return;
+    for (;;) {
+      while (!eof() && (p[i] == ' ' || p[i] == '\t' || p[i] == '\n' || p[i] == '\r' || p[i] == '\f' || p[i] == '\v')) i++;
+      if (!eof() && p[i] == '#') { while (!eof() && p[i] != '\n') i++; continue; }
+      break;
+    }
+  }
+  static bool is_alpha(unsigned c) { return (c >= 'a' && c <= 'z') || (c >= 'A' && c <= 'Z'); }
+
+  // one ASCII set (after case folding) -> node, adding the two non-ASCII simple case folds
+  NodeP ascii_set_node(ByteSet s) {
+    if (!f_i) return leaf(s);
+    for (unsigned c = 'a'; c <= 'z'; c++) if (s.has(c) || s.has(c - 32)) { s.add(c); s.add(c - 32); }
+    std::vector<NodeP> alts{leaf(s)};
+    static const unsigned char kelvin[3] = {0xE2, 0x84, 0xAA}, long_s[2] = {0xC5, 0xBF};
+    if (s.has('k')) alts.push_back(bytes_seq(kelvin, 3));
+    if (s.has('s')) alts.push_back(bytes_seq(long_s, 2));
+    return alt(std::move(alts));
+  }
+
+  bool utf8_len(size_t at, size_t& len) {
+    const unsigned c = p[at];
+    len = c < 0x80 ? 1 : (c >> 5) == 6 ? 2 : (c >> 4) == 14 ? 3 : (c >> 3) == 30 ? 4 : 0;
+    if (len == 0 || at + len > n) return fail("pattern is not valid UTF-8");
+    for (size_t k = 1; k < len; k++) if ((p[at + k] & 0xC0) != 0x80) return fail("pattern is not valid UTF-8");
+    return true;
+  }
+  NodeP literal_at(size_t at, size_t len) {
+    if (len == 1) { ByteSet s; s.add(p[at]); return ascii_set_node(s); }
+    if (f_i) { fail("non-ASCII literal under the `i` flag"); return nullptr; }
+    return bytes_seq(p + at, len);
+  }
+
+  // escape after '\\': returns a single byte value in `c` (is_byte) or fails
+  bool escape_byte(unsigned& c) {
+    if (eof()) return fail("trailing backslash");
+    const unsigned e = p[i++];
+    switch (e) {
+      case 'n': c = '\n'; return true;   case 'r': c = '\r'; return true;   case 't': c = '\t'; return true;
+      case 'f': c = '\f'; return true;   case 'v': c = '\v'; return true;   case 'a': c = 7; return true;
+      case 'x': {
+        if (i + 2 > n) return fail("bad \\x escape");
+        unsigned v = 0;
+        for (int k = 0; k < 2; k++) {
+          const unsigned h = p[i++];
+          const int d = h >= '0' && h <= '9' ? (int)(h - '0') : h >= 'a' && h <= 'f' ? (int)(h - 'a' + 10) : h >= 'A' && h <= 'F' ? (int)(h - 'A' + 10) : -1;
+          if (d < 0) return fail("bad \\x escape");
+          v = v * 16 + (unsigned)d;
+        }
+        if (v >= 0x80) return fail("non-ASCII \\x escape");
+        c = v; return true;
+      }
+      default:
+        // escapable = any ASCII character that is not a letter, a digit, '<' or '>' (the crate's is_escapeable_character)
+        if (e < 0x80 && !is_alpha(e) && !(e >= '0' && e <= '9') && e != '<' && e != '>') { c = e; return true; }
+        return fail("escape class needs Unicode tables or is not an escape");
+    }
+  }
+
+  NodeP parse_class() {   // after '['
+    bool neg = false;
+    if (!eof() && p[i] == '^') { neg = true; i++; }
+    ByteSet s; bool first = true;
+    for (;;) {
+      if (eof()) { fail("unclosed class"); return nullptr; }
+      unsigned c = p[i];
+      if (c == ']' && !first) { i++; break; }
+      first = false;
+      if (c == '[') { fail("nested / POSIX classes"); return nullptr; }
+      if (c >= 0x80) { fail("non-ASCII class member"); return nullptr; }
+      if ((c == '&' || c == '-' || c == '~') && i + 1 < n && p[i + 1] == c && c != '-') { fail("class set operation"); return nullptr; }
+      i++;
+      if (c == '\\') { if (!escape_byte(c)) return nullptr; }
+      unsigned hi = c;
+      if (!eof() && p[i] == '-' && i + 1 < n && p[i + 1] != ']') {   // range
+        if (p[i + 1] == '-') { fail("class set operation"); return nullptr; }
+        i++;
+        hi = p[i];
+        if (hi >= 0x80 || hi == '[') { fail("non-ASCII class member"); return nullptr; }
+        i++;
+        if (hi == '\\') { if (!escape_byte(hi)) return nullptr; }
+        if (hi < c) { fail("invalid class range"); return nullptr; }
+      }
+      s.add_range(c, hi);
+    }
+    if (!neg) return ascii_set_node(s);
+    if (f_i) {
+      for (unsigned c = 'a'; c <= 'z'; c++) if (s.has(c) || s.has(c - 32)) { s.add(c); s.add(c - 32); }
+      if (s.has('k') || s.has('s')) { fail("negated class with k / s under the `i` flag"); return nullptr; }
+    }
+    ByteSet inv; for (unsigned c = 0; c < 0x80; c++) if (!s.has(c)) inv.add(c);
+    return alt({leaf(inv), non_ascii_char()});
+  }
+
+  NodeP parse_atom() {
+    const unsigned c = p[i];
+    if (c == '(') {
+      i++;
+      if (!eof() && p[i] == '?') {
+        if (i + 1 < n && p[i + 1] == ':') i += 2;
+        else if (i + 1 < n && (p[i + 1] == 'P' || p[i + 1] == '<')) {   // named group: the name is irrelevant for is_match
+          i += p[i + 1] == 'P' ? 2 : 1;
+          if (eof() || p[i] != '<') { fail("bad group"); return nullptr; }
+          while (!eof() && p[i] != '>') i++;
+          if (eof()) { fail("bad group name"); return nullptr; }
+          i++;
+        } else { fail("inline flags"); return nullptr; }
+      }
+      NodeP inner = parse_alt();
+      if (!inner) return nullptr;
+      if (eof() || p[i] != ')') { fail("unclosed group"); return nullptr; }
+      i++;
+      return inner;
+    }
+    if (c == '[') { i++; return parse_class(); }
+    if (c == '.') {
+      i++;
+      ByteSet s; s.add_range(0, 0x7F);
+      if (!f_s) s.w[0] &= ~(1ull << '\n');
+      return alt({leaf(s), non_ascii_char()});
+    }
+    if (c == '^') { i++; return mk(A_START); }
+    if (c == '$') { i++; return mk(A_END); }
+    if (c == '\\') {
+      i++;
+      if (!eof() && p[i] == 'A') { i++; auto a = mk(A_START); a->set.add(1); return a; }   // set bit 1: not affected by `m`
+      if (!eof() && p[i] == 'z') { i++; auto a = mk(A_END); a->set.add(1); return a; }
+      unsigned b;
+      if (!escape_byte(b)) return nullptr;
+      ByteSet s; s.add(b);
+      return ascii_set_node(s);
+    }
+    if (c == '*' || c == '+' || c == '?' || c == '{') { fail("repetition operator without an expression"); return nullptr; }
+    if (c == ')' || c == '|') { fail("unexpected character"); return nullptr; }
+    size_t len;
+    if (!utf8_len(i, len)) return nullptr;
+    NodeP l = literal_at(i, len);
+    i += len;
+    return l;
+  }
+
+  static NodeP clone(const NodeP& a) {
+    auto n = std::make_shared<Node>(*a);
+    for (auto& k : n->kids) k = clone(k);
+    return n;
+  }
+  bool parse_uint(unsigned& v) {
+    if (eof() || p[i] < '0' || p[i] > '9') return false;
+    v = 0;
+    while (!eof() && p[i] >= '0' && p[i] <= '9') { v = v * 10 + (p[i] - '0'); if (v > 1000) return fail("repetition count too large"); i++; }
+    return true;
+  }
+  NodeP parse_repeat() {
+    NodeP a = parse_atom();
+    if (!a) return nullptr;
+    for (;;) {
+      skip_x();
+      if (eof()) break;
+      const unsigned c = p[i];
+      if (c != '*' && c != '+' && c != '?' && c != '{') break;
+      if (a->kind == A_START || a->kind == A_END) { fail("repeated anchor"); return nullptr; }
+      if (c == '{') {
+        i++;
+        unsigned lo = 0, hi = 0; bool open = false;
+        if (!parse_uint(lo)) { fail("bad repetition"); return nullptr; }
+        if (!eof() && p[i] == ',') { i++; if (!parse_uint(hi)) { if (!err.empty()) return nullptr; open = true; } }
+        else hi = lo;
+        if (eof() || p[i] != '}') { fail("bad repetition"); return nullptr; }
+        i++;
+        if (!open && hi < lo) { fail("bad repetition range"); return nullptr; }
+        std::vector<NodeP> k;
+        for (unsigned r = 0; r < lo; r++) k.push_back(clone(a));
+        if (open) k.push_back(un(STAR, clone(a)));
+        else for (unsigned r = lo; r < hi; r++) k.push_back(un(OPT, clone(a)));
+        if (k.size() > 64) { fail("more than 64 positions"); return nullptr; }
+        a = cat(std::move(k));
+      } else {
+        i++;
+        a = un(c == '*' ? STAR : c == '+' ? PLUS : OPT, a);
+      }
+      if (!eof() && p[i] == '?') i++;   // lazy: irrelevant for is_match
+    }
+    return a;
+  }
+  NodeP parse_cat() {
+    std::vector<NodeP> k;
+    for (;;) {
+      skip_x();
+      if (eof() || p[i] == '|' || p[i] == ')') break;
+      NodeP r = parse_repeat();
+      if (!r) return nullptr;
+      k.push_back(r);
+    }
+    return cat(std::move(k));
+  }
+  NodeP parse_alt() {
+    std::vector<NodeP> k;
+    for (;;) {
+      NodeP c = parse_cat();
+      if (!c) return nullptr;
+      k.push_back(c);
+      skip_x();
+      if (!eof() && p[i] == '|') { i++; continue; }
+      break;
+    }
+    return alt(std::move(k));
+  }
+};
+
+struct Info { bool nullable; uint64_t first, last; };
+
+struct Builder {
+  RegexProg* out; uint32_t n_pos = 0; bool too_big = false; bool stray_anchor = false;
+  Info build(const NodeP& a) {
+    switch (a->kind) {
+      case EMPTY: return {true, 0, 0};
+      case A_START: case A_END: stray_anchor = true; return {true, 0, 0};
+      case LEAF: {
+        if (n_pos >= 64) { too_big = true; return {false, 0, 0}; }
+        const uint32_t id = n_pos++;
+        for (unsigned b = 0; b < 256; b++) if (a->set.has(b)) out->byte_mask[b] |= 1ull << id;
+        return {false, 1ull << id, 1ull << id};
+      }
+      case CAT: {
+        Info acc{true, 0, 0};
+        for (const NodeP& k : a->kids) {
+          const Info b = build(k);
+          for (uint64_t l = acc.last; l; l &= l - 1) out->follow[__builtin_ctzll(l)] |= b.first;
+          const Info r{acc.nullable && b.nullable, acc.first | (acc.nullable ? b.first : 0), b.last | (b.nullable ? acc.last : 0)};
+          acc = r;
+        }
+        return acc;
+      }
+      case ALT: {
+        Info acc{false, 0, 0};
+        for (const NodeP& k : a->kids) { const Info b = build(k); acc.nullable = acc.nullable || b.nullable; acc.first |= b.first; acc.last |= b.last; }
+        return acc;
+      }
+      default: {   // STAR, PLUS, OPT
+        const Info b = build(a->kids[0]);
+        if (a->kind != OPT) for (uint64_t l = b.last; l; l &= l - 1) out->follow[__builtin_ctzll(l)] |= b.first;
+        return {a->kind == PLUS ? b.nullable : true, b.first, b.last};
+      }
+    }
+  }
+};
+
+}  // namespace regex_detail
+
+enum RegexStatus { REGEX_OK = 0, REGEX_UNSUPPORTED = 1 };
+
+// Compiles `pattern` with SPARQL `flags` (regex.rs:107-141).  REGEX_UNSUPPORTED + `why` for anything outside the
+// subset above (which includes patterns the crate itself rejects: those would be the error value on every row,
+// but telling them apart needs the crate's whole grammar, so they are refused as well).
+inline RegexStatus regex_compile(const char* pattern, size_t n, const char* flags, size_t n_flags, RegexProg& out, std::string& why) {
+  using namespace regex_detail;
+  std::memset(&out, 0, sizeof out);
+  bool q = false, multiline = false;
+  Parser ps{reinterpret_cast<const unsigned char*>(pattern), n};
+  for (size_t k = 0; k < n_flags; k++) {
+    switch (flags[k]) {
+      case 's': ps.f_s = true; break;
+      case 'm': multiline = true; break;
+      case 'i': ps.f_i = true; break;
+      case 'x': ps.f_x = true; break;
+      case 'q': q = true; break;
+      default: out.always_error = 1; return REGEX_OK;   // invalid option => error on every row (regex.rs:137)
+    }
+  }
+  NodeP root;
+  if (q) {   // regex::escape: the whole pattern is a literal (the `x` flag then has nothing left to strip but
+             // whitespace, which `regex::escape` does not protect: refuse that corner)
+    if (ps.f_x) { why = "flags q and x together"; return REGEX_UNSUPPORTED; }
+    std::vector<NodeP> k;
+    size_t at = 0;
+    while (at < n) {
+      size_t len;
+      if (!ps.utf8_len(at, len)) { why = ps.err; return REGEX_UNSUPPORTED; }
+      NodeP l = ps.literal_at(at, len);
+      if (!l) { why = ps.err; return REGEX_UNSUPPORTED; }
+      k.push_back(l);
+      at += len;
+    }
+    root = cat(std::move(k));
+  } else {
+    root = ps.parse_alt();
+    if (root && !ps.eof()) { ps.fail("unbalanced parenthesis"); root = nullptr; }
+    if (!root) { why = ps.err; return REGEX_UNSUPPORTED; }
+  }
+  // anchors: only the first / last element of a top-level concatenation
+  if (root->kind == A_START || root->kind == A_END) { auto c = mk(CAT); c->kids.push_back(root); root = c; }
+  if (root->kind == CAT) {
+    if (!root->kids.empty() && root->kids.front()->kind == A_START) {
+      out.anchor_start = 1; out.ml_start = multiline && !root->kids.front()->set.has(1);
+      root->kids.erase(root->kids.begin());
+    }
+    if (!root->kids.empty() && root->kids.back()->kind == A_END) {
+      out.anchor_end = 1; out.ml_end = multiline && !root->kids.back()->set.has(1);
+      root->kids.pop_back();
+    }
+  }
+  Builder b{&out};
+  const Info info = b.build(root);
+  if (b.stray_anchor) { why = "anchor that is not the first / last element of the pattern"; return REGEX_UNSUPPORTED; }
+  if (b.too_big) { why = "more than 64 positions"; return REGEX_UNSUPPORTED; }
+  out.first = info.first; out.last = info.last; out.nullable = info.nullable ? 1 : 0; out.n_pos = b.n_pos;
+  return REGEX_OK;
+}
+
+}  // namespace rdfgpu

@@ -168,6 +168,8 @@ Store::~Store() {
   for (auto& ix : idx) for (auto& c : ix.col) if (c) (void)hipFree(c);
   if (tv) (void)hipFree(tv);
   if (dec) (void)hipFree(dec);
+  if (str_off) (void)hipFree(str_off);
+  if (heap) (void)hipFree(heap);
   if (stream) (void)hipStreamDestroy(stream);
 }
 
@@ -322,6 +324,21 @@ void Store::set_typed_values(const rdfgpu_typed_value* v, u64 n, const int64_t* 
     RDFGPU_HIP(hipMalloc((void**)&dec, nd * 16));
     RDFGPU_HIP(hipMemcpy(dec, d, nd * 16, hipMemcpyHostToDevice));
   }
+}
+
+void Store::set_strings(const u64* offsets, u64 n, const unsigned char* heap_host, u64 heap_bytes) {
+  std::unique_lock<std::shared_mutex> lock(mu);
+  activate();
+  if (n && !offsets) fail(RDFGPU_ERR_INVALID, "set_strings: null offsets");
+  for (u64 i = 0; i < n; i++) if (offsets[i] > offsets[i + 1] || offsets[i + 1] > heap_bytes) fail(RDFGPU_ERR_INVALID, "set_strings: offsets of id %llu are not monotone / inside the heap", (unsigned long long)i);
+  if (str_off) { RDFGPU_HIP(hipFree(str_off)); str_off = nullptr; }
+  if (heap) { RDFGPU_HIP(hipFree(heap)); heap = nullptr; }
+  n_str_ids = n;
+  if (!n) return;
+  RDFGPU_HIP(hipMalloc((void**)&str_off, (n + 1) * sizeof(u64)));
+  RDFGPU_HIP(hipMemcpy(str_off, offsets, (n + 1) * sizeof(u64), hipMemcpyHostToDevice));
+  RDFGPU_HIP(hipMalloc((void**)&heap, heap_bytes ? heap_bytes : 1));
+  if (heap_bytes) RDFGPU_HIP(hipMemcpy(heap, heap_host, heap_bytes, hipMemcpyHostToDevice));
 }
 
 }  // namespace rdfgpu

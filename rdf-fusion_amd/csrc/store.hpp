@@ -78,6 +78,8 @@ struct Store {
   // typed-value side table (object_id_mapping.rs:376-399), 16 B per id
   rdfgpu_typed_value* tv = nullptr; u64 n_ids = 0;
   int64_t* dec = nullptr; u64 n_dec = 0;
+  // lexical forms of string ids (the slice of the dictionary string builtins read): offsets[n_str_ids + 1] + UTF-8 heap
+  u64* str_off = nullptr; unsigned char* heap = nullptr; u64 n_str_ids = 0;
   DevicePool pool;
   hipStream_t stream = nullptr;  // load-path stream
   std::shared_mutex mu;   // readers = running plans (a snapshot), writers = extend / remove / clear
@@ -101,7 +103,8 @@ struct Store {
   u64 remove_host(const u32* g, const u32* s, const u32* p, const u32* o, u64 n);
   void clear();
   void set_typed_values(const rdfgpu_typed_value* v, u64 n_ids, const int64_t* dec, u64 n_dec);
-  TypedTable typed_table() const { return TypedTable{tv, n_ids, dec, n_dec}; }
+  void set_strings(const u64* offsets, u64 n_ids, const unsigned char* heap_host, u64 heap_bytes);
+  TypedTable typed_table() const { return TypedTable{tv, n_ids, dec, n_dec, str_off, heap, n_str_ids}; }
 };
 
 Store* store_create(const rdfgpu_config* cfg);

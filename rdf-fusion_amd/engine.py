@@ -56,6 +56,7 @@ def load_library():
     lib.rdfgpu_store_clear.argtypes = [vp]
     lib.rdfgpu_store_len.argtypes = [vp, u64p]
     lib.rdfgpu_store_set_typed_values.argtypes = [vp, vp, C.c_uint64, vp, C.c_uint64]
+    lib.rdfgpu_store_set_strings.argtypes = [vp, vp, C.c_uint64, vp, C.c_uint64]
     lib.rdfgpu_store_read_index.argtypes = [vp, C.c_uint32, vp, vp, vp, vp, C.c_uint64, u64p]
     lib.rdfgpu_plan_compile.argtypes = [vp, C.POINTER(abi.PlanDesc), C.POINTER(vp)]
     lib.rdfgpu_plan_destroy.argtypes = [vp]
@@ -79,6 +80,7 @@ def load_library():
     lib.rdfgpu_predicate_and.argtypes = [C.POINTER(abi.Predicate), C.POINTER(abi.Predicate),
                                          C.POINTER(abi.Predicate), u32p]
     lib.rdfgpu_pushdown_to_scan_predicate.argtypes = [C.c_uint32, C.c_uint32, C.POINTER(abi.Predicate)]
+    lib.rdfgpu_regex_check.argtypes = [C.c_char_p, C.c_uint32, C.c_char_p, C.c_uint32, C.POINTER(C.c_uint32)]
     if lib.rdfgpu_abi_version() != abi.ABI_VERSION:
         raise RdfGpuError(abi.ERR_INVALID, "ABI version mismatch between abi.py and librdfgpu.so")
     _LIB = lib
@@ -167,6 +169,15 @@ def pushdown_to_scan_predicate(op, value, lib_fn=None):
     return _pred_from_struct(out, None)
 
 
+def regex_check(pattern, flags=""):
+    """compile_pattern for the device (regex.rs:107-141): number of automaton positions; raises RdfGpuError
+    (UNSUPPORTED) for syntax outside the supported subset."""
+    p, f = (x.encode("utf-8") if isinstance(x, str) else bytes(x) for x in (pattern, flags))
+    n = C.c_uint32(0)
+    _check(load_library().rdfgpu_regex_check(p, len(p), f, len(f), C.byref(n)))
+    return n.value
+
+
 # ------------------------------------------------------------------------------------------------
 # store and plans
 # ------------------------------------------------------------------------------------------------
@@ -216,6 +227,13 @@ class GpuQuadStore:
         n = C.c_uint64()
         _check(self._lib.rdfgpu_store_len(self._h, C.byref(n)))
         return n.value
+
+    def set_strings(self, offsets, heap):
+        """Lexical forms of the string ids: id i = heap[offsets[i]:offsets[i+1]] (UTF-8); len(offsets) = n_ids + 1."""
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        heap = np.frombuffer(bytes(heap), dtype=np.uint8) if not isinstance(heap, np.ndarray) else np.ascontiguousarray(heap, dtype=np.uint8)
+        _check(self._lib.rdfgpu_store_set_strings(self._h, offsets.ctypes.data_as(C.c_void_p), len(offsets) - 1,
+                                                   heap.ctypes.data_as(C.c_void_p), len(heap)))
 
     def set_typed_values(self, values, decimals=None):
         """values: numpy structured array / bytes of rdfgpu_typed_value, index = object id."""

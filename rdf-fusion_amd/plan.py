@@ -164,6 +164,12 @@ def NEQ(a, b): return a._bin(b, abi.EX_NEQ)
 def ADD(a, b): return a._bin(b, abi.EX_ADD)
 def SUB(a, b): return a._bin(b, abi.EX_SUB)
 def EBV(e): return e._un(abi.EX_EBV)
+
+
+def REGEX(e, pattern, flags=""):
+    """REGEX(value, "pattern"[, "flags"]) with constant pattern / flags (scalar/strings/regex.rs:47-141)."""
+    enc = lambda x: x.encode("utf-8") if isinstance(x, str) else bytes(x)
+    return Expr(e.nodes + [(abi.EX_REGEX, 0, 0, (enc(pattern), enc(flags)), 0, 0)])
 def ID_EQ(a, b): return a._bin(b, abi.EX_ID_EQ)
 def ID_NEQ(a, b): return a._bin(b, abi.EX_ID_NEQ)
 def AND(a, b): return a._bin(b, abi.EX_AND)
@@ -180,13 +186,15 @@ def BOOLEAN_AS_TERM(e): return e._un(abi.EX_BOOL_AS_TV)
 class PlanDescription:
     """Owns the ctypes arrays behind one ``rdfgpu_plan_desc``."""
 
-    def __init__(self, nodes, exprs, pool, root, n_columns):
+    def __init__(self, nodes, exprs, pool, root, n_columns, regexes=()):
         self.n_columns = n_columns  # output width per node (host-side bookkeeping)
         self._nodes = (abi.PlanNode * max(1, len(nodes)))(*nodes)
         self._exprs = (abi.ExprNode * max(1, len(exprs)))(*exprs)
         self._pool = (C.c_uint32 * max(1, len(pool)))(*pool)
+        self._regex_bytes = [(bytes(p), bytes(f)) for p, f in regexes]      # keeps the char buffers alive
+        self._regexes = (abi.Regex * max(1, len(regexes)))(*[abi.Regex(p, f, len(p), len(f)) for p, f in self._regex_bytes])
         self.desc = abi.PlanDesc(self._nodes, len(nodes), root, self._exprs, len(exprs), self._pool,
-                                 len(pool), 0)
+                                 len(pool), 0, self._regexes, len(regexes), 0)
         self.root = root
 
     @property
@@ -197,6 +205,7 @@ class PlanDescription:
 class PlanBuilder:
     def __init__(self):
         self.nodes, self.exprs, self.pool, self.width = [], [], [], []
+        self.regexes = []
         self.vars = {}
 
     # -- helpers -------------------------------------------------------------------------------
@@ -227,6 +236,10 @@ class PlanBuilder:
             return
         node.expr_off, node.expr_len = len(self.exprs), len(e.nodes)
         for (op, tag, flags, u, lo, hi) in e.nodes:
+            if op == abi.EX_REGEX:      # u carries (pattern, flags): register the plan constant, keep its index
+                if u not in self.regexes:
+                    self.regexes.append(u)
+                u = self.regexes.index(u)
             self.exprs.append(abi.ExprNode(op, tag, flags, 0, u, lo, hi))
 
     def _proj(self, node, projection, full):
@@ -288,4 +301,4 @@ class PlanBuilder:
         return self._push(n, n_cols)
 
     def build(self, root):
-        return PlanDescription(self.nodes, self.exprs, self.pool, root, list(self.width))
+        return PlanDescription(self.nodes, self.exprs, self.pool, root, list(self.width), list(self.regexes))

@@ -99,3 +99,94 @@ def numeric_kat_plans(kats):
             expr = AND(EBV(LT(x, double(c["value"] + c["tol"]))), EBV(GT(x, double(c["value"] - c["tol"]))))
         out.append((f'decimal->double {c["raw"]}', pb.build(pb.filter(pb.table(0, 1), expr)), 1))
     return out
+
+
+# ---------------------------------------------------------------------------------------------------
+# REGEX: random patterns inside the supported subset, rendered for the reference's syntax (Rust `regex`
+# crate, what the oracle and the device parse) and for Python's `re` (a third opinion in the tests)
+# ---------------------------------------------------------------------------------------------------
+REGEX_ALPHABET = ["a", "b", "c", "k", "K", "s", "S", "x", "0", " ", ".", "\n", "é", "€", "K", "ſ", "😀"]
+_META = set(".+*?()|[]{}^$\\#&-~")
+
+
+def _lit(ch):
+    return ("\\" + ch) if ch in _META else ch
+
+
+def random_regex(rng, depth=0):
+    """Returns (pattern, flags, python_pattern, python_flags)."""
+    import re
+    flags = "".join(f for f in "ismx" if rng.random() < 0.25)
+    # non-ASCII letters under `i` need the Unicode case-folding tables: outside the restated / supported subset
+    letters = [c for c in REGEX_ALPHABET if ord(c) < 0x80] if "i" in flags else REGEX_ALPHABET
+
+    def atom(d):
+        r = rng.random()
+        if r < 0.45:
+            ch = letters[int(rng.integers(0, len(letters)))]
+            if ch == "\n":
+                return "\\n", "\\n"
+            if ch == " ":
+                return "\\ ", "\\ "          # stays a literal under the x flag too
+            return _lit(ch), re.escape(ch)
+        if r < 0.6:
+            return ".", "."
+        if r < 0.8:
+            members = [m for m in ["a", "b", "c", "k", "s", "x", "0", "."] if rng.random() < 0.4] or ["a"]
+            body = "".join("\\." if m == "." else m for m in members)
+            if rng.random() < 0.3:
+                body += "a-c"
+            neg = "^" if rng.random() < 0.3 else ""
+            return f"[{neg}{body}]", f"[{neg}{body}]"
+        if d < 2:
+            a, b = alt(d + 1)
+            grp = "(?:" if rng.random() < 0.5 else "("
+            return f"{grp}{a})", f"{grp}{b})"
+        return "a", "a"
+
+    def repeat(d):
+        a, b = atom(d)
+        r = rng.random()
+        suffix = ""
+        if r < 0.15:
+            suffix = "*"
+        elif r < 0.3:
+            suffix = "+"
+        elif r < 0.4:
+            suffix = "?"
+        elif r < 0.5:
+            lo = int(rng.integers(0, 3))
+            suffix = "{%d,%d}" % (lo, lo + int(rng.integers(0, 3))) if rng.random() < 0.6 else "{%d,}" % lo if rng.random() < 0.5 else "{%d}" % lo
+        return a + suffix, b + suffix
+
+    def cat(d):
+        parts = [repeat(d) for _ in range(int(rng.integers(1, 4)))]
+        return "".join(p[0] for p in parts), "".join(p[1] for p in parts)
+
+    def alt(d):
+        parts = [cat(d) for _ in range(1 if rng.random() < 0.7 else 2)]
+        return "|".join(p[0] for p in parts), "|".join(p[1] for p in parts)
+
+    top_alt = rng.random() < 0.2
+    pat, py = alt(depth) if top_alt else cat(depth)
+    if not top_alt:                       # anchors only around a pattern without top-level alternation
+        multiline = "m" in flags
+        if rng.random() < 0.3:
+            pat, py = "^" + pat, "^" + py
+        if rng.random() < 0.3:
+            pat, py = pat + "$", py + ("$" if multiline else "\\Z")   # Python's bare $ also matches before a final \n
+    py_flags = 0
+    for f, v in (("i", re.I), ("s", re.S), ("m", re.M), ("x", re.X)):
+        if f in flags:
+            py_flags |= v
+    return pat, flags, py, py_flags
+
+
+def regex_needs_unicode_fold_care(pattern, flags):
+    """Negated classes containing k / s under `i` are outside the device subset (KELVIN SIGN / LONG S)."""
+    return "i" in flags and "[^" in pattern
+
+
+def random_subject(rng):
+    n = int(rng.integers(0, 9))
+    return "".join(REGEX_ALPHABET[int(rng.integers(0, len(REGEX_ALPHABET)))] for _ in range(n))

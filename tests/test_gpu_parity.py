@@ -12,7 +12,7 @@ from rdf_fusion_amd.engine import TV_DTYPE
 from rdf_fusion_amd.plan import (PlanBuilder, MemIndexScanInstruction as I, MemIndexScanPredicate as P,
                                  quad_pattern, col, lit_id, lit_tv, lit_bool, integer, int32, double, float32,
                                  decimal, boolean, ENC_TV, GT, LT, GEQ, LEQ, EQ, NEQ, ADD, SUB, EBV, ID_EQ,
-                                 ID_NEQ, AND, OR, NOT, IS_COMPATIBLE, BOUND, BOOLEAN_AS_TERM)
+                                 ID_NEQ, AND, OR, NOT, IS_COMPATIBLE, BOUND, BOOLEAN_AS_TERM, REGEX)
 from oracle import oracle as orc
 import kat_util as ku
 
@@ -486,6 +486,138 @@ def test_index_join_against_store_slice(torch_cuda, shape, n_tab):
         flt = None if mk is None else mk(col(4), col(1))
         run_both(gs, os_, pb.build(pb.hash_join(scan, t, on=[(k_scan, 1)], filter=flt, projection=[2, 3, 0, 1])),
                  gpu_tables=[(ptrs, n_tab)], cpu_tables=[tab])
+
+
+# ---------------------------------------------------------------------------------------------------
+# REGEX: device position automaton vs the oracle's Pike VM, through plans
+# ---------------------------------------------------------------------------------------------------
+def string_dictionary(strings, n_other=5):
+    """Typed values + string heap for ids 1..len(strings) (simple / language-tagged literals) followed by `n_other`
+    non-string ids (integers): REGEX over those is the error value."""
+    n_ids = 1 + len(strings) + n_other
+    tv = np.zeros(n_ids, dtype=TV_DTYPE)
+    order = {s: r for r, s in enumerate(sorted(set(strings)))}
+    offsets = np.zeros(n_ids + 1, dtype=np.uint64)
+    heap = bytearray()
+    for k, s_ in enumerate(strings):
+        i = 1 + k
+        b = s_.encode("utf-8")
+        tv["tag"][i] = abi.TV_STRING
+        tv["lo"][i] = order[s_]
+        tv["aux"][i] = 0 if k % 5 else 7          # every fifth literal carries a language tag: REGEX matches those too
+        tv["flags"][i] = abi.TVF_EMPTY_STRING if not b else 0
+        offsets[i] = len(heap)
+        heap += b
+        offsets[i + 1] = len(heap)
+    for i in range(1 + len(strings), n_ids):
+        tv["tag"][i] = abi.TV_INTEGER
+        tv["lo"][i] = i
+        offsets[i + 1] = len(heap)
+    return tv, offsets, bytes(heap)
+
+
+def test_regex_filter_matches_oracle(torch_cuda):
+    import re
+    rng = np.random.default_rng(99)
+    strings = [ku.random_subject(rng) for _ in range(1500)] + ["", "a", "b", "ab\n", "K", "ſ", "😀"]
+    tv, offsets, heap = string_dictionary(strings)
+    gs, os_ = both_stores((np.zeros(0, np.uint32),) * 4, typed=tv)
+    gs.set_strings(offsets, heap)
+    os_.set_strings(offsets, heap)
+    ids = rng.integers(0, len(tv), 20_000).astype(np.uint32)              # includes 0 (null) and the non-string ids
+    payload = np.arange(len(ids), dtype=np.uint32) + 1
+    keep, ptrs = table_on_device(torch_cuda, [ids, payload])
+    fixed = [("^a$", ""), ("a.c", "s"), ("(ab|cd)+e", ""), ("k", "i"), ("^$", ""), ("b$", "m"), ("a", "z"), ("x{2,}", ""), (".", "q"), ("[^a]", "")]
+    n_random, matched_some = 0, 0
+    while n_random < 150:
+        pat, flags, py, py_flags = ku.random_regex(rng)
+        try:
+            rf.engine.regex_check(pat, flags)
+        except rf.engine.RdfGpuError:
+            continue                                                      # outside the device subset: refused at compile (tested on CPU)
+        fixed.append((pat, flags))
+        n_random += 1
+    for pat, flags in fixed:
+        for negate in (False, True):
+            e = EBV(REGEX(ENC_TV(col(0)), pat, flags))
+            pb = PlanBuilder()
+            desc = pb.build(pb.filter(pb.table(0, 2), NOT(e) if negate else e))
+            plan, got = run_both(gs, os_, desc, gpu_tables=[(ptrs, len(ids))], cpu_tables=[[ids, payload]])
+            matched_some += plan.result_info()[0] > 0
+    assert matched_some > 100
+    # an independent spot check of the device against Python's `re` (not via the oracle)
+    for pat, py in (("(ab|cd)+e", "(ab|cd)+e"), ("^k.*x$", "^k.*x\\Z"), ("[^a]b", "[^a]b")):
+        pb = PlanBuilder()
+        plan = gs.plan(pb.build(pb.filter(pb.table(0, 2), EBV(REGEX(ENC_TV(col(0)), pat, "")), projection=[1])))
+        plan.bind_table(0, ptrs, len(ids))
+        got = np.sort(plan.execute().fetch()[0])
+        rx = re.compile(py)
+        is_str = (ids >= 1) & (ids <= len(strings))
+        exp = np.array([bool(is_str[r]) and rx.search(strings[ids[r] - 1]) is not None for r in range(len(ids))])
+        np.testing.assert_array_equal(got, payload[exp])
+
+
+def test_regex_unsupported_is_refused_loudly(torch_cuda):
+    tv, offsets, heap = string_dictionary(["abc"])
+    gs, _ = both_stores((np.zeros(0, np.uint32),) * 4, typed=tv)
+    pb = PlanBuilder()
+    desc = pb.build(pb.filter(pb.table(0, 1), EBV(REGEX(ENC_TV(col(0)), "a", ""))))
+    with pytest.raises(rf.RdfGpuError):          # no strings installed
+        gs.plan(desc)
+    gs.set_strings(offsets, heap)
+    gs.plan(desc)
+    for bad in ("\\d+", "(?i)a", "a|^b", "[é]"):
+        pb = PlanBuilder()
+        with pytest.raises(rf.RdfGpuError):
+            gs.plan(pb.build(pb.filter(pb.table(0, 1), EBV(REGEX(ENC_TV(col(0)), bad, "")))))
+    pb = PlanBuilder()
+    with pytest.raises(rf.RdfGpuError):          # REGEX over a literal has no lexical form on the device
+        gs.plan(pb.build(pb.filter(pb.table(0, 1), EBV(REGEX(lit_tv(abi.TV_STRING, 0), "a", "")))))
+
+
+def test_lubm_shaped_optional_plus_regex(torch_cuda):
+    """BASELINE config 5 shape: a star join, an OPTIONAL (left-outer join) and a REGEX FILTER over a string-valued
+    variable — `?s type Student . ?s name ?n . OPTIONAL { ?s email ?e } FILTER regex(?n, "^Grad.*[0-9]7$")`."""
+    rng = np.random.default_rng(5)
+    n_students = 4000
+    TYPE, NAME, EMAIL, STUDENT = 1, 2, 3, 4
+    base = 10
+    names = [("GraduateStudent" if rng.random() < 0.5 else "UndergraduateStudent") + str(int(rng.integers(0, 500))) for _ in range(n_students)]
+    emails = [f"s{k}@dept{int(rng.integers(0, 20))}.univ.edu" for k in range(n_students)]
+    strings = names + emails
+    tv, offsets, heap = string_dictionary(strings, n_other=0)
+    # string ids start at 1: shift every id by the entity ids that come first
+    n_entities = base + n_students
+    shift = n_entities
+    tv2 = np.zeros(shift + len(tv), dtype=TV_DTYPE)
+    tv2[shift:] = tv
+    tv2["tag"][1:shift] = abi.TV_NAMED_NODE
+    tv2["lo"][1:shift] = np.arange(1, shift)
+    off2 = np.concatenate([np.zeros(shift, np.uint64), offsets])
+    stu = base + np.arange(n_students, dtype=np.uint32)
+    name_id = (shift + 1 + np.arange(n_students)).astype(np.uint32)
+    email_id = (shift + 1 + n_students + np.arange(n_students)).astype(np.uint32)
+    has_email = rng.random(n_students) < 0.6
+    s_col = np.concatenate([stu, stu, stu[has_email]])
+    p_col = np.concatenate([np.full(n_students, TYPE), np.full(n_students, NAME), np.full(has_email.sum(), EMAIL)]).astype(np.uint32)
+    o_col = np.concatenate([np.full(n_students, STUDENT, np.uint32), name_id, email_id[has_email]])
+    gs, os_ = both_stores((np.zeros(len(s_col), np.uint32), s_col.astype(np.uint32), p_col, o_col.astype(np.uint32)), typed=tv2)
+    gs.set_strings(off2, heap)
+    os_.set_strings(off2, heap)
+    total = 0
+    for pat, flags in (("^Grad.*[0-9]7$", ""), ("student1[0-9]$", "i"), ("^Under", ""), ("7", "q")):
+        pb = PlanBuilder()
+        typ = pb.data_source(quad_pattern("s", TYPE, STUDENT))            # (s)
+        nam = pb.data_source(quad_pattern("s", NAME, "n"))                # (s, n)
+        eml = pb.data_source(quad_pattern("s", EMAIL, "e"))               # (s, e)
+        j = pb.hash_join(typ, nam, on=[(0, 0)], projection=[0, 2])        # (s, n)
+        opt = pb.hash_join(j, eml, on=[(0, 0)], join_type=abi.JOIN_LEFT, projection=[0, 1, 3])   # (s, n, e?)
+        flt = pb.filter(opt, EBV(REGEX(ENC_TV(col(1)), pat, flags)))
+        plan, got = run_both(gs, os_, pb.build(flt))
+        total += plan.result_info()[0]
+        if pat == "^Under":
+            assert (got[2] == 0).any() and (got[2] != 0).any()             # OPTIONAL: bound and unbound ?e both survive
+    assert total > 0
 
 
 def test_generic_vm_equals_specialised_kernels(bsbm_stores, monkeypatch):
