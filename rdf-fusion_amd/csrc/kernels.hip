@@ -494,6 +494,34 @@ __device__ __forceinline__ Val lit_val(const TvLiteral& l) {
 // what the resolve phase runs four-wide; whatever it cannot decide (undecided = true) goes to ljoin_filter_slow,
 // the full reference semantics, of which the kernel holds ONE copy run one candidate at a time — so the promotion
 // machinery (i128 decimals, float/double casts) costs neither registers nor instruction cache on the fast path.
+// The numeric-window predicate  cmp0(ENC_TV(x0), ENC_TV(y0) +/- lit0) AND cmp1(ENC_TV(x1), ENC_TV(y1) +/- lit1)  on four
+// object ids.  window_fast decides the all-xsd:integer case (the BSBM numeric properties) with checked i64 arithmetic;
+// window_slow is the full reference semantics.
+__device__ __forceinline__ bool window_fast(const TypedTable& tt, u32 ix0, u32 iy0, u32 ix1, u32 iy1, bool same,
+                                            const TvLiteral& l0, const TvLiteral& l1, bool& undecided) {
+  const u64 n_ids = tt.n_ids;
+  const bool valid = ix0 && iy0 && ix1 && iy1 && ix0 < n_ids && iy0 < n_ids && ix1 < n_ids && iy1 < n_ids;
+  if (!valid) { undecided = true; return false; }
+  const int4* tv = reinterpret_cast<const int4*>(tt.tv);
+  const int4 rx0 = tv[ix0], ry0 = tv[iy0];
+  const int4 rx1 = same ? rx0 : tv[ix1], ry1 = same ? ry0 : tv[iy1];
+  const u32 tags = ((u32)rx0.w & 0xff) | (((u32)ry0.w & 0xff) << 8) | (((u32)rx1.w & 0xff) << 16) | (((u32)ry1.w & 0xff) << 24);
+  if (tags != RDFGPU_TV_INTEGER * 0x01010101u || l0.tag != RDFGPU_TV_INTEGER || l1.tag != RDFGPU_TV_INTEGER) { undecided = true; return false; }
+  auto i64 = [](const int4& r) { return (long long)(((u64)(u32)r.y << 32) | (u32)r.x); };
+  long long z0, z1;
+  const bool o0 = l0.arith_sub ? __builtin_sub_overflow(i64(ry0), (long long)l0.lo, &z0) : __builtin_add_overflow(i64(ry0), (long long)l0.lo, &z0);
+  const bool o1 = l1.arith_sub ? __builtin_sub_overflow(i64(ry1), (long long)l1.lo, &z1) : __builtin_add_overflow(i64(ry1), (long long)l1.lo, &z1);
+  if (o0 || o1) return false;   // overflow => error => null => not `true`
+  const long long p0 = i64(rx0), p1 = i64(rx1);
+  return cmp_holds(l0.cmp_op, p0 < z0 ? -1 : p0 > z0) && cmp_holds(l1.cmp_op, p1 < z1 ? -1 : p1 > z1);
+}
+__device__ __forceinline__ bool window_slow(const TypedTable& tt, u32 ix0, u32 iy0, u32 ix1, u32 iy1, const TvLiteral& l0, const TvLiteral& l1) {
+  const Val x0 = enc_tv(tt, ix0), y0 = enc_tv(tt, iy0), x1 = enc_tv(tt, ix1), y1 = enc_tv(tt, iy1);
+  const Val z0 = tv_arith(y0, lit_val(l0), l0.arith_sub != 0);
+  const Val z1 = tv_arith(y1, lit_val(l1), l1.arith_sub != 0);
+  return cmp_holds(l0.cmp_op, tv_partial_cmp(x0, z0)) && cmp_holds(l1.cmp_op, tv_partial_cmp(x1, z1));
+}
+
 template <int FS>
 __device__ __forceinline__ bool ljoin_filter_fast(const LdsJoinArgs& a, u32 i, u32 j, bool& undecided) {
   undecided = false;
@@ -503,42 +531,60 @@ __device__ __forceinline__ bool ljoin_filter_fast(const LdsJoinArgs& a, u32 i, u
     if (va == 0 || vb == 0) return false;   // null => not `true`
     return (va == vb) == (a.idp.is_eq != 0);
   } else if constexpr (FS == 3) {
-    // all four operands and both literals xsd:integer (the BSBM numeric properties): checked i64 arithmetic
     const WindowFilter& w = a.win;
     const bool same = w.x0 == w.x1 && w.y0 == w.y1;   // wave-uniform
     const u32 ix0 = ljoin_col(a, w.x0, i, j), iy0 = ljoin_col(a, w.y0, i, j);
     const u32 ix1 = same ? ix0 : ljoin_col(a, w.x1, i, j), iy1 = same ? iy0 : ljoin_col(a, w.y1, i, j);
-    const u64 n_ids = a.tt.n_ids;
-    const bool valid = ix0 && iy0 && ix1 && iy1 && ix0 < n_ids && iy0 < n_ids && ix1 < n_ids && iy1 < n_ids;
-    if (!valid) { undecided = true; return false; }
-    const int4* tv = reinterpret_cast<const int4*>(a.tt.tv);
-    const int4 rx0 = tv[ix0], ry0 = tv[iy0];
-    const int4 rx1 = same ? rx0 : tv[ix1], ry1 = same ? ry0 : tv[iy1];
-    const u32 tags = ((u32)rx0.w & 0xff) | (((u32)ry0.w & 0xff) << 8) | (((u32)rx1.w & 0xff) << 16) | (((u32)ry1.w & 0xff) << 24);
-    if (tags != RDFGPU_TV_INTEGER * 0x01010101u || w.l0.tag != RDFGPU_TV_INTEGER || w.l1.tag != RDFGPU_TV_INTEGER) { undecided = true; return false; }
-    auto i64 = [](const int4& r) { return (long long)(((u64)(u32)r.y << 32) | (u32)r.x); };
-    long long z0, z1;
-    const bool o0 = w.l0.arith_sub ? __builtin_sub_overflow(i64(ry0), (long long)w.l0.lo, &z0) : __builtin_add_overflow(i64(ry0), (long long)w.l0.lo, &z0);
-    const bool o1 = w.l1.arith_sub ? __builtin_sub_overflow(i64(ry1), (long long)w.l1.lo, &z1) : __builtin_add_overflow(i64(ry1), (long long)w.l1.lo, &z1);
-    if (o0 || o1) return false;   // overflow => error => null => not `true`
-    const long long p0 = i64(rx0), p1 = i64(rx1);
-    return cmp_holds(w.l0.cmp_op, p0 < z0 ? -1 : p0 > z0) && cmp_holds(w.l1.cmp_op, p1 < z1 ? -1 : p1 > z1);
+    return window_fast(a.tt, ix0, iy0, ix1, iy1, same, w.l0, w.l1, undecided);
   } else { undecided = true; return false; }
 }
 template <int FS>
 __device__ __forceinline__ bool ljoin_filter_slow(const LdsJoinArgs& a, u32 i, u32 j) {
   if constexpr (FS == 3) {
     const WindowFilter& w = a.win;
-    const Val x0 = enc_tv(a.tt, ljoin_col(a, w.x0, i, j)), y0 = enc_tv(a.tt, ljoin_col(a, w.y0, i, j));
-    const Val x1 = enc_tv(a.tt, ljoin_col(a, w.x1, i, j)), y1 = enc_tv(a.tt, ljoin_col(a, w.y1, i, j));
-    const Val z0 = tv_arith(y0, lit_val(w.l0), w.l0.arith_sub != 0);
-    const Val z1 = tv_arith(y1, lit_val(w.l1), w.l1.arith_sub != 0);
-    return cmp_holds(w.l0.cmp_op, tv_partial_cmp(x0, z0)) && cmp_holds(w.l1.cmp_op, tv_partial_cmp(x1, z1));
+    return window_slow(a.tt, ljoin_col(a, w.x0, i, j), ljoin_col(a, w.y0, i, j), ljoin_col(a, w.x1, i, j), ljoin_col(a, w.y1, i, j), w.l0, w.l1);
   } else if constexpr (FS == 1) {
     const Val r = eval_program(*a.prog, a.tt, [&](u32 col) { return ljoin_col(a, col, i, j); });
     return r.lo == 1;
   } else return false;   // FS 0 / 2 are always decided by the fast half
 }
+// ---- fused lookup chain (ChainStage): stage = direct-table lookup of a base key column + the stage's join filter ----
+__device__ __forceinline__ u32 chain_val(const ColRef& c, u32 i, u32 j, u32 r) { return c.ptr[c.src == 0 ? j : c.src == 1 ? i : r]; }
+__device__ __forceinline__ u32 chain_lookup(const ChainStage& st, u32 i, u32 j) {
+  const u32 key = st.key.ptr[st.key.src ? i : j];
+  const u32 d = key - st.kmin;
+  return (key != 0 && d < st.kn) ? st.direct[d] : kNil;   // null keys never join; kNil = no row with this key
+}
+__device__ __forceinline__ bool stage_filter_fast(const LdsJoinArgs& a, const ChainStage& st, u32 i, u32 j, u32 r, bool& undecided) {
+  undecided = false;
+  if (st.fs == 2) {
+    const u32 va = chain_val(st.f[0], i, j, r), vb = chain_val(st.f[1], i, j, r);
+    if (va == 0 || vb == 0) return false;
+    return (va == vb) == (st.is_eq != 0);
+  }
+  const bool same = st.f[0].ptr == st.f[2].ptr && st.f[0].src == st.f[2].src && st.f[1].ptr == st.f[3].ptr && st.f[1].src == st.f[3].src;
+  const u32 ix0 = chain_val(st.f[0], i, j, r), iy0 = chain_val(st.f[1], i, j, r);
+  const u32 ix1 = same ? ix0 : chain_val(st.f[2], i, j, r), iy1 = same ? iy0 : chain_val(st.f[3], i, j, r);
+  return window_fast(a.tt, ix0, iy0, ix1, iy1, same, st.l0, st.l1, undecided);
+}
+// the whole verdict of one candidate with the full semantics everywhere (base filter + every stage): the single slow copy
+template <int FS>
+__device__ __forceinline__ bool chain_eval_slow(const LdsJoinArgs& a, u32 i, u32 j) {
+  bool und;
+  if constexpr (FS == 1 || FS == 3) { if (!ljoin_filter_slow<FS>(a, i, j)) return false; }
+  else if (!ljoin_filter_fast<FS>(a, i, j, und)) return false;
+  for (u32 t = 0; t < a.n_chain; t++) {
+    const ChainStage& st = a.chain[t];
+    const u32 r = chain_lookup(st, i, j);
+    if (r == kNil) return false;
+    if (st.fs == 2) { if (!stage_filter_fast(a, st, i, j, r, und)) return false; }
+    else if (st.fs == 3) {
+      if (!window_slow(a.tt, chain_val(st.f[0], i, j, r), chain_val(st.f[1], i, j, r), chain_val(st.f[2], i, j, r), chain_val(st.f[3], i, j, r), st.l0, st.l1)) return false;
+    }
+  }
+  return true;
+}
+
 // Fused FilterExec of the probe child: PFS 0 = none, 1 = col <ID_EQ|ID_NEQ> literal, 2 = generic VM.
 template <int PFS>
 __device__ __forceinline__ bool lprobe_filter(const LdsJoinArgs& a, u64 j) {
@@ -610,7 +656,7 @@ void launch_gjoin_build(const LdsJoinArgs& a, hipStream_t s) {
 // of matches per thousand probe rows) pay one atomic per workgroup, dense ones one per a.wave_q matches.
 constexpr int kResolveUnroll = 4;
 
-template <int FS, int PFS, int ITEMS, int MODE>
+template <int FS, int PFS, int ITEMS, int MODE, bool CHAIN>
 __global__ __launch_bounds__(kLdsBlock) void lds_join_kernel(const LdsJoinArgs a) {
   constexpr bool GLOBAL = MODE != kJoinTableLds;      // the table lives in HBM / L2
   constexpr bool DIRECT = MODE == kJoinTableDirect;   // direct-address table: row = direct[key - direct_min]
@@ -654,22 +700,34 @@ __global__ __launch_bounds__(kLdsBlock) void lds_join_kernel(const LdsJoinArgs a
     // four columns at a time: their pointers are fetched (scalar loads) once per call, and a lane has four
     // independent gathers in flight per entry instead of one load -> store chain per column
     for (u32 oc0 = 0; oc0 < a.n_out_cols; oc0 += 4) {
-      const u32* src[4]; u32* dst[4]; bool from_build[4], on[4];
+      const u32* src[4]; u32* dst[4]; u32 from[4]; bool on[4];   // from: 0 probe row, 1 build row, 2 + t chain stage t
 #pragma unroll
       for (u32 u = 0; u < 4; u++) {
         on[u] = oc0 + u < a.n_out_cols;
         const u32 oc = on[u] ? oc0 + u : oc0;
-        const u32 c = a.proj[oc];
-        from_build[u] = (c < a.n_left_cols) == (a.build_is_left != 0);
-        src[u] = a.cols[c]; dst[u] = a.out[oc];
+        if constexpr (CHAIN) { src[u] = a.chain_out[oc].ptr; from[u] = a.chain_out[oc].src; }
+        else {
+          const u32 c = a.proj[oc];
+          from[u] = (c < a.n_left_cols) == (a.build_is_left != 0) ? 1u : 0u;
+          src[u] = a.cols[c];
+        }
+        dst[u] = a.out[oc];
       }
       for (u32 e = lane; e < qn; e += 64) {
         const uint2 m = wq[e];
         const u64 pos = base + e;
         if (pos >= a.out_cap) continue;
+        u32 rr[kMaxChain] = {0, 0, 0};
+        if constexpr (CHAIN) {   // survivors only: the stage rows are looked up again instead of being carried through the queue
+#pragma unroll
+          for (u32 t = 0; t < (u32)kMaxChain; t++) if (t < a.n_chain) rr[t] = chain_lookup(a.chain[t], m.x, m.y);
+        }
         u32 v[4];
 #pragma unroll
-        for (u32 u = 0; u < 4; u++) if (on[u]) v[u] = src[u][from_build[u] ? m.x : m.y];
+        for (u32 u = 0; u < 4; u++) if (on[u]) {
+          const u32 row = from[u] == 0 ? m.y : from[u] == 1 ? m.x : from[u] == 2 ? rr[0] : from[u] == 3 ? rr[1] : rr[2];
+          v[u] = src[u][row];
+        }
 #pragma unroll
         for (u32 u = 0; u < 4; u++) if (on[u]) dst[u][pos] = v[u];
       }
@@ -754,7 +812,7 @@ __global__ __launch_bounds__(kLdsBlock) void lds_join_kernel(const LdsJoinArgs a
     }
     // ---- resolve: join filter over the queued candidates, survivors compacted in place ----
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    if constexpr (FS != 0) {
+    if constexpr (FS != 0 || CHAIN) {
       u32 kept = 0;
       for (u32 g0 = 0; g0 < qn; g0 += 64 * kResolveUnroll) {
         uint2 m[kResolveUnroll]; bool ok[kResolveUnroll];
@@ -770,7 +828,24 @@ __global__ __launch_bounds__(kLdsBlock) void lds_join_kernel(const LdsJoinArgs a
           slow[u] = false;
           if (ok[u]) ok[u] = ljoin_filter_fast<FS>(a, m[u].x, m[u].y, slow[u]);
         }
-        if constexpr (FS == 1 || FS == 3) {
+        if constexpr (CHAIN) {   // stage-major, four candidates wide: each stage's loads are in flight together
+          for (u32 t = 0; t < a.n_chain; t++) {
+            const ChainStage& st = a.chain[t];
+            u32 r[kResolveUnroll];
+#pragma unroll
+            for (int u = 0; u < kResolveUnroll; u++) { r[u] = kNil; if (ok[u]) r[u] = chain_lookup(st, m[u].x, m[u].y); }
+#pragma unroll
+            for (int u = 0; u < kResolveUnroll; u++) {
+              ok[u] = ok[u] && r[u] != kNil;
+              if (ok[u] && st.fs != 0) {
+                bool und;
+                const bool pass = stage_filter_fast(a, st, m[u].x, m[u].y, r[u], und);
+                if (und) { slow[u] = true; ok[u] = false; } else ok[u] = pass;
+              }
+            }
+          }
+        }
+        if constexpr (FS == 1 || FS == 3 || CHAIN) {
           for (;;) {   // the undecided candidates, one per lane and round, through the single copy of the full semantics
             int pick = -1;
 #pragma unroll
@@ -780,7 +855,8 @@ __global__ __launch_bounds__(kLdsBlock) void lds_join_kernel(const LdsJoinArgs a
               uint2 mm = m[0];
 #pragma unroll
               for (int u = 1; u < kResolveUnroll; u++) mm = pick == u ? m[u] : mm;   // value selects keep m[] in registers
-              const bool r = ljoin_filter_slow<FS>(a, mm.x, mm.y);
+              bool r;
+              if constexpr (CHAIN) r = chain_eval_slow<FS>(a, mm.x, mm.y); else r = ljoin_filter_slow<FS>(a, mm.x, mm.y);
 #pragma unroll
               for (int u = 0; u < kResolveUnroll; u++) { ok[u] = pick == u ? r : ok[u]; slow[u] = pick == u ? false : slow[u]; }
             }
@@ -826,14 +902,21 @@ __global__ __launch_bounds__(kLdsBlock) void lds_join_kernel(const LdsJoinArgs a
   write_out(out_base);
 }
 
-template <int FS, int PFS, int ITEMS, int MODE>
-static void launch_lds_join_t(const LdsJoinArgs& a, dim3 g, size_t lds, hipStream_t s) {
+template <int FS, int PFS, int ITEMS, int MODE, bool CHAIN>
+static void launch_lds_join_tc(const LdsJoinArgs& a, dim3 g, size_t lds, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {   // dynamic LDS above 64 KiB has to be opted into, per kernel instance
-    RDFGPU_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lds_join_kernel<FS, PFS, ITEMS, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
+    RDFGPU_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lds_join_kernel<FS, PFS, ITEMS, MODE, CHAIN>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
     attr_set = true;
   }
-  hipLaunchKernelGGL((lds_join_kernel<FS, PFS, ITEMS, MODE>), g, dim3(kLdsBlock), lds, s, a);
+  hipLaunchKernelGGL((lds_join_kernel<FS, PFS, ITEMS, MODE, CHAIN>), g, dim3(kLdsBlock), lds, s, a);
+}
+template <int FS, int PFS, int ITEMS, int MODE>
+static void launch_lds_join_t(const LdsJoinArgs& a, dim3 g, size_t lds, hipStream_t s) {
+  // the fused lookup chain exists for HBM-table joins without a VM filter or a fused probe-side FilterExec
+  if constexpr (FS != 1 && PFS == 0 && MODE != kJoinTableLds) { if (a.n_chain) return launch_lds_join_tc<FS, PFS, ITEMS, MODE, true>(a, g, lds, s); }
+  if (a.n_chain) fail(RDFGPU_ERR_INVALID, "lds join: lookup chain on an unsupported join shape");
+  launch_lds_join_tc<FS, PFS, ITEMS, MODE, false>(a, g, lds, s);
 }
 // Rows per lane and tile: 4 for multi-million-row probes and for LDS tables over ~1 M-row probes (amortises
 // the per-workgroup LDS build), else 1 (many short workgroups; an HBM table has no per-workgroup build to

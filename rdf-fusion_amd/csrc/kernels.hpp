@@ -109,6 +109,20 @@ struct WindowFilter {   // EBV(cmp0(ENC_TV(x0), y0 +/- lit0)) AND EBV(cmp1(ENC_T
 struct IdFilter { u32 col, lit, is_eq; };   // col <ID_EQ | ID_NEQ> object-id literal
 struct IdPairFilter { u32 a, b, is_eq; };   // col a <ID_EQ | ID_NEQ> col b
 
+// A chain of follow-up joins fused into a join's resolve phase: every stage is an inner single-key lookup of a
+// key column of the BASE join in a direct-address table of a store slice (unique dense key), plus the stage's join
+// filter.  Columns are addressed by (source row, pointer): nothing between the base join and the last stage is
+// materialised — late materialisation by row id.
+constexpr int kMaxChain = 3;
+struct ColRef { const u32* ptr; u32 src; u32 pad; };   // src: 0 = base probe row, 1 = base build row, 2 + t = row found by stage t
+struct ChainStage {
+  ColRef key;                 // src 0 / 1 only
+  const u32* direct; u32 kmin, kn;
+  u32 fs;                     // 0 none / 2 `col <=|!=> col` / 3 numeric window
+  ColRef f[4];                // id pair: a, b ; window: x0, y0, x1, y1
+  TvLiteral l0, l1; u32 is_eq, pad;
+};
+
 // ---- K4+K5 fused: LDS-staged hash join for build sides that fit one workgroup's LDS ----
 constexpr u32 kLdsJoinMaxBuild = 8192;   // rows; 16384 slots x 8 B = 128 KiB of the CU's 160 KiB
 struct LdsJoinArgs {
@@ -130,6 +144,9 @@ struct LdsJoinArgs {
   const u32* csr_off;       // non-null: CSR table instead (single dense key, duplicates allowed): direct_n + 1 offsets into csr_rows
   const u32* csr_rows;      // row ids grouped by key; null = identity (the build column is sorted by the key)
   u32 row_lanes_log2;       // CSR: lanes sharing one probe row (its matches are dealt round-robin)
+  u32 n_chain;              // fused follow-up lookups (0 = none); then the output columns are chain_out[], not proj[]
+  ChainStage chain[kMaxChain];
+  ColRef chain_out[kMaxCols];
   u64* n_out_dev;           // exact number of matches (zeroed before launch)
   u64 out_cap;              // rows the out columns can hold (optimistic)
   u32 wave_q;               // entries of each wave's LDS candidate queue (>= 64; 8 queues x 8 B x wave_q of LDS)

@@ -326,13 +326,13 @@ const char* kernel_class_name(int kc) {
       "void rdfgpu::nlj_kernel<true>", "rocprim device scan", "rdfgpu::gjoin_build_kernel", "rdfgpu::gdirect_build_kernel",
       "rdfgpu::minmax_u32_kernel", "rdfgpu::csr_hist_kernel", "rdfgpu::csr_scatter_kernel"};
   if (kc < KC_LDS_JOIN0) return fixed[kc];
-  static std::string names[96];
+  static std::string names[192];
   static std::once_flag once;
   std::call_once(once, [] {
     const char* items[2] = {"4", "1"};
-    for (int f = 0; f < 4; f++) for (int p = 0; p < 3; p++) for (int w = 0; w < 2; w++) for (int m = 0; m < 4; m++)
-      names[((f * 3 + p) * 2 + w) * 4 + m] = "void rdfgpu::lds_join_kernel<" + std::to_string(f) + ", " + std::to_string(p) + ", " +
-                                             items[w] + ", " + std::to_string(m) + ">";
+    for (int f = 0; f < 4; f++) for (int p = 0; p < 3; p++) for (int w = 0; w < 2; w++) for (int m = 0; m < 4; m++) for (int c = 0; c < 2; c++)
+      names[(((f * 3 + p) * 2 + w) * 4 + m) * 2 + c] = "void rdfgpu::lds_join_kernel<" + std::to_string(f) + ", " + std::to_string(p) + ", " +
+                                                       items[w] + ", " + std::to_string(m) + ", " + (c ? "true" : "false") + ">";
   });
   return names[kc - KC_LDS_JOIN0].c_str();
 }
@@ -421,6 +421,7 @@ void Plan::execute() {
   RDFGPU_HIP(hipMemsetAsync(counters, 0, 256 * sizeof(u64), stream));
 
   spec_checks.clear();
+  memo.assign(nodes.size(), DevTable{}); memo_valid.assign(nodes.size(), 0);
   speculative = allow_speculation && !std::getenv("RDFGPU_NO_SPECULATION");
 
   // K1: locate every data source's range in one launch, one host round trip for all of them.  The ranges
@@ -479,6 +480,7 @@ void Plan::execute() {
 }
 
 DevTable Plan::exec_node(u32 idx) {
+  if (memo_valid[idx]) return memo[idx];   // a node runs once per execution, however many operators consume it
   NodeInfo& nd = nodes[idx];
   DevTable t;
   switch (nd.d.kind) {
@@ -502,6 +504,7 @@ DevTable Plan::exec_node(u32 idx) {
     default: fail(RDFGPU_ERR_INVALID, "unknown node kind");
   }
   if (idx != root) metrics.intermediate_rows += t.cap;   // upper bound when the exact count stays on the device
+  if (!(pending_chain && pending_chain->consumed)) { memo[idx] = t; memo_valid[idx] = 1; }   // (a fused chain's output belongs to its top node)
   return t;
 }
 
@@ -617,8 +620,114 @@ bool Plan::choose_build_left(const NodeInfo& nd, const DevTable& L, const DevTab
   return slice_left;
 }
 
+// Fused lookup chain (R4): walks down from `top` through inner single-key hash joins whose one input is a pure store
+// slice with a cached DIRECT-address table and whose other input is a hash join consumed only here.  Only tried on
+// speculative re-executions (cardinalities and tables known from the first run).
+bool Plan::plan_chain(NodeInfo& top, ChainRequest& req) {
+  if (!speculative || !top.has_last || std::getenv("RDFGPU_NO_CHAIN_FUSION") || std::getenv("RDFGPU_NO_TABLE_CACHE")) return false;
+  req.top = &top;
+  std::vector<ChainLink> down;
+  NodeInfo* cur = &top;
+  while ((int)down.size() < kMaxChain) {
+    const rdfgpu_plan_node& d = cur->d;
+    if (d.kind != RDFGPU_NODE_HASH_JOIN || d.join_type != RDFGPU_JOIN_INNER || d.n_keys != 1) break;
+    if (cur->prog.n != 0 && cur->shape != 2 && cur->shape != 3) break;
+    bool found = false;
+    for (int side = 0; side < 2 && !found; side++) {
+      const u32 cs = (u32)(side == 0 ? d.left : d.right), co = (u32)(side == 0 ? d.right : d.left);
+      const NodeInfo& sn = nodes[cs]; const NodeInfo& on = nodes[co];
+      if (sn.d.kind != RDFGPU_NODE_DATA_SOURCE || sources[sn.source].has_residual) continue;
+      if (on.d.kind != RDFGPU_NODE_HASH_JOIN || on.refs != 1) continue;
+      const DevTable S = exec_node(cs);   // a slice: no launch
+      if (S.cap == 0 || S.stable_id == 0) continue;
+      SliceKey sk; sk.n_keys = 1; sk.rows = S.cap; sk.key[0] = S.cols[side == 0 ? d.left_keys[0] : d.right_keys[0]];
+      const SliceTable* st = store->find_slice_table(sk);
+      if (!st || !st->direct) continue;
+      down.push_back(ChainLink{cur, side == 0, S, st});
+      cur = &nodes[co];
+      found = true;
+    }
+    if (!found) break;
+  }
+  if (down.empty()) return false;
+  req.links.assign(down.rbegin(), down.rend());   // bottom-up: links[0] sits directly above the base join
+  return true;
+}
+
+// Resolves the chain against the base join's inputs; false (nothing changed in `a` that matters) if some column cannot
+// be addressed the way the kernel needs.
+bool Plan::apply_chain(const ChainRequest& req, NodeInfo& base, const DevTable& L, const DevTable& R, bool build_left, LdsJoinArgs& a, u64& stage_bytes) {
+  std::vector<ColRef> cur(base.n_proj);
+  for (u32 k = 0; k < base.n_proj; k++) {
+    const u32 c = base.proj[k];
+    const bool from_left = c < L.n_cols;
+    cur[k] = ColRef{from_left ? L.cols[c] : R.cols[c - L.n_cols], (from_left == build_left) ? 1u : 0u, 0u};
+  }
+  ChainStage stages[kMaxChain];
+  stage_bytes = 0;
+  for (size_t t = 0; t < req.links.size(); t++) {
+    const ChainLink& ln = req.links[t];
+    const NodeInfo& N = *ln.node;
+    const u32 wl = nodes[N.d.left].width;
+    const u32 prev_w = ln.slice_is_left ? nodes[N.d.right].width : wl;
+    if (prev_w != cur.size()) return false;
+    bool bad = false;
+    auto resolve = [&](u32 c) -> ColRef {
+      const bool in_left = c < wl; const u32 local = in_left ? c : c - wl;
+      if (in_left == ln.slice_is_left) { if (local >= ln.slice.n_cols) { bad = true; return ColRef{}; } return ColRef{ln.slice.cols[local], 2u + (u32)t, 0u}; }
+      if (local >= cur.size()) { bad = true; return ColRef{}; }
+      return cur[local];
+    };
+    ChainStage& st = stages[t];
+    std::memset(&st, 0, sizeof st);
+    const u32 prev_key = ln.slice_is_left ? N.d.right_keys[0] : N.d.left_keys[0];
+    if (prev_key >= cur.size()) return false;
+    st.key = cur[prev_key];
+    if (st.key.src > 1) return false;                       // the kernel looks a stage up from a BASE column
+    st.direct = ln.table->direct; st.kmin = ln.table->kmin; st.kn = ln.table->kn;
+    u32 n_fcols = 0;
+    if (N.prog.n == 0) st.fs = 0;
+    else if (N.shape == 2) {
+      st.fs = 2; n_fcols = 2;
+      st.f[0] = resolve(N.prog.nodes[0].u); st.f[1] = resolve(N.prog.nodes[1].u);
+      st.is_eq = N.prog.nodes[2].op == RDFGPU_EX_ID_EQ;
+    } else if (N.shape == 3) {
+      const rdfgpu_expr_node* e = N.prog.nodes;
+      auto lit = [&](u32 o) { TvLiteral l{}; l.lo = e[o + 4].lo; l.hi = e[o + 4].hi; l.aux = e[o + 4].u; l.tag = e[o + 4].tag; l.flags = e[o + 4].flags;
+                              l.arith_sub = e[o + 5].op == RDFGPU_EX_SUB; l.cmp_op = e[o + 6].op; return l; };
+      st.fs = 3; n_fcols = 4;
+      st.f[0] = resolve(e[0].u); st.f[1] = resolve(e[2].u); st.f[2] = resolve(e[8].u); st.f[3] = resolve(e[10].u);
+      st.l0 = lit(0); st.l1 = lit(8);
+    } else return false;
+    for (u32 q = 0; q < n_fcols; q++) if (st.f[q].src > 1 && st.f[q].src != 2u + (u32)t) return false;   // base columns or this stage's
+    std::vector<ColRef> next(N.n_proj);
+    for (u32 k = 0; k < N.n_proj; k++) next[k] = resolve(N.proj[k]);
+    if (bad) return false;
+    cur.swap(next);
+    stage_bytes += base.last_rows * (8ull + 4ull * n_fcols);   // per candidate: key + table slot + filter operands (estimate)
+  }
+  if (cur.size() != req.top->n_proj || cur.size() > (size_t)kMaxCols) return false;
+  a.n_chain = (u32)req.links.size();
+  for (size_t t = 0; t < req.links.size(); t++) a.chain[t] = stages[t];
+  for (size_t k = 0; k < cur.size(); k++) a.chain_out[k] = cur[k];
+  a.n_out_cols = (u32)cur.size();
+  return true;
+}
+
 DevTable Plan::exec_join(NodeInfo& nd) {
   const bool left_join = nd.d.join_type == RDFGPU_JOIN_LEFT;
+  if (!pending_chain) {
+    ChainRequest req;
+    if (plan_chain(nd, req)) {
+      NodeInfo* base = req.links.front().slice_is_left ? &nodes[req.links.front().node->d.right] : &nodes[req.links.front().node->d.left];
+      req.base = base;
+      pending_chain = &req;
+      const DevTable fused = exec_node((u32)(base - nodes.data()));
+      pending_chain = nullptr;
+      if (req.consumed) return fused;      // `fused` already has this node's schema
+      // not taken (the base join ran normally and is memoised): continue the ordinary way
+    }
+  }
   // Pipeline fusion: a FilterExec child (identity projection, consumed by this join only) is not
   // materialised when it ends up on the probe side of the LDS join — its predicate runs inside the probe.
   auto fusable = [&](int32_t ci) {
@@ -922,13 +1031,25 @@ DevTable Plan::exec_lds_join(NodeInfo& nd, const DevTable& L, const DevTable& R,
   // the overflow flag is checked once at the end of the plan (Plan::execute), which re-runs exactly if any
   // speculation failed.
   if (speculative && nd.has_last) {
-    const u64 spec_cap = std::max<u64>(1024, nd.last_rows + nd.last_rows / 4 + 256);   // 25 % head room over the previous run
+    // a fusable run of follow-up lookups above this join (Plan::plan_chain) executes inside this join's resolve
+    // phase: the output is then the TOP node's, sized from the top node's history
+    NodeInfo* size_node = &nd;
+    u64 stage_bytes = 0;
+    if (pending_chain && pending_chain->base == &nd && !pending_chain->consumed && global_table && !left_join && !probe_filter && nd.shape != 1 &&
+        apply_chain(*pending_chain, nd, L, R, build_left, a, stage_bytes)) {
+      pending_chain->consumed = true;
+      size_node = pending_chain->top;
+      t.n_cols = a.n_out_cols;
+    }
+    const bool chained = a.n_chain != 0;
+    const u64 spec_cap = std::max<u64>(1024, size_node->last_rows + size_node->last_rows / 4 + 256);   // 25 % head room over the previous run
     a.out_cap = spec_cap;
-    for (u32 c = 0; c < nd.n_proj; c++) { a.out[c] = scratch<u32>(spec_cap + tail); t.cols[c] = a.out[c]; }
+    for (u32 c = 0; c < a.n_out_cols; c++) { a.out[c] = scratch<u32>(spec_cap + tail); t.cols[c] = a.out[c]; }
     if (left_join) RDFGPU_HIP(hipMemsetAsync(a.visited, 0, L.cap, stream));
-    timed(lds_join_class(a.has_filter, a.has_probe_filter, lds_join_items(P.cap << a.row_lanes_log2, global_table), lds_join_mode(a)), global_table ? 0 : fixed, P.cap, P.n_dev,
-          4ull * probe_cols + 8, n_out, 0, 4ull * nd.n_proj, [&] { launch_lds_join(a, stream); });
-    spec_checks.push_back({&nd, (u32)(n_out - counters), left_join});
+    timed(lds_join_class(a.has_filter, a.has_probe_filter, lds_join_items(P.cap << a.row_lanes_log2, global_table), lds_join_mode(a), chained),
+          (global_table ? 0 : fixed) + stage_bytes, P.cap, P.n_dev,
+          4ull * probe_cols + 8, n_out, 0, 4ull * a.n_out_cols, [&] { launch_lds_join(a, stream); });
+    spec_checks.push_back({size_node, (u32)(n_out - counters), left_join});
     t.cap = spec_cap + tail; t.n_dev = n_out;
     if (left_join) {
       JoinArgs ja{};

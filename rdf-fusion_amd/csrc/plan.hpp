@@ -34,6 +34,11 @@ struct NodeInfo {
 };
 struct SpecCheck { NodeInfo* node; u32 counter; bool left_join; };   // counter = n_out slot, counter+1 = overflow flag
 
+// A run of inner single-key joins above a base join whose other inputs are store slices with cached direct-address
+// tables: handed to the base join, which runs them inside its resolve phase (kernels.hpp ChainStage).
+struct ChainLink { NodeInfo* node; bool slice_is_left; DevTable slice; const SliceTable* table; };
+struct ChainRequest { NodeInfo* top = nullptr; NodeInfo* base = nullptr; std::vector<ChainLink> links /* bottom-up */; bool consumed = false; };
+
 struct BoundTable { std::vector<const u32*> cols; u64 n_rows = 0; bool bound = false; };
 
 // Kernel classes for per-kernel timing; names are what rocprofv3 --kernel-trace prints.
@@ -42,12 +47,12 @@ enum KernelClass {
   KC_JOIN_COUNT, KC_JOIN_WRITE, KC_LEFT_TAIL, KC_NLJ_COUNT, KC_NLJ_WRITE, KC_DEVICE_SCAN,
   KC_GJOIN_BUILD,
   KC_GDIRECT_BUILD, KC_MINMAX, KC_CSR_HIST, KC_CSR_SCATTER,
-  KC_LDS_JOIN0,                      // 96 instantiations: lds_join_kernel<FS in {0..3}, PFS in {0,1,2}, ITEMS in {4,1}, MODE in {0,1,2,3}>
-  KC__N = KC_LDS_JOIN0 + 96
+  KC_LDS_JOIN0,                      // 192 names: lds_join_kernel<FS in {0..3}, PFS in {0,1,2}, ITEMS in {4,1}, MODE in {0,1,2,3}, CHAIN>
+  KC__N = KC_LDS_JOIN0 + 192
 };
 const char* kernel_class_name(int kc);
-inline int lds_join_class(u32 fs, u32 pfs, int items, int mode) {
-  return KC_LDS_JOIN0 + (int)(((fs * 3 + pfs) * 2 + (items == 4 ? 0 : 1)) * 4) + mode;
+inline int lds_join_class(u32 fs, u32 pfs, int items, int mode, bool chain = false) {
+  return KC_LDS_JOIN0 + (int)((((fs * 3 + pfs) * 2 + (items == 4 ? 0 : 1)) * 4 + mode) * 2) + (chain ? 1 : 0);
 }
 
 struct KernelStat { u32 launches = 0; double ms = 0; u64 bytes = 0; u64 rows = 0; };
@@ -89,6 +94,8 @@ struct Plan {
   bool allow_speculation = true, speculative = false;
   std::vector<SpecCheck> spec_checks;
   std::vector<PendingLaunch> pending;
+  std::vector<DevTable> memo; std::vector<char> memo_valid;   // node results of the current execution
+  ChainRequest* pending_chain = nullptr;                        // set while the base join of a fusable chain executes
   u32 events_used = 0;
   KernelStat kstats[KC__N];
   // Arrow batch stream over a host copy of the result
@@ -105,6 +112,8 @@ struct Plan {
   DevTable exec_join(NodeInfo& nd);
   DevTable apply_filter(NodeInfo& nd, const DevTable& in);
   DevTable exec_lds_join(NodeInfo& nd, const DevTable& L, const DevTable& R, bool build_left, const NodeInfo* probe_filter);
+  bool plan_chain(NodeInfo& top, ChainRequest& req);
+  bool apply_chain(const ChainRequest& req, NodeInfo& base, const DevTable& L, const DevTable& R, bool build_left, LdsJoinArgs& a, u64& stage_bytes);
   bool choose_build_left(const NodeInfo& nd, const DevTable& L, const DevTable& R, bool left_join, bool lf, bool rf) const;
   void release_intermediates();
   template <class T> T* scratch(u64 n);

@@ -475,10 +475,10 @@ def test_index_join_against_store_slice(torch_cuda, shape, n_tab):
         plan.enable_kernel_timing(True)
         again = plan.execute().fetch()                                    # second run: cached table, speculative sizes
         np.testing.assert_array_equal(ku.multiset(again), ku.multiset(got))
-        if n_tab == 700:   # the table mode is the last template argument of the kernel name: 2 direct, 3 CSR, 1 hash
+        if n_tab == 700:   # the table mode is the fourth template argument of the kernel name: 2 direct, 3 CSR, 1 hash
             mode = {"unique_dense": "2", "dup_sorted": "3", "dup_scattered": "3", "sparse": "1"}[shape]
             joins = [k[0] for k in plan.kernel_stats() if "lds_join_kernel" in k[0]]
-            assert joins and all(k.rstrip(">").split(", ")[-1] == mode for k in joins), (shape, joins)
+            assert joins and all(k.rstrip(">").split(", ")[3] == mode for k in joins), (shape, joins)
         # and with the inputs swapped (the slice as the plan's left child: (s, o) at 0, 1; the table at 2, 3, 4)
         pb = PlanBuilder()
         scan = pb.data_source(quad_pattern("s", pred, "o"))
@@ -618,6 +618,36 @@ def test_lubm_shaped_optional_plus_regex(torch_cuda):
         if pat == "^Under":
             assert (got[2] == 0).any() and (got[2] != 0).any()             # OPTIONAL: bound and unbound ?e both survive
     assert total > 0
+
+
+def test_fused_lookup_chain_equals_unfused(bsbm_stores, torch_cuda, monkeypatch):
+    """Re-executions of the batched Q5 run the window / label joins inside the candidate join's resolve phase (one
+    kernel, nothing materialised in between); every execution must still equal the oracle, also when the parameters
+    change between executions, and equal the unfused engine."""
+    ds, gs, os_ = bsbm_stores
+    desc = bsbm.q5_batch_plan(ds)
+    plan = gs.plan(desc)
+    rng = np.random.default_rng(77)
+    fused_seen = False
+    for it in range(4):
+        batch = 150 + 40 * it
+        prods = np.array([ds.product(i) for i in rng.choice(ds.n_products, batch, replace=False)], dtype=np.uint32)
+        params = [np.arange(1, batch + 1, dtype=np.uint32), prods]
+        keep, ptrs = table_on_device(torch_cuda, params)
+        plan.bind_table(0, ptrs, batch)
+        plan.enable_kernel_timing(True)
+        got = plan.execute().fetch()
+        exp, n_exp, _ = os_.execute(desc, [params])
+        np.testing.assert_array_equal(ku.multiset(got), ku.multiset(exp, n_exp))
+        names = [k[0] for k in plan.kernel_stats()]
+        fused_seen = fused_seen or any(n.endswith("true>") for n in names)
+        if it == 3:
+            monkeypatch.setenv("RDFGPU_NO_CHAIN_FUSION", "1")
+            plain = plan.execute().fetch()
+            assert not any(k[0].endswith("true>") for k in plan.kernel_stats())
+            np.testing.assert_array_equal(ku.multiset(plain), ku.multiset(got))
+            monkeypatch.delenv("RDFGPU_NO_CHAIN_FUSION")
+    assert fused_seen, "the lookup chain was never fused"
 
 
 def test_generic_vm_equals_specialised_kernels(bsbm_stores, monkeypatch):
