@@ -497,23 +497,33 @@ __device__ __forceinline__ Val lit_val(const TvLiteral& l) {
 // The numeric-window predicate  cmp0(ENC_TV(x0), ENC_TV(y0) +/- lit0) AND cmp1(ENC_TV(x1), ENC_TV(y1) +/- lit1)  on four
 // object ids.  window_fast decides the all-xsd:integer case (the BSBM numeric properties) with checked i64 arithmetic;
 // window_slow is the full reference semantics.
+// BRANCH-FREE on purpose: every lane-divergent `if` costs ~5 scalar instructions of exec-mask bookkeeping, and this
+// runs once per candidate pair; dead or invalid lanes read entry 0 of the typed-value table (the null id: tag 0), which
+// simply fails the all-integer test.
 __device__ __forceinline__ bool window_fast(const TypedTable& tt, u32 ix0, u32 iy0, u32 ix1, u32 iy1, bool same,
                                             const TvLiteral& l0, const TvLiteral& l1, bool& undecided) {
+  if (tt.n_ids == 0) { undecided = true; return false; }   // wave-uniform
   const u64 n_ids = tt.n_ids;
-  const bool valid = ix0 && iy0 && ix1 && iy1 && ix0 < n_ids && iy0 < n_ids && ix1 < n_ids && iy1 < n_ids;
-  if (!valid) { undecided = true; return false; }
+  ix0 = ix0 < n_ids ? ix0 : 0u; iy0 = iy0 < n_ids ? iy0 : 0u; ix1 = ix1 < n_ids ? ix1 : 0u; iy1 = iy1 < n_ids ? iy1 : 0u;
   const int4* tv = reinterpret_cast<const int4*>(tt.tv);
   const int4 rx0 = tv[ix0], ry0 = tv[iy0];
-  const int4 rx1 = same ? rx0 : tv[ix1], ry1 = same ? ry0 : tv[iy1];
+  const int4 rx1 = same ? rx0 : tv[ix1], ry1 = same ? ry0 : tv[iy1];   // `same` is wave-uniform
   const u32 tags = ((u32)rx0.w & 0xff) | (((u32)ry0.w & 0xff) << 8) | (((u32)rx1.w & 0xff) << 16) | (((u32)ry1.w & 0xff) << 24);
-  if (tags != RDFGPU_TV_INTEGER * 0x01010101u || l0.tag != RDFGPU_TV_INTEGER || l1.tag != RDFGPU_TV_INTEGER) { undecided = true; return false; }
+  undecided = tags != RDFGPU_TV_INTEGER * 0x01010101u || l0.tag != RDFGPU_TV_INTEGER || l1.tag != RDFGPU_TV_INTEGER;
   auto i64 = [](const int4& r) { return (long long)(((u64)(u32)r.y << 32) | (u32)r.x); };
+  // y +/- lit as y + d with d = +/-lit (wave-uniform; lit = i64::MIN under SUB cannot be negated: left to the slow half)
+  const bool neg0 = l0.arith_sub != 0, neg1 = l1.arith_sub != 0;
+  undecided = undecided || (neg0 && l0.lo == INT64_MIN) || (neg1 && l1.lo == INT64_MIN);
+  const long long d0 = neg0 ? -(long long)(l0.lo == INT64_MIN ? 0 : l0.lo) : (long long)l0.lo;
+  const long long d1 = neg1 ? -(long long)(l1.lo == INT64_MIN ? 0 : l1.lo) : (long long)l1.lo;
   long long z0, z1;
-  const bool o0 = l0.arith_sub ? __builtin_sub_overflow(i64(ry0), (long long)l0.lo, &z0) : __builtin_add_overflow(i64(ry0), (long long)l0.lo, &z0);
-  const bool o1 = l1.arith_sub ? __builtin_sub_overflow(i64(ry1), (long long)l1.lo, &z1) : __builtin_add_overflow(i64(ry1), (long long)l1.lo, &z1);
-  if (o0 || o1) return false;   // overflow => error => null => not `true`
+  const bool o0 = __builtin_add_overflow(i64(ry0), d0, &z0), o1 = __builtin_add_overflow(i64(ry1), d1, &z1);
   const long long p0 = i64(rx0), p1 = i64(rx1);
-  return cmp_holds(l0.cmp_op, p0 < z0 ? -1 : p0 > z0) && cmp_holds(l1.cmp_op, p1 < z1 ? -1 : p1 > z1);
+  // cmp_holds as a 3-bit truth table over (less, equal, greater): wave-uniform masks, two selects per comparison
+  auto mask_of = [](u8 op) -> u32 { return op == RDFGPU_EX_GT ? 4u : op == RDFGPU_EX_LT ? 1u : op == RDFGPU_EX_GEQ ? 6u : op == RDFGPU_EX_LEQ ? 3u : op == RDFGPU_EX_EQ ? 2u : 5u; };
+  const u32 m0 = mask_of(l0.cmp_op), m1 = mask_of(l1.cmp_op);
+  const u32 c0 = p0 < z0 ? 1u : p0 > z0 ? 4u : 2u, c1 = p1 < z1 ? 1u : p1 > z1 ? 4u : 2u;
+  return !o0 && !o1 && (m0 & c0) != 0 && (m1 & c1) != 0;   // overflow => error => null => not `true`
 }
 __device__ __forceinline__ bool window_slow(const TypedTable& tt, u32 ix0, u32 iy0, u32 ix1, u32 iy1, const TvLiteral& l0, const TvLiteral& l1) {
   const Val x0 = enc_tv(tt, ix0), y0 = enc_tv(tt, iy0), x1 = enc_tv(tt, ix1), y1 = enc_tv(tt, iy1);
@@ -549,18 +559,20 @@ __device__ __forceinline__ bool ljoin_filter_slow(const LdsJoinArgs& a, u32 i, u
   } else return false;   // FS 0 / 2 are always decided by the fast half
 }
 // ---- fused lookup chain (ChainStage): stage = direct-table lookup of a base key column + the stage's join filter ----
+// (branch-free like window_fast: a dead lane passes live = false and reads row 0 of whatever it is pointed at)
 __device__ __forceinline__ u32 chain_val(const ColRef& c, u32 i, u32 j, u32 r) { return c.ptr[c.src == 0 ? j : c.src == 1 ? i : r]; }
-__device__ __forceinline__ u32 chain_lookup(const ChainStage& st, u32 i, u32 j) {
-  const u32 key = st.key.ptr[st.key.src ? i : j];
+__device__ __forceinline__ u32 chain_lookup(const ChainStage& st, u32 i, u32 j, bool live = true) {
+  const u32 key = st.key.ptr[live ? (st.key.src ? i : j) : 0u];
   const u32 d = key - st.kmin;
-  return (key != 0 && d < st.kn) ? st.direct[d] : kNil;   // null keys never join; kNil = no row with this key
+  const bool in = live && key != 0 && d < st.kn;          // null keys never join
+  const u32 row = st.direct[in ? d : 0u];
+  return in ? row : kNil;                                  // kNil = no row with this key
 }
 __device__ __forceinline__ bool stage_filter_fast(const LdsJoinArgs& a, const ChainStage& st, u32 i, u32 j, u32 r, bool& undecided) {
   undecided = false;
-  if (st.fs == 2) {
+  if (st.fs == 2) {   // wave-uniform
     const u32 va = chain_val(st.f[0], i, j, r), vb = chain_val(st.f[1], i, j, r);
-    if (va == 0 || vb == 0) return false;
-    return (va == vb) == (st.is_eq != 0);
+    return va != 0 && vb != 0 && (va == vb) == (st.is_eq != 0);
   }
   const bool same = st.f[0].ptr == st.f[2].ptr && st.f[0].src == st.f[2].src && st.f[1].ptr == st.f[3].ptr && st.f[1].src == st.f[3].src;
   const u32 ix0 = chain_val(st.f[0], i, j, r), iy0 = chain_val(st.f[1], i, j, r);
@@ -833,14 +845,17 @@ __global__ __launch_bounds__(kLdsBlock) void lds_join_kernel(const LdsJoinArgs a
             const ChainStage& st = a.chain[t];
             u32 r[kResolveUnroll];
 #pragma unroll
-            for (int u = 0; u < kResolveUnroll; u++) { r[u] = kNil; if (ok[u]) r[u] = chain_lookup(st, m[u].x, m[u].y); }
+            for (int u = 0; u < kResolveUnroll; u++) r[u] = chain_lookup(st, m[u].x, m[u].y, ok[u]);   // branch-free: dead lanes read row 0
 #pragma unroll
-            for (int u = 0; u < kResolveUnroll; u++) {
-              ok[u] = ok[u] && r[u] != kNil;
-              if (ok[u] && st.fs != 0) {
+            for (int u = 0; u < kResolveUnroll; u++) ok[u] = ok[u] && r[u] != kNil;
+            if (st.fs != 0) {   // wave-uniform
+#pragma unroll
+              for (int u = 0; u < kResolveUnroll; u++) {
                 bool und;
-                const bool pass = stage_filter_fast(a, st, m[u].x, m[u].y, r[u], und);
-                if (und) { slow[u] = true; ok[u] = false; } else ok[u] = pass;
+                const u32 ci = ok[u] ? m[u].x : 0u, cj = ok[u] ? m[u].y : 0u, cr = ok[u] ? r[u] : 0u;
+                const bool pass = stage_filter_fast(a, st, ci, cj, cr, und);
+                slow[u] = slow[u] || (ok[u] && und);
+                ok[u] = ok[u] && !und && pass;
               }
             }
           }
