@@ -824,7 +824,7 @@ __global__ __launch_bounds__(kLdsBlock) void lds_join_kernel(const LdsJoinArgs a
     }
     // ---- resolve: join filter over the queued candidates, survivors compacted in place ----
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    if constexpr (FS != 0 || CHAIN) {
+    if (FS != 0 || CHAIN || a.has_post) {
       u32 kept = 0;
       for (u32 g0 = 0; g0 < qn; g0 += 64 * kResolveUnroll) {
         uint2 m[kResolveUnroll]; bool ok[kResolveUnroll];
@@ -835,6 +835,15 @@ __global__ __launch_bounds__(kLdsBlock) void lds_join_kernel(const LdsJoinArgs a
           if (ok[u]) m[u] = wq[e];
         }
         bool slow[kResolveUnroll];
+        if (a.has_post) {   // wave-uniform: the former build-side FilterExec (`col <=|!=> literal`)
+          const bool post_from_build = (a.post.col < a.n_left_cols) == (a.build_is_left != 0);
+          const u32* pc = a.cols[a.post.col];
+#pragma unroll
+          for (int u = 0; u < kResolveUnroll; u++) {
+            const u32 v = pc[ok[u] ? (post_from_build ? m[u].x : m[u].y) : 0u];
+            ok[u] = ok[u] && v != 0 && a.post.lit != 0 && ((v == a.post.lit) == (a.post.is_eq != 0));
+          }
+        }
 #pragma unroll
         for (int u = 0; u < kResolveUnroll; u++) {
           slow[u] = false;

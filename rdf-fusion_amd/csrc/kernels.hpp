@@ -162,6 +162,9 @@ struct LdsJoinArgs {
   WindowFilter win;               // has_filter == 3
   IdPairFilter idp;               // has_filter == 2
   IdFilter pid;                   // has_probe_filter == 1; pid.col indexes cols[] directly
+  // A `col <=|!=> literal` FilterExec that sat on the BUILD side's input (a store slice whose cached table must stay
+  // unfiltered): applied to every candidate pair as one more conjunct of the join filter.  post.col indexes cols[].
+  u32 has_post; IdFilter post;
 };
 void launch_lds_join(const LdsJoinArgs& a, hipStream_t s);
 void launch_gjoin_build(const LdsJoinArgs& a, hipStream_t s);   // fills a.gslots (memset to 0xFF first)

@@ -600,11 +600,12 @@ static u32 pow2_at_least(u64 v) { u64 p = 1024; while (p < v && p < (1ull << 31)
 // built once and cached on the node, so building there costs nothing per execution and the probe is the SMALL side
 // (an index nested-loop join against the store's own permutation: `PARAMS JOIN (?s p ?o)` touches |PARAMS| rows,
 // not the 5 M-row predicate partition).
-bool Plan::choose_build_left(const NodeInfo& nd, const DevTable& L, const DevTable& R, bool left_join, bool lf, bool rf) const {
+bool Plan::choose_build_left(const NodeInfo& nd, const DevTable& L, const DevTable& R, bool left_join, bool lf, bool rf, bool lpost, bool rpost) const {
   if (left_join) return true;
   const bool smaller_left = L.cap <= R.cap;
   if (nd.d.kind != RDFGPU_NODE_HASH_JOIN || nd.d.n_keys != 1 || std::getenv("RDFGPU_NO_TABLE_CACHE") || std::getenv("RDFGPU_NO_INDEX_JOIN")) return smaller_left;
-  const bool ls = L.stable_id != 0 && L.n_dev == nullptr && !lf, rs = R.stable_id != 0 && R.n_dev == nullptr && !rf;
+  // (a slice under a `col <=|!=> literal` FilterExec still counts: that filter can run as a conjunct of the join filter)
+  const bool ls = L.stable_id != 0 && L.n_dev == nullptr && (!lf || lpost), rs = R.stable_id != 0 && R.n_dev == nullptr && (!rf || rpost);
   if (!ls && !rs) return smaller_left;
   // candidate: build on the slice (the larger one when both inputs are slices), probe with the other input
   const bool slice_left = ls && rs ? !smaller_left : ls;
@@ -740,9 +741,19 @@ DevTable Plan::exec_join(NodeInfo& nd) {
   bool lf = !left_join && fusable(nd.d.left), rf = fusable(nd.d.right);
   DevTable L = lf ? exec_node((u32)nodes[nd.d.left].d.left) : exec_node((u32)nd.d.left);
   DevTable R = rf ? exec_node((u32)nodes[nd.d.right].d.left) : exec_node((u32)nd.d.right);
+  const NodeInfo* post = nullptr;   // a build-side FilterExec kept as a conjunct of the join filter (see below)
   if (lf || rf) {
-    const bool build_left = choose_build_left(nd, L, R, left_join, lf, rf);
+    // `col <=|!=> literal` over a store slice: if the join builds on that slice (index join through the slice's cached
+    // table) the FilterExec is neither materialised nor fused into the probe — it becomes one more conjunct of the
+    // join filter, evaluated on the candidate pairs
+    auto postable = [&](bool has, int32_t ci, const DevTable& in) {
+      return has && nodes[ci].shape == 1 && in.stable_id != 0 && in.n_dev == nullptr && in.cap > 1024 && nd.d.n_keys == 1 && !std::getenv("RDFGPU_NO_INDEX_JOIN");
+    };
+    const bool lpost = postable(lf, nd.d.left, L), rpost = postable(rf, nd.d.right, R);
+    const bool build_left = choose_build_left(nd, L, R, left_join, lf, rf, lpost, rpost);
     const bool lds = ((build_left ? L.cap : R.cap) <= kLdsJoinMaxBuild || !std::getenv("RDFGPU_NO_GLOBAL_TABLE_JOIN")) && L.cap && R.cap;
+    if (lds && lf && build_left && lpost) { post = &nodes[nd.d.left]; lf = false; }
+    else if (lds && rf && !build_left && rpost) { post = &nodes[nd.d.right]; rf = false; }
     // a fused filter survives only on the probe side of the LDS join; anything else is materialised now
     if (lf && (!lds || build_left)) { L = apply_filter(nodes[nd.d.left], L); lf = false; }
     if (rf && (!lds || !build_left)) { R = apply_filter(nodes[nd.d.right], R); rf = false; }
@@ -776,7 +787,8 @@ DevTable Plan::exec_join(NodeInfo& nd) {
     const bool build_left = choose_build_left(nd, L, R, left_join, lf, rf);
     if ((build_left ? L.cap : R.cap) <= kLdsJoinMaxBuild || !std::getenv("RDFGPU_NO_GLOBAL_TABLE_JOIN")) {
       const NodeInfo* pf = lf ? &nodes[nd.d.left] : rf ? &nodes[nd.d.right] : nullptr;
-      return exec_lds_join(nd, L, R, build_left, pf);
+      if (post && build_left != (post == &nodes[nd.d.left])) fail(RDFGPU_ERR_DEVICE, "join: build side changed under a residual filter");
+      return exec_lds_join(nd, L, R, build_left, pf, post);
     }
   }
   JoinArgs a{};
@@ -847,7 +859,7 @@ DevTable Plan::exec_join(NodeInfo& nd) {
 }
 
 // HashJoinExec whose build side fits one workgroup's LDS: one fused kernel, optimistic output capacity.
-DevTable Plan::exec_lds_join(NodeInfo& nd, const DevTable& L, const DevTable& R, bool build_left, const NodeInfo* probe_filter) {
+DevTable Plan::exec_lds_join(NodeInfo& nd, const DevTable& L, const DevTable& R, bool build_left, const NodeInfo* probe_filter, const NodeInfo* post_filter) {
   const bool left_join = nd.d.join_type == RDFGPU_JOIN_LEFT;
   const DevTable& B = build_left ? L : R;
   const DevTable& P = build_left ? R : L;
@@ -941,7 +953,8 @@ DevTable Plan::exec_lds_join(NodeInfo& nd, const DevTable& L, const DevTable& R,
       if (st->csr_off) {
         a.csr_off = st->csr_off; a.csr_rows = st->csr_rows; a.direct_min = st->kmin; a.direct_n = st->kn;
         // lanes per probe row: a small probe side with a large fan-out is spread over the chip
-        const u64 fan = nd.has_last ? nd.last_rows / (P.cap ? P.cap : 1) : 1;
+        // (first execution: the table's mean rows per key stands in for the unknown fan-out)
+        const u64 fan = nd.has_last ? nd.last_rows / (P.cap ? P.cap : 1) : B.cap / (st->kn ? st->kn : 1);
         u32 rl = 0;
         while (rl < 6 && (2ull << rl) <= fan && (P.cap << (rl + 1)) <= (1ull << 21)) rl++;
         a.row_lanes_log2 = rl;
@@ -1000,6 +1013,11 @@ DevTable Plan::exec_lds_join(NodeInfo& nd, const DevTable& L, const DevTable& R,
       a.pid.col = a.probe_col_base + e[0].u; a.pid.lit = e[1].u; a.pid.is_eq = e[2].op == RDFGPU_EX_ID_EQ;
     } else a.probe_prog = upload_program(probe_filter->prog);
   }
+  if (post_filter) {   // FilterExec of the build side's input, columns relative to that input
+    const rdfgpu_expr_node* e = post_filter->prog.nodes;
+    a.has_post = 1;
+    a.post.col = (build_left ? 0 : L.n_cols) + e[0].u; a.post.lit = e[1].u; a.post.is_eq = e[2].op == RDFGPU_EX_ID_EQ;
+  }
   a.tt = store->typed_table();
   if (left_join) a.visited = scratch<u8>(L.cap);
   u64* n_out = new_counter();
@@ -1030,7 +1048,17 @@ DevTable Plan::exec_lds_join(NodeInfo& nd, const DevTable& L, const DevTable& R,
   // previous cardinality of this operator and NOTHING is waited for — the exact count stays on the device,
   // the overflow flag is checked once at the end of the plan (Plan::execute), which re-runs exactly if any
   // speculation failed.
-  if (speculative && nd.has_last) {
+  // First execution of a plan (DataFusion compiles a fresh plan per query): no history, but the table form bounds or
+  // estimates the output — a direct-address table yields at most one match per probe row (exact bound), a CSR table
+  // about its mean rows per key, a hash table is assumed unique-ish — so the join can run without a host round
+  // trip as well; the overflow flag at the end of the plan catches a wrong guess (exact re-run).
+  u64 first_guess = 0;
+  if (speculative && !nd.has_last && !left_join && !std::getenv("RDFGPU_NO_FIRST_RUN_SPECULATION")) {
+    if (a.direct) first_guess = P.cap;
+    else if (a.csr_off) first_guess = 2 * P.cap * ((B.cap + a.direct_n - 1) / (a.direct_n ? a.direct_n : 1)) + 1024;
+    else first_guess = P.cap + 1024;
+  }
+  if (speculative && (nd.has_last || first_guess)) {
     // a fusable run of follow-up lookups above this join (Plan::plan_chain) executes inside this join's resolve
     // phase: the output is then the TOP node's, sized from the top node's history
     NodeInfo* size_node = &nd;
@@ -1042,7 +1070,8 @@ DevTable Plan::exec_lds_join(NodeInfo& nd, const DevTable& L, const DevTable& R,
       t.n_cols = a.n_out_cols;
     }
     const bool chained = a.n_chain != 0;
-    const u64 spec_cap = std::max<u64>(1024, size_node->last_rows + size_node->last_rows / 4 + 256);   // 25 % head room over the previous run
+    const u64 spec_cap = nd.has_last ? std::max<u64>(1024, size_node->last_rows + size_node->last_rows / 4 + 256)   // 25 % head room over the previous run
+                                     : std::max<u64>(1024, first_guess);
     a.out_cap = spec_cap;
     for (u32 c = 0; c < a.n_out_cols; c++) { a.out[c] = scratch<u32>(spec_cap + tail); t.cols[c] = a.out[c]; }
     if (left_join) RDFGPU_HIP(hipMemsetAsync(a.visited, 0, L.cap, stream));
@@ -1063,6 +1092,7 @@ DevTable Plan::exec_lds_join(NodeInfo& nd, const DevTable& L, const DevTable& R,
     return t;
   }
   u64 out_cap = P.cap < 1024 ? 1024 : P.cap;   // optimistic: at most one match per probe row on average
+  if (a.csr_off) out_cap = std::max<u64>(out_cap, 2 * P.cap * ((B.cap + a.direct_n - 1) / (a.direct_n ? a.direct_n : 1)) + 1024);   // CSR: twice the mean rows per key
   u64 total = 0;
   for (int attempt = 0; attempt < 2; attempt++) {
     a.out_cap = out_cap;

@@ -111,10 +111,10 @@ struct Plan {
   DevTable exec_filter(NodeInfo& nd);
   DevTable exec_join(NodeInfo& nd);
   DevTable apply_filter(NodeInfo& nd, const DevTable& in);
-  DevTable exec_lds_join(NodeInfo& nd, const DevTable& L, const DevTable& R, bool build_left, const NodeInfo* probe_filter);
+  DevTable exec_lds_join(NodeInfo& nd, const DevTable& L, const DevTable& R, bool build_left, const NodeInfo* probe_filter, const NodeInfo* post_filter = nullptr);
   bool plan_chain(NodeInfo& top, ChainRequest& req);
   bool apply_chain(const ChainRequest& req, NodeInfo& base, const DevTable& L, const DevTable& R, bool build_left, LdsJoinArgs& a, u64& stage_bytes);
-  bool choose_build_left(const NodeInfo& nd, const DevTable& L, const DevTable& R, bool left_join, bool lf, bool rf) const;
+  bool choose_build_left(const NodeInfo& nd, const DevTable& L, const DevTable& R, bool left_join, bool lf, bool rf, bool lpost = false, bool rpost = false) const;
   void release_intermediates();
   template <class T> T* scratch(u64 n);
   u64* new_counter();
