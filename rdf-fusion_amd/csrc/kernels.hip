@@ -579,22 +579,10 @@ __device__ __forceinline__ bool stage_filter_fast(const LdsJoinArgs& a, const Ch
   const u32 ix1 = same ? ix0 : chain_val(st.f[2], i, j, r), iy1 = same ? iy0 : chain_val(st.f[3], i, j, r);
   return window_fast(a.tt, ix0, iy0, ix1, iy1, same, st.l0, st.l1, undecided);
 }
-// the whole verdict of one candidate with the full semantics everywhere (base filter + every stage): the single slow copy
-template <int FS>
-__device__ __forceinline__ bool chain_eval_slow(const LdsJoinArgs& a, u32 i, u32 j) {
-  bool und;
-  if constexpr (FS == 1 || FS == 3) { if (!ljoin_filter_slow<FS>(a, i, j)) return false; }
-  else if (!ljoin_filter_fast<FS>(a, i, j, und)) return false;
-  for (u32 t = 0; t < a.n_chain; t++) {
-    const ChainStage& st = a.chain[t];
-    const u32 r = chain_lookup(st, i, j);
-    if (r == kNil) return false;
-    if (st.fs == 2) { if (!stage_filter_fast(a, st, i, j, r, und)) return false; }
-    else if (st.fs == 3) {
-      if (!window_slow(a.tt, chain_val(st.f[0], i, j, r), chain_val(st.f[1], i, j, r), chain_val(st.f[2], i, j, r), chain_val(st.f[3], i, j, r), st.l0, st.l1)) return false;
-    }
-  }
-  return true;
+// the stage's filter with the full reference semantics (fs 2 is always decided by the fast half)
+__device__ __forceinline__ bool stage_filter_slow(const LdsJoinArgs& a, const ChainStage& st, u32 i, u32 j, u32 r) {
+  if (st.fs != 3) { bool und; return stage_filter_fast(a, st, i, j, r, und); }
+  return window_slow(a.tt, chain_val(st.f[0], i, j, r), chain_val(st.f[1], i, j, r), chain_val(st.f[2], i, j, r), chain_val(st.f[3], i, j, r), st.l0, st.l1);
 }
 
 // Fused FilterExec of the probe child: PFS 0 = none, 1 = col <ID_EQ|ID_NEQ> literal, 2 = generic VM.
@@ -824,7 +812,7 @@ __global__ __launch_bounds__(kLdsBlock) void lds_join_kernel(const LdsJoinArgs a
     }
     // ---- resolve: join filter over the queued candidates, survivors compacted in place ----
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    if (FS != 0 || CHAIN || a.has_post) {
+    if (FS != 0 || a.has_post) {   // pass 0: the base join's own filter
       u32 kept = 0;
       for (u32 g0 = 0; g0 < qn; g0 += 64 * kResolveUnroll) {
         uint2 m[kResolveUnroll]; bool ok[kResolveUnroll];
@@ -849,27 +837,7 @@ __global__ __launch_bounds__(kLdsBlock) void lds_join_kernel(const LdsJoinArgs a
           slow[u] = false;
           if (ok[u]) ok[u] = ljoin_filter_fast<FS>(a, m[u].x, m[u].y, slow[u]);
         }
-        if constexpr (CHAIN) {   // stage-major, four candidates wide: each stage's loads are in flight together
-          for (u32 t = 0; t < a.n_chain; t++) {
-            const ChainStage& st = a.chain[t];
-            u32 r[kResolveUnroll];
-#pragma unroll
-            for (int u = 0; u < kResolveUnroll; u++) r[u] = chain_lookup(st, m[u].x, m[u].y, ok[u]);   // branch-free: dead lanes read row 0
-#pragma unroll
-            for (int u = 0; u < kResolveUnroll; u++) ok[u] = ok[u] && r[u] != kNil;
-            if (st.fs != 0) {   // wave-uniform
-#pragma unroll
-              for (int u = 0; u < kResolveUnroll; u++) {
-                bool und;
-                const u32 ci = ok[u] ? m[u].x : 0u, cj = ok[u] ? m[u].y : 0u, cr = ok[u] ? r[u] : 0u;
-                const bool pass = stage_filter_fast(a, st, ci, cj, cr, und);
-                slow[u] = slow[u] || (ok[u] && und);
-                ok[u] = ok[u] && !und && pass;
-              }
-            }
-          }
-        }
-        if constexpr (FS == 1 || FS == 3 || CHAIN) {
+        if constexpr (FS == 1 || FS == 3) {
           for (;;) {   // the undecided candidates, one per lane and round, through the single copy of the full semantics
             int pick = -1;
 #pragma unroll
@@ -879,8 +847,7 @@ __global__ __launch_bounds__(kLdsBlock) void lds_join_kernel(const LdsJoinArgs a
               uint2 mm = m[0];
 #pragma unroll
               for (int u = 1; u < kResolveUnroll; u++) mm = pick == u ? m[u] : mm;   // value selects keep m[] in registers
-              bool r;
-              if constexpr (CHAIN) r = chain_eval_slow<FS>(a, mm.x, mm.y); else r = ljoin_filter_slow<FS>(a, mm.x, mm.y);
+              const bool r = ljoin_filter_slow<FS>(a, mm.x, mm.y);
 #pragma unroll
               for (int u = 0; u < kResolveUnroll; u++) { ok[u] = pick == u ? r : ok[u]; slow[u] = pick == u ? false : slow[u]; }
             }
@@ -895,6 +862,59 @@ __global__ __launch_bounds__(kLdsBlock) void lds_join_kernel(const LdsJoinArgs a
       }
       qn = kept;
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+    if constexpr (CHAIN) {
+      // One pass over the (shrinking) queue per fused stage, survivors compacted in place after each: a selective
+      // stage (a numeric window keeps ~10 %) leaves the later stages a tenth of the candidates, packed into full waves.
+      for (u32 t = 0; t < a.n_chain; t++) {
+        const ChainStage& st = a.chain[t];
+        u32 kept = 0;
+        for (u32 g0 = 0; g0 < qn; g0 += 64 * kResolveUnroll) {
+          uint2 m[kResolveUnroll]; bool ok[kResolveUnroll], slow[kResolveUnroll]; u32 r[kResolveUnroll];
+#pragma unroll
+          for (int u = 0; u < kResolveUnroll; u++) {
+            const u32 e = g0 + (u32)u * 64 + lane;
+            ok[u] = e < qn; m[u] = make_uint2(0u, 0u); slow[u] = false;
+            if (ok[u]) m[u] = wq[e];
+          }
+#pragma unroll
+          for (int u = 0; u < kResolveUnroll; u++) r[u] = chain_lookup(st, m[u].x, m[u].y, ok[u]);   // branch-free: dead lanes read row 0
+#pragma unroll
+          for (int u = 0; u < kResolveUnroll; u++) ok[u] = ok[u] && r[u] != kNil;
+          if (st.fs != 0) {   // wave-uniform
+#pragma unroll
+            for (int u = 0; u < kResolveUnroll; u++) {
+              bool und;
+              const u32 ci = ok[u] ? m[u].x : 0u, cj = ok[u] ? m[u].y : 0u, cr = ok[u] ? r[u] : 0u;
+              const bool pass = stage_filter_fast(a, st, ci, cj, cr, und);
+              slow[u] = ok[u] && und;
+              ok[u] = ok[u] && !und && pass;
+            }
+            for (;;) {   // undecided candidates: this stage's filter with the full semantics, one per lane and round
+              int pick = -1;
+#pragma unroll
+              for (int u = kResolveUnroll - 1; u >= 0; u--) pick = slow[u] ? u : pick;
+              if (!__any(pick >= 0)) break;
+              if (pick >= 0) {
+                uint2 mm = m[0]; u32 rr = r[0];
+#pragma unroll
+                for (int u = 1; u < kResolveUnroll; u++) { mm = pick == u ? m[u] : mm; rr = pick == u ? r[u] : rr; }
+                const bool res = stage_filter_slow(a, st, mm.x, mm.y, rr);
+#pragma unroll
+                for (int u = 0; u < kResolveUnroll; u++) { ok[u] = pick == u ? res : ok[u]; slow[u] = pick == u ? false : slow[u]; }
+              }
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < kResolveUnroll; u++) {
+            const unsigned long long mask = __ballot(ok[u]);
+            if (ok[u]) wq[kept + lane_prefix(mask)] = m[u];
+            kept += (u32)__popcll(mask);
+          }
+        }
+        qn = kept;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      }
     }
     if (exhausted) break;
     unsigned long long b = 0;
