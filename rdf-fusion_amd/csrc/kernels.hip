@@ -812,7 +812,7 @@ __global__ __launch_bounds__(kLdsBlock) void lds_join_kernel(const LdsJoinArgs a
     }
     // ---- resolve: join filter over the queued candidates, survivors compacted in place ----
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    if (FS != 0 || a.has_post) {   // pass 0: the base join's own filter
+    auto base_pass = [&]() {   // the base join's own filter (+ a former build-side FilterExec), survivors compacted in place
       u32 kept = 0;
       for (u32 g0 = 0; g0 < qn; g0 += 64 * kResolveUnroll) {
         uint2 m[kResolveUnroll]; bool ok[kResolveUnroll];
@@ -862,7 +862,10 @@ __global__ __launch_bounds__(kLdsBlock) void lds_join_kernel(const LdsJoinArgs a
       }
       qn = kept;
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    }
+    };
+    // Conjuncts commute: with a fused chain the (selective) stage filters run first and the base filter — in practice
+    // a barely selective `!=` — only sees what they left; without a chain it is the only pass.
+    if constexpr (!CHAIN) { if (FS != 0 || a.has_post) base_pass(); }
     if constexpr (CHAIN) {
       // One pass over the (shrinking) queue per fused stage, survivors compacted in place after each: a selective
       // stage (a numeric window keeps ~10 %) leaves the later stages a tenth of the candidates, packed into full waves.
@@ -916,6 +919,7 @@ __global__ __launch_bounds__(kLdsBlock) void lds_join_kernel(const LdsJoinArgs a
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       }
     }
+    if constexpr (CHAIN) { if (FS != 0 || a.has_post) base_pass(); }
     if (exhausted) break;
     unsigned long long b = 0;
     if (lane == 0 && qn) {
