@@ -39,7 +39,7 @@ int rdfgpu_store_create(const rdfgpu_config* cfg, rdfgpu_store** out) {
   *out = reinterpret_cast<rdfgpu_store*>(store_create(cfg));
   ABI_END
 }
-void rdfgpu_store_destroy(rdfgpu_store* store) { delete reinterpret_cast<Store*>(store); }
+void rdfgpu_store_destroy(rdfgpu_store* store) { if (store) reinterpret_cast<Store*>(store)->release(); }
 
 int rdfgpu_store_extend(rdfgpu_store* store, const uint32_t* g, const uint32_t* s, const uint32_t* p, const uint32_t* o, uint64_t n, uint64_t* inserted) {
   ABI_BEGIN

@@ -130,6 +130,7 @@ Plan* plan_compile(Store* store, const rdfgpu_plan_desc* d) {
   if (d->root >= d->n_nodes) fail(RDFGPU_ERR_INVALID, "plan_compile: root %u out of range", d->root);
   std::unique_ptr<Plan> plan(new Plan());
   plan->store = store;
+  store->retain();
   plan->root = d->root;
   plan->nodes.resize(d->n_nodes);
   std::vector<u32> scan_ids;  // sorted IN sets of all sources, uploaded once
@@ -314,6 +315,7 @@ Plan::~Plan() {
   if (regex_dev) (void)hipFree(regex_dev);
 
   if (store && ctx) store->release_context(ctx);
+  if (store) store->release();
 }
 
 // Names as rocprofv3 --kernel-trace prints them (prefix up to the argument list).

@@ -83,6 +83,12 @@ struct Store {
   DevicePool pool;
   hipStream_t stream = nullptr;  // load-path stream
   std::shared_mutex mu;   // readers = running plans (a snapshot), writers = extend / remove / clear
+  // Shared ownership like the reference's Arc<...>: the handle holds one reference, every compiled plan one more; the
+  // store goes away with the last of them, so a plan may outlive rdfgpu_store_destroy (scan.rs:418-419 keeps its
+  // snapshot alive the same way).
+  std::atomic<int> refs{1};
+  void retain() { refs.fetch_add(1); }
+  void release() { if (refs.fetch_sub(1) == 1) delete this; }
   std::atomic<u64> version{0};   // bumped by every extend / remove / clear: cached scan ranges of plans are keyed on it
   // slice join tables: looked up under slice_mu; a table is built (and its stream synchronised) with slice_build_mu
   // held, so concurrent plans never see a half-built one.  Dropped by every mutation (which holds `mu` exclusively).
