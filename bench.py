@@ -99,7 +99,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--products", type=int, default=285_000, help="BSBM scale (285000 products = ~100 M triples)")
-    ap.add_argument("--queries", type=int, default=16384, help="Q5 instances per step (the batch)")
+    ap.add_argument("--queries", type=int, default=65536, help="Q5 instances per step (the batch)")
     ap.add_argument("--per-instance", action="store_true", help="one reference plan per instance instead of one batched tree")
     ap.add_argument("--threads", type=int, default=4, help="--per-instance: host threads submitting queries")
     ap.add_argument("--cpu-sample", type=int, default=14, help="Q5 instances timed on the CPU oracle (rank 0, N=1)")
