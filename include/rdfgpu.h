@@ -239,6 +239,13 @@ enum {
                                  must come from ENC_TV of a column; simple / language strings match, anything else is
                                  the error value.  Patterns that are not plan constants (regex_variable.rq) and
                                  syntax outside csrc/regex_compile.hpp's subset are RDFGPU_ERR_UNSUPPORTED.        */
+  RDFGPU_EX_CONTAINS = 24,    /* TV -> TV(boolean|null)  CONTAINS(value, <constant string>), scalar/strings/contains.rs;
+                                 `u` indexes rdfgpu_plan_desc.regexes (the entry's pattern is the needle, taken literally; its
+                                 flags are ignored), `lo` = language id of the constant (0 = simple literal).  Argument
+                                 compatibility (string_literal.rs:80-95): the value must be a string and the constant must
+                                 have no language or the value's, else the error value.                                  */
+  RDFGPU_EX_STRSTARTS = 25,   /* same shape: STRSTARTS, scalar/strings/str_starts.rs                                     */
+  RDFGPU_EX_STRENDS = 26,     /* same shape: STRENDS, scalar/strings/str_ends.rs                                         */
   RDFGPU_EX__COUNT
 };
 

@@ -645,6 +645,26 @@ static int eval_prog(const orc_store* s, const rdfgpu_expr_node* p, u32 n, const
                                    s->heap + s->str_off[a.id], (size_t)(s->str_off[a.id + 1] - s->str_off[a.id]));
         if (m >= 0) v = tv_bool(m);
         break; }
+      case RDFGPU_EX_CONTAINS: case RDFGPU_EX_STRSTARTS: case RDFGPU_EX_STRENDS: {
+        /* contains.rs / str_starts.rs / str_ends.rs: both arguments string literals, compatible per
+           string_literal.rs:80-95 (the constant has no language, or the value's); then str::contains / starts_with / ends_with */
+        if (sp < 1 || st[sp - 1].kind != 1) FAIL("string function needs a typed value");
+        if (e->u >= g_n_regexes) FAIL("string constant %u out of range", e->u);
+        val a = st[--sp];
+        v = tv_null();
+        if (a.tag != RDFGPU_TV_STRING || a.id == 0 || a.id >= s->n_str_ids) break;
+        if (e->lo > 0 && (int64_t)a.aux != e->lo) break;
+        const rdfgpu_regex* rx = &g_regexes[e->u];
+        const unsigned char* hay = s->heap + s->str_off[a.id];
+        const size_t hl = (size_t)(s->str_off[a.id + 1] - s->str_off[a.id]), nl = rx->pattern_len;
+        int r = 0;
+        if (nl <= hl) {
+          if (e->op == RDFGPU_EX_STRSTARTS) r = memcmp(hay, rx->pattern, nl) == 0;
+          else if (e->op == RDFGPU_EX_STRENDS) r = memcmp(hay + hl - nl, rx->pattern, nl) == 0;
+          else { for (size_t k = 0; k + nl <= hl && !r; k++) r = memcmp(hay + k, rx->pattern, nl) == 0; }
+        }
+        v = tv_bool(r);
+        break; }
       case RDFGPU_EX_EBV: if (sp < 1 || st[sp - 1].kind != 1) FAIL("EBV needs a typed value"); { val a = st[--sp]; v.kind = 2; v.b = tv_ebv(&a); } break;
       case RDFGPU_EX_ID_EQ: case RDFGPU_EX_ID_NEQ: {
         if (sp < 2 || st[sp - 1].kind != 0 || st[sp - 2].kind != 0) FAIL("id comparison needs two ids");

@@ -226,8 +226,11 @@ __device__ __forceinline__ uint32_t tv_ebv(const Val& v) {
 // REGEX, scalar/strings/regex.rs:47-141: unanchored search (`Regex::is_match`) by simulating the pattern's position
 // automaton with ONE u64 of state per row: next = (U follow[s] for s in cur  |  first if a match may start here)
 // & byte_mask[byte].  Simple and language-tagged strings match; every other kind is the error value.
-__device__ __forceinline__ Val tv_regex(const RegexProg& p, const TypedTable& t, const Val& v) {
+// `rhs_lang` >= 0: CONTAINS / STRSTARTS / STRENDS argument compatibility (string_literal.rs:80-95) — the constant has no
+// language (0) or the value's; REGEX passes -1 (no such rule).
+__device__ __forceinline__ Val tv_regex(const RegexProg& p, const TypedTable& t, const Val& v, int64_t rhs_lang = -1) {
   if (v.tag != RDFGPU_TV_STRING || p.always_error || t.str_off == nullptr) return val_tv_null();
+  if (rhs_lang > 0 && (int64_t)v.aux != rhs_lang) return val_tv_null();
   const uint64_t id = (uint64_t)v.hi;
   if (id == 0 || id >= t.n_str_ids) return val_tv_null();   // a string literal of the plan has no lexical form on the device
   const uint64_t b0 = t.str_off[id], len = t.str_off[id + 1] - b0;
@@ -274,6 +277,7 @@ __device__ __forceinline__ Val eval_program(const ExprProgram& prog, const Typed
       case RDFGPU_EX_ADD: case RDFGPU_EX_SUB: { const Val b = st[--sp]; const Val a = st[--sp]; v = tv_arith(a, b, e.op == RDFGPU_EX_SUB); break; }
       case RDFGPU_EX_EBV: v = val_bool(tv_ebv(st[--sp])); break;
       case RDFGPU_EX_REGEX: v = tv_regex(prog.regex[e.u], tt, st[--sp]); break;
+      case RDFGPU_EX_CONTAINS: case RDFGPU_EX_STRSTARTS: case RDFGPU_EX_STRENDS: v = tv_regex(prog.regex[e.u], tt, st[--sp], e.lo < 0 ? 0 : e.lo); break;
       case RDFGPU_EX_ID_EQ: case RDFGPU_EX_ID_NEQ: {
         const uint32_t b = (uint32_t)st[--sp].lo, a = (uint32_t)st[--sp].lo;
         v = val_bool((a == 0 || b == 0) ? 2u : (uint32_t)((a == b) == (e.op == RDFGPU_EX_ID_EQ))); break; }

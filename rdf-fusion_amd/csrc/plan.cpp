@@ -48,10 +48,10 @@ u32 check_program(const rdfgpu_expr_node* p, u32 n, u32 n_cols, u32 n_regexes = 
       case RDFGPU_EX_GT: case RDFGPU_EX_LT: case RDFGPU_EX_GEQ: case RDFGPU_EX_LEQ: case RDFGPU_EX_EQ: case RDFGPU_EX_NEQ:
       case RDFGPU_EX_ADD: case RDFGPU_EX_SUB: pop(VK_TV, "binary typed op"); pop(VK_TV, "binary typed op"); out = VK_TV; break;
       case RDFGPU_EX_EBV: pop(VK_TV, "EBV"); out = VK_BOOL; break;
-      case RDFGPU_EX_REGEX:
+      case RDFGPU_EX_REGEX: case RDFGPU_EX_CONTAINS: case RDFGPU_EX_STRSTARTS: case RDFGPU_EX_STRENDS:
         if (e.u >= n_regexes) fail(RDFGPU_ERR_INVALID, "expression: REGEX pattern %u out of range (%u patterns)", e.u, n_regexes);
         // the lexical form lives in HBM under the value's object id: the operand has to be ENC_TV(column)
-        if (i < 2 || p[i - 1].op != RDFGPU_EX_ENC_TV || p[i - 2].op != RDFGPU_EX_COLUMN) fail(RDFGPU_ERR_UNSUPPORTED, "REGEX over anything but ENC_TV(column)");
+        if (i < 2 || p[i - 1].op != RDFGPU_EX_ENC_TV || p[i - 2].op != RDFGPU_EX_COLUMN) fail(RDFGPU_ERR_UNSUPPORTED, "REGEX / CONTAINS / STRSTARTS / STRENDS over anything but ENC_TV(column)");
         pop(VK_TV, "REGEX"); out = VK_TV; break;
       case RDFGPU_EX_ID_EQ: case RDFGPU_EX_ID_NEQ: case RDFGPU_EX_IS_COMPATIBLE: pop(VK_ID, "id comparison"); pop(VK_ID, "id comparison"); out = VK_BOOL; break;
       case RDFGPU_EX_AND: case RDFGPU_EX_OR: pop(VK_BOOL, "AND/OR"); pop(VK_BOOL, "AND/OR"); out = VK_BOOL; break;
@@ -137,12 +137,27 @@ Plan* plan_compile(Store* store, const rdfgpu_plan_desc* d) {
   if (d->n_regexes) {   // REGEX patterns are plan constants: compiled here, simulated per row on the device
     if (!d->regexes) fail(RDFGPU_ERR_INVALID, "plan_compile: %u regexes but no table", d->n_regexes);
     if (!store->str_off) fail(RDFGPU_ERR_INVALID, "plan uses REGEX but the store has no strings (rdfgpu_store_set_strings)");
+    // how each table entry is used decides how it is compiled: REGEX = a pattern with flags; CONTAINS / STRSTARTS /
+    // STRENDS = a literal needle (like the `q` flag), anchored at the start / end for the latter two
+    std::vector<int> use(d->n_regexes, -1);
+    for (u32 i = 0; i < d->n_exprs; i++) {
+      const rdfgpu_expr_node& e = d->exprs[i];
+      if (e.op != RDFGPU_EX_REGEX && e.op != RDFGPU_EX_CONTAINS && e.op != RDFGPU_EX_STRSTARTS && e.op != RDFGPU_EX_STRENDS) continue;
+      if (e.u >= d->n_regexes) fail(RDFGPU_ERR_INVALID, "expression: string pattern %u out of range", e.u);
+      if (use[e.u] >= 0 && use[e.u] != (int)e.op) fail(RDFGPU_ERR_INVALID, "string pattern %u is used by two different functions", e.u);
+      use[e.u] = (int)e.op;
+    }
     std::vector<RegexProg> progs(d->n_regexes);
     for (u32 r = 0; r < d->n_regexes; r++) {
       const rdfgpu_regex& rx = d->regexes[r];
       std::string why;
-      if (regex_compile(rx.pattern ? rx.pattern : "", rx.pattern_len, rx.flags ? rx.flags : "", rx.flags ? rx.flags_len : 0, progs[r], why) != REGEX_OK)
-        fail(RDFGPU_ERR_UNSUPPORTED, "REGEX pattern %u: %s", r, why.c_str());
+      const bool literal = use[r] == RDFGPU_EX_CONTAINS || use[r] == RDFGPU_EX_STRSTARTS || use[r] == RDFGPU_EX_STRENDS;
+      const char* flags = literal ? "q" : (rx.flags ? rx.flags : "");
+      const size_t n_flags = literal ? 1 : (rx.flags ? rx.flags_len : 0);
+      if (regex_compile(rx.pattern ? rx.pattern : "", rx.pattern_len, flags, n_flags, progs[r], why) != REGEX_OK)
+        fail(RDFGPU_ERR_UNSUPPORTED, "string pattern %u: %s", r, why.c_str());
+      if (use[r] == RDFGPU_EX_STRSTARTS) progs[r].anchor_start = 1;
+      if (use[r] == RDFGPU_EX_STRENDS) progs[r].anchor_end = 1;
     }
     store->activate();
     RDFGPU_HIP(hipMalloc((void**)&plan->regex_dev, progs.size() * sizeof(RegexProg)));

@@ -169,7 +169,19 @@ def EBV(e): return e._un(abi.EX_EBV)
 def REGEX(e, pattern, flags=""):
     """REGEX(value, "pattern"[, "flags"]) with constant pattern / flags (scalar/strings/regex.rs:47-141)."""
     enc = lambda x: x.encode("utf-8") if isinstance(x, str) else bytes(x)
-    return Expr(e.nodes + [(abi.EX_REGEX, 0, 0, (enc(pattern), enc(flags)), 0, 0)])
+    return Expr(e.nodes + [(abi.EX_REGEX, 0, 0, (enc(pattern), enc(flags), abi.EX_REGEX), 0, 0)])
+
+
+def _string_fn(op):
+    def f(e, needle, language_id=0):
+        """<fn>(value, "constant"[@lang]) — contains.rs / str_starts.rs / str_ends.rs; language_id = the constant's
+        language id in the typed-value table's `aux` numbering (0 = simple literal)."""
+        b = needle.encode("utf-8") if isinstance(needle, str) else bytes(needle)
+        return Expr(e.nodes + [(op, 0, 0, (b, b"", op), int(language_id), 0)])
+    return f
+
+
+CONTAINS, STRSTARTS, STRENDS = _string_fn(abi.EX_CONTAINS), _string_fn(abi.EX_STRSTARTS), _string_fn(abi.EX_STRENDS)
 def ID_EQ(a, b): return a._bin(b, abi.EX_ID_EQ)
 def ID_NEQ(a, b): return a._bin(b, abi.EX_ID_NEQ)
 def AND(a, b): return a._bin(b, abi.EX_AND)
@@ -206,6 +218,7 @@ class PlanBuilder:
     def __init__(self):
         self.nodes, self.exprs, self.pool, self.width = [], [], [], []
         self.regexes = []
+        self._regex_keys = []
         self.vars = {}
 
     # -- helpers -------------------------------------------------------------------------------
@@ -236,10 +249,12 @@ class PlanBuilder:
             return
         node.expr_off, node.expr_len = len(self.exprs), len(e.nodes)
         for (op, tag, flags, u, lo, hi) in e.nodes:
-            if op == abi.EX_REGEX:      # u carries (pattern, flags): register the plan constant, keep its index
-                if u not in self.regexes:
-                    self.regexes.append(u)
-                u = self.regexes.index(u)
+            if op in (abi.EX_REGEX, abi.EX_CONTAINS, abi.EX_STRSTARTS, abi.EX_STRENDS):
+                # u carries (pattern, flags, op): register the plan constant (one entry per function), keep its index
+                if u not in self._regex_keys:
+                    self._regex_keys.append(u)
+                    self.regexes.append(u[:2])
+                u = self._regex_keys.index(u)
             self.exprs.append(abi.ExprNode(op, tag, flags, 0, u, lo, hi))
 
     def _proj(self, node, projection, full):

@@ -190,3 +190,30 @@ def regex_needs_unicode_fold_care(pattern, flags):
 def random_subject(rng):
     n = int(rng.integers(0, 9))
     return "".join(REGEX_ALPHABET[int(rng.integers(0, len(REGEX_ALPHABET)))] for _ in range(n))
+
+
+def string_dictionary(strings, n_other=5, lang_every=5, lang_id=7):
+    """Typed values + string heap for ids 1..len(strings) (simple / language-tagged literals) followed by `n_other`
+    non-string ids (integers).  Every `lang_every`-th literal carries language id `lang_id`."""
+    from rdf_fusion_amd import abi
+    from rdf_fusion_amd.engine import TV_DTYPE
+    n_ids = 1 + len(strings) + n_other
+    tv = np.zeros(n_ids, dtype=TV_DTYPE)
+    order = {s: r for r, s in enumerate(sorted(set(strings)))}
+    offsets = np.zeros(n_ids + 1, dtype=np.uint64)
+    heap = bytearray()
+    for k, s_ in enumerate(strings):
+        i = 1 + k
+        b = s_.encode("utf-8")
+        tv["tag"][i] = abi.TV_STRING
+        tv["lo"][i] = order[s_]
+        tv["aux"][i] = 0 if k % lang_every else lang_id
+        tv["flags"][i] = abi.TVF_EMPTY_STRING if not b else 0
+        offsets[i] = len(heap)
+        heap += b
+        offsets[i + 1] = len(heap)
+    for i in range(1 + len(strings), n_ids):
+        tv["tag"][i] = abi.TV_INTEGER
+        tv["lo"][i] = i
+        offsets[i + 1] = len(heap)
+    return tv, offsets, bytes(heap)

@@ -12,7 +12,7 @@ from rdf_fusion_amd.engine import TV_DTYPE
 from rdf_fusion_amd.plan import (PlanBuilder, MemIndexScanInstruction as I, MemIndexScanPredicate as P,
                                  quad_pattern, col, lit_id, lit_tv, lit_bool, integer, int32, double, float32,
                                  decimal, boolean, ENC_TV, GT, LT, GEQ, LEQ, EQ, NEQ, ADD, SUB, EBV, ID_EQ,
-                                 ID_NEQ, AND, OR, NOT, IS_COMPATIBLE, BOUND, BOOLEAN_AS_TERM, REGEX)
+                                 ID_NEQ, AND, OR, NOT, IS_COMPATIBLE, BOUND, BOOLEAN_AS_TERM, REGEX, CONTAINS, STRSTARTS, STRENDS)
 from oracle import oracle as orc
 import kat_util as ku
 
@@ -495,29 +495,7 @@ def test_index_join_against_store_slice(torch_cuda, shape, n_tab):
 # ---------------------------------------------------------------------------------------------------
 # REGEX: device position automaton vs the oracle's Pike VM, through plans
 # ---------------------------------------------------------------------------------------------------
-def string_dictionary(strings, n_other=5):
-    """Typed values + string heap for ids 1..len(strings) (simple / language-tagged literals) followed by `n_other`
-    non-string ids (integers): REGEX over those is the error value."""
-    n_ids = 1 + len(strings) + n_other
-    tv = np.zeros(n_ids, dtype=TV_DTYPE)
-    order = {s: r for r, s in enumerate(sorted(set(strings)))}
-    offsets = np.zeros(n_ids + 1, dtype=np.uint64)
-    heap = bytearray()
-    for k, s_ in enumerate(strings):
-        i = 1 + k
-        b = s_.encode("utf-8")
-        tv["tag"][i] = abi.TV_STRING
-        tv["lo"][i] = order[s_]
-        tv["aux"][i] = 0 if k % 5 else 7          # every fifth literal carries a language tag: REGEX matches those too
-        tv["flags"][i] = abi.TVF_EMPTY_STRING if not b else 0
-        offsets[i] = len(heap)
-        heap += b
-        offsets[i + 1] = len(heap)
-    for i in range(1 + len(strings), n_ids):
-        tv["tag"][i] = abi.TV_INTEGER
-        tv["lo"][i] = i
-        offsets[i + 1] = len(heap)
-    return tv, offsets, bytes(heap)
+string_dictionary = ku.string_dictionary
 
 
 def test_regex_filter_matches_oracle(torch_cuda):
@@ -559,6 +537,40 @@ def test_regex_filter_matches_oracle(torch_cuda):
         is_str = (ids >= 1) & (ids <= len(strings))
         exp = np.array([bool(is_str[r]) and rx.search(strings[ids[r] - 1]) is not None for r in range(len(ids))])
         np.testing.assert_array_equal(got, payload[exp])
+
+
+def test_string_functions_match_oracle(torch_cuda):
+    """CONTAINS / STRSTARTS / STRENDS with a constant second argument (contains.rs, str_starts.rs, str_ends.rs), incl.
+    the argument-compatibility rule for language-tagged constants."""
+    rng = np.random.default_rng(3)
+    strings = [ku.random_subject(rng) for _ in range(1200)] + ["", "abc", "ab", "bc", "€uro", "x€"]
+    tv, offsets, heap = string_dictionary(strings)
+    gs, os_ = both_stores((np.zeros(0, np.uint32),) * 4, typed=tv)
+    gs.set_strings(offsets, heap)
+    os_.set_strings(offsets, heap)
+    ids = rng.integers(0, len(tv), 15_000).astype(np.uint32)
+    payload = np.arange(len(ids), dtype=np.uint32) + 1
+    keep, ptrs = table_on_device(torch_cuda, [ids, payload])
+    needles = ["", "a", "ab", "b", "€", "k ", "\n", ".", "abc", "x" * 64]
+    for fn, py in ((CONTAINS, lambda s_, n: n in s_), (STRSTARTS, str.startswith), (STRENDS, str.endswith)):
+        for needle in needles:
+            for lang in (0, 7, 9):
+                e = EBV(fn(ENC_TV(col(0)), needle, lang))
+                for negate in (False, True):
+                    pb = PlanBuilder()
+                    run_both(gs, os_, pb.build(pb.filter(pb.table(0, 2), NOT(e) if negate else e, projection=[1])),
+                             gpu_tables=[(ptrs, len(ids))], cpu_tables=[[ids, payload]])
+            # independent of the oracle: Python's own substring tests, simple-literal constant
+            pb = PlanBuilder()
+            plan = gs.plan(pb.build(pb.filter(pb.table(0, 2), EBV(fn(ENC_TV(col(0)), needle)), projection=[1])))
+            plan.bind_table(0, ptrs, len(ids))
+            got = np.sort(plan.execute().fetch()[0])
+            is_str = (ids >= 1) & (ids <= len(strings))
+            exp = np.array([bool(is_str[r]) and py(strings[ids[r] - 1], needle) for r in range(len(ids))])
+            np.testing.assert_array_equal(got, payload[exp])
+    pb = PlanBuilder()
+    with pytest.raises(rf.RdfGpuError):          # needles beyond 64 bytes are outside the device subset
+        gs.plan(pb.build(pb.filter(pb.table(0, 2), EBV(CONTAINS(ENC_TV(col(0)), "y" * 65)))))
 
 
 def test_regex_unsupported_is_refused_loudly(torch_cuda):

@@ -71,3 +71,27 @@ def test_device_compiler_accepts_the_subset_and_refuses_the_rest():
             engine.regex_check(bad, "")
     with pytest.raises(engine.RdfGpuError):
         engine.regex_check("é", "i")                            # non-ASCII letter under `i` needs the Unicode fold tables
+
+
+def test_oracle_string_functions_agree_with_python():
+    """CONTAINS / STRSTARTS / STRENDS in the oracle (through a FILTER plan) against Python's substring tests."""
+    from rdf_fusion_amd.plan import PlanBuilder, col, ENC_TV, EBV, CONTAINS, STRSTARTS, STRENDS
+    rng = np.random.default_rng(4)
+    strings = [ku.random_subject(rng) for _ in range(400)] + ["", "abc", "€uro"]
+    tv, offsets, heap = ku.string_dictionary(strings)
+    os_ = orc.OracleStore()
+    os_.set_typed_values(tv)
+    os_.set_strings(offsets, heap)
+    ids = rng.integers(0, len(tv), 3000).astype(np.uint32)
+    payload = np.arange(len(ids), dtype=np.uint32) + 1
+    is_str = (ids >= 1) & (ids <= len(strings))
+    lang = np.array([0] + [0 if k % 5 else 7 for k in range(len(strings))] + [0] * 5)
+    for fn, py in ((CONTAINS, lambda s_, n: n in s_), (STRSTARTS, str.startswith), (STRENDS, str.endswith)):
+        for needle in ("", "a", "ab", "€", "k ", "abc"):
+            for const_lang in (0, 7, 9):
+                pb = PlanBuilder()
+                desc = pb.build(pb.filter(pb.table(0, 2), EBV(fn(ENC_TV(col(0)), needle, const_lang)), projection=[1]))
+                got, n, _ = os_.execute(desc, [[ids, payload]])
+                ok = np.array([bool(is_str[r]) and (const_lang == 0 or lang[ids[r]] == const_lang) and py(strings[ids[r] - 1], needle)
+                               for r in range(len(ids))])
+                np.testing.assert_array_equal(np.sort(got[0][:n]), payload[ok])
