@@ -104,6 +104,7 @@ def main():
     ap.add_argument("--threads", type=int, default=4, help="--per-instance: host threads submitting queries")
     ap.add_argument("--cpu-sample", type=int, default=14, help="Q5 instances timed on the CPU oracle (rank 0, N=1)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-shard-check", action="store_true", help="N > 1: skip comparing the shards' bindings with an unsharded run on rank 0")
     ap.add_argument("--no-scan", action="store_true", help="skip the scaled scan+FILTER roofline measurement")
     ap.add_argument("--scan-log2-rows", type=int, default=26)
     args = ap.parse_args()
@@ -295,6 +296,34 @@ def main():
         tsum = t.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
         elapsed = float(tmax[0].item()); total_rows = int(tsum[1].item())
 
+    # ------------------------------------------------------------------ sharded run: are the shards' bindings the unsharded answer?
+    shard_check = None
+    if dist is not None and not args.no_shard_check:
+        def checksum(cols):      # order-independent (count, sum of per-row mixes mod 2^64) of a binding table
+            a, b, c = (np.asarray(x, dtype=np.uint64) for x in cols)
+            with np.errstate(over="ignore"):
+                mix = a * np.uint64(0x9E3779B97F4A7C15) ^ b * np.uint64(0xC2B2AE3D27D4EB4F) ^ c * np.uint64(0x165667B19E3779F9)
+                return len(a), int(mix.sum(dtype=np.uint64))
+        probe_batch = batches[args.warmup][:min(Q, 8192)].copy()
+        step(probe_batch, False)
+        n_loc, sum_loc = checksum(plan_b.fetch())
+        t = torch.tensor([n_loc, sum_loc - (1 << 64) if sum_loc >= (1 << 63) else sum_loc], dtype=torch.int64, device=xdev)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)                 # int64 addition wraps: the sum is mod 2^64
+        n_all, sum_all = int(t[0].item()), int(t[1].item()) & ((1 << 64) - 1)
+        if rank == 0:                                            # the whole graph on one GPU, same batch, one operator tree
+            full = rf.GpuQuadStore(device=local_rank)
+            full.extend(ds.g, ds.s, ds.p, ds.o)
+            full.set_typed_values(ds.typed_values)
+            pf = full.plan(bsbm.q5_batch_plan(ds))
+            tt, pp, nn = dev_table([np.arange(1, len(probe_batch) + 1, dtype=np.uint32), probe_batch])
+            pf.bind_table(0, pp, nn)
+            n_ref, sum_ref = checksum(pf.execute().fetch())
+            pf.close(); full.close()
+            if (n_ref, sum_ref) != (n_all, sum_all):
+                raise RuntimeError(f"sharded bindings differ from the unsharded run: {n_all} rows / {sum_all:#x} vs {n_ref} rows / {sum_ref:#x}")
+            shard_check = f"{len(probe_batch)} instances: {n_all} bindings over {world} shards, count and multiset checksum equal to the unsharded run on rank 0"
+        barrier()
+
     # ------------------------------------------------------------------ roofline of the dominant kernel
     roofline = None
     if kstats:
@@ -389,6 +418,7 @@ def main():
                                    + ("one reference plan per instance" if args.per_instance else "batched into one operator tree (shared scans)"),
                        "mode": "per-instance" if args.per_instance else "batched",
                        "triples_per_gpu": n_local, "sharding": "hash(subject) mod N, all-gatherv of constant-pattern bindings" if world > 1 else "none",
+                       "sharded_result_check": shard_check,
                        "queries_per_s": round(n_q / elapsed, 2), "bindings": total_rows,
                        "host_threads": args.threads if args.per_instance else 1,
                        "single_instance_latency_ms": single,
