@@ -1,0 +1,7 @@
+// join_fs2.hip — the lds_join_kernel instantiations with join-filter shape FS = 2 (one translation unit per shape so
+// that the build parallelises; the code is join_device.hpp).
+#include "join_device.hpp"
+
+namespace rdfgpu {
+RDFGPU_DEFINE_JOIN_FS(2)
+}  // namespace rdfgpu
