@@ -268,8 +268,18 @@ enum {
   RDFGPU_NODE_CROSS_JOIN = 4,  /* CrossJoinExec                                                            */
   RDFGPU_NODE_NESTED_LOOP_JOIN = 5, /* NestedLoopJoinExec: inner | left with a filter and no equi keys     */
   RDFGPU_NODE_PROJECTION = 6,  /* ProjectionExec of plain columns                                          */
-  RDFGPU_NODE_TABLE = 7        /* bindings supplied by the caller (device columns), e.g. all-gathered rows */
+  RDFGPU_NODE_TABLE = 7,       /* bindings supplied by the caller (device columns), e.g. all-gathered rows */
+  RDFGPU_NODE_TOPK = 8         /* The operators directly above the path in the reference's explore plans (SURVEY §8f-3,
+                                  ..Q5 (Execution Plan).snap:5-9): AggregateExec(gby = sort keys, first_value) = DISTINCT,
+                                  then SortExec TopK(fetch = k), optionally per group (a batch of queries in one tree).
+                                  left = input; n_keys sort keys (<= 2), all ascending, NULLS FIRST: left_keys[i] = column,
+                                  right_keys[i] = RDFGPU_SORT_BY_ID (the UInt32 id itself, `product@1 ASC`) or
+                                  RDFGPU_SORT_BY_TERM (ENC_SORT of the term: defined here for columns of one kind among
+                                  strings / IRIs / blank nodes, whose typed value carries the rank); table_cols = k;
+                                  table_slot = 1 + group column (0 = one group).  Rows equal on (group, keys) collapse to
+                                  one; every output column must be the group column or a key column.               */
 };
+enum { RDFGPU_SORT_BY_ID = 0, RDFGPU_SORT_BY_TERM = 1 };
 enum { RDFGPU_JOIN_INNER = 0, RDFGPU_JOIN_LEFT = 1 };
 #define RDFGPU_MAX_KEYS 4u
 #define RDFGPU_MAX_COLUMNS 16u

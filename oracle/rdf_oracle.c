@@ -839,6 +839,59 @@ done:
   return rc;
 }
 
+/* DISTINCT + TopK per group (..Q5 (Execution Plan).snap:5-9: AggregateExec gby = sort keys with first_value, then
+   SortExec TopK(fetch)): sort rows by (group, keys), drop adjacent duplicates, keep the first k of every group. */
+typedef struct { u32 g; u64 k[2]; u64 row; } topk_row;
+static int topk_cmp(const void* a, const void* b) {
+  const topk_row* x = (const topk_row*)a; const topk_row* y = (const topk_row*)b;
+  if (x->g != y->g) return x->g < y->g ? -1 : 1;
+  for (int i = 0; i < 2; i++) if (x->k[i] != y->k[i]) return x->k[i] < y->k[i] ? -1 : 1;
+  return 0;
+}
+static int exec_topk(const pctx* c, const rdfgpu_plan_node* nd, orc_table* out) {
+  orc_table in; memset(&in, 0, sizeof in);
+  if (exec_node(c, (u32)nd->left, &in)) return -1;
+  const u32* proj; u32 np; if (out_width(c, nd, in.n_cols, &proj, &np)) { orc_table_free(&in); return -1; }
+  if (nd->n_keys < 1 || nd->n_keys > 2) { orc_table_free(&in); FAIL("TopK needs 1 or 2 sort keys"); }
+  const int has_group = nd->table_slot != 0; const u32 gcol = has_group ? nd->table_slot - 1 : 0;
+  for (u32 i = 0; i < nd->n_keys; i++) if (nd->left_keys[i] >= in.n_cols) { orc_table_free(&in); FAIL("TopK: key column out of range"); }
+  if (has_group && gcol >= in.n_cols) { orc_table_free(&in); FAIL("TopK: group column out of range"); }
+  for (u32 q = 0; q < np; q++) {
+    const u32 pc = proj ? proj[q] : q;
+    int covered = has_group && pc == gcol;
+    for (u32 i = 0; i < nd->n_keys; i++) covered = covered || pc == nd->left_keys[i];
+    if (!covered) { orc_table_free(&in); FAIL("TopK: output column %u is neither the group nor a sort key", pc); }
+  }
+  topk_row* rows = (topk_row*)malloc((in.n_rows ? in.n_rows : 1) * sizeof(topk_row));
+  for (u64 r = 0; r < in.n_rows; r++) {
+    rows[r].g = has_group ? in.cols[gcol][r] : 0; rows[r].row = r; rows[r].k[1] = 0;
+    for (u32 i = 0; i < nd->n_keys; i++) {
+      const u32 id = in.cols[nd->left_keys[i]][r];
+      if (nd->right_keys[i] == RDFGPU_SORT_BY_ID) { rows[r].k[i] = id; continue; }
+      const val v = enc_tv(c->s, id);   /* NULLS FIRST: tag 0 sorts before everything */
+      if (v.tag != RDFGPU_TV_NULL && v.tag != RDFGPU_TV_STRING && v.tag != RDFGPU_TV_NAMED_NODE && v.tag != RDFGPU_TV_BLANK_NODE) {
+        free(rows); orc_table_free(&in); FAIL("TopK: sort by term over a typed value of tag %u", v.tag);
+      }
+      rows[r].k[i] = ((u64)v.tag << 56) | ((u64)v.lo & 0x00FFFFFFFFFFFFFFull);
+    }
+  }
+  qsort(rows, in.n_rows, sizeof(topk_row), topk_cmp);
+  tbuilder b; tb_init(&b, np, in.n_rows);
+  u64 taken = 0;
+  for (u64 r = 0; r < in.n_rows; r++) {
+    if (r > 0 && rows[r].g != rows[r - 1].g) taken = 0;
+    if (r > 0 && topk_cmp(&rows[r], &rows[r - 1]) == 0) continue;   /* DISTINCT */
+    if (taken >= nd->table_cols) continue;
+    taken++;
+    tb_reserve(&b);
+    for (u32 q = 0; q < np; q++) b.t.cols[q][b.t.n_rows] = in.cols[proj ? proj[q] : q][rows[r].row];
+    b.t.n_rows++;
+  }
+  free(rows); orc_table_free(&in);
+  *out = b.t;
+  return 0;
+}
+
 static int exec_node(const pctx* c, u32 idx, orc_table* out) {
   if (idx >= c->d->n_nodes) FAIL("node index out of range");
   const rdfgpu_plan_node* nd = &c->d->nodes[idx];
@@ -855,6 +908,7 @@ static int exec_node(const pctx* c, u32 idx, orc_table* out) {
     case RDFGPU_NODE_FILTER: rc = exec_filter(c, nd, out); break;
     case RDFGPU_NODE_PROJECTION: { rdfgpu_plan_node f = *nd; f.expr_len = 0; rc = exec_filter(c, &f, out); break; }
     case RDFGPU_NODE_HASH_JOIN: case RDFGPU_NODE_CROSS_JOIN: case RDFGPU_NODE_NESTED_LOOP_JOIN: rc = exec_join(c, nd, out); break;
+    case RDFGPU_NODE_TOPK: rc = exec_topk(c, nd, out); break;
     case RDFGPU_NODE_TABLE: {
       if (nd->table_slot >= c->n_tables) FAIL("table slot %u not bound", nd->table_slot);
       const orc_bound_table* t = &c->tables[nd->table_slot];

@@ -31,7 +31,8 @@ TVF_EMPTY_STRING = 1
 
 # plan nodes
 (NODE_DATA_SOURCE, NODE_FILTER, NODE_HASH_JOIN, NODE_CROSS_JOIN, NODE_NESTED_LOOP_JOIN,
- NODE_PROJECTION, NODE_TABLE) = range(1, 8)
+ NODE_PROJECTION, NODE_TABLE, NODE_TOPK) = range(1, 9)
+SORT_BY_ID, SORT_BY_TERM = 0, 1
 JOIN_INNER, JOIN_LEFT = 0, 1
 MAX_KEYS = 4
 MAX_COLUMNS = 16

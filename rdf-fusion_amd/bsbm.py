@@ -188,7 +188,7 @@ def generate(n_products, seed=None, offers_per_product=20, reviews_per_product=1
 # --------------------------------------------------------------------------------------------------
 # The reference's physical plans (bench/tests/plans/snapshots/*.snap)
 # --------------------------------------------------------------------------------------------------
-def q5_plan(ds, product_id, w1=120, w2=170):
+def q5_plan(ds, product_id, w1=120, w2=170, topk=False):
     """BSBM Explore Q5 ("similar products"), 7 triple patterns, as planned by the reference:
     J3(J2(J1(label x features(X), productFeature), numeric1), numeric2) — Q5 (Execution Plan).snap:10-30.
     Output: (product, productLabel) bindings before DISTINCT / ORDER BY / LIMIT."""
@@ -210,7 +210,7 @@ def q5_plan(ds, product_id, w1=120, w2=170):
         flt = AND(EBV(LT(ENC_TV(col(4)), ADD(ENC_TV(col(2)), integer(w)))),
                   EBV(GT(ENC_TV(col(4)), SUB(ENC_TV(col(2)), integer(w)))))
         node = pb.hash_join(cx, sim, on=[(0, 0)], filter=flt, projection=[0, 1])
-    return pb.build(node)
+    return pb.build(q5_topk(pb, node, False) if topk else node)
 
 
 def _window(sim, orig, w):
@@ -234,7 +234,7 @@ def q5_batch_const_plans(ds):
     return out
 
 
-def q5_batch_plan(ds, w1=120, w2=170, tables=None):
+def q5_batch_plan(ds, w1=120, w2=170, tables=None, topk=False):
     """BSBM Q5 for a BATCH of instances in one operator tree (shared scans: every triple-pattern partition
     is streamed once per batch instead of once per query).  Same operators as q5_plan; the per-instance
     constant becomes a column: tables F(inst, X, prodFeature), O1(inst, X, origProperty1), O2(inst, X,
@@ -266,7 +266,18 @@ def q5_batch_plan(ds, w1=120, w2=170, tables=None):
         sim = pb.data_source(quad_pattern("product", pr[f"bsbm:productPropertyNumeric{k}"], f"simProperty{k}"))
         node = pb.hash_join(node, sim, on=[(1, 0)], filter=_window(5, orig, w), projection=[0, 1, 2, 3])
     label = pb.data_source(quad_pattern("product", pr["rdfs:label"], "productLabel"))           # (product, label)
-    return pb.build(pb.hash_join(node, label, on=[(1, 0)], projection=[0, 1, 5]))                # (inst, product, label)
+    out = pb.hash_join(node, label, on=[(1, 0)], projection=[0, 1, 5])                           # (inst, product, label)
+    return pb.build(q5_topk(pb, out, True) if topk else out)
+
+
+def q5_topk(pb_or_desc_builder, node, batched):
+    """The operators above the join pipeline in the reference's Q5 plan (Q5 (Execution Plan).snap:5-9): DISTINCT
+    (AggregateExec gby = sort keys, first_value) + SortExec TopK(fetch=5) ORDER BY ENC_SORT(ENC_PT(productLabel)) ASC,
+    product ASC — per instance when `batched` (input columns (inst, product, label)), else over (product, label)."""
+    pb = pb_or_desc_builder
+    if batched:
+        return pb.topk(node, keys=[(2, abi.SORT_BY_TERM), (1, abi.SORT_BY_ID)], limit=5, group=0)
+    return pb.topk(node, keys=[(1, abi.SORT_BY_TERM), (0, abi.SORT_BY_ID)], limit=5)
 
 
 def q1_plan(ds, type_id, feature1, feature2, threshold):

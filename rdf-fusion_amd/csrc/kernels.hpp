@@ -176,6 +176,31 @@ void launch_csr_hist(const u32* keys, u64 n, u32 kmin, u32 kn, u32* counts /* ze
 void launch_csr_scatter(const u32* keys, u64 n, u32 kmin, u32 kn, u32* cursor /* copy of the offsets */, u32* rows, hipStream_t s);
 void launch_gdirect_build(const u32* keys, u64 n, u32* direct /* 0xFF-filled */, u32 kmin, u32 kn, u32* dup_dev, hipStream_t s);
 
+// ---- DISTINCT + TopK per group (the operators directly above the path; topk.hip) ----
+struct TopkArgs {
+  const u32* in[kMaxCols];
+  const u64* n_in_dev; u64 n_in_cap;
+  u32 has_group, group_col;
+  u32 n_keys, key_col[2], key_by_term[2];
+  u32 k, n_groups;            // rows kept per group; group ids are < n_groups
+  TypedTable tt;
+  u32* counts;                // [n_groups + 1], zeroed: rows per group
+  u32* offsets;               // [n_groups + 1]: exclusive scan of counts
+  u32* cursor;                // [n_groups]: copy of offsets, consumed by the scatter
+  u32* perm;                  // [n_in_cap]: row ids grouped by group
+  u32* picked;                // [n_groups * k]
+  u32* out_counts;            // [n_groups + 1], zeroed
+  u32* out_offsets;           // [n_groups + 1]
+  u32* out[kMaxCols]; u32 n_out_cols; u32 proj[kMaxCols];
+  u64* n_out_dev;
+  u32* bad;                   // raised when a SORT_BY_TERM column holds a kind whose order is not defined here
+};
+void launch_topk_max(const u32* col, const u64* n_dev, u64 cap, u32* out_max /* zeroed */, hipStream_t s);
+void launch_topk_hist(const TopkArgs& a, hipStream_t s);
+void launch_topk_scatter(const TopkArgs& a, hipStream_t s);
+void launch_topk_select(const TopkArgs& a, hipStream_t s);
+void launch_topk_write(const TopkArgs& a, hipStream_t s);
+
 // ---- utilities ----
 void launch_fill_u32(u32* p, u32 v, u64 n, hipStream_t s);
 void launch_gather_u32(const u32* src, const u32* idx, u32* dst, u64 n, hipStream_t s);

@@ -228,6 +228,24 @@ Plan* plan_compile(Store* store, const rdfgpu_plan_desc* d) {
         if (plan->tables.size() <= r.table_slot) plan->tables.resize(r.table_slot + 1);
         break;
       }
+      case RDFGPU_NODE_TOPK: {   // DISTINCT + TopK(fetch) per group, ..Q5 (Execution Plan).snap:5-9
+        const NodeInfo& c = child(r.left, "input");
+        if (r.n_keys < 1 || r.n_keys > 2) fail(RDFGPU_ERR_UNSUPPORTED, "node %u: TopK with %u sort keys (1 or 2)", i, r.n_keys);
+        if (r.table_cols < 1 || r.table_cols > 1024) fail(RDFGPU_ERR_UNSUPPORTED, "node %u: TopK fetch = %u", i, r.table_cols);
+        for (u32 k = 0; k < r.n_keys; k++) {
+          if (r.left_keys[k] >= c.width) fail(RDFGPU_ERR_INVALID, "node %u: sort key column %u out of range", i, r.left_keys[k]);
+          if (r.right_keys[k] > RDFGPU_SORT_BY_TERM) fail(RDFGPU_ERR_INVALID, "node %u: unknown sort mode %u", i, r.right_keys[k]);
+        }
+        if (r.table_slot > c.width) fail(RDFGPU_ERR_INVALID, "node %u: group column out of range", i);
+        load_projection(nd, d, c.width, "TopK");
+        for (u32 q = 0; q < nd.n_proj; q++) {   // DISTINCT is over (group, keys): the output may not carry anything else
+          bool covered = r.table_slot != 0 && nd.proj[q] == r.table_slot - 1;
+          for (u32 k = 0; k < r.n_keys; k++) covered = covered || nd.proj[q] == r.left_keys[k];
+          if (!covered) fail(RDFGPU_ERR_UNSUPPORTED, "node %u: TopK output column %u is neither the group nor a sort key", i, nd.proj[q]);
+        }
+        nd.width = nd.n_proj;
+        break;
+      }
       default: fail(RDFGPU_ERR_INVALID, "node %u: unknown kind %u", i, r.kind);
     }
   }
@@ -341,7 +359,9 @@ const char* kernel_class_name(int kc) {
       "rdfgpu::cross_kernel", "rdfgpu::join_build_kernel", "void rdfgpu::join_probe_kernel<false>",
       "void rdfgpu::join_probe_kernel<true>", "rdfgpu::join_left_unmatched_kernel", "void rdfgpu::nlj_kernel<false>",
       "void rdfgpu::nlj_kernel<true>", "rocprim device scan", "rdfgpu::gjoin_build_kernel", "rdfgpu::gdirect_build_kernel",
-      "rdfgpu::minmax_u32_kernel", "rdfgpu::csr_hist_kernel", "rdfgpu::csr_scatter_kernel"};
+      "rdfgpu::minmax_u32_kernel", "rdfgpu::csr_hist_kernel", "rdfgpu::csr_scatter_kernel",
+      "rdfgpu::topk_max_kernel", "rdfgpu::topk_hist_kernel", "rdfgpu::topk_scatter_kernel", "rdfgpu::topk_select_kernel",
+      "rdfgpu::topk_write_kernel"};
   if (kc < KC_LDS_JOIN0) return fixed[kc];
   static std::string names[192];
   static std::once_flag once;
@@ -510,6 +530,7 @@ DevTable Plan::exec_node(u32 idx) {
       break;
     }
     case RDFGPU_NODE_HASH_JOIN: case RDFGPU_NODE_CROSS_JOIN: case RDFGPU_NODE_NESTED_LOOP_JOIN: t = exec_join(nd); break;
+    case RDFGPU_NODE_TOPK: t = exec_topk(nd); break;
     case RDFGPU_NODE_TABLE: {
       const BoundTable& b = tables[nd.d.table_slot];
       if (!b.bound) fail(RDFGPU_ERR_INVALID, "table slot %u is not bound", nd.d.table_slot);
@@ -610,6 +631,63 @@ DevTable Plan::apply_filter(NodeInfo& nd, const DevTable& in) {
 }
 
 static u32 pow2_at_least(u64 v) { u64 p = 1024; while (p < v && p < (1ull << 31)) p <<= 1; return (u32)p; }
+
+// DISTINCT + ORDER BY keys LIMIT k (per group): counting sort of row ids by group, one wave per group selecting the k
+// smallest distinct key tuples, compaction by offsets.  Two host round trips (largest group id; final count + the
+// "unsupported kind in a SORT_BY_TERM column" flag): this operator ends a query, it is not inside the join pipeline.
+DevTable Plan::exec_topk(NodeInfo& nd) {
+  const DevTable in = exec_node((u32)nd.d.left);
+  DevTable t;
+  t.n_cols = nd.n_proj;
+  if (in.cap == 0) { t.cap = 0; return t; }
+  if (in.cap >= (1ull << 32)) fail(RDFGPU_ERR_UNSUPPORTED, "TopK over %llu rows", (unsigned long long)in.cap);
+  TopkArgs a{};
+  for (u32 c = 0; c < in.n_cols; c++) a.in[c] = in.cols[c];
+  a.n_in_dev = in.n_dev; a.n_in_cap = in.cap;
+  a.has_group = nd.d.table_slot != 0; a.group_col = a.has_group ? nd.d.table_slot - 1 : 0;
+  a.n_keys = nd.d.n_keys;
+  for (u32 k = 0; k < a.n_keys; k++) { a.key_col[k] = nd.d.left_keys[k]; a.key_by_term[k] = nd.d.right_keys[k] == RDFGPU_SORT_BY_TERM; }
+  a.k = nd.d.table_cols;
+  a.tt = store->typed_table();
+  u64* n_out = new_counter();
+  u32* flags = reinterpret_cast<u32*>(new_counter());   // {largest group id, unsupported-kind flag}
+  a.n_out_dev = n_out; a.bad = flags + 1;
+  a.n_groups = 1;
+  if (a.has_group) {
+    timed(KC_TOPK_MAX, 0, in.cap, in.n_dev, 4, nullptr, 0, 0, [&] { launch_topk_max(a.in[a.group_col], in.n_dev, in.cap, flags, stream); });
+    u32 mx = 0;
+    RDFGPU_HIP(hipMemcpyAsync(&mx, flags, sizeof(u32), hipMemcpyDeviceToHost, stream));
+    RDFGPU_HIP(hipStreamSynchronize(stream)); metrics.host_syncs++;
+    if (mx >= (1u << 24)) fail(RDFGPU_ERR_UNSUPPORTED, "TopK: group ids up to %u (dense ids below 2^24 expected)", mx);
+    a.n_groups = mx + 1;
+  }
+  const u64 ng = a.n_groups;
+  a.counts = scratch<u32>(ng + 1); a.offsets = scratch<u32>(ng + 1); a.cursor = scratch<u32>(ng);
+  a.perm = scratch<u32>(in.cap); a.picked = scratch<u32>(ng * a.k);
+  a.out_counts = scratch<u32>(ng + 1); a.out_offsets = scratch<u32>(ng + 1);
+  const u64 out_cap = std::min<u64>(in.cap, ng * a.k);
+  a.n_out_cols = nd.n_proj;
+  for (u32 c = 0; c < nd.n_proj; c++) { a.proj[c] = nd.proj[c]; a.out[c] = scratch<u32>(out_cap); t.cols[c] = a.out[c]; }
+  RDFGPU_HIP(hipMemsetAsync(a.counts, 0, (ng + 1) * sizeof(u32), stream));
+  RDFGPU_HIP(hipMemsetAsync(a.out_counts, 0, (ng + 1) * sizeof(u32), stream));
+  const size_t tb = scan_temp_bytes(ng + 1);
+  void* temp = scratch<unsigned char>(tb);
+  const u32 key_bytes = 4 * a.n_keys + 16 * (a.key_by_term[0] + (a.n_keys > 1 ? a.key_by_term[1] : 0));
+  timed(KC_TOPK_HIST, 0, in.cap, in.n_dev, 4, nullptr, 0, 0, [&] { launch_topk_hist(a, stream); });
+  exclusive_scan_u32(a.counts, a.offsets, ng + 1, temp, tb, stream);
+  RDFGPU_HIP(hipMemcpyAsync(a.cursor, a.offsets, ng * sizeof(u32), hipMemcpyDeviceToDevice, stream));
+  timed(KC_TOPK_SCATTER, 0, in.cap, in.n_dev, 8, nullptr, 0, 0, [&] { launch_topk_scatter(a, stream); });
+  timed(KC_TOPK_SELECT, 0, in.cap, in.n_dev, (4ull + key_bytes) * a.k, nullptr, 0, 0, [&] { launch_topk_select(a, stream); });
+  exclusive_scan_u32(a.out_counts, a.out_offsets, ng + 1, temp, tb, stream);
+  timed(KC_TOPK_WRITE, 0, 0, nullptr, 0, n_out, 0, 8ull * nd.n_proj, [&] { launch_topk_write(a, stream); });
+  const u32 i0 = (u32)(n_out - counters);
+  RDFGPU_HIP(hipMemcpyAsync(ctx->counters_host + i0, counters + i0, 2 * sizeof(u64), hipMemcpyDeviceToHost, stream));
+  RDFGPU_HIP(hipStreamSynchronize(stream)); metrics.host_syncs++;
+  if ((ctx->counters_host[i0 + 1] >> 32) != 0) fail(RDFGPU_ERR_UNSUPPORTED, "TopK: SORT_BY_TERM over a column that is not all strings / IRIs / blank nodes");
+  t.cap = std::min<u64>(out_cap, ctx->counters_host[i0]);
+  t.n_dev = n_out;
+  return t;
+}
 
 // Which input the hash join builds on.  A left join must build on the preserved (left) side.  An inner join builds
 // on the smaller input — unless exactly one input is a pure slice of the store (the same rows on every execution

@@ -47,6 +47,7 @@ enum KernelClass {
   KC_JOIN_COUNT, KC_JOIN_WRITE, KC_LEFT_TAIL, KC_NLJ_COUNT, KC_NLJ_WRITE, KC_DEVICE_SCAN,
   KC_GJOIN_BUILD,
   KC_GDIRECT_BUILD, KC_MINMAX, KC_CSR_HIST, KC_CSR_SCATTER,
+  KC_TOPK_MAX, KC_TOPK_HIST, KC_TOPK_SCATTER, KC_TOPK_SELECT, KC_TOPK_WRITE,
   KC_LDS_JOIN0,                      // 192 names: lds_join_kernel<FS in {0..3}, PFS in {0,1,2}, ITEMS in {4,1}, MODE in {0,1,2,3}, CHAIN>
   KC__N = KC_LDS_JOIN0 + 192
 };
@@ -110,6 +111,7 @@ struct Plan {
   DevTable exec_source(NodeInfo& nd);
   DevTable exec_filter(NodeInfo& nd);
   DevTable exec_join(NodeInfo& nd);
+  DevTable exec_topk(NodeInfo& nd);
   DevTable apply_filter(NodeInfo& nd, const DevTable& in);
   DevTable exec_lds_join(NodeInfo& nd, const DevTable& L, const DevTable& R, bool build_left, const NodeInfo* probe_filter, const NodeInfo* post_filter = nullptr);
   bool plan_chain(NodeInfo& top, ChainRequest& req);

@@ -1,0 +1,104 @@
+// topk.hip — DISTINCT + ORDER BY ... LIMIT k (per group) on binding tables: the AggregateExec(gby = sort keys,
+// first_value) + SortExec TopK(fetch = k) pair that sits directly above the join pipeline in the reference's explore
+// plans (bench/tests/plans/snapshots/..Q5 (Execution Plan).snap:5-9), so a whole query — or a whole batch of queries,
+// grouped by instance — shrinks to its final <= k rows per query before anything leaves HBM.
+//
+// No global sort: rows are grouped by a counting sort on the (dense) group id (histogram -> scan -> scatter of row
+// ids), then ONE WAVE PER GROUP runs k rounds of "smallest key tuple strictly greater than the previous pick" — a
+// strided scan of the group's rows per lane and a 6-step shuffle reduction — which orders, de-duplicates and limits in
+// one go (equal tuples are skipped by the strict comparison).  Groups here hold ~10^2 rows (BSBM Q5: ~117 per query).
+#include <hip/hip_runtime.h>
+
+#include "join_device.hpp"
+
+namespace rdfgpu {
+
+__global__ __launch_bounds__(256) void topk_max_kernel(const u32* col, const u64* n_dev, u64 cap, u32* out_max) {
+  const u64 n = live_rows(n_dev, cap);
+  u32 hi = 0;
+  for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) { const u32 v = col[i]; hi = v > hi ? v : hi; }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) { const u32 o = __shfl_xor(hi, d, 64); hi = o > hi ? o : hi; }
+  if ((threadIdx.x & 63) == 0) atomicMax(out_max, hi);
+}
+
+__global__ __launch_bounds__(256) void topk_hist_kernel(const TopkArgs a) {
+  const u64 n = live_rows(a.n_in_dev, a.n_in_cap);
+  const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const u32 g = a.has_group ? a.in[a.group_col][i] : 0u;
+  atomicAdd(&a.counts[g], 1u);
+}
+__global__ __launch_bounds__(256) void topk_scatter_kernel(const TopkArgs a) {
+  const u64 n = live_rows(a.n_in_dev, a.n_in_cap);
+  const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const u32 g = a.has_group ? a.in[a.group_col][i] : 0u;
+  a.perm[atomicAdd(&a.cursor[g], 1u)] = (u32)i;
+}
+
+// sort key of one row: the id itself, or (tag, rank) of its typed value for kinds that carry a rank (ENC_SORT of
+// strings / IRIs / blank nodes of one kind); tag 0 (null / unbound) sorts first (NULLS FIRST)
+__device__ __forceinline__ u64 topk_key(const TopkArgs& a, u32 which, u32 row) {
+  const u32 id = a.in[a.key_col[which]][row];
+  if (!a.key_by_term[which]) return id;
+  if (id == 0 || id >= a.tt.n_ids) return 0;
+  const int4 raw = *reinterpret_cast<const int4*>(a.tt.tv + id);
+  const u32 tag = (u32)raw.w & 0xff;
+  if (tag != RDFGPU_TV_STRING && tag != RDFGPU_TV_NAMED_NODE && tag != RDFGPU_TV_BLANK_NODE && tag != RDFGPU_TV_NULL) *a.bad = 1u;
+  const u64 lo = ((u64)(u32)raw.y << 32) | (u32)raw.x;
+  return ((u64)tag << 56) | (lo & 0x00FFFFFFFFFFFFFFull);
+}
+
+__global__ __launch_bounds__(256) void topk_select_kernel(const TopkArgs a) {
+  const u32 g = (u32)(((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+  if (g >= a.n_groups) return;   // whole waves leave together
+  const u32 lane = threadIdx.x & 63;
+  const u32 begin = a.offsets[g], end = a.offsets[g + 1];
+  u64 p1 = 0, p2 = 0; bool have_prev = false;
+  u32 cnt = 0;
+  for (u32 r = 0; r < a.k; r++) {
+    u64 b1 = ~0ull, b2 = ~0ull; u32 brow = kNil;
+    for (u32 e = begin + lane; e < end; e += 64) {
+      const u32 row = a.perm[e];
+      const u64 k1 = topk_key(a, 0, row), k2 = a.n_keys > 1 ? topk_key(a, 1, row) : 0ull;
+      const bool after_prev = !have_prev || k1 > p1 || (k1 == p1 && k2 > p2);
+      const bool better = brow == kNil || k1 < b1 || (k1 == b1 && k2 < b2);
+      if (after_prev && better) { b1 = k1; b2 = k2; brow = row; }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+      const u64 o1 = __shfl_xor(b1, d, 64), o2 = __shfl_xor(b2, d, 64); const u32 orow = __shfl_xor(brow, d, 64);
+      const bool take = orow != kNil && (brow == kNil || o1 < b1 || (o1 == b1 && (o2 < b2 || (o2 == b2 && orow < brow))));
+      if (take) { b1 = o1; b2 = o2; brow = orow; }
+    }
+    if (brow == kNil) break;        // wave-uniform after the reduction
+    if (lane == 0) a.picked[(u64)g * a.k + r] = brow;
+    p1 = b1; p2 = b2; have_prev = true; cnt++;
+  }
+  if (lane == 0) a.out_counts[g] = cnt;
+}
+
+__global__ __launch_bounds__(256) void topk_write_kernel(const TopkArgs a) {
+  const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t == 0) *a.n_out_dev = a.out_offsets[a.n_groups];
+  const u64 g = t / a.k; const u32 r = (u32)(t % a.k);
+  if (g >= a.n_groups) return;
+  const u32 n = a.out_offsets[g + 1] - a.out_offsets[g];
+  if (r >= n) return;
+  const u32 row = a.picked[g * a.k + r];
+  const u32 pos = a.out_offsets[g] + r;
+  for (u32 c = 0; c < a.n_out_cols; c++) a.out[c][pos] = a.in[a.proj[c]][row];
+}
+
+static inline dim3 grid256(u64 n) { const u64 g = (n + 255) / 256; return dim3((unsigned)(g ? g : 1)); }
+void launch_topk_max(const u32* col, const u64* n_dev, u64 cap, u32* out_max, hipStream_t s) {
+  const u64 g = (cap + 256 * 16 - 1) / (256 * 16);
+  hipLaunchKernelGGL(topk_max_kernel, dim3((unsigned)(g ? (g > 2048 ? 2048 : g) : 1)), dim3(256), 0, s, col, n_dev, cap, out_max);
+}
+void launch_topk_hist(const TopkArgs& a, hipStream_t s) { hipLaunchKernelGGL(topk_hist_kernel, grid256(a.n_in_cap), dim3(256), 0, s, a); }
+void launch_topk_scatter(const TopkArgs& a, hipStream_t s) { hipLaunchKernelGGL(topk_scatter_kernel, grid256(a.n_in_cap), dim3(256), 0, s, a); }
+void launch_topk_select(const TopkArgs& a, hipStream_t s) { hipLaunchKernelGGL(topk_select_kernel, grid256((u64)a.n_groups * 64), dim3(256), 0, s, a); }
+void launch_topk_write(const TopkArgs& a, hipStream_t s) { hipLaunchKernelGGL(topk_write_kernel, grid256((u64)a.n_groups * a.k), dim3(256), 0, s, a); }
+
+}  // namespace rdfgpu

@@ -315,5 +315,15 @@ class PlanBuilder:
         n.n_proj = abi.NO_PROJECTION
         return self._push(n, n_cols)
 
+    def topk(self, left, keys, limit, group=None, projection=None):
+        """DISTINCT + ORDER BY keys ASC LIMIT `limit` (per `group` column if given) — the AggregateExec(first_value) +
+        SortExec TopK(fetch) pair above the path in the reference's explore plans.  keys = [(column, abi.SORT_BY_ID |
+        abi.SORT_BY_TERM), ...] (at most 2)."""
+        n = abi.PlanNode(kind=abi.NODE_TOPK, left=left, right=-1, n_keys=len(keys), table_cols=int(limit),
+                         table_slot=0 if group is None else int(group) + 1)
+        for i, (c, how) in enumerate(keys):
+            n.left_keys[i], n.right_keys[i] = int(c), int(how)
+        return self._push(n, self._proj(n, projection, self.width[left]))
+
     def build(self, root):
         return PlanDescription(self.nodes, self.exprs, self.pool, root, list(self.width), list(self.regexes))

@@ -707,6 +707,67 @@ def test_plan_outlives_its_store_handle(torch_cuda):
     plan.close()
 
 
+def test_topk_distinct_matches_oracle(torch_cuda):
+    """DISTINCT + ORDER BY ... LIMIT k per group (the operators above the path) against the oracle,
+    incl. empty input, a single group, many tiny groups, unbound sort values, duplicates."""
+    rng = np.random.default_rng(12)
+    strings = [f"label {i:04d}" for i in rng.permutation(500)]
+    tv, _, _ = string_dictionary(strings, n_other=3)
+    tv["tag"][-3:] = abi.TV_NAMED_NODE
+    gs, os_ = both_stores((np.zeros(0, np.uint32),) * 4, typed=tv)
+    for n, n_groups, limit in ((0, 3, 5), (1, 1, 5), (7000, 50, 5), (60_000, 1, 6), (4000, 900, 2), (200_000, 3000, 5)):
+        g = rng.integers(1, n_groups + 1, n).astype(np.uint32)
+        lab = rng.integers(0, len(tv), n).astype(np.uint32)
+        prod = rng.integers(1000, 1060, n).astype(np.uint32)
+        tab = [g, lab, prod]
+        keep, ptrs = table_on_device(torch_cuda, tab)
+        for group, proj in ((0, None), (None, [1, 2]), (0, [2, 0, 1])):
+            pb = PlanBuilder()
+            desc = pb.build(pb.topk(pb.table(0, 3), keys=[(1, abi.SORT_BY_TERM), (2, abi.SORT_BY_ID)], limit=limit, group=group, projection=proj))
+            run_both(gs, os_, desc, gpu_tables=[(ptrs, n)], cpu_tables=[tab])
+        pb = PlanBuilder()                                                 # one key, by id
+        run_both(gs, os_, pb.build(pb.topk(pb.table(0, 3), keys=[(2, abi.SORT_BY_ID)], limit=limit, group=0, projection=[0, 2])),
+                 gpu_tables=[(ptrs, n)], cpu_tables=[tab])
+    # a numeric column cannot be ordered as a term here: refused loudly
+    tv2 = tv.copy(); tv2["tag"][5] = abi.TV_INTEGER
+    gs2, _ = both_stores((np.zeros(0, np.uint32),) * 4, typed=tv2)
+    tab = [np.ones(10, np.uint32), np.full(10, 5, np.uint32), np.arange(10, dtype=np.uint32) + 1]
+    keep, ptrs = table_on_device(torch_cuda, tab)
+    pb = PlanBuilder()
+    plan = gs2.plan(pb.build(pb.topk(pb.table(0, 3), keys=[(1, abi.SORT_BY_TERM), (2, abi.SORT_BY_ID)], limit=3, group=0)))
+    plan.bind_table(0, ptrs, 10)
+    with pytest.raises(rf.RdfGpuError):
+        plan.execute()
+    pb = PlanBuilder()
+    with pytest.raises(rf.RdfGpuError):          # an output column outside (group, keys) would make DISTINCT ambiguous
+        gs.plan(pb.build(pb.topk(pb.table(0, 3), keys=[(1, abi.SORT_BY_TERM)], limit=3, group=0)))
+
+
+def test_bsbm_q5_whole_query_on_device(bsbm_stores, torch_cuda):
+    """Q5 including DISTINCT + ORDER BY ?productLabel LIMIT 5: per query and as a batch grouped by instance."""
+    ds, gs, os_ = bsbm_stores
+    rng = np.random.default_rng(21)
+    for x in rng.choice(ds.n_products, 4, replace=False):
+        plan, got = run_both(gs, os_, bsbm.q5_plan(ds, ds.product(int(x)), topk=True))
+        assert plan.result_info()[0] <= 5
+    desc = bsbm.q5_batch_plan(ds, topk=True)
+    plan = gs.plan(desc)
+    for batch in (1, 90, 300):
+        prods = np.array([ds.product(i) for i in rng.choice(ds.n_products, batch, replace=False)], dtype=np.uint32)
+        params = [np.arange(1, batch + 1, dtype=np.uint32), prods]
+        keep, ptrs = table_on_device(torch_cuda, params)
+        plan.bind_table(0, ptrs, batch)
+        got = plan.execute().fetch()
+        exp, n_exp, _ = os_.execute(desc, [params])
+        np.testing.assert_array_equal(ku.multiset(got), ku.multiset(exp, n_exp))
+        assert len(got[0]) <= 5 * batch
+        # per instance the batch's rows are exactly the single-query plan's rows
+        for i in (0, batch - 1):
+            c, m, _ = os_.execute(bsbm.q5_plan(ds, int(prods[i]), topk=True))
+            sel = got[0] == i + 1
+            np.testing.assert_array_equal(ku.multiset([got[1][sel], got[2][sel]]), ku.multiset(c, m))
+
+
 def test_generic_vm_equals_specialised_kernels(bsbm_stores, monkeypatch):
     ds, gs, os_ = bsbm_stores
     desc = bsbm.q5_plan(ds, ds.product(17))

@@ -82,3 +82,30 @@ def test_integer_filter_agrees_with_arrow_compute(op, pc_op):
     vals = pa.array(values[ids], type=pa.int64(), mask=(ids == 0))
     keep = np.asarray(pc.fill_null(pc_op(vals, 17), False))
     np.testing.assert_array_equal(ku.multiset(got, n), ku.multiset([payload[keep], ids[keep]]))
+
+
+def test_topk_distinct_agrees_with_python_sorting():
+    """DISTINCT + ORDER BY (term, id) LIMIT k per group in the oracle vs plain Python sorted(set(..))[:k]."""
+    from rdf_fusion_amd.plan import PlanBuilder as PB
+    rng = np.random.default_rng(8)
+    strings = [f"label {i:04d}" for i in rng.permutation(300)]
+    tv, _, _ = ku.string_dictionary(strings, lang_every=10 ** 9)
+    os_ = orc.OracleStore()
+    os_.set_typed_values(tv)
+    for n, n_groups, limit in ((0, 3, 5), (1, 1, 5), (5000, 40, 5), (20_000, 1, 7), (3000, 600, 2)):
+        g = rng.integers(1, n_groups + 1, n).astype(np.uint32)
+        lab = rng.integers(0, 301, n).astype(np.uint32)                   # 0 = unbound: sorts first
+        prod = rng.integers(1000, 1040, n).astype(np.uint32)
+        for group in (0, None):
+            pb = PB()
+            desc = pb.build(pb.topk(pb.table(0, 3), keys=[(1, abi.SORT_BY_TERM), (2, abi.SORT_BY_ID)], limit=limit, group=group,
+                                    projection=None if group == 0 else [1, 2]))
+            cols, m, _ = os_.execute(desc, [[g, lab, prod]])
+            exp = []
+            for gg in (np.unique(g) if group == 0 else [None]):
+                sel = slice(None) if gg is None else g == gg
+                key = lambda l: (0, 0) if l == 0 else (int(tv["tag"][l]), int(tv["lo"][l]))
+                rows = sorted(set((key(int(l)), int(p), int(l)) for l, p in zip(lab[sel], prod[sel])))[:limit]
+                exp += [((int(gg),) if gg is not None else ()) + (l, p) for _, p, l in rows]
+            got = sorted(tuple(int(c[r]) for c in cols) for r in range(m))
+            assert got == sorted(exp), (n, n_groups, limit, group)
