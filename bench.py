@@ -182,6 +182,7 @@ def main():
         return resident[key]
 
     lat_ms = []
+    phase_ms = [0.0, 0.0, 0.0]    # sharded run, this rank: phase A (constant patterns), exchange (all-gather + table layout), phase B
 
     # ------------------------------------------------------------------ the step
     if args.per_instance:
@@ -231,6 +232,8 @@ def main():
         offs = [0, 3 * caps[0], 3 * (caps[0] + caps[1])]      # int32 offset of each table inside the exchange buffer
         buf_len = 3 * sum(caps)
 
+        send_buf = torch.zeros(buf_len, dtype=torch.int32, device="cuda")
+
         class _DevCol:
             """A result column in HBM, as torch sees it (zero copy)."""
             def __init__(self, ptr, n):
@@ -242,8 +245,10 @@ def main():
             a padding row has inst = 0 = null, and a null key never joins (NullEqualsNothing), so the gathered
             buffer is bound as it is: no counts travel, nothing is unpacked on the host.
             Phase B: the batch's join / FILTER pipeline over the local shard of the product-side patterns."""
+            t_a = time.perf_counter()
             t, ptrs, n = params_on_device(batch)
-            mine = torch.zeros(buf_len, dtype=torch.int32, device="cuda")
+            mine = send_buf.zero_()
+
             for pa, cap, off in zip(plans_a, caps, offs):
                 pa.bind_table(0, ptrs, n)
                 pa.enable_kernel_timing(timing)
@@ -256,6 +261,8 @@ def main():
                 for k in range(3):
                     if rows:
                         mine[off + k * cap:off + k * cap + rows] = torch.as_tensor(_DevCol(cols[k], rows), device="cuda")
+            torch.cuda.current_stream().synchronize()
+            t_x = time.perf_counter()
             send = mine.to(xdev)
             out = torch.empty(world * buf_len, dtype=torch.int32, device=send.device)
             dist.all_gather_into_tensor(out, send)
@@ -267,11 +274,13 @@ def main():
                 keep.append(tab)
                 plan_b.bind_table(slot, [tab.data_ptr() + 4 * world * cap * k for k in range(3)], world * cap)
             torch.cuda.current_stream().synchronize()      # the tables are complete before the plan's stream reads them
+            t_b = time.perf_counter()
             plan_b.enable_kernel_timing(timing)
             plan_b.execute()
             rows, _ = plan_b.result_info()
             if timing:
                 account(plan_b)
+                phase_ms[0] += (t_x - t_a) * 1e3; phase_ms[1] += (t_b - t_x) * 1e3; phase_ms[2] += (time.perf_counter() - t_b) * 1e3
             return rows
 
     if not args.per_instance:
@@ -419,6 +428,8 @@ def main():
                        "mode": "per-instance" if args.per_instance else "batched",
                        "triples_per_gpu": n_local, "sharding": "hash(subject) mod N, all-gatherv of constant-pattern bindings" if world > 1 else "none",
                        "sharded_result_check": shard_check,
+                       "rank0_phase_ms_per_step": ({"constant_patterns": round(phase_ms[0] / args.steps, 3), "exchange": round(phase_ms[1] / args.steps, 3),
+                                                    "join_pipeline": round(phase_ms[2] / args.steps, 3)} if world > 1 else None),
                        "queries_per_s": round(n_q / elapsed, 2), "bindings": total_rows,
                        "host_threads": args.threads if args.per_instance else 1,
                        "single_instance_latency_ms": single,
