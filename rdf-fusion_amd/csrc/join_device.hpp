@@ -4,6 +4,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdlib>
+#include <mutex>
 
 #include "kernels.hpp"
 
@@ -497,11 +498,10 @@ __global__ __launch_bounds__(kLdsBlock) void lds_join_kernel(const LdsJoinArgs a
 
 template <int FS, int PFS, int ITEMS, int MODE, bool CHAIN>
 static void launch_lds_join_tc(const LdsJoinArgs& a, dim3 g, size_t lds, hipStream_t s) {
-  static bool attr_set = false;
-  if (!attr_set) {   // dynamic LDS above 64 KiB has to be opted into, per kernel instance
+  static std::once_flag attr_once;   // dynamic LDS above 64 KiB has to be opted into, once per kernel instance (plans run on many host threads)
+  std::call_once(attr_once, [] {
     RDFGPU_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lds_join_kernel<FS, PFS, ITEMS, MODE, CHAIN>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
-    attr_set = true;
-  }
+  });
   hipLaunchKernelGGL((lds_join_kernel<FS, PFS, ITEMS, MODE, CHAIN>), g, dim3(kLdsBlock), lds, s, a);
 }
 template <int FS, int PFS, int ITEMS, int MODE>
