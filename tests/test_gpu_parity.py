@@ -768,6 +768,42 @@ def test_bsbm_q5_whole_query_on_device(bsbm_stores, torch_cuda):
             np.testing.assert_array_equal(ku.multiset([got[1][sel], got[2][sel]]), ku.multiset(c, m))
 
 
+def test_bsbm_10m_scale_configs(torch_cuda):
+    """BASELINE config 2 (BSBM scale-10M, Q1 single-pattern scan + FILTER) and the Q5 / batched-Q5 plans at that scale:
+    the scan + FILTER against numpy (a size-independent property: the survivors are exactly the products whose value
+    exceeds the threshold), the plans against the oracle (which adopts the device-built permutations)."""
+    ds = bsbm.generate(28_500)                                   # ~10 M triples
+    gs = rf.GpuQuadStore()
+    gs.extend(ds.g, ds.s, ds.p, ds.o)
+    gs.set_typed_values(ds.typed_values)
+    assert len(gs) > 9_000_000
+    os_ = orc.OracleStore()
+    for comp in (abi.GSPO, abi.GPOS, abi.GOSP):
+        os_.adopt_sorted(comp, gs.read_index(comp))
+    os_.set_typed_values(ds.typed_values)
+    num1 = ds.p == ds.pred["bsbm:productPropertyNumeric1"]
+    values = ds.o[num1].astype(np.int64) - ds.int_base + 1
+    for thr in (1, 400, 1000, 1999):
+        plan = gs.plan(bsbm.q1_scan_filter_plan(ds, thr)).execute()
+        got = np.sort(plan.fetch()[0])
+        np.testing.assert_array_equal(got, np.sort(ds.s[num1][values > thr]))
+    rng = np.random.default_rng(10)
+    for x in rng.choice(ds.n_products, 3, replace=False):
+        run_both(gs, os_, bsbm.q5_plan(ds, ds.product(int(x))))
+    run_both(gs, os_, bsbm.q1_plan(ds, *bsbm.q1_instance(ds, rng)))
+    batch = 64
+    prods = np.array([ds.product(i) for i in rng.choice(ds.n_products, batch, replace=False)], dtype=np.uint32)
+    params = [np.arange(1, batch + 1, dtype=np.uint32), prods]
+    keep, ptrs = table_on_device(torch_cuda, params)
+    desc = bsbm.q5_batch_plan(ds, topk=True)
+    plan = gs.plan(desc)
+    plan.bind_table(0, ptrs, batch)
+    for _ in range(2):                                           # second run: speculative, fused
+        got = plan.execute().fetch()
+        exp, n_exp, _ = os_.execute(desc, [params])
+        np.testing.assert_array_equal(ku.multiset(got), ku.multiset(exp, n_exp))
+
+
 def test_generic_vm_equals_specialised_kernels(bsbm_stores, monkeypatch):
     ds, gs, os_ = bsbm_stores
     desc = bsbm.q5_plan(ds, ds.product(17))
