@@ -140,7 +140,9 @@ void launch_scan_write(const ScanJob& job, const u32* block_offsets, hipStream_t
 // Predicate on a value already in a register (the specialised shapes read exactly one column).
 template <int SHAPE>
 __device__ __forceinline__ bool filter_pred_value(const FilterArgs& a, u32 v) {
-  if constexpr (SHAPE == 1) {  // col <ID_EQ|ID_NEQ> object-id literal; null on either side => dropped
+  if constexpr (SHAPE == 3) {  // string predicate, answered per distinct term beforehand: one byte gather (L2-resident table)
+    return v != 0 && v < a.n_verdict && a.verdict[v] == 1;
+  } else if constexpr (SHAPE == 1) {  // col <ID_EQ|ID_NEQ> object-id literal; null on either side => dropped
     const u32 lit = a.prog.nodes[1].u;
     if (v == 0 || lit == 0) return false;
     return (v == lit) == (a.prog.nodes[2].op == RDFGPU_EX_ID_EQ);
@@ -250,6 +252,21 @@ __global__ __launch_bounds__(kBlock) void filter_kernel(const FilterArgs a) {
     }
   }
 }
+// REGEX / CONTAINS / STRSTARTS / STRENDS per DISTINCT TERM: one lane per object id walks its string once (consecutive
+// ids = consecutive heap ranges, so the dictionary streams through), instead of once per row of every query — a 50 M-row
+// filter over 4 M distinct strings then gathers one byte per row from a 4 MB table.
+__global__ __launch_bounds__(256) void regex_verdict_kernel(const RegexProg* prog, const TypedTable tt, int64_t rhs_lang, unsigned char* out, u64 n_ids) {
+  const u64 id = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (id >= n_ids) return;
+  const Val v = enc_tv(tt, (u32)id);
+  const Val r = tv_regex(*prog, tt, v, rhs_lang);
+  out[id] = r.tag == RDFGPU_TV_BOOLEAN ? (unsigned char)(r.lo != 0) : (unsigned char)2;
+}
+void launch_regex_verdicts(const RegexProg* prog_dev, const TypedTable& tt, int64_t rhs_lang, unsigned char* out, u64 n_ids, hipStream_t s) {
+  if (!n_ids) return;
+  hipLaunchKernelGGL(regex_verdict_kernel, dim3((unsigned)((n_ids + 255) / 256)), dim3(256), 0, s, prog_dev, tt, rhs_lang, out, n_ids);
+}
+
 void launch_filter(const FilterArgs& a0, int shape, hipStream_t s) {
   FilterArgs a = a0;
   // rows per workgroup: enough workgroups to fill the chip (>= ~1024), few enough reservations
@@ -270,7 +287,8 @@ void launch_filter(const FilterArgs& a0, int shape, hipStream_t s) {
   const u64 chunk = (u64)kTile * a.iters;
   const u64 g = (a.n_in_cap + a.head_skip + chunk - 1) / chunk;
   const dim3 grid((unsigned)(g ? g : 1));
-  if (shape == 1) hipLaunchKernelGGL(filter_kernel<1>, grid, dim3(kBlock), 0, s, a);
+  if (shape == 3) hipLaunchKernelGGL(filter_kernel<3>, grid, dim3(kBlock), 0, s, a);
+  else if (shape == 1) hipLaunchKernelGGL(filter_kernel<1>, grid, dim3(kBlock), 0, s, a);
   else if (shape == 2) hipLaunchKernelGGL(filter_kernel<2>, grid, dim3(kBlock), 0, s, a);
   else hipLaunchKernelGGL(filter_kernel<0>, grid, dim3(kBlock), 0, s, a);
 }

@@ -57,9 +57,13 @@ struct FilterArgs {
   u32 iters, head_skip, vec_ok, vec_proj_ok;   // set by launch_filter: rounds per workgroup, alignment head, 16-B loads allowed
   TypedTable tt;
   ExprProgram prog;
+  const unsigned char* verdict; u64 n_verdict;   // shape 3: per-id verdicts of a string predicate (0 false / 1 true / 2 error)
 };
-// shape 0 = generic VM; 1 = `col <op> object-id literal` (ID_EQ / ID_NEQ); 2 = EBV(cmp(ENC_TV(col), literal))
+// shape 0 = generic VM; 1 = `col <op> object-id literal` (ID_EQ / ID_NEQ); 2 = EBV(cmp(ENC_TV(col), literal));
+// 3 = EBV(REGEX | CONTAINS | STRSTARTS | STRENDS (ENC_TV(col), constant)) through a per-distinct-term verdict table
 void launch_filter(const FilterArgs& a, int shape, hipStream_t s);
+// Evaluates one string predicate for EVERY object id once (streaming through the string heap): out[id] = 0 / 1 / 2.
+void launch_regex_verdicts(const RegexProg* prog_dev, const TypedTable& tt, int64_t rhs_lang, unsigned char* out, u64 n_ids, hipStream_t s);
 
 // ---- K6: CrossJoinExec ----
 struct CrossArgs {

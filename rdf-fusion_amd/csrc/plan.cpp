@@ -72,6 +72,10 @@ int detect_shape(const ExprProgram& pr) {
   const rdfgpu_expr_node* e = pr.nodes;
   if (pr.n == 3 && e[0].op == RDFGPU_EX_COLUMN && e[1].op == RDFGPU_EX_LIT_ID && (e[2].op == RDFGPU_EX_ID_EQ || e[2].op == RDFGPU_EX_ID_NEQ)) return 1;
   if (pr.n == 5 && e[0].op == RDFGPU_EX_COLUMN && e[1].op == RDFGPU_EX_ENC_TV && e[2].op == RDFGPU_EX_LIT_TV && is_cmp(e[3].op) && e[4].op == RDFGPU_EX_EBV) return 2;
+  // EBV(REGEX | CONTAINS | STRSTARTS | STRENDS (ENC_TV(col), constant)): answered per distinct term (shape 3) when the
+  // table is large enough to pay for a pass over the dictionary, else by the VM per row
+  if (pr.n == 4 && e[0].op == RDFGPU_EX_COLUMN && e[1].op == RDFGPU_EX_ENC_TV && e[3].op == RDFGPU_EX_EBV &&
+      (e[2].op == RDFGPU_EX_REGEX || e[2].op == RDFGPU_EX_CONTAINS || e[2].op == RDFGPU_EX_STRSTARTS || e[2].op == RDFGPU_EX_STRENDS)) return 3;
   return 0;
 }
 
@@ -158,6 +162,17 @@ Plan* plan_compile(Store* store, const rdfgpu_plan_desc* d) {
         fail(RDFGPU_ERR_UNSUPPORTED, "string pattern %u: %s", r, why.c_str());
       if (use[r] == RDFGPU_EX_STRSTARTS) progs[r].anchor_start = 1;
       if (use[r] == RDFGPU_EX_STRENDS) progs[r].anchor_end = 1;
+    }
+    for (u32 r = 0; r < d->n_regexes; r++) {   // own copies of the texts: they key the store's per-term verdict tables
+      const rdfgpu_regex& rx = d->regexes[r];
+      plan->regex_strings.emplace_back(rx.pattern ? std::string(rx.pattern, rx.pattern_len) : std::string());
+      plan->regex_strings.emplace_back(rx.flags ? std::string(rx.flags, rx.flags_len) : std::string());
+    }
+    for (u32 r = 0; r < d->n_regexes; r++) {
+      rdfgpu_regex rx{};
+      rx.pattern = plan->regex_strings[2 * r].data(); rx.pattern_len = (u32)plan->regex_strings[2 * r].size();
+      rx.flags = plan->regex_strings[2 * r + 1].data(); rx.flags_len = (u32)plan->regex_strings[2 * r + 1].size();
+      plan->regex_text.push_back(rx);
     }
     store->activate();
     RDFGPU_HIP(hipMalloc((void**)&plan->regex_dev, progs.size() * sizeof(RegexProg)));
@@ -361,7 +376,7 @@ const char* kernel_class_name(int kc) {
       "void rdfgpu::nlj_kernel<true>", "rocprim device scan", "rdfgpu::gjoin_build_kernel", "rdfgpu::gdirect_build_kernel",
       "rdfgpu::minmax_u32_kernel", "rdfgpu::csr_hist_kernel", "rdfgpu::csr_scatter_kernel",
       "rdfgpu::topk_max_kernel", "rdfgpu::topk_hist_kernel", "rdfgpu::topk_scatter_kernel", "rdfgpu::topk_select_kernel",
-      "rdfgpu::topk_write_kernel"};
+      "rdfgpu::topk_write_kernel", "void rdfgpu::filter_kernel<3>", "rdfgpu::regex_verdict_kernel"};
   if (kc < KC_LDS_JOIN0) return fixed[kc];
   static std::string names[192];
   static std::once_flag once;
@@ -622,10 +637,36 @@ DevTable Plan::apply_filter(NodeInfo& nd, const DevTable& in) {
   a.n_out_dev = new_counter();
   a.tt = store->typed_table();
   a.prog = nd.prog;
-  // FilterExec bytes: 4·c_r·N + t·N + 4·c_w·σN with t = 9 B per typed gather (tag + i64)
-  const int kc = nd.shape == 1 ? KC_FILTER_ID : nd.shape == 2 ? KC_FILTER_TV : KC_FILTER_VM;
-  timed(kc, 0, in.cap, in.n_dev, 4ull * nd.n_cols_read + 9ull * nd.n_enc_tv, a.n_out_dev, 0, 4ull * nd.n_proj,
-        [&] { launch_filter(a, nd.shape, stream); });
+  int shape = nd.shape;
+  if (shape == 3) {
+    // per-distinct-term verdicts: worth a pass over the dictionary when the table has at least a quarter as many rows
+    // as there are ids (or the verdicts exist already); the table lives on the store, keyed by the predicate
+    const rdfgpu_expr_node& e = nd.prog.nodes[2];
+    const rdfgpu_regex& rx = regex_text[e.u];
+    std::string key(1, (char)e.op);
+    key.append(reinterpret_cast<const char*>(&e.lo), sizeof e.lo);
+    key.append(rx.flags ? std::string(rx.flags, rx.flags_len) : std::string()).push_back('\0');
+    key.append(rx.pattern ? std::string(rx.pattern, rx.pattern_len) : std::string());
+    const u64 n_ids = std::min<u64>(store->n_ids, store->n_str_ids);
+    unsigned char* verdict = nullptr;
+    if (!std::getenv("RDFGPU_NO_STRING_VERDICTS") && n_ids > 0) {
+      std::unique_lock<std::mutex> building(store->slice_build_mu);
+      { std::lock_guard<std::mutex> l(store->slice_mu); auto it = store->string_verdicts.find(key); if (it != store->string_verdicts.end()) verdict = it->second; }
+      if (!verdict && in.cap * 4 >= n_ids) {
+        RDFGPU_HIP(hipMalloc((void**)&verdict, n_ids));
+        const int64_t lang = e.op == RDFGPU_EX_REGEX ? -1 : (e.lo < 0 ? 0 : e.lo);
+        timed(KC_REGEX_VERDICTS, 0, n_ids, nullptr, 16 + 8 + 1, nullptr, 0, 0, [&] { launch_regex_verdicts(regex_dev + e.u, a.tt, lang, verdict, n_ids, stream); });
+        RDFGPU_HIP(hipStreamSynchronize(stream)); metrics.host_syncs++;   // complete before other plans may see it
+        std::lock_guard<std::mutex> l(store->slice_mu);
+        store->string_verdicts[key] = verdict;
+      }
+    }
+    if (verdict) { a.verdict = verdict; a.n_verdict = n_ids; } else shape = 0;
+  }
+  // FilterExec bytes: 4·c_r·N + t·N + 4·c_w·σN with t = 9 B per typed gather (tag + i64); shape 3: t = 1 B
+  const int kc = shape == 1 ? KC_FILTER_ID : shape == 2 ? KC_FILTER_TV : shape == 3 ? KC_FILTER_VERDICT : KC_FILTER_VM;
+  timed(kc, 0, in.cap, in.n_dev, shape == 3 ? 4ull * nd.n_cols_read + 1 : 4ull * nd.n_cols_read + 9ull * nd.n_enc_tv, a.n_out_dev, 0, 4ull * nd.n_proj,
+        [&] { launch_filter(a, shape, stream); });
   t.cap = in.cap; t.n_dev = a.n_out_dev;
   return t;
 }

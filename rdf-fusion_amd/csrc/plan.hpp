@@ -1,6 +1,7 @@
 // plan.hpp — compiled operator tree: DataSourceExec / FilterExec / HashJoinExec / CrossJoinExec /
 // NestedLoopJoinExec / ProjectionExec over HBM-resident binding tables.
 #pragma once
+#include <string>
 #include <vector>
 
 #include "host_logic.hpp"
@@ -48,6 +49,7 @@ enum KernelClass {
   KC_GJOIN_BUILD,
   KC_GDIRECT_BUILD, KC_MINMAX, KC_CSR_HIST, KC_CSR_SCATTER,
   KC_TOPK_MAX, KC_TOPK_HIST, KC_TOPK_SCATTER, KC_TOPK_SELECT, KC_TOPK_WRITE,
+  KC_FILTER_VERDICT, KC_REGEX_VERDICTS,
   KC_LDS_JOIN0,                      // 192 names: lds_join_kernel<FS in {0..3}, PFS in {0,1,2}, ITEMS in {4,1}, MODE in {0,1,2,3}, CHAIN>
   KC__N = KC_LDS_JOIN0 + 192
 };
@@ -78,6 +80,7 @@ struct Plan {
   std::vector<u32> pool;          // IN-set ids of residual predicates (host copy)
   u32* pool_dev = nullptr;        // same, on device
   RegexProg* regex_dev = nullptr; // compiled REGEX patterns of the plan (device)
+  std::vector<std::string> regex_strings; std::vector<rdfgpu_regex> regex_text;   // their texts (pattern, flags per entry)
   u32 root = 0;
   ExecContext* ctx = nullptr;     // stream, events, counters (pooled per store)
   hipStream_t stream = nullptr;

@@ -161,9 +161,16 @@ void Store::drop_slice_tables() {
   slice_tables.clear();
 }
 
+void Store::drop_string_verdicts() {
+  std::lock_guard<std::mutex> lock(slice_mu);
+  for (auto& kv : string_verdicts) if (kv.second) (void)hipFree(kv.second);
+  string_verdicts.clear();
+}
+
 Store::~Store() {
   (void)hipSetDevice(device);
   drop_slice_tables();
+  drop_string_verdicts();
   for (ExecContext* c : free_ctx) delete c;
   for (auto& ix : idx) for (auto& c : ix.col) if (c) (void)hipFree(c);
   if (tv) (void)hipFree(tv);
@@ -313,6 +320,7 @@ u64 Store::remove_host(const u32* g, const u32* s_, const u32* p, const u32* o, 
 void Store::set_typed_values(const rdfgpu_typed_value* v, u64 n, const int64_t* d, u64 nd) {
   std::unique_lock<std::shared_mutex> lock(mu);
   activate();
+  drop_string_verdicts();
   if (tv) { RDFGPU_HIP(hipFree(tv)); tv = nullptr; }
   if (dec) { RDFGPU_HIP(hipFree(dec)); dec = nullptr; }
   n_ids = n; n_dec = nd;
@@ -329,6 +337,7 @@ void Store::set_typed_values(const rdfgpu_typed_value* v, u64 n, const int64_t* 
 void Store::set_strings(const u64* offsets, u64 n, const unsigned char* heap_host, u64 heap_bytes) {
   std::unique_lock<std::shared_mutex> lock(mu);
   activate();
+  drop_string_verdicts();
   if (n && !offsets) fail(RDFGPU_ERR_INVALID, "set_strings: null offsets");
   for (u64 i = 0; i < n; i++) if (offsets[i] > offsets[i + 1] || offsets[i + 1] > heap_bytes) fail(RDFGPU_ERR_INVALID, "set_strings: offsets of id %llu are not monotone / inside the heap", (unsigned long long)i);
   if (str_off) { RDFGPU_HIP(hipFree(str_off)); str_off = nullptr; }

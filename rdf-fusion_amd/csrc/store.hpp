@@ -6,6 +6,7 @@
 #include <map>
 #include <mutex>
 #include <shared_mutex>
+#include <string>
 #include <vector>
 
 #include "common.hpp"
@@ -94,6 +95,10 @@ struct Store {
   // held, so concurrent plans never see a half-built one.  Dropped by every mutation (which holds `mu` exclusively).
   std::mutex slice_mu, slice_build_mu;
   std::map<SliceKey, SliceTable> slice_tables;
+  // per-distinct-term verdicts of constant string predicates (key = function, language, flags, pattern): one byte per
+  // object id, computed once per dictionary, shared by all plans; dropped when the dictionary or typed values change
+  std::map<std::string, unsigned char*> string_verdicts;
+  void drop_string_verdicts();
   SliceTable* slice_table(const SliceKey& k);
   const SliceTable* find_slice_table(const SliceKey& k);
   void drop_slice_tables();

@@ -498,7 +498,7 @@ def test_index_join_against_store_slice(torch_cuda, shape, n_tab):
 string_dictionary = ku.string_dictionary
 
 
-def test_regex_filter_matches_oracle(torch_cuda):
+def test_regex_filter_matches_oracle(torch_cuda, monkeypatch):
     import re
     rng = np.random.default_rng(99)
     strings = [ku.random_subject(rng) for _ in range(1500)] + ["", "a", "b", "ab\n", "K", "ſ", "😀"]
@@ -527,6 +527,19 @@ def test_regex_filter_matches_oracle(torch_cuda):
             plan, got = run_both(gs, os_, desc, gpu_tables=[(ptrs, len(ids))], cpu_tables=[[ids, payload]])
             matched_some += plan.result_info()[0] > 0
     assert matched_some > 100
+    # per-distinct-term verdict table (filter_kernel<3>) vs per-row VM evaluation: same rows
+    for pat, flags in fixed[:12]:
+        pb = PlanBuilder()
+        desc = pb.build(pb.filter(pb.table(0, 2), EBV(REGEX(ENC_TV(col(0)), pat, flags)), projection=[1]))
+        p1 = gs.plan(desc); p1.bind_table(0, ptrs, len(ids)); p1.enable_kernel_timing(True)
+        a_rows = np.sort(p1.execute().fetch()[0])
+        assert any("filter_kernel<3>" in k[0] for k in p1.kernel_stats()) or ENGINE_TOGGLED
+        monkeypatch.setenv("RDFGPU_NO_STRING_VERDICTS", "1")
+        p2 = gs.plan(desc); p2.bind_table(0, ptrs, len(ids)); p2.enable_kernel_timing(True)
+        b_rows = np.sort(p2.execute().fetch()[0])
+        assert not any("filter_kernel<3>" in k[0] for k in p2.kernel_stats())
+        monkeypatch.delenv("RDFGPU_NO_STRING_VERDICTS")
+        np.testing.assert_array_equal(a_rows, b_rows)
     # an independent spot check of the device against Python's `re` (not via the oracle)
     for pat, py in (("(ab|cd)+e", "(ab|cd)+e"), ("^k.*x$", "^k.*x\\Z"), ("[^a]b", "[^a]b")):
         pb = PlanBuilder()
