@@ -653,12 +653,18 @@ DevTable Plan::apply_filter(NodeInfo& nd, const DevTable& in) {
       std::unique_lock<std::mutex> building(store->slice_build_mu);
       { std::lock_guard<std::mutex> l(store->slice_mu); auto it = store->string_verdicts.find(key); if (it != store->string_verdicts.end()) verdict = it->second; }
       if (!verdict && in.cap * 4 >= n_ids) {
-        RDFGPU_HIP(hipMalloc((void**)&verdict, n_ids));
+        // bounded cache: a workload of ever-changing patterns must not pile up one table per pattern — beyond 64
+        // entries the table is this execution's scratch
+        bool cache_it;
+        { std::lock_guard<std::mutex> l(store->slice_mu); cache_it = store->string_verdicts.size() < 64; }
+        if (cache_it) RDFGPU_HIP(hipMalloc((void**)&verdict, n_ids)); else verdict = scratch<unsigned char>(n_ids);
         const int64_t lang = e.op == RDFGPU_EX_REGEX ? -1 : (e.lo < 0 ? 0 : e.lo);
         timed(KC_REGEX_VERDICTS, 0, n_ids, nullptr, 16 + 8 + 1, nullptr, 0, 0, [&] { launch_regex_verdicts(regex_dev + e.u, a.tt, lang, verdict, n_ids, stream); });
-        RDFGPU_HIP(hipStreamSynchronize(stream)); metrics.host_syncs++;   // complete before other plans may see it
-        std::lock_guard<std::mutex> l(store->slice_mu);
-        store->string_verdicts[key] = verdict;
+        if (cache_it) {
+          RDFGPU_HIP(hipStreamSynchronize(stream)); metrics.host_syncs++;   // complete before other plans may see it
+          std::lock_guard<std::mutex> l(store->slice_mu);
+          store->string_verdicts[key] = verdict;
+        }
       }
     }
     if (verdict) { a.verdict = verdict; a.n_verdict = n_ids; } else shape = 0;
