@@ -93,6 +93,28 @@ __device__ __forceinline__ bool window_fast(const TypedTable& tt, u32 ix0, u32 i
   const u32 c0 = p0 < z0 ? 1u : p0 > z0 ? 4u : 2u, c1 = p1 < z1 ? 1u : p1 > z1 ? 4u : 2u;
   return !o0 && !o1 && (m0 & c0) != 0 && (m1 & c1) != 0;   // overflow => error => null => not `true`
 }
+// the same test with x already decoded (x0 == x1 = an xsd:integer from a slice's value table): only the y side is gathered
+__device__ __forceinline__ bool window_fast_x(const TypedTable& tt, long long x, u32 iy0, u32 iy1, const TvLiteral& l0, const TvLiteral& l1, bool& undecided) {
+  if (tt.n_ids == 0) { undecided = true; return false; }
+  const u64 n_ids = tt.n_ids;
+  iy0 = iy0 < n_ids ? iy0 : 0u; iy1 = iy1 < n_ids ? iy1 : 0u;
+  const int4* tv = reinterpret_cast<const int4*>(tt.tv);
+  const bool same = iy0 == iy1;
+  const int4 ry0 = tv[iy0];
+  const int4 ry1 = tv[iy1];
+  (void)same;
+  undecided = ((u32)ry0.w & 0xff) != RDFGPU_TV_INTEGER || ((u32)ry1.w & 0xff) != RDFGPU_TV_INTEGER || l0.tag != RDFGPU_TV_INTEGER || l1.tag != RDFGPU_TV_INTEGER;
+  auto i64 = [](const int4& r) { return (long long)(((u64)(u32)r.y << 32) | (u32)r.x); };
+  const bool neg0 = l0.arith_sub != 0, neg1 = l1.arith_sub != 0;
+  undecided = undecided || (neg0 && l0.lo == INT64_MIN) || (neg1 && l1.lo == INT64_MIN);
+  const long long d0 = neg0 ? -(long long)(l0.lo == INT64_MIN ? 0 : l0.lo) : (long long)l0.lo;
+  const long long d1 = neg1 ? -(long long)(l1.lo == INT64_MIN ? 0 : l1.lo) : (long long)l1.lo;
+  long long z0, z1;
+  const bool o0 = __builtin_add_overflow(i64(ry0), d0, &z0), o1 = __builtin_add_overflow(i64(ry1), d1, &z1);
+  auto mask_of = [](u8 op) -> u32 { return op == RDFGPU_EX_GT ? 4u : op == RDFGPU_EX_LT ? 1u : op == RDFGPU_EX_GEQ ? 6u : op == RDFGPU_EX_LEQ ? 3u : op == RDFGPU_EX_EQ ? 2u : 5u; };
+  const u32 c0 = x < z0 ? 1u : x > z0 ? 4u : 2u, c1 = x < z1 ? 1u : x > z1 ? 4u : 2u;
+  return !o0 && !o1 && (mask_of(l0.cmp_op) & c0) != 0 && (mask_of(l1.cmp_op) & c1) != 0;
+}
 __device__ __forceinline__ bool window_slow(const TypedTable& tt, u32 ix0, u32 iy0, u32 ix1, u32 iy1, const TvLiteral& l0, const TvLiteral& l1) {
   const Val x0 = enc_tv(tt, ix0), y0 = enc_tv(tt, iy0), x1 = enc_tv(tt, ix1), y1 = enc_tv(tt, iy1);
   const Val z0 = tv_arith(y0, lit_val(l0), l0.arith_sub != 0);
@@ -426,11 +448,37 @@ __global__ __launch_bounds__(kLdsBlock) void lds_join_kernel(const LdsJoinArgs a
             ok[u] = e < qn; m[u] = make_uint2(0u, 0u); slow[u] = false;
             if (ok[u]) m[u] = wq[e];
           }
+          if (st.val != nullptr) {   // wave-uniform: integer window over the slice's decoded value table — one load by key
+                                     // instead of lookup -> column gather -> typed-value gather
+#pragma unroll
+            for (int u = 0; u < kResolveUnroll; u++) {
+              const u32 key = st.key.ptr[ok[u] ? (st.key.src ? m[u].x : m[u].y) : 0u];
+              const u32 d = key - st.kmin;
+              const bool in = ok[u] && key != 0 && d < st.kn;
+              const long long x = st.val[in ? d : 0u];
+              const bool have = in && x != INT64_MIN;
+              const u32 iy0 = chain_val(st.f[1], have ? m[u].x : 0u, have ? m[u].y : 0u, 0u);   // y operands are base columns here
+              const u32 iy1 = chain_val(st.f[3], have ? m[u].x : 0u, have ? m[u].y : 0u, 0u);
+              bool und;
+              const bool pass = window_fast_x(a.tt, x, iy0, iy1, st.l0, st.l1, und);
+              slow[u] = have && und;
+              ok[u] = have && !und && pass;
+              r[u] = kNil;
+            }
+            bool any_slow = false;
+#pragma unroll
+            for (int u = 0; u < kResolveUnroll; u++) any_slow = any_slow || slow[u];
+            if (__any(any_slow)) {   // rare: a y operand that is not an xsd:integer — look the row up after all
+#pragma unroll
+              for (int u = 0; u < kResolveUnroll; u++) if (slow[u]) r[u] = chain_lookup(st, m[u].x, m[u].y, true);
+            }
+          } else {
 #pragma unroll
           for (int u = 0; u < kResolveUnroll; u++) r[u] = chain_lookup(st, m[u].x, m[u].y, ok[u]);   // branch-free: dead lanes read row 0
 #pragma unroll
           for (int u = 0; u < kResolveUnroll; u++) ok[u] = ok[u] && r[u] != kNil;
-          if (st.fs != 0) {   // wave-uniform
+          }
+          if (st.fs != 0 && st.val == nullptr) {   // wave-uniform
 #pragma unroll
             for (int u = 0; u < kResolveUnroll; u++) {
               bool und;
@@ -439,6 +487,8 @@ __global__ __launch_bounds__(kLdsBlock) void lds_join_kernel(const LdsJoinArgs a
               slow[u] = ok[u] && und;
               ok[u] = ok[u] && !und && pass;
             }
+          }
+          if (st.fs != 0) {
             for (;;) {   // undecided candidates: this stage's filter with the full semantics, one per lane and round
               int pick = -1;
 #pragma unroll

@@ -550,6 +550,22 @@ __global__ __launch_bounds__(kBlock) void gdirect_build_kernel(const u32* keys, 
   if (d >= kn) { *dup = 1u; return; }   // cannot happen when kmin / kn come from minmax of the same column
   if (atomicCAS(&direct[d], kNil, (u32)i) != kNil) *dup = 1u;
 }
+__global__ __launch_bounds__(256) void fill_i64_kernel(long long* p, long long v, u64 n) { const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; if (i < n) p[i] = v; }
+void launch_fill_i64(long long* p, long long v, u64 n, hipStream_t s) { if (n) hipLaunchKernelGGL(fill_i64_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, v, n); }
+__global__ __launch_bounds__(256) void direct_values_kernel(const u32* keys, const u32* valcol, u64 n, u32 kmin, u32 kn, const TypedTable tt, long long* val, u32* bad) {
+  const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const u32 k = keys[i];
+  if (k == 0) return;
+  const u32 d = k - kmin;
+  if (d >= kn) return;
+  const Val v = enc_tv(tt, valcol[i]);
+  if (v.tag != RDFGPU_TV_INTEGER || v.lo == INT64_MIN) { *bad = 1u; return; }
+  val[d] = v.lo;
+}
+void launch_direct_values(const u32* keys, const u32* valcol, u64 n, u32 kmin, u32 kn, const TypedTable& tt, long long* val, u32* bad_dev, hipStream_t s) {
+  if (n) hipLaunchKernelGGL(direct_values_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, keys, valcol, n, kmin, kn, tt, val, bad_dev);
+}
 void launch_gdirect_build(const u32* keys, u64 n, u32* direct, u32 kmin, u32 kn, u32* dup_dev, hipStream_t s) {
   const u64 g = (n + kBlock - 1) / kBlock;
   hipLaunchKernelGGL(gdirect_build_kernel, dim3((unsigned)(g ? g : 1)), dim3(kBlock), 0, s, keys, n, direct, kmin, kn, dup_dev);

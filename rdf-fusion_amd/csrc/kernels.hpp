@@ -125,6 +125,9 @@ struct ChainStage {
   u32 fs;                     // 0 none / 2 `col <=|!=> col` / 3 numeric window
   ColRef f[4];                // id pair: a, b ; window: x0, y0, x1, y1
   TvLiteral l0, l1; u32 is_eq, pad;
+  // window stages whose x operand is a column of the stage's own slice with all-integer values: the decoded value
+  // by key, val[key - kmin] (INT64_MIN = no row) — replaces the lookup -> column gather -> typed-value gather chain
+  const long long* val;
 };
 
 // ---- K4+K5 fused: LDS-staged hash join for build sides that fit one workgroup's LDS ----
@@ -178,6 +181,10 @@ int lds_join_mode(const LdsJoinArgs& a);
 void launch_minmax_u32(const u32* col, u64 n, u32* out_dev /* {min, max}: preset to {~0, 0} */, hipStream_t s);   // nulls (0) skipped
 void launch_csr_hist(const u32* keys, u64 n, u32 kmin, u32 kn, u32* counts /* zeroed, kn + 1 */, u32* unsorted_dev, hipStream_t s);
 void launch_csr_scatter(const u32* keys, u64 n, u32 kmin, u32 kn, u32* cursor /* copy of the offsets */, u32* rows, hipStream_t s);
+// val[key - kmin] = xsd:integer value of valcol[row] for every row of a direct table's slice (val preset to INT64_MIN);
+// *bad is raised when a value is not an xsd:integer or equals the sentinel
+void launch_direct_values(const u32* keys, const u32* valcol, u64 n, u32 kmin, u32 kn, const TypedTable& tt, long long* val, u32* bad_dev, hipStream_t s);
+void launch_fill_i64(long long* p, long long v, u64 n, hipStream_t s);
 void launch_gdirect_build(const u32* keys, u64 n, u32* direct /* 0xFF-filled */, u32 kmin, u32 kn, u32* dup_dev, hipStream_t s);
 
 // ---- DISTINCT + TopK per group (the operators directly above the path; topk.hip) ----

@@ -843,6 +843,30 @@ bool Plan::apply_chain(const ChainRequest& req, NodeInfo& base, const DevTable& 
       st.l0 = lit(0); st.l1 = lit(8);
     } else return false;
     for (u32 q = 0; q < n_fcols; q++) if (st.f[q].src > 1 && st.f[q].src != 2u + (u32)t) return false;   // base columns or this stage's
+    // integer window whose x operand is a column of this stage's slice and whose y operands are base columns: use the
+    // slice's decoded value table (built once per store version, kept with the direct table)
+    if (st.fs == 3 && st.f[0].src == 2u + (u32)t && st.f[2].src == st.f[0].src && st.f[2].ptr == st.f[0].ptr && st.f[1].src <= 1 && st.f[3].src <= 1 &&
+        !std::getenv("RDFGPU_NO_VALUE_TABLES")) {
+      SliceTable* tab = const_cast<SliceTable*>(ln.table);
+      std::unique_lock<std::mutex> building(store->slice_build_mu);
+      SliceTable::ValueColumn* vc = nullptr;
+      for (auto& v : tab->values) if (v.col == st.f[0].ptr) vc = &v;
+      if (!vc) {
+        const u32 key_local = ln.slice_is_left ? N.d.left_keys[0] : N.d.right_keys[0];
+        long long* val = nullptr;
+        RDFGPU_HIP(hipMalloc((void**)&val, (size_t)tab->kn * sizeof(long long)));
+        u32* bad = reinterpret_cast<u32*>(new_counter());
+        launch_fill_i64(val, INT64_MIN, tab->kn, stream);
+        launch_direct_values(ln.slice.cols[key_local], st.f[0].ptr, ln.slice.cap, tab->kmin, tab->kn, store->typed_table(), val, bad, stream);
+        u32 is_bad = 0;
+        RDFGPU_HIP(hipMemcpyAsync(&is_bad, bad, sizeof(u32), hipMemcpyDeviceToHost, stream));
+        RDFGPU_HIP(hipStreamSynchronize(stream)); metrics.host_syncs++;
+        if (is_bad) { RDFGPU_HIP(hipFree(val)); val = nullptr; }
+        tab->values.push_back(SliceTable::ValueColumn{st.f[0].ptr, val, val != nullptr});
+        vc = &tab->values.back();
+      }
+      if (vc->usable) st.val = vc->val;
+    }
     std::vector<ColRef> next(N.n_proj);
     for (u32 k = 0; k < N.n_proj; k++) next[k] = resolve(N.proj[k]);
     if (bad) return false;

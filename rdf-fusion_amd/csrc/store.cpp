@@ -157,6 +157,7 @@ void Store::drop_slice_tables() {
     if (t.csr_off) (void)hipFree(t.csr_off);
     if (t.csr_rows) (void)hipFree(t.csr_rows);
     if (t.slots) (void)hipFree(t.slots);
+    for (auto& v : t.values) if (v.val) (void)hipFree(v.val);
   }
   slice_tables.clear();
 }
@@ -321,6 +322,7 @@ void Store::set_typed_values(const rdfgpu_typed_value* v, u64 n, const int64_t* 
   std::unique_lock<std::shared_mutex> lock(mu);
   activate();
   drop_string_verdicts();
+  drop_slice_tables();   // (decoded value tables depend on the typed values)
   if (tv) { RDFGPU_HIP(hipFree(tv)); tv = nullptr; }
   if (dec) { RDFGPU_HIP(hipFree(dec)); dec = nullptr; }
   n_ids = n; n_dec = nd;

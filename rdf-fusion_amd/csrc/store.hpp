@@ -61,6 +61,10 @@ struct SliceTable {
   u32* direct = nullptr; u32 kmin = 0, kn = 0;      // row = direct[key - kmin]
   u32* csr_off = nullptr; u32* csr_rows = nullptr;  // rows of key k: csr_rows[csr_off[k - kmin] .. csr_off[k - kmin + 1]); null rows = identity
   void* slots = nullptr; u32 mask = 0;              // {key0,row} open-addressing table (uint2[mask + 1])
+  // decoded payload columns of a direct table: val[key - kmin] = the xsd:integer value of that row's `col` (INT64_MIN =
+  // no row); usable == false when some value is not an xsd:integer (then the generic path is the only one)
+  struct ValueColumn { const u32* col; long long* val; bool usable; };
+  std::vector<ValueColumn> values;
 };
 struct SliceKey {
   const u32* key[RDFGPU_MAX_KEYS] = {}; u32 n_keys = 0; u64 rows = 0;

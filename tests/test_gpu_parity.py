@@ -681,7 +681,7 @@ def test_fused_lookup_chain_equals_unfused(bsbm_stores, torch_cuda, monkeypatch)
 
 TOGGLES = ["RDFGPU_NO_CHAIN_FUSION", "RDFGPU_NO_INDEX_JOIN", "RDFGPU_NO_TABLE_CACHE", "RDFGPU_NO_SPECULATION",
            "RDFGPU_NO_FIRST_RUN_SPECULATION", "RDFGPU_NO_DIRECT_TABLE", "RDFGPU_FORCE_GENERIC_VM", "RDFGPU_NO_LDS_JOIN",
-           "RDFGPU_NO_GLOBAL_TABLE_JOIN", "RDFGPU_NO_FILTER_FUSION"]
+           "RDFGPU_NO_GLOBAL_TABLE_JOIN", "RDFGPU_NO_FILTER_FUSION", "RDFGPU_NO_VALUE_TABLES"]
 
 
 @pytest.mark.parametrize("toggle", TOGGLES)
@@ -815,6 +815,45 @@ def test_bsbm_10m_scale_configs(torch_cuda):
         got = plan.execute().fetch()
         exp, n_exp, _ = os_.execute(desc, [params])
         np.testing.assert_array_equal(ku.multiset(got), ku.multiset(exp, n_exp))
+
+
+def test_fused_chain_with_mixed_numeric_kinds(torch_cuda):
+    """The fused window stages decide all-xsd:integer candidates on a fast path (decoded value tables, checked i64
+    arithmetic); anything else must fall back to the full promotion rules: some numeric literals become doubles and
+    decimals here, on the slice side and on the instance side."""
+    import struct
+    ds = bsbm.generate(1500)
+    tv = ds.typed_values.copy()
+    dec = []
+    for v in range(1, 2001, 7):            # every 7th integer literal "v" becomes the double v + 0.5
+        tv["tag"][ds.int_base + v - 1] = abi.TV_DOUBLE
+        tv["lo"][ds.int_base + v - 1] = struct.unpack("<q", struct.pack("<d", v + 0.5))[0]
+    for k, v in enumerate(range(3, 2001, 11)):   # every 11th: the decimal v.25
+        tv["tag"][ds.int_base + v - 1] = abi.TV_DECIMAL
+        tv["lo"][ds.int_base + v - 1] = k
+        raw = v * 10 ** 18 + 25 * 10 ** 16
+        dec += [raw & ((1 << 64) - 1), raw >> 64]
+    dec = np.array(dec, dtype=np.uint64).astype(np.int64)
+    gs, os_ = rf.GpuQuadStore(), orc.OracleStore()
+    assert gs.extend(ds.g, ds.s, ds.p, ds.o) == os_.extend(ds.g, ds.s, ds.p, ds.o)
+    gs.set_typed_values(tv, dec)
+    os_.set_typed_values(tv, dec)
+    rng = np.random.default_rng(31)
+    desc = bsbm.q5_batch_plan(ds)
+    plan = gs.plan(desc)
+    for it in range(3):
+        batch = 200
+        prods = np.array([ds.product(i) for i in rng.choice(ds.n_products, batch, replace=False)], dtype=np.uint32)
+        params = [np.arange(1, batch + 1, dtype=np.uint32), prods]
+        keep, ptrs = table_on_device(torch_cuda, params)
+        plan.bind_table(0, ptrs, batch)
+        plan.enable_kernel_timing(True)
+        got = plan.execute().fetch()
+        exp, n_exp, _ = os_.execute(desc, [params])
+        np.testing.assert_array_equal(ku.multiset(got), ku.multiset(exp, n_exp))
+    assert any("lds_join_kernel" in k[0] and k[0].endswith("true>") for k in plan.kernel_stats()) or ENGINE_TOGGLED
+    for x in prods[:3]:
+        run_both(gs, os_, bsbm.q5_plan(ds, int(x)))
 
 
 def test_generic_vm_equals_specialised_kernels(bsbm_stores, monkeypatch):
