@@ -331,7 +331,45 @@ __global__ __launch_bounds__(kLdsBlock) void lds_join_kernel(const LdsJoinArgs a
           } else if constexpr (CSR) {   // dense keys with duplicates: s = [cursor, end) into the key's row list
             h[k] = key[k].k[0] - a.direct_min;
             s[k] = make_uint2(0u, 0u);
-            if (walking[k] && h[k] < a.direct_n) { s[k].x = a.csr_off[h[k]] + (tid & ((1u << rl) - 1u)); s[k].y = a.csr_off[h[k] + 1]; }
+            if (walking[k] && h[k] < a.direct_n) { s[k].x = a.csr_off[h[k]]; s[k].y = a.csr_off[h[k] + 1]; }
+            if constexpr (CHAIN) {
+              if (a.range_vals != nullptr && walking[k] && s[k].x < s[k].y) {
+                // the group is ordered by the first stage's value: keep only [lower_bound(lo), upper_bound(hi)) of it,
+                // lo / hi = the integer interval the stage's window allows for this probe row (a superset is enough:
+                // the stage pass re-checks every candidate)
+                const ChainStage& st0 = a.chain[0];
+                const u32 iy0 = st0.f[1].ptr[j], iy1 = st0.f[3].ptr[j];
+                long long lo = INT64_MIN + 1, hi = INT64_MAX;
+                bool restrict_ok = a.tt.n_ids != 0 && iy0 != 0 && iy1 != 0 && iy0 < a.tt.n_ids && iy1 < a.tt.n_ids &&
+                                   st0.l0.tag == RDFGPU_TV_INTEGER && st0.l1.tag == RDFGPU_TV_INTEGER;
+                if (restrict_ok) {
+                  const int4* tv = reinterpret_cast<const int4*>(a.tt.tv);
+                  const int4 r0 = tv[iy0], r1 = tv[iy1];
+                  restrict_ok = ((u32)r0.w & 0xff) == RDFGPU_TV_INTEGER && ((u32)r1.w & 0xff) == RDFGPU_TV_INTEGER;
+                  auto i64 = [](const int4& r) { return (long long)(((u64)(u32)r.y << 32) | (u32)r.x); };
+                  auto bound = [&](const TvLiteral& l, long long y) {
+                    long long z;
+                    const bool ovf = l.arith_sub ? __builtin_sub_overflow(y, (long long)l.lo, &z) : __builtin_add_overflow(y, (long long)l.lo, &z);
+                    if (ovf) { restrict_ok = false; return; }              // error value: leave it to the stage pass
+                    if (l.cmp_op == RDFGPU_EX_LT) { if (z == INT64_MIN) hi = INT64_MIN; else hi = z - 1 < hi ? z - 1 : hi; }
+                    else if (l.cmp_op == RDFGPU_EX_LEQ) hi = z < hi ? z : hi;
+                    else if (l.cmp_op == RDFGPU_EX_GT) { if (z == INT64_MAX) lo = INT64_MAX, hi = INT64_MIN; else lo = z + 1 > lo ? z + 1 : lo; }
+                    else if (l.cmp_op == RDFGPU_EX_GEQ) lo = z > lo ? z : lo;
+                    else restrict_ok = false;
+                  };
+                  if (restrict_ok) { bound(st0.l0, i64(r0)); bound(st0.l1, i64(r1)); }
+                }
+                if (restrict_ok) {
+                  u32 b = s[k].x, e = s[k].y;
+                  while (b < e) { const u32 mid = b + ((e - b) >> 1); if (a.range_vals[mid] < lo) b = mid + 1; else e = mid; }   // lower_bound(lo)
+                  const u32 first = b;
+                  e = s[k].y;
+                  while (b < e) { const u32 mid = b + ((e - b) >> 1); if (a.range_vals[mid] <= hi) b = mid + 1; else e = mid; }  // upper_bound(hi)
+                  s[k].x = first; s[k].y = b;
+                }
+              }
+            }
+            s[k].x += tid & ((1u << rl) - 1u);
           } else {
             h[k] = hash_keys4(key[k], a.n_keys) & a.tbl_mask;
             if (walking[k]) s[k] = slots[h[k]];
@@ -350,7 +388,10 @@ __global__ __launch_bounds__(kLdsBlock) void lds_join_kernel(const LdsJoinArgs a
             if (walking[k]) { hit = s[k].y; walking[k] = false; }
           } else if constexpr (CSR) {
             if (hit == kNil && walking[k]) {
-              if (s[k].x < s[k].y) { hit = a.csr_rows ? a.csr_rows[s[k].x] : s[k].x; s[k].x += 1u << rl; }
+              if (s[k].x < s[k].y) {
+                const u32* rows = CHAIN && a.range_rows ? a.range_rows : a.csr_rows;
+                hit = rows ? rows[s[k].x] : s[k].x; s[k].x += 1u << rl;
+              }
               else walking[k] = false;
             }
           } else if (hit == kNil) {

@@ -566,6 +566,51 @@ __global__ __launch_bounds__(256) void direct_values_kernel(const u32* keys, con
 void launch_direct_values(const u32* keys, const u32* valcol, u64 n, u32 kmin, u32 kn, const TypedTable& tt, long long* val, u32* bad_dev, hipStream_t s) {
   if (n) hipLaunchKernelGGL(direct_values_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, keys, valcol, n, kmin, kn, tt, val, bad_dev);
 }
+// ---- range index: CSR groups re-ordered by a decoded value of another slice (see LdsJoinArgs::range_rows) ----
+__device__ __forceinline__ long long range_value_of(const u32* stage_key_col, const u32* csr_rows, u64 p, const long long* val, u32 vmin_key, u32 vn, u32& row) {
+  row = csr_rows ? csr_rows[p] : (u32)p;
+  const u32 k = stage_key_col[row];
+  const u32 d = k - vmin_key;
+  return (k != 0 && d < vn) ? val[d] : INT64_MIN;   // INT64_MIN: the stage has no row for this key — such a candidate can never pass
+}
+__global__ __launch_bounds__(256) void range_minmax_kernel(const u32* stage_key_col, const u32* csr_rows, u64 n, const long long* val, u32 vmin_key, u32 vn, long long* out) {
+  long long lo = INT64_MAX, hi = INT64_MIN + 1;
+  for (u64 p = (u64)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (u64)gridDim.x * blockDim.x) {
+    u32 row; const long long v = range_value_of(stage_key_col, csr_rows, p, val, vmin_key, vn, row);
+    if (v == INT64_MIN) continue;
+    lo = v < lo ? v : lo; hi = v > hi ? v : hi;
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) { const long long l2 = __shfl_xor(lo, d, 64), h2 = __shfl_xor(hi, d, 64); lo = l2 < lo ? l2 : lo; hi = h2 > hi ? h2 : hi; }
+  if ((threadIdx.x & 63) == 0) { atomicMin(&out[0], lo); atomicMax(&out[1], hi); }
+}
+__global__ __launch_bounds__(256) void range_keys_kernel(const u32* group_col, u32 gmin, const u32* stage_key_col, const u32* csr_rows, u64 n, const long long* val,
+                                                          u32 vmin_key, u32 vn, long long vbase, u64* key64, u32* rows_in) {
+  const u64 p = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  u32 row; const long long v = range_value_of(stage_key_col, csr_rows, p, val, vmin_key, vn, row);
+  const u64 g = group_col[row] - gmin;
+  key64[p] = (g << 32) | (v == INT64_MIN ? 0ull : (u64)(v - vbase) + 1ull);   // biased value; 0 = no stage row
+  rows_in[p] = row;
+}
+__global__ __launch_bounds__(256) void range_decode_kernel(const u64* key64, u64 n, long long vbase, long long* vals) {
+  const u64 p = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  const u64 b = key64[p] & 0xFFFFFFFFull;
+  vals[p] = b == 0 ? INT64_MIN : (long long)(b - 1) + vbase;
+}
+void launch_range_minmax(const u32* stage_key_col, const u32* csr_rows, u64 n, const long long* val, u32 vmin_key, u32 vn, long long* out, hipStream_t s) {
+  const u64 g = (n + 256 * 16 - 1) / (256 * 16);
+  hipLaunchKernelGGL(range_minmax_kernel, dim3((unsigned)(g ? (g > 2048 ? 2048 : g) : 1)), dim3(256), 0, s, stage_key_col, csr_rows, n, val, vmin_key, vn, out);
+}
+void launch_range_keys(const u32* group_col, u32 gmin, const u32* stage_key_col, const u32* csr_rows, u64 n, const long long* val, u32 vmin_key, u32 vn,
+                       long long vbase, u64* key64, u32* rows_in, hipStream_t s) {
+  if (n) hipLaunchKernelGGL(range_keys_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, group_col, gmin, stage_key_col, csr_rows, n, val, vmin_key, vn, vbase, key64, rows_in);
+}
+void launch_range_decode(const u64* key64_sorted, u64 n, long long vbase, long long* vals_out, hipStream_t s) {
+  if (n) hipLaunchKernelGGL(range_decode_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, key64_sorted, n, vbase, vals_out);
+}
+
 void launch_gdirect_build(const u32* keys, u64 n, u32* direct, u32 kmin, u32 kn, u32* dup_dev, hipStream_t s) {
   const u64 g = (n + kBlock - 1) / kBlock;
   hipLaunchKernelGGL(gdirect_build_kernel, dim3((unsigned)(g ? g : 1)), dim3(kBlock), 0, s, keys, n, direct, kmin, kn, dup_dev);

@@ -151,6 +151,11 @@ struct LdsJoinArgs {
   const u32* csr_off;       // non-null: CSR table instead (single dense key, duplicates allowed): direct_n + 1 offsets into csr_rows
   const u32* csr_rows;      // row ids grouped by key; null = identity (the build column is sorted by the key)
   u32 row_lanes_log2;       // CSR: lanes sharing one probe row (its matches are dealt round-robin)
+  // CSR + fused chain whose first stage is an integer window on a decoded value of the stage's slice: the CSR groups
+  // re-ordered by that value (range_rows / range_vals, built once per store version), so that a probe row expands only
+  // the sub-range of its group that can pass the window (two binary searches) instead of the whole group.  A pruning
+  // only: the stage itself still checks every candidate.
+  const u32* range_rows; const long long* range_vals;
   u32 n_chain;              // fused follow-up lookups (0 = none); then the output columns are chain_out[], not proj[]
   ChainStage chain[kMaxChain];
   ColRef chain_out[kMaxCols];
@@ -185,6 +190,11 @@ void launch_csr_scatter(const u32* keys, u64 n, u32 kmin, u32 kn, u32* cursor /*
 // *bad is raised when a value is not an xsd:integer or equals the sentinel
 void launch_direct_values(const u32* keys, const u32* valcol, u64 n, u32 kmin, u32 kn, const TypedTable& tt, long long* val, u32* bad_dev, hipStream_t s);
 void launch_fill_i64(long long* p, long long v, u64 n, hipStream_t s);
+// range index build: key64[p] = (group << 32) | biased value of the row at CSR position p, rows_in[p] = that row
+void launch_range_minmax(const u32* stage_key_col, const u32* csr_rows, u64 n, const long long* val, u32 vmin_key, u32 vn, long long* out_minmax /* {min,max} preset */, hipStream_t s);
+void launch_range_keys(const u32* group_col, u32 gmin, const u32* stage_key_col, const u32* csr_rows, u64 n, const long long* val, u32 vmin_key, u32 vn,
+                       long long vbase, u64* key64, u32* rows_in, hipStream_t s);
+void launch_range_decode(const u64* key64_sorted, u64 n, long long vbase, long long* vals_out, hipStream_t s);
 void launch_gdirect_build(const u32* keys, u64 n, u32* direct /* 0xFF-filled */, u32 kmin, u32 kn, u32* dup_dev, hipStream_t s);
 
 // ---- DISTINCT + TopK per group (the operators directly above the path; topk.hip) ----

@@ -874,6 +874,47 @@ bool Plan::apply_chain(const ChainRequest& req, NodeInfo& base, const DevTable& 
     stage_bytes += base.last_rows * (8ull + 4ull * n_fcols);   // per candidate: key + table slot + filter operands (estimate)
   }
   if (cur.size() != req.top->n_proj || cur.size() > (size_t)kMaxCols) return false;
+  // Range index: a CSR base whose first stage is an integer window (GT / LT / GEQ / LEQ) between the stage's decoded
+  // value and probe-side columns expands, per probe row, only the part of the key's group whose value can pass —
+  // the group is kept sorted by that value (built once per store version, kept with the CSR table).
+  {
+    const ChainStage& s0 = stages[0];
+    auto range_op = [](u8 op) { return op == RDFGPU_EX_GT || op == RDFGPU_EX_LT || op == RDFGPU_EX_GEQ || op == RDFGPU_EX_LEQ; };
+    const DevTable& B = build_left ? L : R;
+    if (a.csr_off && cur_build_table && s0.val && s0.fs == 3 && s0.key.src == 1 && s0.f[1].src == 0 && s0.f[3].src == 0 &&
+        range_op(s0.l0.cmp_op) && range_op(s0.l1.cmp_op) && !std::getenv("RDFGPU_NO_RANGE_INDEX")) {
+      SliceTable* tab = cur_build_table;
+      std::unique_lock<std::mutex> building(store->slice_build_mu);
+      SliceTable::RangeIndex* ri = nullptr;
+      for (auto& r : tab->ranges) if (r.val == s0.val && r.link_col == s0.key.ptr) ri = &r;
+      if (!ri) {
+        SliceTable::RangeIndex fresh{s0.val, s0.key.ptr, nullptr, nullptr, false};
+        const u64 n = B.cap;
+        long long* mm = reinterpret_cast<long long*>(new_counter()); (void)new_counter();   // {min, max}: two slots
+        const long long init[2] = {INT64_MAX, INT64_MIN + 1};
+        RDFGPU_HIP(hipMemcpyAsync(mm, init, sizeof init, hipMemcpyHostToDevice, stream));
+        launch_range_minmax(s0.key.ptr, a.csr_rows, n, s0.val, s0.kmin, s0.kn, mm, stream);
+        long long got[2];
+        RDFGPU_HIP(hipMemcpyAsync(got, mm, sizeof got, hipMemcpyDeviceToHost, stream));
+        RDFGPU_HIP(hipStreamSynchronize(stream)); metrics.host_syncs++;
+        if (got[0] <= got[1] && (unsigned long long)(got[1] - got[0]) < 0xFFFFFFF0ull && n < (1ull << 32)) {
+          u64* key_in = scratch<u64>(n); u64* key_out = scratch<u64>(n); u32* rows_in = scratch<u32>(n);
+          RDFGPU_HIP(hipMalloc((void**)&fresh.rows, n * sizeof(u32)));
+          RDFGPU_HIP(hipMalloc((void**)&fresh.vals, n * sizeof(long long)));
+          launch_range_keys(a.build_key[0], a.direct_min, s0.key.ptr, a.csr_rows, n, s0.val, s0.kmin, s0.kn, got[0], key_in, rows_in, stream);
+          const size_t tb = sort_temp_bytes(n);
+          void* temp = scratch<unsigned char>(tb);
+          sort_pairs_u64_u32(key_in, key_out, rows_in, fresh.rows, n, temp, tb, stream);
+          launch_range_decode(key_out, n, got[0], fresh.vals, stream);
+          RDFGPU_HIP(hipStreamSynchronize(stream)); metrics.host_syncs++;
+          fresh.usable = true;
+        }
+        tab->ranges.push_back(fresh);
+        ri = &tab->ranges.back();
+      }
+      if (ri->usable) { a.range_rows = ri->rows; a.range_vals = ri->vals; }
+    }
+  }
   a.n_chain = (u32)req.links.size();
   for (size_t t = 0; t < req.links.size(); t++) a.chain[t] = stages[t];
   for (size_t k = 0; k < cur.size(); k++) a.chain_out[k] = cur[k];
@@ -1032,6 +1073,7 @@ DevTable Plan::exec_lds_join(NodeInfo& nd, const DevTable& L, const DevTable& R,
   DevTable t;
   t.n_cols = nd.n_proj;
   LdsJoinArgs a{};
+  cur_build_table = nullptr;
   for (u32 c = 0; c < L.n_cols; c++) a.cols[c] = L.cols[c];
   for (u32 c = 0; c < R.n_cols; c++) a.cols[L.n_cols + c] = R.cols[c];
   a.n_left_cols = L.n_cols; a.n_out_cols = nd.n_proj;
@@ -1067,6 +1109,7 @@ DevTable Plan::exec_lds_join(NodeInfo& nd, const DevTable& L, const DevTable& R,
       SliceKey sk; sk.n_keys = a.n_keys; sk.rows = B.cap;
       for (u32 k = 0; k < a.n_keys; k++) sk.key[k] = a.build_key[k];
       SliceTable* st = store->slice_table(sk);
+      cur_build_table = st;
       std::unique_lock<std::mutex> building(store->slice_build_mu);
       // Dense forms first (one single key over a dense id range): direct-address if the keys are unique, CSR if not.
       // Decided once per slice; costs a few small kernels and host syncs at that time, nothing afterwards.
@@ -1121,8 +1164,10 @@ DevTable Plan::exec_lds_join(NodeInfo& nd, const DevTable& L, const DevTable& R,
         // lanes per probe row: a small probe side with a large fan-out is spread over the chip
         // (first execution: the table's mean rows per key stands in for the unknown fan-out)
         const u64 fan = nd.has_last ? nd.last_rows / (P.cap ? P.cap : 1) : B.cap / (st->kn ? st->kn : 1);
+        // measured on the BSBM candidate join (fan-out 111): 8 lanes per row is best at 75 k and at 1.2 M probe rows alike
         u32 rl = 0;
-        while (rl < 6 && (2ull << rl) <= fan && (P.cap << (rl + 1)) <= (1ull << 21)) rl++;
+        while (rl < 3 && (16ull << rl) <= fan && (P.cap << (rl + 1)) <= (1ull << 25)) rl++;
+        if (const char* e = std::getenv("RDFGPU_CSR_ROW_LANES_LOG2")) rl = (u32)std::atoi(e) > 6 ? 6 : (u32)std::atoi(e);
         a.row_lanes_log2 = rl;
       } else if (st->direct) {
         a.direct = st->direct; a.direct_min = st->kmin; a.direct_n = st->kn;

@@ -100,6 +100,7 @@ struct Plan {
   std::vector<PendingLaunch> pending;
   std::vector<DevTable> memo; std::vector<char> memo_valid;   // node results of the current execution
   ChainRequest* pending_chain = nullptr;                        // set while the base join of a fusable chain executes
+  SliceTable* cur_build_table = nullptr;                        // the store-level table of the join being set up (if any)
   u32 events_used = 0;
   KernelStat kstats[KC__N];
   // Arrow batch stream over a host copy of the result

@@ -158,6 +158,7 @@ void Store::drop_slice_tables() {
     if (t.csr_rows) (void)hipFree(t.csr_rows);
     if (t.slots) (void)hipFree(t.slots);
     for (auto& v : t.values) if (v.val) (void)hipFree(v.val);
+    for (auto& r : t.ranges) { if (r.rows) (void)hipFree(r.rows); if (r.vals) (void)hipFree(r.vals); }
   }
   slice_tables.clear();
 }

@@ -65,6 +65,10 @@ struct SliceTable {
   // no row); usable == false when some value is not an xsd:integer (then the generic path is the only one)
   struct ValueColumn { const u32* col; long long* val; bool usable; };
   std::vector<ValueColumn> values;
+  // a CSR table's groups re-ordered by a decoded value of ANOTHER slice (reached through `link_col`, a column of this
+  // slice holding that slice's key): rows[p] / vals[p] for every CSR position p, ascending by value inside each group
+  struct RangeIndex { const long long* val; const u32* link_col; u32* rows; long long* vals; bool usable; };
+  std::vector<RangeIndex> ranges;
 };
 struct SliceKey {
   const u32* key[RDFGPU_MAX_KEYS] = {}; u32 n_keys = 0; u64 rows = 0;

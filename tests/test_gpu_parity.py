@@ -681,7 +681,7 @@ def test_fused_lookup_chain_equals_unfused(bsbm_stores, torch_cuda, monkeypatch)
 
 TOGGLES = ["RDFGPU_NO_CHAIN_FUSION", "RDFGPU_NO_INDEX_JOIN", "RDFGPU_NO_TABLE_CACHE", "RDFGPU_NO_SPECULATION",
            "RDFGPU_NO_FIRST_RUN_SPECULATION", "RDFGPU_NO_DIRECT_TABLE", "RDFGPU_FORCE_GENERIC_VM", "RDFGPU_NO_LDS_JOIN",
-           "RDFGPU_NO_GLOBAL_TABLE_JOIN", "RDFGPU_NO_FILTER_FUSION", "RDFGPU_NO_VALUE_TABLES"]
+           "RDFGPU_NO_GLOBAL_TABLE_JOIN", "RDFGPU_NO_FILTER_FUSION", "RDFGPU_NO_VALUE_TABLES", "RDFGPU_NO_RANGE_INDEX"]
 
 
 @pytest.mark.parametrize("toggle", TOGGLES)
