@@ -42,9 +42,17 @@ __device__ __forceinline__ u32 wave_incl_scan(u32 v) {
   for (int d = 1; d < 64; d <<= 1) { const u32 t = __shfl_up(v, d, 64); if ((int)(threadIdx.x & 63) >= d) v += t; }
   return v;
 }
+// A build-side column at candidate `i`.  Normally i is the build row.  In range-index mode (LdsJoinArgs::range_link) a
+// candidate carries its POSITION in the value-ordered CSR instead: the link column (the stage key, e.g. ?product) is
+// then read from its value-ordered copy — consecutive positions, coalesced — and any other build column through the
+// row ids of the index.
+__device__ __forceinline__ u32 bcol(const LdsJoinArgs& a, const u32* ptr, u64 i) {
+  if (a.range_link != nullptr) return ptr == a.range_link_col ? a.range_link[i] : ptr[a.range_rows[i]];   // wave-uniform branches
+  return ptr[i];
+}
 __device__ __forceinline__ u32 ljoin_col(const LdsJoinArgs& a, u32 c, u64 i, u64 j) {  // column c of [left cols, right cols]
   const bool from_build = (c < a.n_left_cols) == (a.build_is_left != 0);   // wave-uniform
-  return a.cols[c][from_build ? i : j];
+  return from_build ? bcol(a, a.cols[c], i) : a.cols[c][j];
 }
 
 // Join filter, specialised: FS 0 = none, 1 = generic VM, 3 = "window" — the BSBM Q5 shape
@@ -150,9 +158,9 @@ __device__ __forceinline__ bool ljoin_filter_slow(const LdsJoinArgs& a, u32 i, u
 }
 // ---- fused lookup chain (ChainStage): stage = direct-table lookup of a base key column + the stage's join filter ----
 // (branch-free like window_fast: a dead lane passes live = false and reads row 0 of whatever it is pointed at)
-__device__ __forceinline__ u32 chain_val(const ColRef& c, u32 i, u32 j, u32 r) { return c.ptr[c.src == 0 ? j : c.src == 1 ? i : r]; }
-__device__ __forceinline__ u32 chain_lookup(const ChainStage& st, u32 i, u32 j, bool live = true) {
-  const u32 key = st.key.ptr[live ? (st.key.src ? i : j) : 0u];
+__device__ __forceinline__ u32 chain_val(const LdsJoinArgs& a, const ColRef& c, u32 i, u32 j, u32 r) { return c.src == 1 ? bcol(a, c.ptr, i) : c.ptr[c.src == 0 ? j : r]; }
+__device__ __forceinline__ u32 chain_lookup(const LdsJoinArgs& a, const ChainStage& st, u32 i, u32 j, bool live = true) {
+  const u32 key = st.key.src ? bcol(a, st.key.ptr, live ? i : 0u) : st.key.ptr[live ? j : 0u];
   const u32 d = key - st.kmin;
   const bool in = live && key != 0 && d < st.kn;          // null keys never join
   const u32 row = st.direct[in ? d : 0u];
@@ -161,18 +169,18 @@ __device__ __forceinline__ u32 chain_lookup(const ChainStage& st, u32 i, u32 j, 
 __device__ __forceinline__ bool stage_filter_fast(const LdsJoinArgs& a, const ChainStage& st, u32 i, u32 j, u32 r, bool& undecided) {
   undecided = false;
   if (st.fs == 2) {   // wave-uniform
-    const u32 va = chain_val(st.f[0], i, j, r), vb = chain_val(st.f[1], i, j, r);
+    const u32 va = chain_val(a, st.f[0], i, j, r), vb = chain_val(a, st.f[1], i, j, r);
     return va != 0 && vb != 0 && (va == vb) == (st.is_eq != 0);
   }
   const bool same = st.f[0].ptr == st.f[2].ptr && st.f[0].src == st.f[2].src && st.f[1].ptr == st.f[3].ptr && st.f[1].src == st.f[3].src;
-  const u32 ix0 = chain_val(st.f[0], i, j, r), iy0 = chain_val(st.f[1], i, j, r);
-  const u32 ix1 = same ? ix0 : chain_val(st.f[2], i, j, r), iy1 = same ? iy0 : chain_val(st.f[3], i, j, r);
+  const u32 ix0 = chain_val(a, st.f[0], i, j, r), iy0 = chain_val(a, st.f[1], i, j, r);
+  const u32 ix1 = same ? ix0 : chain_val(a, st.f[2], i, j, r), iy1 = same ? iy0 : chain_val(a, st.f[3], i, j, r);
   return window_fast(a.tt, ix0, iy0, ix1, iy1, same, st.l0, st.l1, undecided);
 }
 // the stage's filter with the full reference semantics (fs 2 is always decided by the fast half)
 __device__ __forceinline__ bool stage_filter_slow(const LdsJoinArgs& a, const ChainStage& st, u32 i, u32 j, u32 r) {
   if (st.fs != 3) { bool und; return stage_filter_fast(a, st, i, j, r, und); }
-  return window_slow(a.tt, chain_val(st.f[0], i, j, r), chain_val(st.f[1], i, j, r), chain_val(st.f[2], i, j, r), chain_val(st.f[3], i, j, r), st.l0, st.l1);
+  return window_slow(a.tt, chain_val(a, st.f[0], i, j, r), chain_val(a, st.f[1], i, j, r), chain_val(a, st.f[2], i, j, r), chain_val(a, st.f[3], i, j, r), st.l0, st.l1);
 }
 
 // Fused FilterExec of the probe child: PFS 0 = none, 1 = col <ID_EQ|ID_NEQ> literal, 2 = generic VM.
@@ -288,13 +296,13 @@ __global__ __launch_bounds__(kLdsBlock) void lds_join_kernel(const LdsJoinArgs a
         u32 rr[kMaxChain] = {0, 0, 0};
         if constexpr (CHAIN) {   // survivors only: the stage rows are looked up again instead of being carried through the queue
 #pragma unroll
-          for (u32 t = 0; t < (u32)kMaxChain; t++) if (t < a.n_chain) rr[t] = chain_lookup(a.chain[t], m.x, m.y);
+          for (u32 t = 0; t < (u32)kMaxChain; t++) if (t < a.n_chain) rr[t] = chain_lookup(a, a.chain[t], m.x, m.y);
         }
         u32 v[4];
 #pragma unroll
         for (u32 u = 0; u < 4; u++) if (on[u]) {
           const u32 row = from[u] == 0 ? m.y : from[u] == 1 ? m.x : from[u] == 2 ? rr[0] : from[u] == 3 ? rr[1] : rr[2];
-          v[u] = src[u][row];
+          v[u] = from[u] == 1 ? bcol(a, src[u], row) : src[u][row];
         }
 #pragma unroll
         for (u32 u = 0; u < 4; u++) if (on[u]) dst[u][pos] = v[u];
@@ -389,8 +397,9 @@ __global__ __launch_bounds__(kLdsBlock) void lds_join_kernel(const LdsJoinArgs a
           } else if constexpr (CSR) {
             if (hit == kNil && walking[k]) {
               if (s[k].x < s[k].y) {
-                const u32* rows = CHAIN && a.range_rows ? a.range_rows : a.csr_rows;
-                hit = rows ? rows[s[k].x] : s[k].x; s[k].x += 1u << rl;
+                if (CHAIN && a.range_link != nullptr) hit = s[k].x;   // the position itself (see bcol)
+                else hit = a.csr_rows ? a.csr_rows[s[k].x] : s[k].x;
+                s[k].x += 1u << rl;
               }
               else walking[k] = false;
             }
@@ -437,7 +446,7 @@ __global__ __launch_bounds__(kLdsBlock) void lds_join_kernel(const LdsJoinArgs a
           const u32* pc = a.cols[a.post.col];
 #pragma unroll
           for (int u = 0; u < kResolveUnroll; u++) {
-            const u32 v = pc[ok[u] ? (post_from_build ? m[u].x : m[u].y) : 0u];
+            const u32 v = post_from_build ? bcol(a, pc, ok[u] ? m[u].x : 0u) : pc[ok[u] ? m[u].y : 0u];
             ok[u] = ok[u] && v != 0 && a.post.lit != 0 && ((v == a.post.lit) == (a.post.is_eq != 0));
           }
         }
@@ -493,13 +502,19 @@ __global__ __launch_bounds__(kLdsBlock) void lds_join_kernel(const LdsJoinArgs a
                                      // instead of lookup -> column gather -> typed-value gather
 #pragma unroll
             for (int u = 0; u < kResolveUnroll; u++) {
-              const u32 key = st.key.ptr[ok[u] ? (st.key.src ? m[u].x : m[u].y) : 0u];
-              const u32 d = key - st.kmin;
-              const bool in = ok[u] && key != 0 && d < st.kn;
-              const long long x = st.val[in ? d : 0u];
+              long long x; bool in;
+              if (t == 0 && a.range_link != nullptr) {   // range-index mode: the candidate's position carries the first stage's value
+                in = ok[u];
+                x = a.range_vals[in ? m[u].x : 0u];
+              } else {
+                const u32 key = st.key.src ? bcol(a, st.key.ptr, ok[u] ? m[u].x : 0u) : st.key.ptr[ok[u] ? m[u].y : 0u];
+                const u32 d = key - st.kmin;
+                in = ok[u] && key != 0 && d < st.kn;
+                x = st.val[in ? d : 0u];
+              }
               const bool have = in && x != INT64_MIN;
-              const u32 iy0 = chain_val(st.f[1], have ? m[u].x : 0u, have ? m[u].y : 0u, 0u);   // y operands are base columns here
-              const u32 iy1 = chain_val(st.f[3], have ? m[u].x : 0u, have ? m[u].y : 0u, 0u);
+              const u32 iy0 = chain_val(a, st.f[1], have ? m[u].x : 0u, have ? m[u].y : 0u, 0u);   // y operands are base columns here
+              const u32 iy1 = chain_val(a, st.f[3], have ? m[u].x : 0u, have ? m[u].y : 0u, 0u);
               bool und;
               const bool pass = window_fast_x(a.tt, x, iy0, iy1, st.l0, st.l1, und);
               slow[u] = have && und;
@@ -511,11 +526,11 @@ __global__ __launch_bounds__(kLdsBlock) void lds_join_kernel(const LdsJoinArgs a
             for (int u = 0; u < kResolveUnroll; u++) any_slow = any_slow || slow[u];
             if (__any(any_slow)) {   // rare: a y operand that is not an xsd:integer — look the row up after all
 #pragma unroll
-              for (int u = 0; u < kResolveUnroll; u++) if (slow[u]) r[u] = chain_lookup(st, m[u].x, m[u].y, true);
+              for (int u = 0; u < kResolveUnroll; u++) if (slow[u]) r[u] = chain_lookup(a, st, m[u].x, m[u].y, true);
             }
           } else {
 #pragma unroll
-          for (int u = 0; u < kResolveUnroll; u++) r[u] = chain_lookup(st, m[u].x, m[u].y, ok[u]);   // branch-free: dead lanes read row 0
+          for (int u = 0; u < kResolveUnroll; u++) r[u] = chain_lookup(a, st, m[u].x, m[u].y, ok[u]);   // branch-free: dead lanes read row 0
 #pragma unroll
           for (int u = 0; u < kResolveUnroll; u++) ok[u] = ok[u] && r[u] != kNil;
           }

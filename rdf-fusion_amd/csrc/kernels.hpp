@@ -156,6 +156,8 @@ struct LdsJoinArgs {
   // the sub-range of its group that can pass the window (two binary searches) instead of the whole group.  A pruning
   // only: the stage itself still checks every candidate.
   const u32* range_rows; const long long* range_vals;
+  const u32* range_link; const u32* range_link_col;   // the link column (range_link_col, a build column) in the index's order;
+                                                      // non-null: candidates carry index positions, not build rows
   u32 n_chain;              // fused follow-up lookups (0 = none); then the output columns are chain_out[], not proj[]
   ChainStage chain[kMaxChain];
   ColRef chain_out[kMaxCols];

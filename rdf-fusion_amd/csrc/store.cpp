@@ -158,7 +158,7 @@ void Store::drop_slice_tables() {
     if (t.csr_rows) (void)hipFree(t.csr_rows);
     if (t.slots) (void)hipFree(t.slots);
     for (auto& v : t.values) if (v.val) (void)hipFree(v.val);
-    for (auto& r : t.ranges) { if (r.rows) (void)hipFree(r.rows); if (r.vals) (void)hipFree(r.vals); }
+    for (auto& r : t.ranges) { if (r.rows) (void)hipFree(r.rows); if (r.vals) (void)hipFree(r.vals); if (r.link) (void)hipFree(r.link); }
   }
   slice_tables.clear();
 }
