@@ -1167,8 +1167,10 @@ DevTable Plan::exec_lds_join(NodeInfo& nd, const DevTable& L, const DevTable& R,
         // (first execution: the table's mean rows per key stands in for the unknown fan-out)
         const u64 fan = nd.has_last ? nd.last_rows / (P.cap ? P.cap : 1) : B.cap / (st->kn ? st->kn : 1);
         // measured on the BSBM candidate join (fan-out 111): 8 lanes per row is best at 75 k and at 1.2 M probe rows alike
+        // (a tiny probe side — a single query's constants — is latency-bound instead: spread each row over up to a whole wave)
+        const bool tiny = P.cap < 4096;
         u32 rl = 0;
-        while (rl < 3 && (16ull << rl) <= fan && (P.cap << (rl + 1)) <= (1ull << 25)) rl++;
+        while (rl < (tiny ? 6u : 3u) && ((tiny ? 2ull : 16ull) << rl) <= fan && (P.cap << (rl + 1)) <= (1ull << 25)) rl++;
         if (const char* e = std::getenv("RDFGPU_CSR_ROW_LANES_LOG2")) rl = (u32)std::atoi(e) > 6 ? 6 : (u32)std::atoi(e);
         a.row_lanes_log2 = rl;
       } else if (st->direct) {
