@@ -230,6 +230,12 @@ __device__ __forceinline__ bool load_keys(const u32* const* key_cols, u32 n_keys
 // The last resolve is shared by the workgroup (one reservation for all eight queues).  Same-address atomics
 // retire at only ~88 per microsecond on this chip, which is what sizes the queue: sparse joins (BSBM: a handful
 // of matches per thousand probe rows) pay one atomic per workgroup, dense ones one per a.wave_q matches.
+// CHAIN = true adds, between the fill and the reservation, one pass over the queue per fused follow-up join
+// (ChainStage: direct-table lookup of a base key column + the stage's filter, survivors compacted in place, selective
+// stages first, the base join's own filter last), and reads the output columns by (source row, pointer) — nothing
+// between the base join and the last stage is materialised.  In range-index mode the fill expands, per probe row,
+// only the value interval of its key's group that the first stage's window allows, and candidates carry index
+// positions (see bcol).
 constexpr int kResolveUnroll = 4;
 
 template <int FS, int PFS, int ITEMS, int MODE, bool CHAIN>
