@@ -374,11 +374,18 @@ __global__ __launch_bounds__(kLdsBlock) void lds_join_kernel(const LdsJoinArgs a
                   if (restrict_ok) { bound(st0.l0, i64(r0)); bound(st0.l1, i64(r1)); }
                 }
                 if (restrict_ok) {
-                  u32 b = s[k].x, e = s[k].y;
-                  while (b < e) { const u32 mid = b + ((e - b) >> 1); if (a.range_vals[mid] < lo) b = mid + 1; else e = mid; }   // lower_bound(lo)
+                  // the index stores value - vbase + 1 in 32 bits (0 = no stage row: below every lower bound)
+                  const long long vb = a.range_vbase;
+                  const unsigned long long dl = (unsigned long long)lo - (unsigned long long)vb;   // exact when lo >= vb (mod 2^64 otherwise unused)
+                  const unsigned long long dh = (unsigned long long)hi - (unsigned long long)vb;   // exact when hi >= vb
+                  const bool empty = hi < vb || lo > hi || (lo > vb && dl >= 0xFFFFFFFEull);
+                  const u32 lo_b = lo <= vb ? 1u : (u32)dl + 1u;
+                  const u32 hi_b = dh >= 0xFFFFFFFEull ? 0xFFFFFFFFu : (u32)dh + 1u;
+                  u32 b = s[k].x, e = empty ? s[k].x : s[k].y;
+                  while (b < e) { const u32 mid = b + ((e - b) >> 1); if (a.range_vals[mid] < lo_b) b = mid + 1; else e = mid; }   // lower_bound(lo)
                   const u32 first = b;
-                  e = s[k].y;
-                  while (b < e) { const u32 mid = b + ((e - b) >> 1); if (a.range_vals[mid] <= hi) b = mid + 1; else e = mid; }  // upper_bound(hi)
+                  e = empty ? s[k].x : s[k].y;
+                  while (b < e) { const u32 mid = b + ((e - b) >> 1); if (a.range_vals[mid] <= hi_b) b = mid + 1; else e = mid; }  // upper_bound(hi)
                   s[k].x = first; s[k].y = b;
                 }
               }
@@ -510,8 +517,9 @@ __global__ __launch_bounds__(kLdsBlock) void lds_join_kernel(const LdsJoinArgs a
             for (int u = 0; u < kResolveUnroll; u++) {
               long long x; bool in;
               if (t == 0 && a.range_link != nullptr) {   // range-index mode: the candidate's position carries the first stage's value
-                in = ok[u];
-                x = a.range_vals[in ? m[u].x : 0u];
+                const u32 biased = a.range_vals[ok[u] ? m[u].x : 0u];
+                in = ok[u] && biased != 0;
+                x = in ? (long long)(biased - 1u) + a.range_vbase : INT64_MIN;
               } else {
                 const u32 key = st.key.src ? bcol(a, st.key.ptr, ok[u] ? m[u].x : 0u) : st.key.ptr[ok[u] ? m[u].y : 0u];
                 const u32 d = key - st.kmin;

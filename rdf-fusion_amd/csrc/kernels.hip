@@ -593,11 +593,9 @@ __global__ __launch_bounds__(256) void range_keys_kernel(const u32* group_col, u
   key64[p] = (g << 32) | (v == INT64_MIN ? 0ull : (u64)(v - vbase) + 1ull);   // biased value; 0 = no stage row
   rows_in[p] = row;
 }
-__global__ __launch_bounds__(256) void range_decode_kernel(const u64* key64, u64 n, long long vbase, long long* vals) {
+__global__ __launch_bounds__(256) void range_decode_kernel(const u64* key64, u64 n, u32* vals) {
   const u64 p = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= n) return;
-  const u64 b = key64[p] & 0xFFFFFFFFull;
-  vals[p] = b == 0 ? INT64_MIN : (long long)(b - 1) + vbase;
+  if (p < n) vals[p] = (u32)(key64[p] & 0xFFFFFFFFull);   // the biased value (0 = no stage row)
 }
 void launch_range_minmax(const u32* stage_key_col, const u32* csr_rows, u64 n, const long long* val, u32 vmin_key, u32 vn, long long* out, hipStream_t s) {
   const u64 g = (n + 256 * 16 - 1) / (256 * 16);
@@ -607,8 +605,8 @@ void launch_range_keys(const u32* group_col, u32 gmin, const u32* stage_key_col,
                        long long vbase, u64* key64, u32* rows_in, hipStream_t s) {
   if (n) hipLaunchKernelGGL(range_keys_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, group_col, gmin, stage_key_col, csr_rows, n, val, vmin_key, vn, vbase, key64, rows_in);
 }
-void launch_range_decode(const u64* key64_sorted, u64 n, long long vbase, long long* vals_out, hipStream_t s) {
-  if (n) hipLaunchKernelGGL(range_decode_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, key64_sorted, n, vbase, vals_out);
+void launch_range_decode(const u64* key64_sorted, u64 n, u32* biased_vals_out, hipStream_t s) {
+  if (n) hipLaunchKernelGGL(range_decode_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, key64_sorted, n, biased_vals_out);
 }
 
 void launch_gdirect_build(const u32* keys, u64 n, u32* direct, u32 kmin, u32 kn, u32* dup_dev, hipStream_t s) {

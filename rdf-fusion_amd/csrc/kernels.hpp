@@ -155,7 +155,8 @@ struct LdsJoinArgs {
   // re-ordered by that value (range_rows / range_vals, built once per store version), so that a probe row expands only
   // the sub-range of its group that can pass the window (two binary searches) instead of the whole group.  A pruning
   // only: the stage itself still checks every candidate.
-  const u32* range_rows; const long long* range_vals;
+  const u32* range_rows; const u32* range_vals;   // values biased: stored = value - range_vbase + 1 (0 = the stage has no row for the key)
+  long long range_vbase;
   const u32* range_link; const u32* range_link_col;   // the link column (range_link_col, a build column) in the index's order;
                                                       // non-null: candidates carry index positions, not build rows
   u32 n_chain;              // fused follow-up lookups (0 = none); then the output columns are chain_out[], not proj[]
@@ -196,7 +197,7 @@ void launch_fill_i64(long long* p, long long v, u64 n, hipStream_t s);
 void launch_range_minmax(const u32* stage_key_col, const u32* csr_rows, u64 n, const long long* val, u32 vmin_key, u32 vn, long long* out_minmax /* {min,max} preset */, hipStream_t s);
 void launch_range_keys(const u32* group_col, u32 gmin, const u32* stage_key_col, const u32* csr_rows, u64 n, const long long* val, u32 vmin_key, u32 vn,
                        long long vbase, u64* key64, u32* rows_in, hipStream_t s);
-void launch_range_decode(const u64* key64_sorted, u64 n, long long vbase, long long* vals_out, hipStream_t s);
+void launch_range_decode(const u64* key64_sorted, u64 n, u32* biased_vals_out, hipStream_t s);
 void launch_gdirect_build(const u32* keys, u64 n, u32* direct /* 0xFF-filled */, u32 kmin, u32 kn, u32* dup_dev, hipStream_t s);
 
 // ---- DISTINCT + TopK per group (the operators directly above the path; topk.hip) ----

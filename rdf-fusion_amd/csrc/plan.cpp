@@ -888,7 +888,7 @@ bool Plan::apply_chain(const ChainRequest& req, NodeInfo& base, const DevTable& 
       SliceTable::RangeIndex* ri = nullptr;
       for (auto& r : tab->ranges) if (r.val == s0.val && r.link_col == s0.key.ptr) ri = &r;
       if (!ri) {
-        SliceTable::RangeIndex fresh{s0.val, s0.key.ptr, nullptr, nullptr, nullptr, false};
+        SliceTable::RangeIndex fresh{s0.val, s0.key.ptr, nullptr, nullptr, 0, nullptr, false};
         const u64 n = B.cap;
         long long* mm = reinterpret_cast<long long*>(new_counter()); (void)new_counter();   // {min, max}: two slots
         const long long init[2] = {INT64_MAX, INT64_MIN + 1};
@@ -900,12 +900,13 @@ bool Plan::apply_chain(const ChainRequest& req, NodeInfo& base, const DevTable& 
         if (got[0] <= got[1] && (unsigned long long)(got[1] - got[0]) < 0xFFFFFFF0ull && n < (1ull << 32)) {
           u64* key_in = scratch<u64>(n); u64* key_out = scratch<u64>(n); u32* rows_in = scratch<u32>(n);
           RDFGPU_HIP(hipMalloc((void**)&fresh.rows, n * sizeof(u32)));
-          RDFGPU_HIP(hipMalloc((void**)&fresh.vals, n * sizeof(long long)));
+          RDFGPU_HIP(hipMalloc((void**)&fresh.vals, n * sizeof(u32)));
+          fresh.vbase = got[0];
           launch_range_keys(a.build_key[0], a.direct_min, s0.key.ptr, a.csr_rows, n, s0.val, s0.kmin, s0.kn, got[0], key_in, rows_in, stream);
           const size_t tb = sort_temp_bytes(n);
           void* temp = scratch<unsigned char>(tb);
           sort_pairs_u64_u32(key_in, key_out, rows_in, fresh.rows, n, temp, tb, stream);
-          launch_range_decode(key_out, n, got[0], fresh.vals, stream);
+          launch_range_decode(key_out, n, fresh.vals, stream);
           RDFGPU_HIP(hipMalloc((void**)&fresh.link, n * sizeof(u32)));
           launch_gather_u32(s0.key.ptr, fresh.rows, fresh.link, n, stream);   // the link column in index order
           RDFGPU_HIP(hipStreamSynchronize(stream)); metrics.host_syncs++;
@@ -914,7 +915,7 @@ bool Plan::apply_chain(const ChainRequest& req, NodeInfo& base, const DevTable& 
         tab->ranges.push_back(fresh);
         ri = &tab->ranges.back();
       }
-      if (ri->usable) { a.range_rows = ri->rows; a.range_vals = ri->vals; a.range_link = ri->link; a.range_link_col = ri->link_col; }
+      if (ri->usable) { a.range_rows = ri->rows; a.range_vals = ri->vals; a.range_vbase = ri->vbase; a.range_link = ri->link; a.range_link_col = ri->link_col; }
     }
   }
   a.n_chain = (u32)req.links.size();

@@ -67,7 +67,7 @@ struct SliceTable {
   std::vector<ValueColumn> values;
   // a CSR table's groups re-ordered by a decoded value of ANOTHER slice (reached through `link_col`, a column of this
   // slice holding that slice's key): rows[p] / vals[p] for every CSR position p, ascending by value inside each group
-  struct RangeIndex { const long long* val; const u32* link_col; u32* rows; long long* vals; u32* link; bool usable; };
+  struct RangeIndex { const long long* val; const u32* link_col; u32* rows; u32* vals; long long vbase; u32* link; bool usable; };
   std::vector<RangeIndex> ranges;
 };
 struct SliceKey {
