@@ -677,6 +677,23 @@ def test_fused_lookup_chain_equals_unfused(bsbm_stores, torch_cuda, monkeypatch)
             np.testing.assert_array_equal(ku.multiset(plain), ku.multiset(got))
             monkeypatch.delenv("RDFGPU_NO_CHAIN_FUSION")
     assert fused_seen or ENGINE_TOGGLED, "the lookup chain was never fused"
+    # the store changes under the compiled plan: every cached table / value table / range index must be rebuilt
+    extra_p = rng.choice(ds.n_products, 300, replace=False)
+    g2 = np.zeros(600, np.uint32)
+    s2 = np.concatenate([[ds.product(int(i)) for i in extra_p]] * 2).astype(np.uint32)
+    p2 = np.concatenate([np.full(300, ds.pred["bsbm:productFeature"]), np.full(300, ds.pred["bsbm:productPropertyNumeric1"])]).astype(np.uint32)
+    o2 = np.concatenate([ds.feature_base + rng.integers(0, ds.n_features, 300), ds.int_base + rng.integers(0, 2000, 300)]).astype(np.uint32)
+    try:
+        assert gs.extend(g2, s2, p2, o2) == os_.extend(g2, s2, p2, o2)
+        for it in range(3):
+            got = plan.execute().fetch()
+            exp, n_exp, _ = os_.execute(desc, [params])
+            np.testing.assert_array_equal(ku.multiset(got), ku.multiset(exp, n_exp))
+    finally:   # the module-scoped stores go back to their original content
+        assert gs.remove(g2, s2, p2, o2) == os_.remove(g2, s2, p2, o2)
+    got = plan.execute().fetch()
+    exp, n_exp, _ = os_.execute(desc, [params])
+    np.testing.assert_array_equal(ku.multiset(got), ku.multiset(exp, n_exp))
 
 
 TOGGLES = ["RDFGPU_NO_CHAIN_FUSION", "RDFGPU_NO_INDEX_JOIN", "RDFGPU_NO_TABLE_CACHE", "RDFGPU_NO_SPECULATION",
