@@ -226,12 +226,8 @@ def main():
     else:
         plans_a = [store.plan(d) for d in bsbm.q5_batch_const_plans(ds)]
         plan_b = store.plan(bsbm.q5_batch_plan(ds, tables=True))
-        # Hash sharding gives a rank ~Q/world of a batch's instances; head room of 1.5x + 64 instances on top.
-        inst_cap = min(Q, int(Q / world * 1.5) + 64)
-        caps = [inst_cap * 28, inst_cap * 2, inst_cap * 2]    # rows per rank and table (fan-out U{9..28}; <= 1 value)
-        offs = [0, 3 * caps[0], 3 * (caps[0] + caps[1])]      # int32 offset of each table inside the exchange buffer
-        buf_len = 3 * sum(caps)
-
+        ex = sharding.BatchExchange(Q, world)                # fixed-size, zero-padded exchange buffer (one all-gather per step)
+        buf_len = ex.buf_len
         send_buf = torch.zeros(buf_len, dtype=torch.int32, device="cuda")
 
         class _DevCol:
@@ -249,30 +245,23 @@ def main():
             t, ptrs, n = params_on_device(batch)
             mine = send_buf.zero_()
 
-            for pa, cap, off in zip(plans_a, caps, offs):
+            for slot, pa in enumerate(plans_a):
                 pa.bind_table(0, ptrs, n)
                 pa.enable_kernel_timing(timing)
                 pa.execute()
                 if timing:
                     account(pa)
                 cols, rows = pa.result_device()
-                if rows > cap:
-                    raise RuntimeError(f"exchange buffer too small: {rows} rows > {cap}")
-                for k in range(3):
-                    if rows:
-                        mine[off + k * cap:off + k * cap + rows] = torch.as_tensor(_DevCol(cols[k], rows), device="cuda")
+                ex.pack(mine, slot, [torch.as_tensor(_DevCol(c, rows), device="cuda") if rows else None for c in cols], rows)
             torch.cuda.current_stream().synchronize()
             t_x = time.perf_counter()
             send = mine.to(xdev)
             out = torch.empty(world * buf_len, dtype=torch.int32, device=send.device)
             dist.all_gather_into_tensor(out, send)
-            out = out.to("cuda").view(world, buf_len)
-            keep = []
-            for slot, (cap, off) in enumerate(zip(caps, offs)):
-                # (world, 3, cap) -> (3, world * cap): one contiguous column per variable
-                tab = out[:, off:off + 3 * cap].reshape(world, 3, cap).permute(1, 0, 2).contiguous()
-                keep.append(tab)
-                plan_b.bind_table(slot, [tab.data_ptr() + 4 * world * cap * k for k in range(3)], world * cap)
+            keep = ex.unpack(out.to("cuda"))                  # per table (3, world * cap): one contiguous column per variable
+            for slot, tab in enumerate(keep):
+                rows_all = tab.shape[1]
+                plan_b.bind_table(slot, [tab.data_ptr() + 4 * rows_all * k for k in range(3)], rows_all)
             torch.cuda.current_stream().synchronize()      # the tables are complete before the plan's stream reads them
             t_b = time.perf_counter()
             plan_b.enable_kernel_timing(timing)

@@ -110,3 +110,34 @@ def run_q5_batch_sharded(ds, products, run_const, run_local, all_gather, pmap=No
     gathered = all_gather(recs)
     tables = unpack_records(gathered)
     return sum(pmap(lambda i: run_local(q5_local_plan(ds, products[i]), list(tables[i])), range(len(products))))
+
+
+class BatchExchange:
+    """The exchange step of a graph-sharded BATCH of Q5 instances (bench.py --gpus N, tests/test_sharding_cpu.py):
+    every rank holds the bindings of the batch's three constant-subject patterns for the subjects of ITS shard, as
+    three (inst, X, v) tables; all ranks need all of them.  One fixed-size int32 buffer per rank, zero padded, ONE
+    all-gather: a padding row has inst = 0 = null, and a null key never joins (NullEqualsNothing), so the gathered
+    buffer is bound as it is — an all-gatherv without the count exchange.  Works on torch tensors of any device."""
+
+    def __init__(self, n_instances, world):
+        # hash sharding gives a rank ~Q/world of a batch's instances; head room of 1.5x + 64 instances on top
+        self.world = world
+        self.inst_cap = min(n_instances, int(n_instances / world * 1.5) + 64)
+        self.caps = [self.inst_cap * 28, self.inst_cap * 2, self.inst_cap * 2]   # rows per rank and table (fan-out U{9..28}; <= 1 value)
+        self.offs = [0, 3 * self.caps[0], 3 * (self.caps[0] + self.caps[1])]  # int32 offset of each table inside the buffer
+        self.buf_len = 3 * sum(self.caps)
+
+    def pack(self, buf, slot, cols, rows):
+        """writes table `slot` (three int32 tensors of `rows` elements) into the zeroed send buffer"""
+        cap, off = self.caps[slot], self.offs[slot]
+        if rows > cap:
+            raise RuntimeError(f"exchange buffer too small: {rows} rows > {cap}")
+        for k in range(3):
+            if rows:
+                buf[off + k * cap:off + k * cap + rows] = cols[k]
+
+    def unpack(self, gathered):
+        """(world * buf_len,) gathered buffer -> per table one contiguous (3, world * cap) tensor: a column per variable"""
+        out = gathered.view(self.world, self.buf_len)
+        return [out[:, off:off + 3 * cap].reshape(self.world, 3, cap).permute(1, 0, 2).contiguous().view(3, self.world * cap)
+                for cap, off in zip(self.caps, self.offs)]

@@ -106,3 +106,102 @@ def test_exchange_record_roundtrip():
     out = sharding.unpack_records(np.stack([np.stack([rec0, rec1]), np.stack([rec1, rec0])]))
     assert out[0][0].tolist() == [5, 9, 4000000000] and out[0][1].tolist() == [77] and out[0][2].tolist() == [88]
     assert out[1][0].tolist() == [5, 9, 4000000000]
+
+
+# --------------------------------------------------------------------------- the batched flow bench.py --gpus N runs
+BATCH = 96          # instances per batch: products drawn WITH repetition, so instances sharing a product are covered
+
+
+def _batch_products(ds):
+    rng = np.random.default_rng(4)
+    return np.array([ds.product(int(i)) for i in rng.integers(0, ds.n_products, BATCH)], dtype=np.uint32)
+
+
+def _batch_worker(rank, world, port, q):
+    """bench.py's N > 1 step with the oracle as executor: phase A (three constant-subject plans over the local shard,
+    whole batch) -> BatchExchange.pack -> ONE all_gather_into_tensor -> unpack -> phase B over the local shard."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
+    import torch.distributed as dist
+    from rdf_fusion_amd import bsbm, sharding
+    from oracle import oracle as orc
+    import kat_util as ku
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ds = bsbm.generate(600)
+        g, s, p, o = sharding.shard_dataset(ds, rank, world)
+        st = orc.OracleStore()
+        st.extend(g, s, p, o)
+        st.set_typed_values(ds.typed_values)
+        batch = _batch_products(ds)
+        params = [np.arange(1, BATCH + 1, dtype=np.uint32), batch]
+        ex = sharding.BatchExchange(BATCH, world)
+        mine = torch.zeros(ex.buf_len, dtype=torch.int32)
+        for slot, desc in enumerate(bsbm.q5_batch_const_plans(ds)):
+            cols, n, _ = st.execute(desc, tables=[params])
+            ex.pack(mine, slot, [torch.from_numpy(np.ascontiguousarray(c[:n]).view(np.int32)) for c in cols], n)
+        out = torch.empty(world * ex.buf_len, dtype=torch.int32)
+        dist.all_gather_into_tensor(out, mine)
+        tabs = [[t[k].numpy().view(np.uint32) for k in range(3)] for t in ex.unpack(out)]
+        assert all(len(t[0]) == world * cap for t, cap in zip(tabs, ex.caps))
+        cols, n, _ = st.execute(bsbm.q5_batch_plan(ds, tables=True), tables=tabs)
+        q.put((rank, n, ku.multiset(cols, n), [int((t[0] != 0).sum()) for t in tabs]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_q5_batch_exchange_equals_unsharded(world):
+    import torch.multiprocessing as mp
+    from rdf_fusion_amd import bsbm
+    from oracle import oracle as orc
+    import kat_util as ku
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_batch_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    ds = bsbm.generate(600)
+    st = orc.OracleStore()
+    st.extend(ds.g, ds.s, ds.p, ds.o)
+    st.set_typed_values(ds.typed_values)
+    batch = _batch_products(ds)
+    cols, n, _ = st.execute(bsbm.q5_batch_plan(ds), tables=[[np.arange(1, BATCH + 1, dtype=np.uint32), batch]])
+    expected = ku.multiset(cols, n)
+    got = np.concatenate([r[2] for r in results])
+    got = ku.multiset(list(got.T))
+    assert sum(r[1] for r in results) == n > 0
+    np.testing.assert_array_equal(got, expected)
+    # every rank saw the same gathered tables; the padding rows (inst = 0) joined with nothing
+    assert all(r[3] == results[0][3] for r in results) and min(results[0][3]) > 0
+
+
+def test_batch_exchange_layout_and_overflow():
+    import torch
+    from rdf_fusion_amd import sharding
+    ex = sharding.BatchExchange(1000, 4)
+    assert ex.inst_cap == 439 and ex.caps == [439 * 28, 878, 878] and ex.buf_len == 3 * sum(ex.caps)
+    assert sharding.BatchExchange(10, 4).inst_cap == 10                       # never more than the batch itself
+    bufs = []
+    for r in range(4):
+        b = torch.zeros(ex.buf_len, dtype=torch.int32)
+        for slot in range(3):
+            rows = r + slot                                                    # ragged, including an empty table
+            ex.pack(b, slot, [torch.full((rows,), 100 * r + 10 * slot + k + 1, dtype=torch.int32) for k in range(3)], rows)
+        bufs.append(b)
+    tabs = ex.unpack(torch.cat(bufs))
+    for slot, t in enumerate(tabs):
+        assert t.shape == (3, 4 * ex.caps[slot]) and t.is_contiguous()
+        for r in range(4):
+            seg = t[:, r * ex.caps[slot]:(r + 1) * ex.caps[slot]]
+            for k in range(3):
+                assert seg[k, :r + slot].tolist() == [100 * r + 10 * slot + k + 1] * (r + slot) and int(seg[k, r + slot:].abs().sum()) == 0
+    with pytest.raises(RuntimeError, match="exchange buffer too small"):
+        ex.pack(torch.zeros(ex.buf_len, dtype=torch.int32), 1, [torch.zeros(879, dtype=torch.int32)] * 3, 879)
