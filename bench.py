@@ -327,7 +327,9 @@ def main():
     if kstats:
         name, (launches, ms, nbytes, rows) = max(kstats.items(), key=lambda kv: kv[1][1])
         achieved = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-        traffic, traffic_src = pmc_traffic(name)
+        # the committed counters are of the default single-GPU command: quoted for that workload only
+        default_workload = world == 1 and not args.per_instance and args.queries == ap.get_default("queries") and args.products == ap.get_default("products")
+        traffic, traffic_src = pmc_traffic(name) if default_workload else (None, None)
         roofline = {"bound": "hbm", "kernel": name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                     "traffic_GBps": (round(traffic / (ms * 1e-3 / max(1, launches)) / 1e9, 1) if traffic and ms > 0 else None),
