@@ -77,18 +77,23 @@ def scan_roofline(rf, device, log2_rows=26, threshold=1000, reps=10):
             "frac": round(gbs / HBM_PEAK_GBS, 4), "frac_of_measured_copy_ceiling": round(gbs / 6290.0, 4)}
 
 
-def pmc_traffic(kernel):
+def pmc_traffic(kernel, queries, products):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of THIS command (FETCH_SIZE and
     WRITE_SIZE in separate runs, gfx950 corrections applied by profiles/summarize.py) — counters cannot be read
-    from inside the benchmark process, so the newest summary under profiles/ is quoted, with its file name."""
+    from inside the benchmark process, so the newest summary under profiles/ whose recorded workload (`_workload`)
+    is the one being run is quoted, with its file name."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_fetch_write_per_kernel.json")))
+    import re
+    files = glob.glob(os.path.join(ROOT, "profiles", "*_pmc_fetch_write_per_kernel.json"))
+    files.sort(key=lambda f: [int(x) for x in re.findall(r"\d+", os.path.basename(f))])
     for f in reversed(files):
         try:
-            e = json.load(open(f)).get(kernel)
+            d = json.load(open(f))
         except (OSError, ValueError):
             continue
-        if e and "hbm_bytes_per_launch" in e:
+        w = d.get("_workload") or {}
+        e = d.get(kernel)
+        if w.get("queries") == queries and w.get("products") == products and e and "hbm_bytes_per_launch" in e:
             return int(e["hbm_bytes_per_launch"]), os.path.relpath(f, ROOT)
     return None, None
 
@@ -99,7 +104,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--products", type=int, default=285_000, help="BSBM scale (285000 products = ~100 M triples)")
-    ap.add_argument("--queries", type=int, default=65536, help="Q5 instances per step (the batch)")
+    ap.add_argument("--queries", type=int, default=262144, help="Q5 instances per step (the batch)")
     ap.add_argument("--per-instance", action="store_true", help="one reference plan per instance instead of one batched tree")
     ap.add_argument("--threads", type=int, default=4, help="--per-instance: host threads submitting queries")
     ap.add_argument("--cpu-sample", type=int, default=14, help="Q5 instances timed on the CPU oracle (rank 0, N=1)")
@@ -151,9 +156,12 @@ def main():
     rng = np.random.default_rng(12345)
     n_batches = args.steps + args.warmup
     Q = args.queries
-    products = np.array([ds.product(i) for i in rng.choice(ds.n_products, size=min(ds.n_products, n_batches * Q), replace=False)], dtype=np.uint32)
-    batches = [products[(i * Q) % len(products):(i * Q) % len(products) + Q] for i in range(n_batches)]
-    batches = [b if len(b) == Q else products[:Q] for b in batches]
+    if Q > ds.n_products:
+        raise SystemExit(f"--queries {Q} exceeds the {ds.n_products} products of this scale (instances of one batch are distinct products)")
+    # every step gets its own query mix: Q distinct products, drawn independently per batch (same seed on every rank)
+    all_products = np.array([ds.product(i) for i in range(ds.n_products)], dtype=np.uint32)
+    batches = [np.ascontiguousarray(all_products[rng.choice(ds.n_products, size=Q, replace=False)]) for _ in range(n_batches)]
+    products = np.concatenate(batches)                   # the instances the latency / CPU-baseline samples are taken from
 
     kstats = {}
     lock = threading.Lock()
@@ -327,9 +335,8 @@ def main():
     if kstats:
         name, (launches, ms, nbytes, rows) = max(kstats.items(), key=lambda kv: kv[1][1])
         achieved = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-        # the committed counters are of the default single-GPU command: quoted for that workload only
-        default_workload = world == 1 and not args.per_instance and args.queries == ap.get_default("queries") and args.products == ap.get_default("products")
-        traffic, traffic_src = pmc_traffic(name) if default_workload else (None, None)
+        # the committed counters are of a single-GPU batched run: quoted only for the workload they were collected on
+        traffic, traffic_src = pmc_traffic(name, args.queries, args.products) if world == 1 and not args.per_instance else (None, None)
         roofline = {"bound": "hbm", "kernel": name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                     "traffic_GBps": (round(traffic / (ms * 1e-3 / max(1, launches)) / 1e9, 1) if traffic and ms > 0 else None),

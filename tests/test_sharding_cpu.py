@@ -187,7 +187,9 @@ def test_batch_exchange_layout_and_overflow():
     import torch
     from rdf_fusion_amd import sharding
     ex = sharding.BatchExchange(1000, 4)
-    assert ex.inst_cap == 439 and ex.caps == [439 * 28, 878, 878] and ex.buf_len == 3 * sum(ex.caps)
+    assert ex.inst_cap == 531 and ex.caps == [531 * 28, 531, 531] and ex.buf_len == 3 * sum(ex.caps)
+    big = sharding.BatchExchange(262144, 8)
+    assert big.inst_cap == 36300 and big.caps[0] == 36300 * 21                # large batches: mean fan-out + margin, not the worst case
     assert sharding.BatchExchange(10, 4).inst_cap == 10                       # never more than the batch itself
     bufs = []
     for r in range(4):
@@ -204,4 +206,4 @@ def test_batch_exchange_layout_and_overflow():
             for k in range(3):
                 assert seg[k, :r + slot].tolist() == [100 * r + 10 * slot + k + 1] * (r + slot) and int(seg[k, r + slot:].abs().sum()) == 0
     with pytest.raises(RuntimeError, match="exchange buffer too small"):
-        ex.pack(torch.zeros(ex.buf_len, dtype=torch.int32), 1, [torch.zeros(879, dtype=torch.int32)] * 3, 879)
+        ex.pack(torch.zeros(ex.buf_len, dtype=torch.int32), 1, [torch.zeros(532, dtype=torch.int32)] * 3, 532)
