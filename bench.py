@@ -232,7 +232,7 @@ def main():
                 account(plan)
             return rows
     else:
-        plans_a = [store.plan(d) for d in bsbm.q5_batch_const_plans(ds)]
+        plan_a = store.plan(bsbm.q5_batch_const_plan(ds))
         plan_b = store.plan(bsbm.q5_batch_plan(ds, tables=True))
         ex = sharding.BatchExchange(Q, world)                # fixed-size, zero-padded exchange buffer (one all-gather per step)
         buf_len = ex.buf_len
@@ -244,32 +244,30 @@ def main():
                 self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<i4", "data": (int(ptr), False), "version": 2}
 
         def step(batch, timing):
-            """Phase A: the constant-subject patterns of the whole batch on the local shard (three tiny plans).
-            Exchange: ONE all-gather of a fixed-size buffer holding the three (inst, X, v) tables, zero padded —
-            a padding row has inst = 0 = null, and a null key never joins (NullEqualsNothing), so the gathered
-            buffer is bound as it is: no counts travel, nothing is unpacked on the host.
+            """Phase A: the constant-subject patterns of the whole batch on the local shard, joined per instance:
+            C(inst, X, prodFeature, origProperty1, origProperty2) for the instances whose %Product% lives here.
+            Exchange: ONE all-gather of a fixed-size, zero-padded buffer holding C — a padding row has inst = 0 = null,
+            and a null key never joins (NullEqualsNothing), so the gathered buffer is bound as it is: no counts
+            travel, nothing is unpacked on the host.
             Phase B: the batch's join / FILTER pipeline over the local shard of the product-side patterns."""
             t_a = time.perf_counter()
             t, ptrs, n = params_on_device(batch)
             mine = send_buf.zero_()
-
-            for slot, pa in enumerate(plans_a):
-                pa.bind_table(0, ptrs, n)
-                pa.enable_kernel_timing(timing)
-                pa.execute()
-                if timing:
-                    account(pa)
-                cols, rows = pa.result_device()
-                ex.pack(mine, slot, [torch.as_tensor(_DevCol(c, rows), device="cuda") if rows else None for c in cols], rows)
+            plan_a.bind_table(0, ptrs, n)
+            plan_a.enable_kernel_timing(timing)
+            plan_a.execute()
+            if timing:
+                account(plan_a)
+            cols, rows = plan_a.result_device()
+            ex.pack(mine, [torch.as_tensor(_DevCol(c, rows), device="cuda") if rows else None for c in cols], rows)
             torch.cuda.current_stream().synchronize()
             t_x = time.perf_counter()
             send = mine.to(xdev)
             out = torch.empty(world * buf_len, dtype=torch.int32, device=send.device)
             dist.all_gather_into_tensor(out, send)
-            keep = ex.unpack(out.to("cuda"))                  # per table (3, world * cap): one contiguous column per variable
-            for slot, tab in enumerate(keep):
-                rows_all = tab.shape[1]
-                plan_b.bind_table(slot, [tab.data_ptr() + 4 * rows_all * k for k in range(3)], rows_all)
+            keep = ex.unpack(out.to("cuda"))                  # (5, world * cap): one contiguous column per variable
+            rows_all = keep.shape[1]
+            plan_b.bind_table(0, [keep.data_ptr() + 4 * rows_all * k for k in range(ex.N_COLS)], rows_all)
             torch.cuda.current_stream().synchronize()      # the tables are complete before the plan's stream reads them
             t_b = time.perf_counter()
             plan_b.enable_kernel_timing(timing)

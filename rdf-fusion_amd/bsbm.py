@@ -219,45 +219,42 @@ def _window(sim, orig, w):
                EBV(GT(ENC_TV(col(sim)), SUB(ENC_TV(col(orig)), integer(w)))))
 
 
-def q5_batch_const_plans(ds):
-    """Phase A of a batched Q5: the constant-subject patterns of ALL instances of a batch at once.
-    Table 0 = PARAMS(inst, X): one row per query instance (inst = position in the batch, X = %Product%).
-    Each plan joins PARAMS with the pattern's (unbound-subject) scan on X = ?s, which is what B separate
-    `<X> p ?v` scans return, tagged with the instance:  (inst, X, v)."""
+def _q5_batch_constants(pb, ds, params):
+    """C(inst, X, prodFeature, origProperty1, origProperty2): the three constant-subject patterns of every instance
+    of PARAMS(inst, X).  `PARAMS JOIN (?s p ?v) ON X = ?s` is what B separate `<X> p ?v` scans return, tagged with
+    the instance; the instance's constants then meet on inst (B x ~19 rows)."""
     pr = ds.pred
-    out = []
-    for pname in ("bsbm:productFeature", "bsbm:productPropertyNumeric1", "bsbm:productPropertyNumeric2"):
-        pb = PlanBuilder()
-        params = pb.table(0, 2)
-        scan = pb.data_source(quad_pattern("s", pr[pname], "v"))          # (s, v)
-        out.append(pb.build(pb.hash_join(params, scan, on=[(1, 0)], projection=[0, 1, 3])))
-    return out
+
+    def const(pname):
+        scan = pb.data_source(quad_pattern("s", pr[pname], "v"))              # (s, v)
+        return pb.hash_join(params, scan, on=[(1, 0)], projection=[0, 1, 3])  # (inst, X, v)
+    F, O1, O2 = const("bsbm:productFeature"), const("bsbm:productPropertyNumeric1"), const("bsbm:productPropertyNumeric2")
+    c = pb.hash_join(F, O1, on=[(0, 0)], projection=[0, 1, 2, 5])
+    return pb.hash_join(c, O2, on=[(0, 0)], projection=[0, 1, 2, 3, 6])
+
+
+def q5_batch_const_plan(ds):
+    """Phase A of a graph-sharded batched Q5: table 0 = PARAMS(inst, X), one row per query instance (inst = 1-based
+    position in the batch, X = %Product%); output C(inst, X, prodFeature, origProperty1, origProperty2) for the
+    instances whose %Product% is a subject of THIS shard (all three patterns have the subject X, so an instance's
+    constants live on one shard).  The union of the shards' C tables is the C of the whole graph."""
+    pb = PlanBuilder()
+    return pb.build(_q5_batch_constants(pb, ds, pb.table(0, 2)))
 
 
 def q5_batch_plan(ds, w1=120, w2=170, tables=None, topk=False):
     """BSBM Q5 for a BATCH of instances in one operator tree (shared scans: every triple-pattern partition
     is streamed once per batch instead of once per query).  Same operators as q5_plan; the per-instance
-    constant becomes a column: tables F(inst, X, prodFeature), O1(inst, X, origProperty1), O2(inst, X,
-    origProperty2) are either bound (slots 0,1,2 — the graph-sharded case, after the all-gather) or, when
-    `tables` is None, computed in-plan from PARAMS(inst, X) bound at slot 0.
+    constant becomes a column: the table C(inst, X, prodFeature, origProperty1, origProperty2) is either bound
+    (slot 0 — the graph-sharded case, after the all-gather of q5_batch_const_plan's outputs) or, when `tables` is
+    None, computed in-plan from PARAMS(inst, X) bound at slot 0.
     `product != X` is applied once, where the instance meets the product (all later joins are on product).
     Inner joins commute, so the batch is free to order them by cost: constants first, then the candidate
     join, then the two selective numeric windows, and the 1:1 label lookup last.
     Output: (inst, product, productLabel) — per instance exactly q5_plan's bindings (as a multiset)."""
     pr = ds.pred
     pb = PlanBuilder()
-    if tables is None:
-        params = pb.table(0, 2)
-
-        def const(pname):
-            scan = pb.data_source(quad_pattern("s", pr[pname], "v"))
-            return pb.hash_join(params, scan, on=[(1, 0)], projection=[0, 1, 3])
-        F, O1, O2 = const("bsbm:productFeature"), const("bsbm:productPropertyNumeric1"), const("bsbm:productPropertyNumeric2")
-    else:
-        F, O1, O2 = pb.table(0, 3), pb.table(1, 3), pb.table(2, 3)
-    # the instance's constants meet first (B x ~19 rows): (inst, X, f) JOIN O1 JOIN O2 ON inst -> (inst, X, f, orig1, orig2)
-    c = pb.hash_join(F, O1, on=[(0, 0)], projection=[0, 1, 2, 5])
-    c = pb.hash_join(c, O2, on=[(0, 0)], projection=[0, 1, 2, 3, 6])
+    c = _q5_batch_constants(pb, ds, pb.table(0, 2)) if tables is None else pb.table(0, 5)
     pf = pb.data_source(quad_pattern("product", pr["bsbm:productFeature"], "prodFeature"))      # (product, prodFeature)
     # candidates: JOIN (product, f) ON f, product != X   ->  (inst, product, orig1, orig2)
     node = pb.hash_join(c, pf, on=[(2, 1)], filter=ID_NEQ(col(5), col(1)), projection=[0, 5, 3, 4])

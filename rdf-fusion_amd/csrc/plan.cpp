@@ -1125,7 +1125,11 @@ DevTable Plan::exec_lds_join(NodeInfo& nd, const DevTable& L, const DevTable& R,
         u32 got[2];
         RDFGPU_HIP(hipMemcpyAsync(got, mm, sizeof(got), hipMemcpyDeviceToHost, stream));
         RDFGPU_HIP(hipStreamSynchronize(stream)); metrics.host_syncs++;
-        const bool dense = got[0] <= got[1] && (u64)(got[1] - got[0]) + 1 <= 4 * B.cap + 1024;
+        // "dense" = the id range is worth a 4-B-per-id table: up to 4 ids per row outright; up to 64 ids per row while
+        // the table stays small (16 M ids = 64 MB) — a subject-hash shard of a slice keeps the slice's id range with
+        // 1/G of its rows, and must not fall off the index-join path for that
+        const u64 range = got[0] <= got[1] ? (u64)(got[1] - got[0]) + 1 : ~0ull;
+        const bool dense = range <= 4 * B.cap + 1024 || (range <= 64 * B.cap + 1024 && range <= (16ull << 20));
         if (!dense) st->dense_failed = true;
         else {
           const u32 kmin = got[0], kn = got[1] - got[0] + 1;

@@ -114,34 +114,32 @@ def run_q5_batch_sharded(ds, products, run_const, run_local, all_gather, pmap=No
 
 class BatchExchange:
     """The exchange step of a graph-sharded BATCH of Q5 instances (bench.py --gpus N, tests/test_sharding_cpu.py):
-    every rank holds the bindings of the batch's three constant-subject patterns for the subjects of ITS shard, as
-    three (inst, X, v) tables; all ranks need all of them.  One fixed-size int32 buffer per rank, zero padded, ONE
-    all-gather: a padding row has inst = 0 = null, and a null key never joins (NullEqualsNothing), so the gathered
-    buffer is bound as it is — an all-gatherv without the count exchange.  Works on torch tensors of any device."""
+    every rank holds C(inst, X, prodFeature, origProperty1, origProperty2) — bsbm.q5_batch_const_plan — for the
+    instances whose %Product% is a subject of ITS shard; all ranks need all of it.  One fixed-size int32 buffer per
+    rank, zero padded, ONE all-gather: a padding row has inst = 0 = null, and a null key never joins
+    (NullEqualsNothing), so the gathered buffer is bound as it is — an all-gatherv without the count exchange.
+    Works on torch tensors of any device."""
+    N_COLS = 5
 
     def __init__(self, n_instances, world, fanout_max=28, fanout_mean=18.5):
         # Hash sharding gives a rank Binomial(Q, 1/world) of a batch's instances: 10 % + 256 instances of head room is
-        # > 15 standard deviations at every batch size.  The feature table holds U{9..28} rows per instance: small
-        # batches get the worst case, large ones the mean + 13 % (the sum of >= 4096 fan-outs is within 1 % of its mean);
-        # the two numeric tables hold at most one value per instance.  pack() refuses a table that does not fit.
+        # > 15 standard deviations at every batch size.  C holds U{9..28} rows per instance: small batches get the
+        # worst case, large ones the mean + 13 % (the sum of >= 4096 fan-outs is within 1 % of its mean).
+        # pack() refuses a table that does not fit.
         self.world = world
         self.inst_cap = min(n_instances, int(n_instances / world * 1.1) + 256)
         per_inst = fanout_max if self.inst_cap <= 4096 else min(fanout_max, int(fanout_mean * 1.13) + 1)
-        self.caps = [self.inst_cap * per_inst, self.inst_cap, self.inst_cap]     # rows per rank and table
-        self.offs = [0, 3 * self.caps[0], 3 * (self.caps[0] + self.caps[1])]     # int32 offset of each table inside the buffer
-        self.buf_len = 3 * sum(self.caps)
+        self.cap = self.inst_cap * per_inst                  # rows per rank
+        self.buf_len = self.N_COLS * self.cap                # int32 elements per rank
 
-    def pack(self, buf, slot, cols, rows):
-        """writes table `slot` (three int32 tensors of `rows` elements) into the zeroed send buffer"""
-        cap, off = self.caps[slot], self.offs[slot]
-        if rows > cap:
-            raise RuntimeError(f"exchange buffer too small: {rows} rows > {cap}")
-        for k in range(3):
+    def pack(self, buf, cols, rows):
+        """writes this rank's C (N_COLS int32 tensors of `rows` elements) into the zeroed send buffer, column-major"""
+        if rows > self.cap:
+            raise RuntimeError(f"exchange buffer too small: {rows} rows > {self.cap}")
+        for k in range(self.N_COLS):
             if rows:
-                buf[off + k * cap:off + k * cap + rows] = cols[k]
+                buf[k * self.cap:k * self.cap + rows] = cols[k]
 
     def unpack(self, gathered):
-        """(world * buf_len,) gathered buffer -> per table one contiguous (3, world * cap) tensor: a column per variable"""
-        out = gathered.view(self.world, self.buf_len)
-        return [out[:, off:off + 3 * cap].reshape(self.world, 3, cap).permute(1, 0, 2).contiguous().view(3, self.world * cap)
-                for cap, off in zip(self.caps, self.offs)]
+        """(world * buf_len,) gathered buffer -> one contiguous (N_COLS, world * cap) tensor: a column per variable"""
+        return gathered.view(self.world, self.N_COLS, self.cap).permute(1, 0, 2).contiguous().view(self.N_COLS, self.world * self.cap)

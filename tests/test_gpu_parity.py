@@ -423,20 +423,14 @@ def test_bsbm_q5_batched_equals_per_instance(bsbm_stores, torch_cuda, batch):
     sel = got[0] <= min(batch, 40)
     np.testing.assert_array_equal(ku.multiset([g[sel] for g in got]), ku.multiset(list(expected.T)))
     # graph-sharded form: phase A (constant patterns of the whole batch) then phase B over bound tables
-    tabs = []
-    for d in bsbm.q5_batch_const_plans(ds):
-        p = gs.plan(d)
-        p.bind_table(0, ptrs, batch)
-        tabs.append(p.execute().fetch())
-    keeps = [table_on_device(torch_cuda, t) for t in tabs]
-    plan_b, got_b = run_both(gs, os_, bsbm.q5_batch_plan(ds, tables=True),
-                             gpu_tables=[(k[1], len(t[0])) for k, t in zip(keeps, tabs)], cpu_tables=tabs)
+    pa, tab = run_both(gs, os_, bsbm.q5_batch_const_plan(ds), gpu_tables=[(ptrs, batch)], cpu_tables=[params])
+    keep_c, ptrs_c = table_on_device(torch_cuda, tab)
+    plan_b, got_b = run_both(gs, os_, bsbm.q5_batch_plan(ds, tables=True), gpu_tables=[(ptrs_c, len(tab[0]))], cpu_tables=[tab])
     np.testing.assert_array_equal(ku.multiset(got_b), ku.multiset(got))
-    # the multi-GPU exchange binds fixed-size, zero-padded buffers: a padding row has inst = 0 = null and must never join
-    padded = [[np.concatenate([c, np.zeros(37, np.uint32)]) for c in t] for t in tabs]
-    keeps_p = [table_on_device(torch_cuda, t) for t in padded]
-    for slot, (k, t) in enumerate(zip(keeps_p, padded)):
-        plan_b.bind_table(slot, k[1], len(t[0]))
+    # the multi-GPU exchange binds a fixed-size, zero-padded buffer: a padding row has inst = 0 = null and must never join
+    padded = [np.concatenate([c, np.zeros(37, np.uint32)]) for c in tab]
+    keep_p, ptrs_p = table_on_device(torch_cuda, padded)
+    plan_b.bind_table(0, ptrs_p, len(padded[0]))
     got_p = plan_b.execute().fetch()
     np.testing.assert_array_equal(ku.multiset(got_p), ku.multiset(got))
 
@@ -871,6 +865,42 @@ def test_fused_chain_with_mixed_numeric_kinds(torch_cuda):
     assert any("lds_join_kernel" in k[0] and k[0].endswith("true>") for k in plan.kernel_stats()) or ENGINE_TOGGLED
     for x in prods[:3]:
         run_both(gs, os_, bsbm.q5_plan(ds, int(x)))
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_subject_hash_shard_keeps_the_index_join_path(torch_cuda, world):
+    """A hash(subject) shard of a predicate slice keeps the slice's id range with 1/G of its rows: the engine must
+    still build its direct-address / CSR tables on it (phase B of the graph-sharded run is the same fused chain as on
+    one GPU), and the union of the shards' bindings is the unsharded answer."""
+    from rdf_fusion_amd import sharding
+    ds = bsbm.generate(12_000)        # 1500 products per shard at G = 8: slices above the LDS-table size
+    full_o = orc.OracleStore()
+    full_o.extend(ds.g, ds.s, ds.p, ds.o)
+    full_o.set_typed_values(ds.typed_values)
+    rng = np.random.default_rng(world)
+    batch = 300
+    prods = np.array([ds.product(i) for i in rng.choice(ds.n_products, batch, replace=False)], dtype=np.uint32)
+    params = [np.arange(1, batch + 1, dtype=np.uint32), prods]
+    c_tab, n_c, _ = full_o.execute(bsbm.q5_batch_const_plan(ds), [params])          # what the all-gather delivers
+    c_tab = [np.ascontiguousarray(c[:n_c]) for c in c_tab]
+    exp_all, n_all, _ = full_o.execute(bsbm.q5_batch_plan(ds), [params])
+    keep, ptrs = table_on_device(torch_cuda, c_tab)
+    desc = bsbm.q5_batch_plan(ds, tables=True)
+    union = []
+    for r in sorted({0, world - 1}) if world > 2 else range(world):
+        g, s, p, o = sharding.shard_dataset(ds, r, world)
+        gs, os_ = both_stores((g, s, p, o), typed=ds.typed_values)
+        plan = gs.plan(desc)
+        for it in range(3):
+            plan.bind_table(0, ptrs, n_c)
+            plan.enable_kernel_timing(True)
+            got = plan.execute().fetch()
+        exp, n_exp, _ = os_.execute(desc, [c_tab])
+        np.testing.assert_array_equal(ku.multiset(got), ku.multiset(exp, n_exp))
+        assert any("lds_join_kernel" in k[0] and k[0].endswith("true>") for k in plan.kernel_stats()) or ENGINE_TOGGLED
+        union.append(ku.multiset(got))
+    if world == 2:
+        np.testing.assert_array_equal(ku.multiset(list(np.concatenate(union).T)), ku.multiset(exp_all, n_all))
 
 
 def test_generic_vm_equals_specialised_kernels(bsbm_stores, monkeypatch):

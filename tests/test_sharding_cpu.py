@@ -119,7 +119,7 @@ def _batch_products(ds):
 
 def _batch_worker(rank, world, port, q):
     """bench.py's N > 1 step with the oracle as executor: phase A (three constant-subject plans over the local shard,
-    whole batch) -> BatchExchange.pack -> ONE all_gather_into_tensor -> unpack -> phase B over the local shard."""
+    whole batch, one plan) -> BatchExchange.pack -> ONE all_gather_into_tensor -> unpack -> phase B over the local shard."""
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import torch
@@ -139,15 +139,14 @@ def _batch_worker(rank, world, port, q):
         params = [np.arange(1, BATCH + 1, dtype=np.uint32), batch]
         ex = sharding.BatchExchange(BATCH, world)
         mine = torch.zeros(ex.buf_len, dtype=torch.int32)
-        for slot, desc in enumerate(bsbm.q5_batch_const_plans(ds)):
-            cols, n, _ = st.execute(desc, tables=[params])
-            ex.pack(mine, slot, [torch.from_numpy(np.ascontiguousarray(c[:n]).view(np.int32)) for c in cols], n)
+        cols, n, _ = st.execute(bsbm.q5_batch_const_plan(ds), tables=[params])
+        ex.pack(mine, [torch.from_numpy(np.ascontiguousarray(c[:n]).view(np.int32)) for c in cols], n)
         out = torch.empty(world * ex.buf_len, dtype=torch.int32)
         dist.all_gather_into_tensor(out, mine)
-        tabs = [[t[k].numpy().view(np.uint32) for k in range(3)] for t in ex.unpack(out)]
-        assert all(len(t[0]) == world * cap for t, cap in zip(tabs, ex.caps))
-        cols, n, _ = st.execute(bsbm.q5_batch_plan(ds, tables=True), tables=tabs)
-        q.put((rank, n, ku.multiset(cols, n), [int((t[0] != 0).sum()) for t in tabs]))
+        tab = [c.numpy().view(np.uint32) for c in ex.unpack(out)]
+        assert len(tab) == 5 and all(len(c) == world * ex.cap for c in tab)
+        cols, n, _ = st.execute(bsbm.q5_batch_plan(ds, tables=True), tables=[tab])
+        q.put((rank, n, ku.multiset(cols, n), int((tab[0] != 0).sum())))
     finally:
         dist.destroy_process_group()
 
@@ -180,30 +179,28 @@ def test_sharded_q5_batch_exchange_equals_unsharded(world):
     assert sum(r[1] for r in results) == n > 0
     np.testing.assert_array_equal(got, expected)
     # every rank saw the same gathered tables; the padding rows (inst = 0) joined with nothing
-    assert all(r[3] == results[0][3] for r in results) and min(results[0][3]) > 0
+    assert all(r[3] == results[0][3] for r in results) and results[0][3] > 0
 
 
 def test_batch_exchange_layout_and_overflow():
     import torch
     from rdf_fusion_amd import sharding
     ex = sharding.BatchExchange(1000, 4)
-    assert ex.inst_cap == 531 and ex.caps == [531 * 28, 531, 531] and ex.buf_len == 3 * sum(ex.caps)
+    assert ex.inst_cap == 531 and ex.cap == 531 * 28 and ex.buf_len == 5 * ex.cap
     big = sharding.BatchExchange(262144, 8)
-    assert big.inst_cap == 36300 and big.caps[0] == 36300 * 21                # large batches: mean fan-out + margin, not the worst case
+    assert big.inst_cap == 36300 and big.cap == 36300 * 21                    # large batches: mean fan-out + margin, not the worst case
     assert sharding.BatchExchange(10, 4).inst_cap == 10                       # never more than the batch itself
     bufs = []
     for r in range(4):
         b = torch.zeros(ex.buf_len, dtype=torch.int32)
-        for slot in range(3):
-            rows = r + slot                                                    # ragged, including an empty table
-            ex.pack(b, slot, [torch.full((rows,), 100 * r + 10 * slot + k + 1, dtype=torch.int32) for k in range(3)], rows)
+        rows = 3 * r                                                           # ragged, including an empty table
+        ex.pack(b, [torch.full((rows,), 100 * r + k + 1, dtype=torch.int32) for k in range(5)], rows)
         bufs.append(b)
-    tabs = ex.unpack(torch.cat(bufs))
-    for slot, t in enumerate(tabs):
-        assert t.shape == (3, 4 * ex.caps[slot]) and t.is_contiguous()
-        for r in range(4):
-            seg = t[:, r * ex.caps[slot]:(r + 1) * ex.caps[slot]]
-            for k in range(3):
-                assert seg[k, :r + slot].tolist() == [100 * r + 10 * slot + k + 1] * (r + slot) and int(seg[k, r + slot:].abs().sum()) == 0
+    t = ex.unpack(torch.cat(bufs))
+    assert t.shape == (5, 4 * ex.cap) and t.is_contiguous()
+    for r in range(4):
+        seg = t[:, r * ex.cap:(r + 1) * ex.cap]
+        for k in range(5):
+            assert seg[k, :3 * r].tolist() == [100 * r + k + 1] * (3 * r) and int(seg[k, 3 * r:].abs().sum()) == 0
     with pytest.raises(RuntimeError, match="exchange buffer too small"):
-        ex.pack(torch.zeros(ex.buf_len, dtype=torch.int32), 1, [torch.zeros(532, dtype=torch.int32)] * 3, 532)
+        ex.pack(torch.zeros(ex.buf_len, dtype=torch.int32), [torch.zeros(ex.cap + 1, dtype=torch.int32)] * 5, ex.cap + 1)
