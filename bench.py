@@ -148,7 +148,7 @@ def main():
     g, s, p, o = sharding.shard_dataset(ds, rank, world)
     store = rf.GpuQuadStore(device=local_rank)
     store.extend(g, s, p, o)
-    store.set_typed_values(ds.typed_values)
+    store.set_typed_values(ds.typed_values, ds.decimals)
     n_local = len(store)
     del g, s, p, o
     load_s = time.time() - t0
@@ -317,7 +317,7 @@ def main():
         if rank == 0:                                            # the whole graph on one GPU, same batch, one operator tree
             full = rf.GpuQuadStore(device=local_rank)
             full.extend(ds.g, ds.s, ds.p, ds.o)
-            full.set_typed_values(ds.typed_values)
+            full.set_typed_values(ds.typed_values, ds.decimals)
             pf = full.plan(bsbm.q5_batch_plan(ds))
             tt, pp, nn = dev_table([np.arange(1, len(probe_batch) + 1, dtype=np.uint32), probe_batch])
             pf.bind_table(0, pp, nn)
@@ -367,7 +367,7 @@ def main():
         os_ = orc.OracleStore()
         for comp in (0, 1, 2):   # adopt the device-built permutations: no second 100 M-row sort on the host
             os_.adopt_sorted(comp, store.read_index(comp))
-        os_.set_typed_values(ds.typed_values)
+        os_.set_typed_values(ds.typed_values, ds.decimals)
         sample = [int(x) for x in products[:args.cpu_sample]]
         cpu_rows, t_cpu, expected = 0, 0.0, []
         for i, x in enumerate(sample):

@@ -111,10 +111,16 @@ enum { RDFGPU_GSPO = 0, RDFGPU_GPOS = 1, RDFGPU_GOSP = 2, RDFGPU_N_INDEXES = 3 }
  *   tag 6 double:  lo = IEEE-754 binary64 bits
  *   tag 7 decimal: lo = index into the i128 side table (value * 10^18, decimal.rs:9-21)
  *   tag 8 int (i32, sign-extended), tag 9 integer (i64)
- *   tag 10..14 (dateTime, time, date, duration, other literal): opaque on device; any
- *              operator that would need their value yields an error (null) -> the plan
- *              compiler rejects such programs with RDFGPU_ERR_UNSUPPORTED unless
- *              RDFGPU_PLAN_ALLOW_OPAQUE is set.
+ *   tag 10 dateTime, 11 time, 12 date: a Timestamp (lib/model/src/xsd/date_time.rs:1599-1603; the host reads it with
+ *              DateTime::timestamp() / Time::timestamp() / Date::timestamp()): lo = index into the i128 side table
+ *              holding Timestamp.value (seconds on the XSD time line * 10^18, already shifted to UTC when a timezone
+ *              is present), aux bit0 = timezone_offset.is_some().  Compared as PartialOrd for Timestamp does
+ *              (date_time.rs:1617-1654): same presence => the values; otherwise the value without a timezone may lie
+ *              14 h either way and the order must hold for both, else the comparison is an error.  Same kind only.
+ *   tag 13 duration, 14 other literal: opaque on device (other literals: equal iff same datatype (aux) and same
+ *              lexical value (lo), typed_value.rs:253-258); an operator that would need their value yields the
+ *              SPARQL error value, i.e. the row is dropped by a FILTER — durations order by calendar arithmetic
+ *              (duration.rs:271-310), not restated here.
  */
 typedef struct rdfgpu_typed_value {
   int64_t lo;
@@ -159,7 +165,8 @@ int rdfgpu_store_len(const rdfgpu_store* store, uint64_t* out);
 /*
  * Installs the id -> typed value table (MemObjectIdMapping::decode_array_to_typed_value,
  * object_id_mapping.rs:376-399).  values[i] describes object id i (values[0] is ignored:
- * id 0 is null).  `decimals` holds n_decimals little-endian i128 as (lo,hi) int64 pairs.
+ * id 0 is null).  `decimals` holds n_decimals little-endian i128 as (lo,hi) int64 pairs: the
+ * values of xsd:decimal literals (tag 7) and the timestamps of tags 10..12.
  */
 int rdfgpu_store_set_typed_values(rdfgpu_store* store, const rdfgpu_typed_value* values,
                                   uint64_t n_ids, const int64_t* decimals, uint64_t n_decimals);
@@ -255,8 +262,8 @@ typedef struct rdfgpu_expr_node {
   uint8_t flags;    /* LIT_TV: rdfgpu_typed_value.flags                                   */
   uint8_t reserved;
   uint32_t u;       /* COLUMN: column index; LIT_ID: id; LIT_TV: aux; LIT_BOOL: 0/1/2     */
-  int64_t lo;       /* LIT_TV payload (decimal literals: low 64 bits)                     */
-  int64_t hi;       /* LIT_TV decimal literal: high 64 bits                               */
+  int64_t lo;       /* LIT_TV payload (decimal / dateTime / time / date literals: low 64 bits of the i128) */
+  int64_t hi;       /* LIT_TV decimal / timestamp literal: high 64 bits; timestamps: u bit0 = has timezone */
 } rdfgpu_expr_node; /* 24 bytes */
 
 /* Physical operators of the path, named as in the reference's execution plans

@@ -181,7 +181,7 @@ class OracleStore:
     def set_typed_values(self, values, decimals=None):
         values = np.ascontiguousarray(values)
         assert values.dtype.itemsize == 16
-        dec = np.ascontiguousarray(decimals if decimals is not None else np.zeros((0, 2), np.int64), dtype=np.int64)
+        dec = np.ascontiguousarray(decimals if decimals is not None else np.zeros((0, 2), np.int64), dtype=np.int64).reshape(-1, 2)   # (lo, hi) per i128
         self._l.orc_store_set_typed_values(self._h, values.ctypes.data_as(C.c_void_p), len(values),
                                            dec.ctypes.data_as(C.c_void_p), len(dec))
 

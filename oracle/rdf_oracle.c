@@ -473,6 +473,7 @@ typedef struct {
 
 static const i128 DEC_POW = (i128)1000000000000000000LL; /* decimal.rs:9-11 */
 
+static int is_timestamp(uint8_t tag) { return tag == RDFGPU_TV_DATE_TIME || tag == RDFGPU_TV_TIME || tag == RDFGPU_TV_DATE; }
 static val tv_null(void) { val v; memset(&v, 0, sizeof v); v.kind = 1; v.tag = RDFGPU_TV_NULL; return v; }
 static val tv_bool(int b) { val v = tv_null(); v.tag = RDFGPU_TV_BOOLEAN; v.lo = b ? 1 : 0; return v; }
 
@@ -488,7 +489,7 @@ static val enc_tv(const orc_store* s, u32 id) {
   }
   const rdfgpu_typed_value* t = &s->tv[slot];
   v.tag = t->tag; v.flags = t->flags; v.aux = t->aux; v.lo = t->lo; v.id = id;
-  if (t->tag == RDFGPU_TV_DECIMAL) { if ((u64)t->lo >= s->n_dec) return tv_null(); v.dec = s->dec[t->lo]; }
+  if (t->tag == RDFGPU_TV_DECIMAL || is_timestamp(t->tag)) { if ((u64)t->lo >= s->n_dec) return tv_null(); v.dec = s->dec[t->lo]; }
   return v;
 }
 
@@ -570,7 +571,20 @@ static int tv_partial_cmp(const val* a, const val* b) {
     if (b->tag == RDFGPU_TV_OTHER && a->aux == b->aux && a->lo == b->lo) return 0;
     return ORD_NONE;
   }
-  /* dateTime / time / date / duration: opaque in this build => incomparable (documented gap) */
+  if (is_timestamp(a->tag)) { /* PartialOrd for Timestamp, lib/model/src/xsd/date_time.rs:1617-1654 */
+    if (b->tag != a->tag) return ORD_NONE;                       /* typed_value.rs:222-242: same kind only */
+    int ta = a->aux & 1, tb = b->aux & 1;                         /* timezone_offset.is_some() */
+    if (ta == tb) return a->dec < b->dec ? -1 : a->dec > b->dec;
+    const i128 shift = (i128)(14 * 3600) * DEC_POW;
+    i128 other = ta ? b->dec : a->dec, plus_v, minus_v;
+    if (__builtin_add_overflow(other, shift, &plus_v)) return ORD_NONE;   /* checked_add(..).ok()? */
+    if (__builtin_sub_overflow(other, shift, &minus_v)) return ORD_NONE;
+    int plus, minus;
+    if (ta) { plus = a->dec < plus_v ? -1 : a->dec > plus_v; minus = a->dec < minus_v ? -1 : a->dec > minus_v; }
+    else { plus = plus_v < b->dec ? -1 : plus_v > b->dec; minus = minus_v < b->dec ? -1 : minus_v > b->dec; }
+    return plus == minus ? plus : ORD_NONE;
+  }
+  /* durations: opaque in this build => incomparable (documented gap; duration.rs:271-310 is calendar arithmetic) */
   return ORD_NONE;
 }
 
@@ -619,7 +633,7 @@ static int eval_prog(const orc_store* s, const rdfgpu_expr_node* p, u32 n, const
       case RDFGPU_EX_COLUMN: if (e->u >= row->nl + row->nr) FAIL("column %u out of range", e->u); v.kind = 0; v.id = row_col(row, e->u); break;
       case RDFGPU_EX_LIT_ID: v.kind = 0; v.id = e->u; break;
       case RDFGPU_EX_LIT_TV: v = tv_null(); v.tag = e->tag; v.flags = e->flags; v.aux = e->u; v.lo = e->lo;
-        if (e->tag == RDFGPU_TV_DECIMAL) { v.dec = ((i128)e->hi << 64) | (i128)(u64)e->lo; }
+        if (e->tag == RDFGPU_TV_DECIMAL || is_timestamp(e->tag)) { v.dec = ((i128)e->hi << 64) | (i128)(u64)e->lo; }
         break;
       case RDFGPU_EX_LIT_BOOL: v.kind = 2; v.b = (uint8_t)(e->u > 2 ? 2 : e->u); break;
       case RDFGPU_EX_ENC_TV: if (sp < 1 || st[sp - 1].kind != 0) FAIL("ENC_TV needs an id"); v = enc_tv(s, st[--sp].id); break;

@@ -19,7 +19,7 @@ print(bench.scan_roofline(rf, 0, int(os.environ.get("SCAN_LOG2", "26")), reps=5)
 ds = bsbm.generate(int(os.environ.get("P", "285000")))
 st = rf.GpuQuadStore()
 st.extend(ds.g, ds.s, ds.p, ds.o)
-st.set_typed_values(ds.typed_values)
+st.set_typed_values(ds.typed_values, ds.decimals)
 rng = np.random.default_rng(1)
 rows = 0
 for i in rng.choice(ds.n_products, 32, replace=False):

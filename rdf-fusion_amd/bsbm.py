@@ -17,9 +17,9 @@ from dataclasses import dataclass, field
 
 import numpy as np
 
-from . import abi
+from . import abi, xsd
 from .engine import TV_DTYPE
-from .plan import (PlanBuilder, quad_pattern, col, lit_id, integer, ENC_TV, GT, LT, ADD, SUB, EBV, AND,
+from .plan import (PlanBuilder, quad_pattern, col, lit_id, integer, date_time, ENC_TV, GT, LT, LEQ, ADD, SUB, EBV, AND,
                    ID_NEQ)
 
 PREDICATES = ["rdf:type", "rdfs:label", "rdfs:comment", "bsbm:producer", "bsbm:productFeature",
@@ -29,7 +29,8 @@ PREDICATES = ["rdf:type", "rdfs:label", "rdfs:comment", "bsbm:producer", "bsbm:p
               "bsbm:productPropertyTextual4", "bsbm:productPropertyTextual5", "dc:publisher", "dc:date",
               "bsbm:product", "bsbm:vendor", "bsbm:price", "bsbm:validFrom", "bsbm:validTo",
               "bsbm:deliveryDays", "bsbm:offerWebpage", "bsbm:reviewFor", "rev:reviewer", "dc:title",
-              "rev:text", "bsbm:rating1", "bsbm:rating2", "bsbm:rating3", "bsbm:rating4", "bsbm:reviewDate"]
+              "rev:text", "bsbm:rating1", "bsbm:rating2", "bsbm:rating3", "bsbm:rating4", "bsbm:reviewDate",
+              "bsbm:country"]
 
 
 @dataclass
@@ -49,6 +50,9 @@ class BsbmDataset:
     int_base: int                     # integer literal v (1..2000) has id int_base + v - 1
     n_ids: int
     class_ids: dict = field(default_factory=dict)
+    decimals: np.ndarray = None       # (n, 2) int64: the i128 side table of the typed values (timestamps of the date literals)
+    country_base: int = 0             # vendor countries are ids country_base .. country_base + n_countries - 1
+    n_countries: int = 0
 
     @property
     def n_triples(self):
@@ -94,7 +98,10 @@ def generate(n_products, seed=None, offers_per_product=20, reviews_per_product=1
     n_prices = 100_000
     price_base = take(n_prices)           # xsd:double price literals
     n_dates = 4000
-    date_base = take(n_dates)             # xsd:date literals (opaque on device)
+    date_base = take(n_dates)             # xsd:date literals: 2000-01-01 + i days (dc:date)
+    datetime_base = take(n_dates)         # xsd:dateTime literals (validFrom / validTo / reviewDate), every 7th with a timezone
+    n_countries = 10
+    country_base = take(n_countries)
     n_ids = next_id[0]
 
     S, Pc, O = [], [], []
@@ -136,8 +143,8 @@ def generate(n_products, seed=None, offers_per_product=20, reviews_per_product=1
     ov = vendor_base + rng.integers(0, n_vendors, n_offers)
     emit(off, pred["bsbm:vendor"], ov)
     emit(off, pred["bsbm:price"], price_base + rng.integers(0, n_prices, n_offers))
-    emit(off, pred["bsbm:validFrom"], date_base + rng.integers(0, n_dates, n_offers))
-    emit(off, pred["bsbm:validTo"], date_base + rng.integers(0, n_dates, n_offers))
+    emit(off, pred["bsbm:validFrom"], datetime_base + rng.integers(0, n_dates, n_offers))
+    emit(off, pred["bsbm:validTo"], datetime_base + rng.integers(0, n_dates, n_offers))
     emit(off, pred["bsbm:deliveryDays"], int_base + rng.integers(1, 22, n_offers) - 1)
     emit(off, pred["bsbm:offerWebpage"], word_base + rng.integers(0, n_words, n_offers))
     emit(off, pred["dc:publisher"], ov)
@@ -153,9 +160,13 @@ def generate(n_products, seed=None, offers_per_product=20, reviews_per_product=1
     for k in (1, 2, 3, 4):
         keep = rng.random(n_reviews) < 0.7
         emit(rev[keep], pred[f"bsbm:rating{k}"], int_base + rng.integers(1, 11, keep.sum()) - 1)
-    emit(rev, pred["bsbm:reviewDate"], date_base + rng.integers(0, n_dates, n_reviews))
+    emit(rev, pred["bsbm:reviewDate"], datetime_base + rng.integers(0, n_dates, n_reviews))
     emit(rev, pred["dc:publisher"], rr)
     emit(rev, pred["dc:date"], date_base + rng.integers(0, n_dates, n_reviews))
+
+    # --- vendors (their own generator: the draws above stay what they were) -----------------------
+    rng_v = np.random.default_rng([P, 1])
+    emit(np.arange(vendor_base, vendor_base + n_vendors), pred["bsbm:country"], country_base + rng_v.integers(0, n_countries, n_vendors))
 
     s = np.concatenate(S)
     p = np.concatenate(Pc)
@@ -178,11 +189,24 @@ def generate(n_products, seed=None, offers_per_product=20, reviews_per_product=1
     pr = slice(price_base, price_base + n_prices)
     tv["tag"][pr] = abi.TV_DOUBLE
     tv["lo"][pr] = (rng.random(n_prices) * 10_000.0).view(np.int64)
-    tv["tag"][date_base:date_base + n_dates] = abi.TV_DATE
-    tv["lo"][date_base:date_base + n_dates] = 0
+    # dates: Timestamp = timeOnTimeline seconds * 10^18 in the i128 side table + "has a timezone" (include/rdfgpu.h)
+    day0 = xsd.time_on_timeline(2000, 1, 1)
+    stamps = []
+    for i in range(n_dates):                                     # "2000-01-01" + i days, no timezone
+        stamps.append((int(day0 + 86400 * i) * xsd.SCALE, 0))
+    for i in range(n_dates):                                     # T06:00:00 local; every 7th one is ...T06:00:00+02:00
+        tz = i % 7 == 3
+        stamps.append((int(day0 + 86400 * i + 6 * 3600 - (7200 if tz else 0)) * xsd.SCALE, int(tz)))
+    dec = np.zeros((len(stamps), 2), dtype=np.int64)
+    for i, (v, _) in enumerate(stamps):
+        dec[i] = np.array([v & ((1 << 64) - 1), v >> 64], dtype=np.uint64).astype(np.int64)
+    for base, tag, first in ((date_base, abi.TV_DATE, 0), (datetime_base, abi.TV_DATE_TIME, n_dates)):
+        tv["tag"][base:base + n_dates] = tag
+        tv["lo"][base:base + n_dates] = first + np.arange(n_dates)
+        tv["aux"][base:base + n_dates] = [z for _, z in stamps[first:first + n_dates]]
 
     return BsbmDataset(P, g, s, p, o, tv, pred, product_base, feature_base, n_features, type_base, n_types,
-                       int_base, n_ids, cls)
+                       int_base, n_ids, cls, dec, country_base, n_countries)
 
 
 # --------------------------------------------------------------------------------------------------
@@ -311,3 +335,23 @@ def q1_instance(ds, rng):
     feats = np.unique(ds.o[sel & (ds.p == ds.pred["bsbm:productFeature"])])
     f = rng.choice(feats, size=2, replace=False) if len(feats) >= 2 else np.array([feats[0], feats[0]])
     return int(types.min()), int(f[0]), int(f[1]), int(rng.integers(1, 501))
+
+
+def q10_plan(ds, product_id, country_id, max_days=3, after="2008-06-20T00:00:00"):
+    """BSBM Explore Q10 below its DISTINCT / ORDER BY: six chained hash joins on ?offer / ?vendor with the FilterExecs
+    `EBV(LEQ(ENC_TV(deliveryDays), 9:3))` and `EBV(GT(ENC_TV(date), 10:{value:6334951680000.0000000000000000,offset:}))`
+    (BSBM Explore - Q10 (Execution Plan).snap:12-27; the dateTime literal is timeOnTimeline("2008-06-20T00:00:00") =
+    63349516800 s, no timezone).  Output: (offer, price)."""
+    pr = ds.pred
+    pb = PlanBuilder()
+    node = pb.hash_join(pb.data_source(quad_pattern("offer", pr["bsbm:product"], int(product_id))),
+                        pb.data_source(quad_pattern("offer", pr["bsbm:vendor"], "vendor")), on=[(0, 0)], projection=[0, 2])
+    node = pb.hash_join(node, pb.data_source(quad_pattern("offer", pr["dc:publisher"], "vendor")), on=[(0, 0), (1, 1)], projection=[0, 1])
+    node = pb.hash_join(node, pb.data_source(quad_pattern("vendor", pr["bsbm:country"], int(country_id))), on=[(1, 0)], projection=[0])
+    days = pb.filter(pb.data_source(quad_pattern("offer", pr["bsbm:deliveryDays"], "deliveryDays")),
+                     EBV(LEQ(ENC_TV(col(1)), integer(max_days))), projection=[0])
+    node = pb.hash_join(node, days, on=[(0, 0)], projection=[0])
+    node = pb.hash_join(node, pb.data_source(quad_pattern("offer", pr["bsbm:price"], "price")), on=[(0, 0)], projection=[0, 2])
+    valid = pb.filter(pb.data_source(quad_pattern("offer", pr["bsbm:validTo"], "date")),
+                      EBV(GT(ENC_TV(col(1)), date_time(*xsd.parse_date_time(after)))), projection=[0])
+    return pb.build(pb.hash_join(node, valid, on=[(0, 0)], projection=[0, 1]))

@@ -59,6 +59,10 @@ __device__ __forceinline__ Val val_id(uint32_t id) { Val v = val_tv_null(); v.ki
 __device__ __forceinline__ i128_t val_dec(const Val& v) { return (i128_t)(((u128_t)(uint64_t)v.hi << 64) | (u128_t)(uint64_t)v.lo); }
 __device__ __forceinline__ void set_dec(Val& v, i128_t d) { v.lo = (int64_t)(uint64_t)(u128_t)d; v.hi = (int64_t)(uint64_t)((u128_t)d >> 64); }
 
+// dateTime / time / date: a Timestamp = timeOnTimeline seconds * 10^18 (i128 side table) + "has a timezone" (aux bit 0),
+// lib/model/src/xsd/date_time.rs:1599-1603
+__device__ __forceinline__ bool tv_is_timestamp(uint8_t tag) { return tag == RDFGPU_TV_DATE_TIME || tag == RDFGPU_TV_TIME || tag == RDFGPU_TV_DATE; }
+
 // ENC_TV: one 16-byte gather (global_load_dwordx4) per row.
 __device__ __forceinline__ Val enc_tv(const TypedTable& t, uint32_t id) {
   Val v = val_tv_null();
@@ -69,7 +73,7 @@ __device__ __forceinline__ Val enc_tv(const TypedTable& t, uint32_t id) {
   v.tag = (uint8_t)((uint32_t)raw.w & 0xff);
   v.flags = (uint8_t)(((uint32_t)raw.w >> 8) & 0xff);
   if (v.tag == RDFGPU_TV_STRING) v.hi = id;   // string builtins find the lexical form through the id
-  if (v.tag == RDFGPU_TV_DECIMAL) {
+  if (v.tag == RDFGPU_TV_DECIMAL || tv_is_timestamp(v.tag)) {   // the i128 lives in the side table
     if ((uint64_t)v.lo >= t.n_dec) return val_tv_null();
     const int64_t* d = t.dec + 2 * v.lo;
     v.lo = d[0]; v.hi = d[1];
@@ -179,7 +183,21 @@ __device__ __forceinline__ int tv_partial_cmp(const Val& a, const Val& b) {
     }
   }
   if (a.tag == RDFGPU_TV_OTHER) return (b.tag == RDFGPU_TV_OTHER && a.aux == b.aux && a.lo == b.lo) ? 0 : ORD_NONE;
-  return ORD_NONE;  // dateTime / time / date / duration are opaque on device
+  if (tv_is_timestamp(a.tag)) {
+    // PartialOrd for Timestamp, date_time.rs:1617-1654: both or neither with a timezone => the values; otherwise the
+    // value without one may lie 14 h either way, and the order must hold for both (an overflowing shift => None)
+    if (b.tag != a.tag) return ORD_NONE;
+    const i128_t x = val_dec(a), y = val_dec(b);
+    const bool ta = a.aux & 1u, tb = b.aux & 1u;
+    if (ta == tb) return x < y ? -1 : x > y;
+    const i128_t shift = (i128_t)50400 * (i128_t)1000000000000000000ll;   // Decimal 14 * 3600
+    i128_t hi, lo;
+    if (__builtin_add_overflow(ta ? y : x, shift, &hi) || __builtin_sub_overflow(ta ? y : x, shift, &lo)) return ORD_NONE;
+    const int plus = ta ? (x < hi ? -1 : x > hi) : (hi < y ? -1 : hi > y);
+    const int minus = ta ? (x < lo ? -1 : x > lo) : (lo < y ? -1 : lo > y);
+    return plus == minus ? plus : ORD_NONE;
+  }
+  return ORD_NONE;  // durations are opaque on device (their order is calendar arithmetic, duration.rs:271-310)
 }
 
 // ADD / SUB, add.rs:40-86

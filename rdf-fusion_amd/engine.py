@@ -239,7 +239,7 @@ class GpuQuadStore:
         """values: numpy structured array / bytes of rdfgpu_typed_value, index = object id."""
         values = np.ascontiguousarray(values)
         assert values.dtype.itemsize == 16, "rdfgpu_typed_value is 16 bytes"
-        dec = np.ascontiguousarray(decimals if decimals is not None else np.zeros((0, 2), np.int64), dtype=np.int64)
+        dec = np.ascontiguousarray(decimals if decimals is not None else np.zeros((0, 2), np.int64), dtype=np.int64).reshape(-1, 2)   # (lo, hi) per i128
         _check(self._lib.rdfgpu_store_set_typed_values(
             self._h, values.ctypes.data_as(C.c_void_p), len(values), dec.ctypes.data_as(C.c_void_p), len(dec)))
 

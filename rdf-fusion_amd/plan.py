@@ -154,6 +154,26 @@ def decimal(scaled_i128):
     return lit_tv(abi.TV_DECIMAL, to_i64(lo), hi=to_i64(hi))
 
 
+def _timestamp(tag, scaled_i128, has_timezone):
+    v = int(scaled_i128) & ((1 << 128) - 1)
+    lo, hi = v & ((1 << 64) - 1), v >> 64
+    to_i64 = lambda x: x - (1 << 64) if x >= (1 << 63) else x
+    return lit_tv(tag, to_i64(lo), aux=1 if has_timezone else 0, hi=to_i64(hi))
+
+
+def date_time(scaled_i128, has_timezone):
+    """xsd:dateTime literal: Timestamp value * 10**18 (rdf_fusion_amd.xsd.parse_date_time) + timezone presence."""
+    return _timestamp(abi.TV_DATE_TIME, scaled_i128, has_timezone)
+
+
+def date(scaled_i128, has_timezone):
+    return _timestamp(abi.TV_DATE, scaled_i128, has_timezone)
+
+
+def time(scaled_i128, has_timezone):
+    return _timestamp(abi.TV_TIME, scaled_i128, has_timezone)
+
+
 def ENC_TV(e): return e._un(abi.EX_ENC_TV)
 def GT(a, b): return a._bin(b, abi.EX_GT)
 def LT(a, b): return a._bin(b, abi.EX_LT)

@@ -6,7 +6,7 @@ import rdf_fusion_amd as rf
 from rdf_fusion_amd import bsbm
 from rdf_fusion_amd.plan import PlanBuilder, quad_pattern
 ds = bsbm.generate(int(os.environ.get("P", "285000")))
-st = rf.GpuQuadStore(); st.extend(ds.g, ds.s, ds.p, ds.o); st.set_typed_values(ds.typed_values)
+st = rf.GpuQuadStore(); st.extend(ds.g, ds.s, ds.p, ds.o); st.set_typed_values(ds.typed_values, ds.decimals)
 n = int(os.environ.get("N", str(8 << 20)))
 rng = np.random.default_rng(1)
 cols = np.stack([rng.integers(1, 4097, n), ds.product_base + rng.integers(0, ds.n_products, n),

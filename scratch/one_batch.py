@@ -4,7 +4,7 @@ import numpy as np, torch
 import rdf_fusion_amd as rf
 from rdf_fusion_amd import bsbm
 ds = bsbm.generate(int(os.environ.get("P", "285000")))
-st = rf.GpuQuadStore(); st.extend(ds.g, ds.s, ds.p, ds.o); st.set_typed_values(ds.typed_values)
+st = rf.GpuQuadStore(); st.extend(ds.g, ds.s, ds.p, ds.o); st.set_typed_values(ds.typed_values, ds.decimals)
 B = int(os.environ.get("B", "256"))
 rng = np.random.default_rng(5)
 plan = st.plan(bsbm.q5_batch_plan(ds, topk=bool(int(os.environ.get("TOPK", "0"))))).enable_kernel_timing(True)

@@ -4,7 +4,7 @@ import numpy as np, torch
 import rdf_fusion_amd as rf
 from rdf_fusion_amd import bsbm
 ds = bsbm.generate(int(os.environ.get("P", "285000")))
-st = rf.GpuQuadStore(); st.extend(ds.g, ds.s, ds.p, ds.o); st.set_typed_values(ds.typed_values)
+st = rf.GpuQuadStore(); st.extend(ds.g, ds.s, ds.p, ds.o); st.set_typed_values(ds.typed_values, ds.decimals)
 for i in (5, 77, 1234, 99999 % ds.n_products):
     plan = st.plan(bsbm.q5_plan(ds, ds.product(i))).enable_kernel_timing(True)
     t=time.perf_counter(); plan.execute(); dt=time.perf_counter()-t

@@ -29,7 +29,7 @@ others = [[None] * W for _ in batches]
 mine_store = None
 for r in range(W):
     g, s, p, o = sharding.shard_dataset(ds, r, W)
-    st = rf.GpuQuadStore(); st.extend(g, s, p, o); st.set_typed_values(ds.typed_values)
+    st = rf.GpuQuadStore(); st.extend(g, s, p, o); st.set_typed_values(ds.typed_values, ds.decimals)
     plans = st.plan(bsbm.q5_batch_const_plan(ds))
     if r == 0:
         mine_store, mine_plans = st, plans

@@ -376,7 +376,7 @@ def test_cross_and_nested_loop_join(torch_cuda):
 @pytest.fixture(scope="module")
 def bsbm_stores():
     ds = bsbm.generate(2000)
-    gs, os_ = both_stores((ds.g, ds.s, ds.p, ds.o), typed=ds.typed_values)
+    gs, os_ = both_stores((ds.g, ds.s, ds.p, ds.o), typed=ds.typed_values, decimals=ds.decimals)
     return ds, gs, os_
 
 
@@ -799,12 +799,12 @@ def test_bsbm_10m_scale_configs(torch_cuda):
     ds = bsbm.generate(28_500)                                   # ~10 M triples
     gs = rf.GpuQuadStore()
     gs.extend(ds.g, ds.s, ds.p, ds.o)
-    gs.set_typed_values(ds.typed_values)
+    gs.set_typed_values(ds.typed_values, ds.decimals)
     assert len(gs) > 9_000_000
     os_ = orc.OracleStore()
     for comp in (abi.GSPO, abi.GPOS, abi.GOSP):
         os_.adopt_sorted(comp, gs.read_index(comp))
-    os_.set_typed_values(ds.typed_values)
+    os_.set_typed_values(ds.typed_values, ds.decimals)
     num1 = ds.p == ds.pred["bsbm:productPropertyNumeric1"]
     values = ds.o[num1].astype(np.int64) - ds.int_base + 1
     for thr in (1, 400, 1000, 1999):
@@ -867,6 +867,64 @@ def test_fused_chain_with_mixed_numeric_kinds(torch_cuda):
         run_both(gs, os_, bsbm.q5_plan(ds, int(x)))
 
 
+def test_bsbm_q10_matches_oracle(bsbm_stores):
+    """BSBM Explore Q10 (Q10 (Execution Plan).snap:12-27): a two-key hash join, an integer FilterExec and a dateTime
+    FilterExec (some validTo values carry a timezone, the literal does not: the +-14 h rule decides)."""
+    ds, gs, os_ = bsbm_stores
+    total = 0
+    for i in range(30):
+        plan, got = run_both(gs, os_, bsbm.q10_plan(ds, ds.product(i * 7), ds.country_base + i % ds.n_countries, max_days=9, after="2004-03-01T06:00:00"))
+        total += plan.result_info()[0]
+    plan, got = run_both(gs, os_, bsbm.q10_plan(ds, ds.product(1), ds.country_base))      # the query's own constants
+    assert total > 10
+
+
+def test_timestamp_comparisons_match_oracle(torch_cuda):
+    """xsd:dateTime / date / time FILTERs (BSBM explore Q7 / Q8 / Q10 compare dates): the Timestamp order of
+    date_time.rs:1617-1654 incl. the +-14 h rule for a missing timezone, i128 edges, other kinds and nulls — per-row VM,
+    the `col cmp literal` kernel and a join filter, all against the oracle (itself pinned by the reference's own
+    equals / cmp known answers in tests/test_timestamp_cpu.py)."""
+    import test_timestamp_cpu as tc
+    from rdf_fusion_amd import xsd
+    from rdf_fusion_amd.plan import date_time, date, time as time_lit, GEQ, LEQ, EQ, NEQ
+    rng = np.random.default_rng(77)
+    values = tc.random_timestamps(rng, 600)
+    tv, dec = tc.timestamp_table(values)
+    tv = np.concatenate([tv, np.zeros(2, dtype=TV_DTYPE)])
+    tv["tag"][-2], tv["lo"][-2] = abi.TV_INTEGER, 5
+    tv["tag"][-1], tv["lo"][-1] = abi.TV_DECIMAL, 3            # a decimal shares the i128 side table
+    gs, os_ = rf.GpuQuadStore(), orc.OracleStore()
+    gs.set_typed_values(tv, dec)
+    os_.set_typed_values(tv, dec)
+    n = 50_000
+    a = rng.integers(0, len(tv) + 2, n).astype(np.uint32)      # incl. null (0) and ids beyond the table
+    b = rng.integers(0, len(tv), n).astype(np.uint32)
+    tag = np.arange(n, dtype=np.uint32)
+    keep, ptrs = table_on_device(torch_cuda, [a, b, tag])
+    total = 0
+    for op in (GT, LT, GEQ, LEQ, EQ, NEQ):
+        pb = PlanBuilder()
+        desc = pb.build(pb.filter(pb.table(0, 3), EBV(op(ENC_TV(col(0)), ENC_TV(col(1)))), projection=[2]))
+        plan, got = run_both(gs, os_, desc, gpu_tables=[(ptrs, n)], cpu_tables=[[a, b, tag]])
+        total += plan.result_info()[0]
+        for lit in (date_time(*xsd.parse_date_time("2008-06-20T00:00:00Z")), date_time(*xsd.parse_date_time("2008-06-20T03:00:00")),
+                    date(*xsd.parse_date("2004-12-25")), time_lit(*xsd.parse_time("12:00:00+01:00")), date_time((1 << 127) - 1, False)):
+            pb = PlanBuilder()
+            desc = pb.build(pb.filter(pb.table(0, 3), EBV(op(ENC_TV(col(0)), lit)), projection=[2, 0]))
+            plan, got = run_both(gs, os_, desc, gpu_tables=[(ptrs, n)], cpu_tables=[[a, b, tag]])
+            total += plan.result_info()[0]
+    assert total > 2 * n
+    # join filter: L(k, a) JOIN R(k, b) ON k WHERE a < b
+    k1, k2 = rng.integers(1, 300, 4000).astype(np.uint32), rng.integers(1, 300, 3000).astype(np.uint32)
+    L, R = [k1, a[:4000]], [k2, b[:3000]]
+    kl, pl = table_on_device(torch_cuda, L)
+    kr, pr = table_on_device(torch_cuda, R)
+    pb = PlanBuilder()
+    desc = pb.build(pb.hash_join(pb.table(0, 2), pb.table(1, 2), on=[(0, 0)], filter=EBV(LT(ENC_TV(col(1)), ENC_TV(col(3))))))
+    plan, got = run_both(gs, os_, desc, gpu_tables=[(pl, 4000), (pr, 3000)], cpu_tables=[L, R])
+    assert plan.result_info()[0] > 1000
+
+
 @pytest.mark.parametrize("world", [2, 8])
 def test_subject_hash_shard_keeps_the_index_join_path(torch_cuda, world):
     """A hash(subject) shard of a predicate slice keeps the slice's id range with 1/G of its rows: the engine must
@@ -876,7 +934,7 @@ def test_subject_hash_shard_keeps_the_index_join_path(torch_cuda, world):
     ds = bsbm.generate(12_000)        # 1500 products per shard at G = 8: slices above the LDS-table size
     full_o = orc.OracleStore()
     full_o.extend(ds.g, ds.s, ds.p, ds.o)
-    full_o.set_typed_values(ds.typed_values)
+    full_o.set_typed_values(ds.typed_values, ds.decimals)
     rng = np.random.default_rng(world)
     batch = 300
     prods = np.array([ds.product(i) for i in rng.choice(ds.n_products, batch, replace=False)], dtype=np.uint32)
@@ -889,7 +947,7 @@ def test_subject_hash_shard_keeps_the_index_join_path(torch_cuda, world):
     union = []
     for r in sorted({0, world - 1}) if world > 2 else range(world):
         g, s, p, o = sharding.shard_dataset(ds, r, world)
-        gs, os_ = both_stores((g, s, p, o), typed=ds.typed_values)
+        gs, os_ = both_stores((g, s, p, o), typed=ds.typed_values, decimals=ds.decimals)
         plan = gs.plan(desc)
         for it in range(3):
             plan.bind_table(0, ptrs, n_c)
@@ -927,7 +985,7 @@ def test_reexecution_is_speculative_but_exact(torch_cuda):
     """A re-executed plan reuses its located ranges and sizes join outputs from the previous run without
     waiting; when the guess is wrong (the batch grows 20x) or the store changes, results must still be exact."""
     ds = bsbm.generate(800)
-    gs, os_ = both_stores((ds.g, ds.s, ds.p, ds.o), typed=ds.typed_values)
+    gs, os_ = both_stores((ds.g, ds.s, ds.p, ds.o), typed=ds.typed_values, decimals=ds.decimals)
     desc = bsbm.q5_batch_plan(ds)
     plan = gs.plan(desc)
     rng = np.random.default_rng(9)

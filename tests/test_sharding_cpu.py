@@ -36,7 +36,7 @@ def _worker(rank, world, port, q):
         g, s, p, o = sharding.shard_dataset(ds, rank, world)
         st = orc.OracleStore()
         st.extend(g, s, p, o)
-        st.set_typed_values(ds.typed_values)
+        st.set_typed_values(ds.typed_values, ds.decimals)
         products = [ds.product(i) for i in PRODUCTS]
         rows = []
 
@@ -83,7 +83,7 @@ def test_sharded_q5_equals_unsharded(world):
     ds = bsbm.generate(600)
     st = orc.OracleStore()
     st.extend(ds.g, ds.s, ds.p, ds.o)
-    st.set_typed_values(ds.typed_values)
+    st.set_typed_values(ds.typed_values, ds.decimals)
     expected = []
     for i in PRODUCTS:
         cols, n, _ = st.execute(bsbm.q5_plan(ds, ds.product(i)))
@@ -134,7 +134,7 @@ def _batch_worker(rank, world, port, q):
         g, s, p, o = sharding.shard_dataset(ds, rank, world)
         st = orc.OracleStore()
         st.extend(g, s, p, o)
-        st.set_typed_values(ds.typed_values)
+        st.set_typed_values(ds.typed_values, ds.decimals)
         batch = _batch_products(ds)
         params = [np.arange(1, BATCH + 1, dtype=np.uint32), batch]
         ex = sharding.BatchExchange(BATCH, world)
@@ -170,7 +170,7 @@ def test_sharded_q5_batch_exchange_equals_unsharded(world):
     ds = bsbm.generate(600)
     st = orc.OracleStore()
     st.extend(ds.g, ds.s, ds.p, ds.o)
-    st.set_typed_values(ds.typed_values)
+    st.set_typed_values(ds.typed_values, ds.decimals)
     batch = _batch_products(ds)
     cols, n, _ = st.execute(bsbm.q5_batch_plan(ds), tables=[[np.arange(1, BATCH + 1, dtype=np.uint32), batch]])
     expected = ku.multiset(cols, n)
