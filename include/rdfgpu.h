@@ -253,6 +253,13 @@ enum {
                                  have no language or the value's, else the error value.                                  */
   RDFGPU_EX_STRSTARTS = 25,   /* same shape: STRSTARTS, scalar/strings/str_starts.rs                                     */
   RDFGPU_EX_STRENDS = 26,     /* same shape: STRENDS, scalar/strings/str_ends.rs                                         */
+  RDFGPU_EX_LANG_IN = 27,     /* TV -> TV(boolean|null)  LANGMATCHES(LANG(value), <constant range>) — scalar/terms/lang.rs:45-58,
+                                 scalar/strings/lang_matches.rs:52-69, as planned for BSBM explore Q8 (`EBV(LANGMATCHES(LANG(ENC_TV(text)),
+                                 3:{value:EN,language:}))`, Q8 (Execution Plan).snap:18).  The range is resolved by the host against its
+                                 (small) language dictionary: regexes[u].pattern holds ONE BYTE PER LANGUAGE ID (the `aux` numbering of
+                                 string values; byte 0 = the empty tag, i.e. every literal without a language), 1 = the tag matches
+                                 the range.  Named / blank nodes and null => error (lang.rs:50-52); a language id beyond the table
+                                 => error.  At most 16384 language ids.                                                       */
   RDFGPU_EX__COUNT
 };
 

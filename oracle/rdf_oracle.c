@@ -679,6 +679,17 @@ static int eval_prog(const orc_store* s, const rdfgpu_expr_node* p, u32 n, const
         }
         v = tv_bool(r);
         break; }
+      case RDFGPU_EX_LANG_IN: {   /* LANGMATCHES(LANG(v), range): lang.rs:45-58 then the host-resolved verdict of lang_matches.rs:52-69 */
+        if (sp < 1 || st[sp - 1].kind != 1) FAIL("LANGMATCHES(LANG()) needs a typed value");
+        if (e->u >= g_n_regexes) FAIL("language table %u out of range", e->u);
+        val a = st[--sp];
+        v = tv_null();
+        if (a.tag == RDFGPU_TV_NULL || a.tag == RDFGPU_TV_NAMED_NODE || a.tag == RDFGPU_TV_BLANK_NODE) break;   /* LANG of a non-literal: error */
+        u32 lang = a.tag == RDFGPU_TV_STRING ? a.aux : 0;   /* every other literal has the empty tag */
+        const rdfgpu_regex* rx = &g_regexes[e->u];
+        if (lang >= rx->pattern_len) break;
+        v = tv_bool(rx->pattern[lang] != 0);
+        break; }
       case RDFGPU_EX_EBV: if (sp < 1 || st[sp - 1].kind != 1) FAIL("EBV needs a typed value"); { val a = st[--sp]; v.kind = 2; v.b = tv_ebv(&a); } break;
       case RDFGPU_EX_ID_EQ: case RDFGPU_EX_ID_NEQ: {
         if (sp < 2 || st[sp - 1].kind != 0 || st[sp - 2].kind != 0) FAIL("id comparison needs two ids");

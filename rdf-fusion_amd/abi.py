@@ -27,7 +27,7 @@ TVF_EMPTY_STRING = 1
 # expression ops
 (EX_COLUMN, EX_LIT_ID, EX_LIT_TV, EX_ENC_TV, EX_GT, EX_LT, EX_GEQ, EX_LEQ, EX_EQ, EX_ADD, EX_SUB,
  EX_EBV, EX_ID_EQ, EX_ID_NEQ, EX_AND, EX_OR, EX_NOT, EX_IS_COMPATIBLE, EX_BOUND, EX_BOOL_AS_TV,
- EX_LIT_BOOL, EX_NEQ, EX_REGEX, EX_CONTAINS, EX_STRSTARTS, EX_STRENDS) = range(1, 27)
+ EX_LIT_BOOL, EX_NEQ, EX_REGEX, EX_CONTAINS, EX_STRSTARTS, EX_STRENDS, EX_LANG_IN) = range(1, 28)
 
 # plan nodes
 (NODE_DATA_SOURCE, NODE_FILTER, NODE_HASH_JOIN, NODE_CROSS_JOIN, NODE_NESTED_LOOP_JOIN,

@@ -296,6 +296,14 @@ __device__ __forceinline__ Val eval_program(const ExprProgram& prog, const Typed
       case RDFGPU_EX_EBV: v = val_bool(tv_ebv(st[--sp])); break;
       case RDFGPU_EX_REGEX: v = tv_regex(prog.regex[e.u], tt, st[--sp]); break;
       case RDFGPU_EX_CONTAINS: case RDFGPU_EX_STRSTARTS: case RDFGPU_EX_STRENDS: v = tv_regex(prog.regex[e.u], tt, st[--sp], e.lo < 0 ? 0 : e.lo); break;
+      case RDFGPU_EX_LANG_IN: {   // LANGMATCHES(LANG(v), range): one verdict bit per language id (bit 0 = no language)
+        const Val a = st[--sp];
+        const RegexProg& p = prog.regex[e.u];
+        v = val_tv_null();
+        if (a.tag == RDFGPU_TV_NULL || a.tag == RDFGPU_TV_NAMED_NODE || a.tag == RDFGPU_TV_BLANK_NODE) break;
+        const uint32_t lang = a.tag == RDFGPU_TV_STRING ? a.aux : 0u;
+        if (lang < p.n_pos) v = val_tv_bool((p.byte_mask[lang >> 6] >> (lang & 63u)) & 1ull);
+        break; }
       case RDFGPU_EX_ID_EQ: case RDFGPU_EX_ID_NEQ: {
         const uint32_t b = (uint32_t)st[--sp].lo, a = (uint32_t)st[--sp].lo;
         v = val_bool((a == 0 || b == 0) ? 2u : (uint32_t)((a == b) == (e.op == RDFGPU_EX_ID_EQ))); break; }

@@ -53,6 +53,9 @@ u32 check_program(const rdfgpu_expr_node* p, u32 n, u32 n_cols, u32 n_regexes = 
         // the lexical form lives in HBM under the value's object id: the operand has to be ENC_TV(column)
         if (i < 2 || p[i - 1].op != RDFGPU_EX_ENC_TV || p[i - 2].op != RDFGPU_EX_COLUMN) fail(RDFGPU_ERR_UNSUPPORTED, "REGEX / CONTAINS / STRSTARTS / STRENDS over anything but ENC_TV(column)");
         pop(VK_TV, "REGEX"); out = VK_TV; break;
+      case RDFGPU_EX_LANG_IN:
+        if (e.u >= n_regexes) fail(RDFGPU_ERR_INVALID, "expression: language table %u out of range (%u tables)", e.u, n_regexes);
+        pop(VK_TV, "LANGMATCHES(LANG())"); out = VK_TV; break;
       case RDFGPU_EX_ID_EQ: case RDFGPU_EX_ID_NEQ: case RDFGPU_EX_IS_COMPATIBLE: pop(VK_ID, "id comparison"); pop(VK_ID, "id comparison"); out = VK_BOOL; break;
       case RDFGPU_EX_AND: case RDFGPU_EX_OR: pop(VK_BOOL, "AND/OR"); pop(VK_BOOL, "AND/OR"); out = VK_BOOL; break;
       case RDFGPU_EX_NOT: pop(VK_BOOL, "NOT"); out = VK_BOOL; break;
@@ -140,13 +143,12 @@ Plan* plan_compile(Store* store, const rdfgpu_plan_desc* d) {
   std::vector<u32> scan_ids;  // sorted IN sets of all sources, uploaded once
   if (d->n_regexes) {   // REGEX patterns are plan constants: compiled here, simulated per row on the device
     if (!d->regexes) fail(RDFGPU_ERR_INVALID, "plan_compile: %u regexes but no table", d->n_regexes);
-    if (!store->str_off) fail(RDFGPU_ERR_INVALID, "plan uses REGEX but the store has no strings (rdfgpu_store_set_strings)");
     // how each table entry is used decides how it is compiled: REGEX = a pattern with flags; CONTAINS / STRSTARTS /
     // STRENDS = a literal needle (like the `q` flag), anchored at the start / end for the latter two
     std::vector<int> use(d->n_regexes, -1);
     for (u32 i = 0; i < d->n_exprs; i++) {
       const rdfgpu_expr_node& e = d->exprs[i];
-      if (e.op != RDFGPU_EX_REGEX && e.op != RDFGPU_EX_CONTAINS && e.op != RDFGPU_EX_STRSTARTS && e.op != RDFGPU_EX_STRENDS) continue;
+      if (e.op != RDFGPU_EX_REGEX && e.op != RDFGPU_EX_CONTAINS && e.op != RDFGPU_EX_STRSTARTS && e.op != RDFGPU_EX_STRENDS && e.op != RDFGPU_EX_LANG_IN) continue;
       if (e.u >= d->n_regexes) fail(RDFGPU_ERR_INVALID, "expression: string pattern %u out of range", e.u);
       if (use[e.u] >= 0 && use[e.u] != (int)e.op) fail(RDFGPU_ERR_INVALID, "string pattern %u is used by two different functions", e.u);
       use[e.u] = (int)e.op;
@@ -154,6 +156,14 @@ Plan* plan_compile(Store* store, const rdfgpu_plan_desc* d) {
     std::vector<RegexProg> progs(d->n_regexes);
     for (u32 r = 0; r < d->n_regexes; r++) {
       const rdfgpu_regex& rx = d->regexes[r];
+      if (use[r] == RDFGPU_EX_LANG_IN) {   // not a pattern: one verdict byte per language id -> a bit set in the slot
+        std::memset(&progs[r], 0, sizeof(RegexProg));
+        if (rx.pattern_len > 256u * 64u) fail(RDFGPU_ERR_UNSUPPORTED, "language table %u: %u language ids (max 16384)", r, rx.pattern_len);
+        for (u32 l = 0; l < rx.pattern_len; l++) if (rx.pattern[l]) progs[r].byte_mask[l >> 6] |= 1ull << (l & 63u);
+        progs[r].n_pos = rx.pattern_len;
+        continue;
+      }
+      if (use[r] >= 0 && !store->str_off) fail(RDFGPU_ERR_INVALID, "plan uses REGEX but the store has no strings (rdfgpu_store_set_strings)");
       std::string why;
       const bool literal = use[r] == RDFGPU_EX_CONTAINS || use[r] == RDFGPU_EX_STRSTARTS || use[r] == RDFGPU_EX_STRENDS;
       const char* flags = literal ? "q" : (rx.flags ? rx.flags : "");

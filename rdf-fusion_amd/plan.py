@@ -202,6 +202,30 @@ def _string_fn(op):
 
 
 CONTAINS, STRSTARTS, STRENDS = _string_fn(abi.EX_CONTAINS), _string_fn(abi.EX_STRSTARTS), _string_fn(abi.EX_STRENDS)
+
+
+def lang_matches(language_tag, language_range):
+    """LANGMATCHES on two plain strings, as scalar/strings/lang_matches.rs:52-69 evaluates it: "*" matches every
+    non-empty tag; otherwise the subtags ('-' separated) are zipped with the longer side padded: a range subtag that is
+    missing from, or differs (ASCII case-insensitively) from, the tag's subtag at that position is a mismatch."""
+    if language_range == "*":
+        return language_tag != ""
+    r, l = language_range.split("-"), language_tag.split("-")
+    ascii_lower = lambda x: "".join(chr(ord(c) + 32) if "A" <= c <= "Z" else c for c in x)
+    for i in range(max(len(r), len(l))):
+        if i < len(r) and (i >= len(l) or ascii_lower(r[i]) != ascii_lower(l[i])):
+            return False
+    return True
+
+
+def LANGMATCHES_LANG(e, language_range, language_tags):
+    """LANGMATCHES(LANG(value), "range") — BSBM explore Q8's FILTER.  `language_tags[i]` = the tag of language id i in the
+    typed-value table's `aux` numbering (language_tags[0] must be "": literals without a language).  The host resolves
+    the range against that (small) dictionary; the device reads one verdict byte per language id."""
+    if not language_tags or language_tags[0] != "":
+        raise ValueError("language_tags[0] is the empty tag")
+    verdicts = bytes(1 if lang_matches(t, language_range) else 0 for t in language_tags)
+    return Expr(e.nodes + [(abi.EX_LANG_IN, 0, 0, (verdicts, b"", abi.EX_LANG_IN), 0, 0)])
 def ID_EQ(a, b): return a._bin(b, abi.EX_ID_EQ)
 def ID_NEQ(a, b): return a._bin(b, abi.EX_ID_NEQ)
 def AND(a, b): return a._bin(b, abi.EX_AND)
@@ -269,7 +293,7 @@ class PlanBuilder:
             return
         node.expr_off, node.expr_len = len(self.exprs), len(e.nodes)
         for (op, tag, flags, u, lo, hi) in e.nodes:
-            if op in (abi.EX_REGEX, abi.EX_CONTAINS, abi.EX_STRSTARTS, abi.EX_STRENDS):
+            if op in (abi.EX_REGEX, abi.EX_CONTAINS, abi.EX_STRSTARTS, abi.EX_STRENDS, abi.EX_LANG_IN):
                 # u carries (pattern, flags, op): register the plan constant (one entry per function), keep its index
                 if u not in self._regex_keys:
                     self._regex_keys.append(u)

@@ -867,6 +867,38 @@ def test_fused_chain_with_mixed_numeric_kinds(torch_cuda):
         run_both(gs, os_, bsbm.q5_plan(ds, int(x)))
 
 
+def test_lang_matches_filter_matches_oracle(torch_cuda):
+    """BSBM explore Q8's FILTER `EBV(LANGMATCHES(LANG(ENC_TV(text)), "EN"))` (Q8 (Execution Plan).snap:18): language-tagged
+    and plain literals, IRIs / blank nodes / unbound (errors), a language id outside the host's table; as a FilterExec,
+    negated, and as a join filter."""
+    import test_lang_cpu as tl
+    from rdf_fusion_amd.plan import LANGMATCHES_LANG, NOT
+    tv = tl.lang_table()
+    gs, os_ = rf.GpuQuadStore(), orc.OracleStore()
+    gs.set_typed_values(tv)
+    os_.set_typed_values(tv)
+    rng = np.random.default_rng(3)
+    n = 30_000
+    ids = rng.integers(0, 15, n).astype(np.uint32)
+    row = np.arange(n, dtype=np.uint32)
+    keep, ptrs = table_on_device(torch_cuda, [ids, row])
+    for lang_range in ("EN", "*", "de", "zh-hant", ""):
+        e = EBV(LANGMATCHES_LANG(ENC_TV(col(0)), lang_range, tl.LANGUAGES))
+        for expr in (e, NOT(e)):
+            pb = PlanBuilder()
+            plan, got = run_both(gs, os_, pb.build(pb.filter(pb.table(0, 2), expr, projection=[1])), gpu_tables=[(ptrs, n)], cpu_tables=[[ids, row]])
+            assert sorted(got[0].tolist()) == tl.expected_rows(ids.tolist(), lang_range, expr is not e)
+    k = rng.integers(1, 200, 3000).astype(np.uint32)
+    R = [k, ids[:3000]]
+    L = [rng.integers(1, 200, 2000).astype(np.uint32), row[:2000]]
+    kl, pl = table_on_device(torch_cuda, L)
+    kr, pr = table_on_device(torch_cuda, R)
+    pb = PlanBuilder()
+    desc = pb.build(pb.hash_join(pb.table(0, 2), pb.table(1, 2), on=[(0, 0)], filter=EBV(LANGMATCHES_LANG(ENC_TV(col(3)), "en", tl.LANGUAGES))))
+    plan, got = run_both(gs, os_, desc, gpu_tables=[(pl, 2000), (pr, 3000)], cpu_tables=[L, R])
+    assert plan.result_info()[0] > 1000
+
+
 def test_bsbm_q10_matches_oracle(bsbm_stores):
     """BSBM Explore Q10 (Q10 (Execution Plan).snap:12-27): a two-key hash join, an integer FilterExec and a dateTime
     FilterExec (some validTo values carry a timezone, the literal does not: the +-14 h rule decides)."""
