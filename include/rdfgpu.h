@@ -283,7 +283,7 @@ enum {
   RDFGPU_NODE_NESTED_LOOP_JOIN = 5, /* NestedLoopJoinExec: inner | left with a filter and no equi keys     */
   RDFGPU_NODE_PROJECTION = 6,  /* ProjectionExec of plain columns                                          */
   RDFGPU_NODE_TABLE = 7,       /* bindings supplied by the caller (device columns), e.g. all-gathered rows */
-  RDFGPU_NODE_TOPK = 8         /* The operators directly above the path in the reference's explore plans (SURVEY §8f-3,
+  RDFGPU_NODE_TOPK = 8,        /* The operators directly above the path in the reference's explore plans (SURVEY §8f-3,
                                   ..Q5 (Execution Plan).snap:5-9): AggregateExec(gby = sort keys, first_value) = DISTINCT,
                                   then SortExec TopK(fetch = k), optionally per group (a batch of queries in one tree).
                                   left = input; n_keys sort keys (<= 2), all ascending, NULLS FIRST: left_keys[i] = column,
@@ -292,6 +292,9 @@ enum {
                                   strings / IRIs / blank nodes, whose typed value carries the rank); table_cols = k;
                                   table_slot = 1 + group column (0 = one group).  Rows equal on (group, keys) collapse to
                                   one; every output column must be the group column or a key column.               */
+  RDFGPU_NODE_UNION = 9        /* UnionExec: the rows of `left` followed by the rows of `right` (bag union; both inputs have
+                                  the same columns) — SPARQL UNION as planned in BSBM Explore - Q4 / Q11 (Execution Plan).snap;
+                                  optional projection */
 };
 enum { RDFGPU_SORT_BY_ID = 0, RDFGPU_SORT_BY_TERM = 1 };
 enum { RDFGPU_JOIN_INNER = 0, RDFGPU_JOIN_LEFT = 1 };

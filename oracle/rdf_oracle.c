@@ -934,6 +934,24 @@ static int exec_node(const pctx* c, u32 idx, orc_table* out) {
     case RDFGPU_NODE_PROJECTION: { rdfgpu_plan_node f = *nd; f.expr_len = 0; rc = exec_filter(c, &f, out); break; }
     case RDFGPU_NODE_HASH_JOIN: case RDFGPU_NODE_CROSS_JOIN: case RDFGPU_NODE_NESTED_LOOP_JOIN: rc = exec_join(c, nd, out); break;
     case RDFGPU_NODE_TOPK: rc = exec_topk(c, nd, out); break;
+    case RDFGPU_NODE_UNION: {   /* UnionExec: every row of the left input, then every row of the right one */
+      if (nd->left < 0 || nd->right < 0) FAIL("UNION needs two inputs");
+      orc_table l, r;
+      if (exec_node(c, (u32)nd->left, &l)) return -1;
+      if (exec_node(c, (u32)nd->right, &r)) { orc_table_free(&l); return -1; }
+      if (l.n_cols != r.n_cols) { orc_table_free(&l); orc_table_free(&r); FAIL("UNION inputs have %u and %u columns", l.n_cols, r.n_cols); }
+      const u32* proj = nd->n_proj == RDFGPU_NO_PROJECTION ? NULL : c->d->pool + nd->proj_off;
+      const u32 np = proj ? nd->n_proj : l.n_cols;
+      out->n_cols = np; out->n_rows = l.n_rows + r.n_rows;
+      for (u32 q = 0; q < np; q++) {
+        const u32 src = proj ? proj[q] : q;
+        if (src >= l.n_cols) { orc_table_free(&l); orc_table_free(&r); FAIL("UNION projection column %u out of range", src); }
+        out->cols[q] = (u32*)malloc((out->n_rows ? out->n_rows : 1) * sizeof(u32));
+        memcpy(out->cols[q], l.cols[src], l.n_rows * sizeof(u32));
+        memcpy(out->cols[q] + l.n_rows, r.cols[src], r.n_rows * sizeof(u32));
+      }
+      orc_table_free(&l); orc_table_free(&r);
+      break; }
     case RDFGPU_NODE_TABLE: {
       if (nd->table_slot >= c->n_tables) FAIL("table slot %u not bound", nd->table_slot);
       const orc_bound_table* t = &c->tables[nd->table_slot];

@@ -355,3 +355,23 @@ def q10_plan(ds, product_id, country_id, max_days=3, after="2008-06-20T00:00:00"
     valid = pb.filter(pb.data_source(quad_pattern("offer", pr["bsbm:validTo"], "date")),
                       EBV(GT(ENC_TV(col(1)), date_time(*xsd.parse_date_time(after)))), projection=[0])
     return pb.build(pb.hash_join(node, valid, on=[(0, 0)], projection=[0, 1]))
+
+
+def q4_plan(ds, type_id, feature1, feature2, feature3, threshold1, threshold2):
+    """BSBM Explore Q4 below its DISTINCT / ORDER BY / OFFSET: a UnionExec of two five-join pipelines that differ in the
+    second feature and the numeric property filtered (`EBV(GT(ENC_TV(p1), 9:457))` / `EBV(GT(ENC_TV(p2), 9:488))`),
+    Q4 (Execution Plan).snap:11-38.  Output: (product, label, propertyTextual)."""
+    pr = ds.pred
+    pb = PlanBuilder()
+
+    def branch(feature_b, k, threshold):
+        node = pb.hash_join(pb.data_source(quad_pattern("product", pr["rdfs:label"], "label")),
+                            pb.data_source(quad_pattern("product", pr["rdf:type"], int(type_id))), on=[(0, 0)], projection=[0, 1])
+        for f in (feature1, feature_b):
+            node = pb.hash_join(node, pb.data_source(quad_pattern("product", pr["bsbm:productFeature"], int(f))), on=[(0, 0)], projection=[0, 1])
+        node = pb.hash_join(node, pb.data_source(quad_pattern("product", pr["bsbm:productPropertyTextual1"], "propertyTextual")),
+                            on=[(0, 0)], projection=[0, 1, 3])
+        num = pb.filter(pb.data_source(quad_pattern("product", pr[f"bsbm:productPropertyNumeric{k}"], f"p{k}")),
+                        EBV(GT(ENC_TV(col(1)), integer(threshold))), projection=[0])
+        return pb.hash_join(node, num, on=[(0, 0)], projection=[0, 1, 2])
+    return pb.build(pb.union(branch(feature2, 1, threshold1), branch(feature3, 2, threshold2)))

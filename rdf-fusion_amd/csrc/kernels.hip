@@ -319,6 +319,27 @@ void launch_cross(const CrossArgs& a, hipStream_t s) {
 }
 
 // --------------------------------------------------------------------------------------------------
+// UnionExec: out = left rows ++ right rows, column by column (coalesced copies; the split point is the left
+// input's live row count, which may only exist on the device).
+// --------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void union_kernel(const UnionArgs a) {
+  const u64 nl = live_rows(a.n_left_dev, a.n_left_cap), nr = live_rows(a.n_right_dev, a.n_right_cap);
+  const u64 n = nl + nr;
+  if (blockIdx.x == 0 && threadIdx.x == 0 && a.n_out_dev) *a.n_out_dev = n;
+  const u64 base = (u64)blockIdx.x * kTile;
+  if (base >= n) return;
+#pragma unroll
+  for (int k = 0; k < kItems; k++) {
+    const u64 r = base + (u64)k * kBlock + threadIdx.x;
+    if (r >= n) break;
+    for (u32 c = 0; c < a.n_cols; c++) a.out[c][r] = r < nl ? a.left[c][r] : a.right[c][r - nl];
+  }
+}
+void launch_union(const UnionArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(union_kernel, grid_for(a.n_left_cap + a.n_right_cap), dim3(kBlock), 0, s, a);
+}
+
+// --------------------------------------------------------------------------------------------------
 // K4/K5 HashJoinExec(CollectLeft), v1: chained hash table in HBM.
 //   build : next[i] = atomicExch(&heads[h(keys_i)], i)            (rows with a null key never enter:
 //           NullEqualsNothing, join/rewrite.rs:89,217)

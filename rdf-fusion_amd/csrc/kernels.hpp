@@ -77,6 +77,17 @@ struct CrossArgs {
 };
 void launch_cross(const CrossArgs& a, hipStream_t s);
 
+// ---- UnionExec: left rows then right rows (either side's row count may live on the device) ----
+struct UnionArgs {
+  const u32* left[kMaxCols]; const u32* right[kMaxCols];
+  u32* out[kMaxCols];
+  u32 n_cols;
+  const u64* n_left_dev; u64 n_left_cap;
+  const u64* n_right_dev; u64 n_right_cap;
+  u64* n_out_dev;
+};
+void launch_union(const UnionArgs& a, hipStream_t s);
+
 // ---- K4/K5: HashJoinExec(CollectLeft) — chained table in HBM (v1) ----
 struct JoinArgs {
   const u32* left[kMaxCols]; const u32* right[kMaxCols];

@@ -247,6 +247,13 @@ Plan* plan_compile(Store* store, const rdfgpu_plan_desc* d) {
         if (l.width > (u32)kMaxCols || rr.width > (u32)kMaxCols) fail(RDFGPU_ERR_UNSUPPORTED, "node %u: too many columns", i);
         break;
       }
+      case RDFGPU_NODE_UNION: {
+        const NodeInfo& l = child(r.left, "left");
+        const NodeInfo& rr = child(r.right, "right");
+        if (l.width != rr.width) fail(RDFGPU_ERR_INVALID, "node %u: UnionExec inputs have %u and %u columns", i, l.width, rr.width);
+        load_projection(nd, d, l.width, "UnionExec");
+        break;
+      }
       case RDFGPU_NODE_TABLE: {
         if (r.table_cols > (u32)kMaxCols) fail(RDFGPU_ERR_UNSUPPORTED, "node %u: table with %u columns", i, r.table_cols);
         nd.width = r.table_cols;
@@ -331,7 +338,7 @@ Plan* plan_compile(Store* store, const rdfgpu_plan_desc* d) {
       seen[i] = true;
       const NodeInfo& nd = plan->nodes[i];
       if (nd.d.kind == RDFGPU_NODE_DATA_SOURCE || nd.d.kind == RDFGPU_NODE_TABLE) continue;
-      const bool binary = nd.d.kind == RDFGPU_NODE_HASH_JOIN || nd.d.kind == RDFGPU_NODE_CROSS_JOIN || nd.d.kind == RDFGPU_NODE_NESTED_LOOP_JOIN;
+      const bool binary = nd.d.kind == RDFGPU_NODE_HASH_JOIN || nd.d.kind == RDFGPU_NODE_CROSS_JOIN || nd.d.kind == RDFGPU_NODE_NESTED_LOOP_JOIN || nd.d.kind == RDFGPU_NODE_UNION;
       if (nd.d.left >= 0) { plan->nodes[nd.d.left].refs++; stack.push_back((u32)nd.d.left); }
       if (binary && nd.d.right >= 0) { plan->nodes[nd.d.right].refs++; stack.push_back((u32)nd.d.right); }
     }
@@ -386,7 +393,7 @@ const char* kernel_class_name(int kc) {
       "void rdfgpu::nlj_kernel<true>", "rocprim device scan", "rdfgpu::gjoin_build_kernel", "rdfgpu::gdirect_build_kernel",
       "rdfgpu::minmax_u32_kernel", "rdfgpu::csr_hist_kernel", "rdfgpu::csr_scatter_kernel",
       "rdfgpu::topk_max_kernel", "rdfgpu::topk_hist_kernel", "rdfgpu::topk_scatter_kernel", "rdfgpu::topk_select_kernel",
-      "rdfgpu::topk_write_kernel", "void rdfgpu::filter_kernel<3>", "rdfgpu::regex_verdict_kernel"};
+      "rdfgpu::topk_write_kernel", "void rdfgpu::filter_kernel<3>", "rdfgpu::regex_verdict_kernel", "rdfgpu::union_kernel"};
   if (kc < KC_LDS_JOIN0) return fixed[kc];
   static std::string names[192];
   static std::once_flag once;
@@ -556,6 +563,26 @@ DevTable Plan::exec_node(u32 idx) {
     }
     case RDFGPU_NODE_HASH_JOIN: case RDFGPU_NODE_CROSS_JOIN: case RDFGPU_NODE_NESTED_LOOP_JOIN: t = exec_join(nd); break;
     case RDFGPU_NODE_TOPK: t = exec_topk(nd); break;
+    case RDFGPU_NODE_UNION: {
+      const DevTable L = exec_node((u32)nd.d.left), R = exec_node((u32)nd.d.right);
+      t.n_cols = nd.n_proj;
+      const u64 cap = L.cap + R.cap;
+      if (cap >= 0xFFFFFFF0ull) fail(RDFGPU_ERR_UNSUPPORTED, "UnionExec of %llu rows", (unsigned long long)cap);
+      if (cap == 0) { t.cap = 0; break; }
+      UnionArgs a{};
+      a.n_cols = nd.n_proj;
+      for (u32 c = 0; c < nd.n_proj; c++) {
+        a.left[c] = L.cap ? L.cols[nd.proj[c]] : nullptr; a.right[c] = R.cap ? R.cols[nd.proj[c]] : nullptr;
+        a.out[c] = scratch<u32>(cap); t.cols[c] = a.out[c];
+      }
+      a.n_left_dev = L.n_dev; a.n_left_cap = L.cap; a.n_right_dev = R.n_dev; a.n_right_cap = R.cap;
+      const bool dyn = L.n_dev || R.n_dev;
+      a.n_out_dev = dyn ? new_counter() : nullptr;
+      // bytes: every projected cell read once and written once
+      timed(KC_UNION, R.n_dev ? 0 : 8ull * nd.n_proj * R.cap, L.cap, L.n_dev, 8ull * nd.n_proj, nullptr, 0, 0, [&] { launch_union(a, stream); });
+      t.cap = cap; t.n_dev = a.n_out_dev;
+      break;
+    }
     case RDFGPU_NODE_TABLE: {
       const BoundTable& b = tables[nd.d.table_slot];
       if (!b.bound) fail(RDFGPU_ERR_INVALID, "table slot %u is not bound", nd.d.table_slot);

@@ -49,7 +49,7 @@ enum KernelClass {
   KC_GJOIN_BUILD,
   KC_GDIRECT_BUILD, KC_MINMAX, KC_CSR_HIST, KC_CSR_SCATTER,
   KC_TOPK_MAX, KC_TOPK_HIST, KC_TOPK_SCATTER, KC_TOPK_SELECT, KC_TOPK_WRITE,
-  KC_FILTER_VERDICT, KC_REGEX_VERDICTS,
+  KC_FILTER_VERDICT, KC_REGEX_VERDICTS, KC_UNION,
   KC_LDS_JOIN0,                      // 192 names: lds_join_kernel<FS in {0..3}, PFS in {0,1,2}, ITEMS in {4,1}, MODE in {0,1,2,3}, CHAIN>
   KC__N = KC_LDS_JOIN0 + 192
 };

@@ -369,5 +369,12 @@ class PlanBuilder:
             n.left_keys[i], n.right_keys[i] = int(c), int(how)
         return self._push(n, self._proj(n, projection, self.width[left]))
 
+    def union(self, left, right, projection=None):
+        """UnionExec: bag union of two inputs with the same columns (SPARQL UNION; Q4 (Execution Plan).snap:11)."""
+        if self.width[left] != self.width[right]:
+            raise ValueError("UNION inputs differ in width")
+        n = abi.PlanNode(kind=abi.NODE_UNION, left=left, right=right)
+        return self._push(n, self._proj(n, projection, self.width[left]))
+
     def build(self, root):
         return PlanDescription(self.nodes, self.exprs, self.pool, root, list(self.width), list(self.regexes))

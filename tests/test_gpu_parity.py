@@ -867,6 +867,45 @@ def test_fused_chain_with_mixed_numeric_kinds(torch_cuda):
         run_both(gs, os_, bsbm.q5_plan(ds, int(x)))
 
 
+@pytest.mark.parametrize("nl,nr", [(0, 0), (0, 900), (1300, 0), (1, 1), (70_000, 130_001)])
+def test_union_matches_oracle(torch_cuda, nl, nr):
+    """UnionExec (Q4 / Q11 (Execution Plan).snap): bag union; inputs with host-known and with device-side row counts
+    (a FilterExec below), empty sides, a projection, a join above the union."""
+    rng = np.random.default_rng(nl + 3 * nr)
+    L = [rng.integers(0, 60, nl).astype(np.uint32) for _ in range(3)]
+    R = [rng.integers(0, 60, nr).astype(np.uint32) for _ in range(3)]
+    kl, pl = table_on_device(torch_cuda, L)
+    kr, pr = table_on_device(torch_cuda, R)
+    gs, os_ = rf.GpuQuadStore(), orc.OracleStore()
+    tabs = dict(gpu_tables=[(pl, nl), (pr, nr)], cpu_tables=[L, R])
+    pb = PlanBuilder()
+    plan, got = run_both(gs, os_, pb.build(pb.union(pb.table(0, 3), pb.table(1, 3))), **tabs)
+    np.testing.assert_array_equal(got[1], np.concatenate([L[1], R[1]]))            # left rows first, order kept
+    pb = PlanBuilder()
+    f = lambda t: pb.filter(t, ID_NEQ(col(0), lit_id(7)))
+    run_both(gs, os_, pb.build(pb.union(f(pb.table(0, 3)), pb.table(1, 3), projection=[2, 0])), **tabs)
+    pb = PlanBuilder()
+    run_both(gs, os_, pb.build(pb.union(pb.table(0, 3), f(pb.table(1, 3)))), **tabs)
+    pb = PlanBuilder()
+    u = pb.union(f(pb.table(0, 3)), f(pb.table(1, 3)), projection=[0, 1])
+    run_both(gs, os_, pb.build(pb.hash_join(u, pb.union(pb.table(1, 3), pb.table(0, 3), projection=[1, 2]), on=[(1, 0)], projection=[0, 3])
+                               if nl + nr < 10_000 else u), **tabs)
+
+
+def test_bsbm_q4_matches_oracle(bsbm_stores):
+    """BSBM Explore Q4 (Q4 (Execution Plan).snap:11-38): UnionExec of two five-join pipelines with integer FilterExecs."""
+    ds, gs, os_ = bsbm_stores
+    rng = np.random.default_rng(4)
+    feats = ds.o[ds.p == ds.pred["bsbm:productFeature"]]
+    common = np.bincount(feats - ds.feature_base).argsort()[::-1][:6] + ds.feature_base
+    total = 0
+    for it in range(10):
+        f1, f2, f3 = (int(x) for x in rng.choice(common, 3, replace=False))
+        plan, got = run_both(gs, os_, bsbm.q4_plan(ds, ds.type_base + ds.n_types - 1, f1, f2, f3, int(rng.integers(100, 900)), int(rng.integers(100, 900))))
+        total += plan.result_info()[0]
+    assert total > 5
+
+
 def test_lang_matches_filter_matches_oracle(torch_cuda):
     """BSBM explore Q8's FILTER `EBV(LANGMATCHES(LANG(ENC_TV(text)), "EN"))` (Q8 (Execution Plan).snap:18): language-tagged
     and plain literals, IRIs / blank nodes / unbound (errors), a language id outside the host's table; as a FilterExec,
