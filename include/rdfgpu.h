@@ -292,9 +292,14 @@ enum {
                                   strings / IRIs / blank nodes, whose typed value carries the rank); table_cols = k;
                                   table_slot = 1 + group column (0 = one group).  Rows equal on (group, keys) collapse to
                                   one; every output column must be the group column or a key column.               */
-  RDFGPU_NODE_UNION = 9        /* UnionExec: the rows of `left` followed by the rows of `right` (bag union; both inputs have
+  RDFGPU_NODE_UNION = 9,       /* UnionExec: the rows of `left` followed by the rows of `right` (bag union; both inputs have
                                   the same columns) — SPARQL UNION as planned in BSBM Explore - Q4 / Q11 (Execution Plan).snap;
                                   optional projection */
+  RDFGPU_NODE_CLOSURE = 10     /* KleenePlusClosureExec (lib/physical/src/paths/kleene_plus/physical.rs:94-157, 246-384): `left` yields
+                                  the inner paths (graph, start, end) — graph 0 = default graph; the output is the SET of all paths
+                                  of one or more inner paths chained end-to-start: within one graph (join_type = 0), or continuing
+                                  through the inner paths of any graph while keeping the first path's graph (join_type = 1 =
+                                  allow_cross_graph_paths).  A null start / end is an execution error, as in the reference. */
 };
 enum { RDFGPU_SORT_BY_ID = 0, RDFGPU_SORT_BY_TERM = 1 };
 enum { RDFGPU_JOIN_INNER = 0, RDFGPU_JOIN_LEFT = 1 };

@@ -917,6 +917,91 @@ static int exec_topk(const pctx* c, const rdfgpu_plan_node* nd, orc_table* out) 
   return 0;
 }
 
+/* KleenePlusClosureExec, lib/physical/src/paths/kleene_plus/physical.rs:246-384.  The reference keeps the inner paths in
+   `initial_paths_map` (graph -> set of (start, end)), every path seen in the set `all_paths`, and extends the paths of
+   `current_delta` by the initial paths that start where they end — of the same graph (compute_new_single_graph_paths,
+   :362-384) or of every graph (compute_new_cross_graph_paths, :344-360) — until an iteration adds nothing.  Sets are
+   sorted arrays here. */
+typedef struct { u32 g, s, e; } cpath;
+static int cpath_cmp(const void* a, const void* b) {
+  const cpath* x = (const cpath*)a; const cpath* y = (const cpath*)b;
+  if (x->g != y->g) return x->g < y->g ? -1 : 1;
+  if (x->s != y->s) return x->s < y->s ? -1 : 1;
+  if (x->e != y->e) return x->e < y->e ? -1 : 1;
+  return 0;
+}
+static int cpath_by_start(const void* a, const void* b) {
+  const cpath* x = (const cpath*)a; const cpath* y = (const cpath*)b;
+  if (x->s != y->s) return x->s < y->s ? -1 : 1;
+  return cpath_cmp(a, b);
+}
+static u64 cpath_unique(cpath* p, u64 n) {
+  if (n == 0) return 0;
+  qsort(p, n, sizeof(cpath), cpath_cmp);
+  u64 m = 1;
+  for (u64 i = 1; i < n; i++) if (cpath_cmp(&p[i], &p[m - 1]) != 0) p[m++] = p[i];
+  return m;
+}
+static int exec_closure(const pctx* c, const rdfgpu_plan_node* nd, orc_table* out) {
+  orc_table in;
+  if (nd->left < 0) FAIL("KleenePlusClosureExec needs an input");
+  if (exec_node(c, (u32)nd->left, &in)) return -1;
+  if (in.n_cols != 3) { orc_table_free(&in); FAIL("inner paths are (graph, start, end)"); }
+  const int cross = nd->join_type == 1;
+  u64 n = in.n_rows;
+  cpath* all = (cpath*)malloc((n ? n : 1) * sizeof(cpath));
+  for (u64 i = 0; i < n; i++) {
+    all[i].g = in.cols[0][i]; all[i].s = in.cols[1][i]; all[i].e = in.cols[2][i];
+    if (all[i].s == 0 || all[i].e == 0) { free(all); orc_table_free(&in); FAIL("Could not obtain start / end value from inner paths."); }   /* :321-326 */
+  }
+  orc_table_free(&in);
+  u64 na = cpath_unique(all, n);                       /* collect_next_batch :309-341: every inner path is in the closure ... */
+  const u64 ni = na;
+  cpath* init = (cpath*)malloc((ni ? ni : 1) * sizeof(cpath));   /* ... the initial paths, ordered for look-up by (graph,) start */
+  memcpy(init, all, ni * sizeof(cpath));
+  if (cross) qsort(init, ni, sizeof(cpath), cpath_by_start);
+  cpath* delta = (cpath*)malloc((na ? na : 1) * sizeof(cpath)); u64 nd_ = na;   /* ... and in the first delta */
+  memcpy(delta, all, na * sizeof(cpath));
+  while (nd_ > 0) {
+    u64 cap = 1024, nn = 0;
+    cpath* next = (cpath*)malloc(cap * sizeof(cpath));
+    for (u64 i = 0; i < nd_; i++) {
+      const cpath p = delta[i];
+      u64 b = 0, e2 = ni;                              /* first initial path (of graph p.g) starting at p.e */
+      while (b < e2) {
+        const u64 m = b + (e2 - b) / 2;
+        const int less = cross ? init[m].s < p.e : (init[m].g < p.g || (init[m].g == p.g && init[m].s < p.e));
+        if (less) b = m + 1; else e2 = m;
+      }
+      for (u64 k = b; k < ni && init[k].s == p.e && (cross || init[k].g == p.g); k++) {
+        cpath q = {p.g, p.s, init[k].e};                /* path_ac :369-373: the graph of the path being extended */
+        if (bsearch(&q, all, na, sizeof(cpath), cpath_cmp)) continue;    /* all_paths.insert() == false */
+        if (nn == cap) { cap *= 2; next = (cpath*)realloc(next, cap * sizeof(cpath)); }
+        next[nn++] = q;
+      }
+    }
+    nn = cpath_unique(next, nn);                        /* a path reached twice in one round enters the set once */
+    if (nn == 0) { free(next); break; }
+    all = (cpath*)realloc(all, (na + nn) * sizeof(cpath));
+    memcpy(all + na, next, nn * sizeof(cpath));
+    na += nn;
+    qsort(all, na, sizeof(cpath), cpath_cmp);
+    free(delta); delta = next; nd_ = nn;
+  }
+  free(delta); free(init);
+  const u32* proj = nd->n_proj == RDFGPU_NO_PROJECTION ? NULL : c->d->pool + nd->proj_off;
+  const u32 np = proj ? nd->n_proj : 3;
+  out->n_cols = np; out->n_rows = na;
+  for (u32 q = 0; q < np; q++) {
+    const u32 src = proj ? proj[q] : q;
+    if (src >= 3) { free(all); FAIL("closure projection column %u out of range", src); }
+    out->cols[q] = (u32*)malloc((na ? na : 1) * sizeof(u32));
+    for (u64 i = 0; i < na; i++) out->cols[q][i] = src == 0 ? all[i].g : src == 1 ? all[i].s : all[i].e;
+  }
+  free(all);
+  return 0;
+}
+
 static int exec_node(const pctx* c, u32 idx, orc_table* out) {
   if (idx >= c->d->n_nodes) FAIL("node index out of range");
   const rdfgpu_plan_node* nd = &c->d->nodes[idx];
@@ -934,6 +1019,7 @@ static int exec_node(const pctx* c, u32 idx, orc_table* out) {
     case RDFGPU_NODE_PROJECTION: { rdfgpu_plan_node f = *nd; f.expr_len = 0; rc = exec_filter(c, &f, out); break; }
     case RDFGPU_NODE_HASH_JOIN: case RDFGPU_NODE_CROSS_JOIN: case RDFGPU_NODE_NESTED_LOOP_JOIN: rc = exec_join(c, nd, out); break;
     case RDFGPU_NODE_TOPK: rc = exec_topk(c, nd, out); break;
+    case RDFGPU_NODE_CLOSURE: rc = exec_closure(c, nd, out); break;
     case RDFGPU_NODE_UNION: {   /* UnionExec: every row of the left input, then every row of the right one */
       if (nd->left < 0 || nd->right < 0) FAIL("UNION needs two inputs");
       orc_table l, r;

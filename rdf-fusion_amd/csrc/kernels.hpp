@@ -1,5 +1,6 @@
 // kernels.hpp — host-callable launchers of the gfx950 kernels (definitions in kernels.hip).
 #pragma once
+#include <functional>
 #include "common.hpp"
 #include "expr_device.hpp"
 
@@ -87,6 +88,11 @@ struct UnionArgs {
   u64* n_out_dev;
 };
 void launch_union(const UnionArgs& a, hipStream_t s);
+
+// ---- KleenePlusClosureExec (closure.hip): transitive closure of (graph, start, end) paths, semi-naive on sorted u64 keys ----
+struct ClosureStats { u32 iterations = 0; u64 nodes = 0, graphs = 0, initial_paths = 0; };
+u64 closure_exec(const u32* g, const u32* s, const u32* e, u64 n, bool cross_graph, hipStream_t stream,
+                 const std::function<u32*(u64)>& alloc, u32* out_cols[3], ClosureStats* stats);
 
 // ---- K4/K5: HashJoinExec(CollectLeft) — chained table in HBM (v1) ----
 struct JoinArgs {

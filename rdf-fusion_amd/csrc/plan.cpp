@@ -247,6 +247,13 @@ Plan* plan_compile(Store* store, const rdfgpu_plan_desc* d) {
         if (l.width > (u32)kMaxCols || rr.width > (u32)kMaxCols) fail(RDFGPU_ERR_UNSUPPORTED, "node %u: too many columns", i);
         break;
       }
+      case RDFGPU_NODE_CLOSURE: {
+        const NodeInfo& c = child(r.left, "inner paths");
+        if (c.width != 3) fail(RDFGPU_ERR_INVALID, "node %u: KleenePlusClosureExec input has %u columns, not (graph, start, end)", i, c.width);
+        if (r.join_type > 1) fail(RDFGPU_ERR_INVALID, "node %u: allow_cross_graph_paths is 0 or 1", i);
+        load_projection(nd, d, 3, "KleenePlusClosureExec");
+        break;
+      }
       case RDFGPU_NODE_UNION: {
         const NodeInfo& l = child(r.left, "left");
         const NodeInfo& rr = child(r.right, "right");
@@ -563,6 +570,21 @@ DevTable Plan::exec_node(u32 idx) {
     }
     case RDFGPU_NODE_HASH_JOIN: case RDFGPU_NODE_CROSS_JOIN: case RDFGPU_NODE_NESTED_LOOP_JOIN: t = exec_join(nd); break;
     case RDFGPU_NODE_TOPK: t = exec_topk(nd); break;
+    case RDFGPU_NODE_CLOSURE: {
+      const DevTable in = exec_node((u32)nd.d.left);
+      u64 n = in.cap;
+      if (in.n_dev && in.cap) {
+        RDFGPU_HIP(hipMemcpyAsync(&n, in.n_dev, sizeof(u64), hipMemcpyDeviceToHost, stream));
+        RDFGPU_HIP(hipStreamSynchronize(stream)); metrics.host_syncs++;
+      }
+      u32* out[3] = {nullptr, nullptr, nullptr};
+      ClosureStats cs;
+      const u64 rows = closure_exec(in.cols[0], in.cols[1], in.cols[2], n, nd.d.join_type == 1, stream, [&](u64 m) { return scratch<u32>(m); }, out, &cs);
+      metrics.host_syncs += 4 + 3 * cs.iterations;
+      t.n_cols = nd.n_proj; t.cap = rows; t.n_dev = nullptr;
+      for (u32 c = 0; c < nd.n_proj; c++) t.cols[c] = out[nd.proj[c]];
+      break;
+    }
     case RDFGPU_NODE_UNION: {
       const DevTable L = exec_node((u32)nd.d.left), R = exec_node((u32)nd.d.right);
       t.n_cols = nd.n_proj;

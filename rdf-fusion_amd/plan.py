@@ -376,5 +376,12 @@ class PlanBuilder:
         n = abi.PlanNode(kind=abi.NODE_UNION, left=left, right=right)
         return self._push(n, self._proj(n, projection, self.width[left]))
 
+    def closure(self, left, allow_cross_graph_paths=False):
+        """KleenePlusClosureExec over inner paths (graph, start, end) — the `+` of a SPARQL property path."""
+        if self.width[left] != 3:
+            raise ValueError("inner paths are (graph, start, end)")
+        n = abi.PlanNode(kind=abi.NODE_CLOSURE, left=left, right=-1, join_type=1 if allow_cross_graph_paths else 0)
+        return self._push(n, self._proj(n, None, 3))
+
     def build(self, root):
         return PlanDescription(self.nodes, self.exprs, self.pool, root, list(self.width), list(self.regexes))

@@ -867,6 +867,55 @@ def test_fused_chain_with_mixed_numeric_kinds(torch_cuda):
         run_both(gs, os_, bsbm.q5_plan(ds, int(x)))
 
 
+@pytest.mark.parametrize("cross", [False, True])
+@pytest.mark.parametrize("n,n_nodes,n_graphs", [(0, 5, 1), (1, 1, 1), (3, 3, 1), (300, 40, 2), (2000, 900, 4), (60_000, 120_000, 3), (5000, 5000, 700)])
+def test_closure_matches_oracle(torch_cuda, cross, n, n_nodes, n_graphs):
+    """KleenePlusClosureExec (physical.rs:246-384) as sorted-key semi-naive iteration on the device vs the oracle's set
+    restatement: random multi-graph inputs incl. the default graph, duplicates and self loops; within and across graphs;
+    behind a FilterExec (device-side row count) and under a join."""
+    import test_closure_cpu as tc
+    rng = np.random.default_rng(n * 31 + n_graphs + cross)
+    g, s, e = tc.random_paths(rng, n, n_nodes, n_graphs)
+    keep, ptrs = table_on_device(torch_cuda, [g, s, e])
+    gs, os_ = rf.GpuQuadStore(), orc.OracleStore()
+    plan, got = run_both(gs, os_, tc.closure_plan(cross), gpu_tables=[(ptrs, n)], cpu_tables=[[g, s, e]])
+    rows = list(zip(*(c.tolist() for c in got)))
+    assert len(rows) == len(set(rows))
+    if n <= 300:
+        assert set(rows) == tc.numpy_closure(g, s, e, cross)
+    pb = PlanBuilder()
+    inner = pb.filter(pb.table(0, 3), ID_NEQ(col(1), lit_id(9)))            # the row count of the inner paths lives on the device
+    reach = pb.closure(inner, allow_cross_graph_paths=cross)
+    run_both(gs, os_, pb.build(pb.hash_join(reach, pb.table(0, 3), on=[(2, 1)], projection=[0, 1, 5]) if n <= 5000 else reach),
+             gpu_tables=[(ptrs, n)], cpu_tables=[[g, s, e]])
+
+
+def test_closure_chain_cycle_fixture_and_null(torch_cuda):
+    import test_closure_cpu as tc
+    gs, os_ = rf.GpuQuadStore(), orc.OracleStore()
+    chain = np.arange(1, 401, dtype=np.uint32)
+    t = [np.zeros(399, np.uint32), chain[:-1], chain[1:]]                    # 399 iterations
+    keep, ptrs = table_on_device(torch_cuda, t)
+    plan, got = run_both(gs, os_, tc.closure_plan(), gpu_tables=[(ptrs, 399)], cpu_tables=[t])
+    assert plan.result_info()[0] == 399 * 400 // 2
+    ring = np.arange(1, 301, dtype=np.uint32)
+    t = [np.full(300, 5, np.uint32), ring, np.roll(ring, -1)]
+    keep, ptrs = table_on_device(torch_cuda, t)
+    plan, got = run_both(gs, os_, tc.closure_plan(), gpu_tables=[(ptrs, 300)], cpu_tables=[t])
+    assert plan.result_info()[0] == 300 * 300
+    # the reference's fixture one_or_more_shared.{ttl,rq,srx}: ?s ex:p+ ?s  =>  ex:s, ex:m
+    t = [np.zeros(3, np.uint32), np.array([11, 12, 12], np.uint32), np.array([12, 11, 13], np.uint32)]
+    keep, ptrs = table_on_device(torch_cuda, t)
+    plan, got = run_both(gs, os_, tc.closure_plan(same_ends=True), gpu_tables=[(ptrs, 3)], cpu_tables=[t])
+    assert sorted(got[0].tolist()) == [11, 12]
+    t = [np.zeros(2, np.uint32), np.array([1, 0], np.uint32), np.array([2, 3], np.uint32)]
+    keep, ptrs = table_on_device(torch_cuda, t)
+    p = gs.plan(tc.closure_plan())
+    p.bind_table(0, ptrs, 2)
+    with pytest.raises(rf.RdfGpuError, match="start / end"):
+        p.execute()
+
+
 @pytest.mark.parametrize("nl,nr", [(0, 0), (0, 900), (1300, 0), (1, 1), (70_000, 130_001)])
 def test_union_matches_oracle(torch_cuda, nl, nr):
     """UnionExec (Q4 / Q11 (Execution Plan).snap): bag union; inputs with host-known and with device-side row counts
