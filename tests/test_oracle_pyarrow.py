@@ -109,3 +109,19 @@ def test_topk_distinct_agrees_with_python_sorting():
                 exp += [((int(gg),) if gg is not None else ()) + (l, p) for _, p, l in rows]
             got = sorted(tuple(int(c[r]) for c in cols) for r in range(m))
             assert got == sorted(exp), (n, n_groups, limit, group)
+
+
+def test_acero_batched_q5_baseline_equals_oracle():
+    """bench.py's tuned columnar CPU baseline (oracle/acero_baseline.py) computes the batched Q5 exactly"""
+    from rdf_fusion_amd import bsbm
+    from oracle import acero_baseline as ab
+    ds = bsbm.generate(2500)
+    st = orc.OracleStore()
+    st.extend(ds.g, ds.s, ds.p, ds.o)
+    st.set_typed_values(ds.typed_values, ds.decimals)
+    rng = np.random.default_rng(1)
+    prep = ab.prepare(ds)
+    for batch_size in (1, 150):
+        batch = np.array([ds.product(i) for i in rng.choice(ds.n_products, batch_size, replace=False)], dtype=np.uint32)
+        cols, n, _ = st.execute(bsbm.q5_batch_plan(ds), [[np.arange(1, batch_size + 1, dtype=np.uint32), batch]])
+        np.testing.assert_array_equal(ku.multiset(ab.run(prep, batch)), ku.multiset(cols, n))
