@@ -704,6 +704,9 @@ def test_engine_toggles_do_not_change_results(bsbm_stores, torch_cuda, monkeypat
     for x in rng.choice(ds.n_products, 3, replace=False):
         run_both(gs, os_, bsbm.q5_plan(ds, ds.product(int(x))))
     run_both(gs, os_, bsbm.q1_plan(ds, *bsbm.q1_instance(ds, rng)))
+    run_both(gs, os_, bsbm.q10_plan(ds, ds.product(3), ds.country_base + 3, max_days=9, after="2004-03-01T06:00:00"))
+    feats = np.bincount(ds.o[ds.p == ds.pred["bsbm:productFeature"]] - ds.feature_base).argsort()[::-1][:3] + ds.feature_base
+    run_both(gs, os_, bsbm.q4_plan(ds, ds.type_base + ds.n_types - 1, int(feats[0]), int(feats[1]), int(feats[2]), 300, 400))
     desc = bsbm.q5_batch_plan(ds)
     plan = gs.plan(desc)
     for batch in (60, 90, 75):                                   # re-executions: speculative sizes, cached tables, fusion
