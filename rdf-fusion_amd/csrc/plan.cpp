@@ -804,7 +804,7 @@ DevTable Plan::exec_topk(NodeInfo& nd) {
 bool Plan::choose_build_left(const NodeInfo& nd, const DevTable& L, const DevTable& R, bool left_join, bool lf, bool rf, bool lpost, bool rpost) const {
   if (left_join) return true;
   const bool smaller_left = L.cap <= R.cap;
-  if (nd.d.kind != RDFGPU_NODE_HASH_JOIN || nd.d.n_keys != 1 || std::getenv("RDFGPU_NO_TABLE_CACHE") || std::getenv("RDFGPU_NO_INDEX_JOIN")) return smaller_left;
+  if (nd.d.kind != RDFGPU_NODE_HASH_JOIN || std::getenv("RDFGPU_NO_TABLE_CACHE") || std::getenv("RDFGPU_NO_INDEX_JOIN")) return smaller_left;
   // (a slice under a `col <=|!=> literal` FilterExec still counts: that filter can run as a conjunct of the join filter)
   const bool ls = L.stable_id != 0 && L.n_dev == nullptr && (!lf || lpost), rs = R.stable_id != 0 && R.n_dev == nullptr && (!rf || rpost);
   if (!ls && !rs) return smaller_left;
@@ -814,11 +814,20 @@ bool Plan::choose_build_left(const NodeInfo& nd, const DevTable& L, const DevTab
   if (O.cap > S.cap) return smaller_left;                   // the slice is already the smaller side
   if (ls && rs && O.cap * 8 > S.cap) return smaller_left;   // two slices of similar size: nothing to gain
   if (S.cap <= 1024) return smaller_left;                   // LDS-table territory
-  // keys known not to be dense (from an earlier attempt on this very slice): a cached HASH table of the slice still
-  // wins when the other side is much smaller, and stays within a sane footprint (16 B per row at load 0.5)
-  SliceKey sk; sk.n_keys = 1; sk.rows = S.cap; sk.key[0] = S.cols[slice_left ? nd.d.left_keys[0] : nd.d.right_keys[0]];
-  const SliceTable* st = store->find_slice_table(sk);
-  if (st && st->dense_failed && (O.cap * 8 > S.cap || S.cap > (64ull << 20))) return smaller_left;
+  // A slice whose keys are not one dense id range (several key columns, or an earlier attempt on this very slice said
+  // so) gets a cached HASH table: built once per store version, probed with the fewer rows.  It loses only to a small
+  // table built on the other side that stays in L2 while the slice's would not (measured on LUBM Q9's two-key join,
+  // 24.6 M rows against a 57 M-row slice: 5.9 ms building on the smaller side every run, 1.3 ms on the cached slice).
+  bool hash_only = nd.d.n_keys != 1;
+  if (!hash_only) {
+    SliceKey sk; sk.n_keys = 1; sk.rows = S.cap; sk.key[0] = S.cols[slice_left ? nd.d.left_keys[0] : nd.d.right_keys[0]];
+    const SliceTable* st = store->find_slice_table(sk);
+    hash_only = st && st->dense_failed;
+  }
+  if (hash_only) {
+    if (S.cap > (256ull << 20)) return smaller_left;                             // 32 B per row: keep the footprint sane
+    if (O.cap * 8 > S.cap && O.cap <= (1ull << 20)) return smaller_left;
+  }
   return slice_left;
 }
 

@@ -1,0 +1,64 @@
+"""BASELINE config 5 at scale: LUBM-shaped store (rdf_fusion_amd/lubm.py), Q9 + OPTIONAL + REGEX through the C ABI.
+The oracle cannot follow to this size; checked instead: (1) every result row is a triangle of the raw triples (sample),
+(2) the bindings (count + order-independent checksum) are the same with the engine's index joins / direct tables / LDS
+joins switched off — different join algorithms, same answer.
+  python scratch/lubm_scale.py [universities]"""
+import sys, os, time, json
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import rdf_fusion_amd as rf
+from rdf_fusion_amd import lubm
+
+U = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
+t0 = time.perf_counter(); ds = lubm.generate(U); t_gen = time.perf_counter() - t0
+print("generated %d universities: %d triples, %d ids, %.1f s" % (U, ds.n_triples, ds.n_ids, t_gen), flush=True)
+st = rf.GpuQuadStore()
+t0 = time.perf_counter(); n = st.extend(ds.g, ds.s, ds.p, ds.o); torch.cuda.synchronize(); t_load = time.perf_counter() - t0
+st.set_typed_values(ds.typed_values); st.set_strings(ds.str_offsets, ds.str_heap)
+free, total = torch.cuda.mem_get_info()
+print("loaded %d quads in %.1f s (3 sorted permutations); HBM in use %.1f GB" % (n, t_load, (total - free) / 1e9), flush=True)
+
+
+def checksum(cols):
+    mix = np.zeros(len(cols[0]), dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        for k, c in enumerate(cols):
+            mix ^= c.astype(np.uint64) * np.uint64([0x9E3779B97F4A7C15, 0xC2B2AE3D27D4EB4F, 0x165667B19E3779F9, 0x27D4EB2F165667C5, 0x85EBCA77C2B2AE63][k])
+        return len(cols[0]), int(mix.sum(dtype=np.uint64))
+
+
+key = lambda a, b: (a.astype(np.uint64) << np.uint64(32)) | b.astype(np.uint64)
+edges = {}
+for pname in ("ub:advisor", "ub:teacherOf", "ub:takesCourse"):      # sorted (s, o) keys of the triangle's predicates, for the membership check
+    m = ds.p == ds.pred[pname]
+    edges[pname] = np.sort(key(ds.s[m], ds.o[m]))
+out = {"universities": U, "triples": int(n), "ids": int(ds.n_ids), "generate_seconds": round(t_gen, 1), "load_seconds": round(t_load, 2),
+       "hbm_in_use_GB": round((total - free) / 1e9, 1), "queries": []}
+for pattern, flags in (("^GraduateStudent1", ""), ("student[0-9]*7$", "i"), (".", "")):
+    desc = lubm.q9_optional_regex_plan(ds, pattern, flags)
+    plan = st.plan(desc).enable_kernel_timing(True)
+    times = []
+    for it in range(3):
+        torch.cuda.synchronize(); t0 = time.perf_counter(); plan.execute(); rows, _ = plan.result_info(); times.append((time.perf_counter() - t0) * 1e3)
+    base = checksum(plan.fetch())
+    kern = sorted(plan.kernel_stats(), key=lambda k: -k[2])[:4]
+    for toggle in ("RDFGPU_NO_INDEX_JOIN", "RDFGPU_NO_DIRECT_TABLE", "RDFGPU_NO_LDS_JOIN"):
+        os.environ[toggle] = "1"
+        alt = st.plan(desc).execute()
+        assert checksum(alt.fetch()) == base, (pattern, toggle)
+        alt.close()
+        del os.environ[toggle]
+    got = plan.fetch()
+    sel = np.random.default_rng(0).choice(len(got[0]), min(len(got[0]), 200_000), replace=False) if len(got[0]) else np.zeros(0, np.int64)
+    for pname, a, b in (("ub:advisor", 0, 1), ("ub:teacherOf", 1, 2), ("ub:takesCourse", 0, 2)):
+        k = key(got[a][sel], got[b][sel])
+        pos = np.searchsorted(edges[pname], k)
+        assert (edges[pname][np.minimum(pos, len(edges[pname]) - 1)] == k).all()
+    q = {"regex": pattern, "flags": flags, "bindings": rows, "ms": [round(x, 2) for x in times], "bindings_per_s": round(rows / (min(times) * 1e-3)),
+         "optional_unbound": int((got[4] == 0).sum()), "same_answer_without": ["index joins", "direct tables", "LDS joins"],
+         "top_kernels": [(k[0], k[1], round(k[2], 3)) for k in kern]}
+    print(json.dumps(q), flush=True)
+    out["queries"].append(q)
+    plan.close()
+os.makedirs("gpurun_out", exist_ok=True)
+json.dump(out, open("gpurun_out/lubm_scale_%d.json" % U, "w"), indent=1)

@@ -643,6 +643,28 @@ def test_lubm_shaped_optional_plus_regex(torch_cuda):
     assert total > 0
 
 
+def test_lubm_q9_optional_regex_matches_oracle():
+    """BASELINE config 5 at test scale: LUBM-shaped data (rdf_fusion_amd/lubm.py), Q9's student - advisor - course
+    triangle (a two-key join closes it), a REGEX FILTER on the student's name and the OPTIONAL e-mail address."""
+    from rdf_fusion_amd import lubm
+    ds = lubm.generate(6)
+    gs, os_ = both_stores((ds.g, ds.s, ds.p, ds.o), typed=ds.typed_values)
+    gs.set_strings(ds.str_offsets, ds.str_heap)
+    os_.set_strings(ds.str_offsets, ds.str_heap)
+    total = 0
+    for pattern, flags in (("^GraduateStudent1", ""), (".", ""), ("student[0-9]*7$", "i"), ("^Undergraduate", ""), ("^Nobody", "")):
+        plan, got = run_both(gs, os_, lubm.q9_optional_regex_plan(ds, pattern, flags))
+        total += plan.result_info()[0]
+        if pattern == ".":
+            assert (got[4] == 0).any() and (got[4] != 0).any()             # OPTIONAL: students with and without an address
+            x, y, z = got[0], got[1], got[2]                                # the triangle, checked on the raw triples
+            key = lambda a, b: (a.astype(np.uint64) << np.uint64(32)) | b.astype(np.uint64)
+            for pname, a, b in (("ub:advisor", x, y), ("ub:teacherOf", y, z), ("ub:takesCourse", x, z)):
+                m = ds.p == ds.pred[pname]
+                assert np.isin(key(a, b), key(ds.s[m], ds.o[m])).all()
+    assert total > 100
+
+
 def test_fused_lookup_chain_equals_unfused(bsbm_stores, torch_cuda, monkeypatch):
     """Re-executions of the batched Q5 run the window / label joins inside the candidate join's resolve phase (one
     kernel, nothing materialised in between); every execution must still equal the oracle, also when the parameters
