@@ -286,7 +286,7 @@ enum {
   RDFGPU_NODE_TOPK = 8,        /* The operators directly above the path in the reference's explore plans (SURVEY §8f-3,
                                   ..Q5 (Execution Plan).snap:5-9): AggregateExec(gby = sort keys, first_value) = DISTINCT,
                                   then SortExec TopK(fetch = k), optionally per group (a batch of queries in one tree).
-                                  left = input; n_keys sort keys (<= 2), all ascending, NULLS FIRST: left_keys[i] = column,
+                                  left = input; n_keys sort keys (<= 3), all ascending, NULLS FIRST: left_keys[i] = column,
                                   right_keys[i] = RDFGPU_SORT_BY_ID (the UInt32 id itself, `product@1 ASC`) or
                                   RDFGPU_SORT_BY_TERM (ENC_SORT of the term: defined here for columns of one kind among
                                   strings / IRIs / blank nodes, whose typed value carries the rank); table_cols = k;

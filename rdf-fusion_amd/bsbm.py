@@ -357,7 +357,7 @@ def q10_plan(ds, product_id, country_id, max_days=3, after="2008-06-20T00:00:00"
     return pb.build(pb.hash_join(node, valid, on=[(0, 0)], projection=[0, 1]))
 
 
-def q4_plan(ds, type_id, feature1, feature2, feature3, threshold1, threshold2):
+def q4_plan(ds, type_id, feature1, feature2, feature3, threshold1, threshold2, topk=False):
     """BSBM Explore Q4 below its DISTINCT / ORDER BY / OFFSET: a UnionExec of two five-join pipelines that differ in the
     second feature and the numeric property filtered (`EBV(GT(ENC_TV(p1), 9:457))` / `EBV(GT(ENC_TV(p2), 9:488))`),
     Q4 (Execution Plan).snap:11-38.  Output: (product, label, propertyTextual)."""
@@ -374,4 +374,7 @@ def q4_plan(ds, type_id, feature1, feature2, feature3, threshold1, threshold2):
         num = pb.filter(pb.data_source(quad_pattern("product", pr[f"bsbm:productPropertyNumeric{k}"], f"p{k}")),
                         EBV(GT(ENC_TV(col(1)), integer(threshold))), projection=[0])
         return pb.hash_join(node, num, on=[(0, 0)], projection=[0, 1, 2])
-    return pb.build(pb.union(branch(feature2, 1, threshold1), branch(feature3, 2, threshold2)))
+    node = pb.union(branch(feature2, 1, threshold1), branch(feature3, 2, threshold2))
+    if topk:    # AggregateExec(gby = the three sort keys, first_value) + SortExec TopK(fetch=15): ORDER BY label, product, propertyTextual
+        node = pb.topk(node, keys=[(1, abi.SORT_BY_TERM), (0, abi.SORT_BY_ID), (2, abi.SORT_BY_ID)], limit=15)
+    return pb.build(node)

@@ -269,7 +269,7 @@ Plan* plan_compile(Store* store, const rdfgpu_plan_desc* d) {
       }
       case RDFGPU_NODE_TOPK: {   // DISTINCT + TopK(fetch) per group, ..Q5 (Execution Plan).snap:5-9
         const NodeInfo& c = child(r.left, "input");
-        if (r.n_keys < 1 || r.n_keys > 2) fail(RDFGPU_ERR_UNSUPPORTED, "node %u: TopK with %u sort keys (1 or 2)", i, r.n_keys);
+        if (r.n_keys < 1 || r.n_keys > 3) fail(RDFGPU_ERR_UNSUPPORTED, "node %u: TopK with %u sort keys (1 to 3)", i, r.n_keys);
         if (r.table_cols < 1 || r.table_cols > 1024) fail(RDFGPU_ERR_UNSUPPORTED, "node %u: TopK fetch = %u", i, r.table_cols);
         for (u32 k = 0; k < r.n_keys; k++) {
           if (r.left_keys[k] >= c.width) fail(RDFGPU_ERR_INVALID, "node %u: sort key column %u out of range", i, r.left_keys[k]);
@@ -778,7 +778,8 @@ DevTable Plan::exec_topk(NodeInfo& nd) {
   RDFGPU_HIP(hipMemsetAsync(a.out_counts, 0, (ng + 1) * sizeof(u32), stream));
   const size_t tb = scan_temp_bytes(ng + 1);
   void* temp = scratch<unsigned char>(tb);
-  const u32 key_bytes = 4 * a.n_keys + 16 * (a.key_by_term[0] + (a.n_keys > 1 ? a.key_by_term[1] : 0));
+  u32 key_bytes = 4 * a.n_keys;
+  for (u32 k = 0; k < a.n_keys; k++) key_bytes += 16 * a.key_by_term[k];
   timed(KC_TOPK_HIST, 0, in.cap, in.n_dev, 4, nullptr, 0, 0, [&] { launch_topk_hist(a, stream); });
   exclusive_scan_u32(a.counts, a.offsets, ng + 1, temp, tb, stream);
   RDFGPU_HIP(hipMemcpyAsync(a.cursor, a.offsets, ng * sizeof(u32), hipMemcpyDeviceToDevice, stream));

@@ -55,26 +55,26 @@ __global__ __launch_bounds__(256) void topk_select_kernel(const TopkArgs a) {
   if (g >= a.n_groups) return;   // whole waves leave together
   const u32 lane = threadIdx.x & 63;
   const u32 begin = a.offsets[g], end = a.offsets[g + 1];
-  u64 p1 = 0, p2 = 0; bool have_prev = false;
+  u64 p1 = 0, p2 = 0, p3 = 0; bool have_prev = false;
   u32 cnt = 0;
   for (u32 r = 0; r < a.k; r++) {
-    u64 b1 = ~0ull, b2 = ~0ull; u32 brow = kNil;
+    u64 b1 = ~0ull, b2 = ~0ull, b3 = ~0ull; u32 brow = kNil;
     for (u32 e = begin + lane; e < end; e += 64) {
       const u32 row = a.perm[e];
-      const u64 k1 = topk_key(a, 0, row), k2 = a.n_keys > 1 ? topk_key(a, 1, row) : 0ull;
-      const bool after_prev = !have_prev || k1 > p1 || (k1 == p1 && k2 > p2);
-      const bool better = brow == kNil || k1 < b1 || (k1 == b1 && k2 < b2);
-      if (after_prev && better) { b1 = k1; b2 = k2; brow = row; }
+      const u64 k1 = topk_key(a, 0, row), k2 = a.n_keys > 1 ? topk_key(a, 1, row) : 0ull, k3 = a.n_keys > 2 ? topk_key(a, 2, row) : 0ull;
+      const bool after_prev = !have_prev || k1 > p1 || (k1 == p1 && (k2 > p2 || (k2 == p2 && k3 > p3)));
+      const bool better = brow == kNil || k1 < b1 || (k1 == b1 && (k2 < b2 || (k2 == b2 && k3 < b3)));
+      if (after_prev && better) { b1 = k1; b2 = k2; b3 = k3; brow = row; }
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
-      const u64 o1 = __shfl_xor(b1, d, 64), o2 = __shfl_xor(b2, d, 64); const u32 orow = __shfl_xor(brow, d, 64);
-      const bool take = orow != kNil && (brow == kNil || o1 < b1 || (o1 == b1 && (o2 < b2 || (o2 == b2 && orow < brow))));
-      if (take) { b1 = o1; b2 = o2; brow = orow; }
+      const u64 o1 = __shfl_xor(b1, d, 64), o2 = __shfl_xor(b2, d, 64), o3 = __shfl_xor(b3, d, 64); const u32 orow = __shfl_xor(brow, d, 64);
+      const bool take = orow != kNil && (brow == kNil || o1 < b1 || (o1 == b1 && (o2 < b2 || (o2 == b2 && (o3 < b3 || (o3 == b3 && orow < brow))))));
+      if (take) { b1 = o1; b2 = o2; b3 = o3; brow = orow; }
     }
     if (brow == kNil) break;        // wave-uniform after the reduction
     if (lane == 0) a.picked[(u64)g * a.k + r] = brow;
-    p1 = b1; p2 = b2; have_prev = true; cnt++;
+    p1 = b1; p2 = b2; p3 = b3; have_prev = true; cnt++;
   }
   if (lane == 0) a.out_counts[g] = cnt;
 }

@@ -362,7 +362,7 @@ class PlanBuilder:
     def topk(self, left, keys, limit, group=None, projection=None):
         """DISTINCT + ORDER BY keys ASC LIMIT `limit` (per `group` column if given) — the AggregateExec(first_value) +
         SortExec TopK(fetch) pair above the path in the reference's explore plans.  keys = [(column, abi.SORT_BY_ID |
-        abi.SORT_BY_TERM), ...] (at most 2)."""
+        abi.SORT_BY_TERM), ...] (at most 3)."""
         n = abi.PlanNode(kind=abi.NODE_TOPK, left=left, right=-1, n_keys=len(keys), table_cols=int(limit),
                          table_slot=0 if group is None else int(group) + 1)
         for i, (c, how) in enumerate(keys):

@@ -774,6 +774,13 @@ def test_topk_distinct_matches_oracle(torch_cuda):
             pb = PlanBuilder()
             desc = pb.build(pb.topk(pb.table(0, 3), keys=[(1, abi.SORT_BY_TERM), (2, abi.SORT_BY_ID)], limit=limit, group=group, projection=proj))
             run_both(gs, os_, desc, gpu_tables=[(ptrs, n)], cpu_tables=[tab])
+        pb = PlanBuilder()                                                 # three keys (Q4's ORDER BY label, product, propertyTextual)
+        four = [g, lab, prod % 7 + 1, prod]
+        keep4, ptrs4 = table_on_device(torch_cuda, four)
+        for group, proj in ((None, [1, 2, 3]), (0, None)):
+            pb = PlanBuilder()
+            run_both(gs, os_, pb.build(pb.topk(pb.table(0, 4), keys=[(1, abi.SORT_BY_TERM), (2, abi.SORT_BY_ID), (3, abi.SORT_BY_ID)], limit=limit + 10,
+                                               group=group, projection=proj)), gpu_tables=[(ptrs4, n)], cpu_tables=[four])
         pb = PlanBuilder()                                                 # one key, by id
         run_both(gs, os_, pb.build(pb.topk(pb.table(0, 3), keys=[(2, abi.SORT_BY_ID)], limit=limit, group=0, projection=[0, 2])),
                  gpu_tables=[(ptrs, n)], cpu_tables=[tab])
@@ -978,6 +985,10 @@ def test_bsbm_q4_matches_oracle(bsbm_stores):
         plan, got = run_both(gs, os_, bsbm.q4_plan(ds, ds.type_base + ds.n_types - 1, f1, f2, f3, int(rng.integers(100, 900)), int(rng.integers(100, 900))))
         total += plan.result_info()[0]
     assert total > 5
+    # the whole query: + DISTINCT + ORDER BY label, product, propertyTextual + TopK(fetch = 15) (Q4 (Execution Plan).snap:7-8;
+    # the OFFSET 5 above it, GlobalLimitExec, drops rows of a 15-row table on the host)
+    plan, got = run_both(gs, os_, bsbm.q4_plan(ds, ds.type_base + ds.n_types - 1, f1, f2, f3, 200, 300, topk=True))
+    assert 0 < plan.result_info()[0] <= 15
 
 
 def test_lang_matches_filter_matches_oracle(torch_cuda):
