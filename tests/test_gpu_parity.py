@@ -21,13 +21,6 @@ import os
 ENGINE_TOGGLED = any(k.startswith(("RDFGPU_NO_", "RDFGPU_FORCE_")) for k in os.environ)   # a debugging toggle is set for the whole run
 
 
-@pytest.fixture(scope="module")
-def torch_cuda():
-    import torch
-    assert torch.cuda.is_available(), "these tests need the MI355X"
-    return torch
-
-
 def both_stores(quads, batch=8192, typed=None, decimals=None):
     g, s, p, o = ku.quad_columns(quads) if not isinstance(quads, tuple) else quads
     gs, os_ = rf.GpuQuadStore(batch_size=batch), orc.OracleStore(batch_size=batch)
