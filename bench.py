@@ -110,6 +110,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=14, help="Q5 instances timed on the CPU oracle (rank 0, N=1)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-shard-check", action="store_true", help="N > 1: skip comparing the shards' bindings with an unsharded run on rank 0")
+    ap.add_argument("--no-overlap", action="store_true", help="N > 1: run exchange and join pipeline of a step back to back instead of pipelining steps")
     ap.add_argument("--no-scan", action="store_true", help="skip the scaled scan+FILTER roofline measurement")
     ap.add_argument("--scan-log2-rows", type=int, default=26)
     args = ap.parse_args()
@@ -236,23 +237,19 @@ def main():
         plan_b = store.plan(bsbm.q5_batch_plan(ds, tables=True))
         ex = sharding.BatchExchange(Q, world)                # fixed-size, zero-padded exchange buffer (one all-gather per step)
         buf_len = ex.buf_len
-        send_buf = torch.zeros(buf_len, dtype=torch.int32, device="cuda")
+        send_bufs = [torch.zeros(buf_len, dtype=torch.int32, device="cuda") for _ in range(2)]
 
         class _DevCol:
             """A result column in HBM, as torch sees it (zero copy)."""
             def __init__(self, ptr, n):
                 self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<i4", "data": (int(ptr), False), "version": 2}
 
-        def step(batch, timing):
+        def phase_a(batch, timing, slot):
             """Phase A: the constant-subject patterns of the whole batch on the local shard, joined per instance:
-            C(inst, X, prodFeature, origProperty1, origProperty2) for the instances whose %Product% lives here.
-            Exchange: ONE all-gather of a fixed-size, zero-padded buffer holding C — a padding row has inst = 0 = null,
-            and a null key never joins (NullEqualsNothing), so the gathered buffer is bound as it is: no counts
-            travel, nothing is unpacked on the host.
-            Phase B: the batch's join / FILTER pipeline over the local shard of the product-side patterns."""
-            t_a = time.perf_counter()
+            C(inst, X, prodFeature, origProperty1, origProperty2) for the instances whose %Product% lives here, packed
+            into this step's fixed-size, zero-padded send buffer."""
             t, ptrs, n = params_on_device(batch)
-            mine = send_buf.zero_()
+            mine = send_bufs[slot].zero_()
             plan_a.bind_table(0, ptrs, n)
             plan_a.enable_kernel_timing(timing)
             plan_a.execute()
@@ -261,35 +258,77 @@ def main():
             cols, rows = plan_a.result_device()
             ex.pack(mine, [torch.as_tensor(_DevCol(c, rows), device="cuda") if rows else None for c in cols], rows)
             torch.cuda.current_stream().synchronize()
-            t_x = time.perf_counter()
+            return mine
+
+        def exchange_start(mine):
+            """ONE all-gather of the buffer holding C — a padding row has inst = 0 = null, and a null key never joins
+            (NullEqualsNothing), so the gathered buffer is bound as it is: no counts travel, nothing is unpacked on the
+            host.  Asynchronous: the collective runs on RCCL's stream while this rank computes."""
             send = mine.to(xdev)
             out = torch.empty(world * buf_len, dtype=torch.int32, device=send.device)
-            dist.all_gather_into_tensor(out, send)
+            return dist.all_gather_into_tensor(out, send, async_op=True), out, send
+
+        def phase_b(pending, timing):
+            """Phase B: the batch's join / FILTER pipeline over the local shard of the product-side patterns, probing
+            with the gathered C."""
+            work, out, _send = pending
+            t_w = time.perf_counter()
+            work.wait()
             keep = ex.unpack(out.to("cuda"))                  # (5, world * cap): one contiguous column per variable
             rows_all = keep.shape[1]
             plan_b.bind_table(0, [keep.data_ptr() + 4 * rows_all * k for k in range(ex.N_COLS)], rows_all)
-            torch.cuda.current_stream().synchronize()      # the tables are complete before the plan's stream reads them
+            torch.cuda.current_stream().synchronize()      # the table is complete before the plan's stream reads it
             t_b = time.perf_counter()
             plan_b.enable_kernel_timing(timing)
             plan_b.execute()
             rows, _ = plan_b.result_info()
             if timing:
                 account(plan_b)
-                phase_ms[0] += (t_x - t_a) * 1e3; phase_ms[1] += (t_b - t_x) * 1e3; phase_ms[2] += (time.perf_counter() - t_b) * 1e3
+                phase_ms[1] += (t_b - t_w) * 1e3             # what is left of the exchange after the overlap + the table layout
+                phase_ms[2] += (time.perf_counter() - t_b) * 1e3
             return rows
+
+        def step(batch, timing):
+            """one batch, start to end (the sharded-result check; the timed loop pipelines the same three phases)"""
+            return phase_b(exchange_start(phase_a(batch, timing, 0)), timing)
+
+        def run_pipelined(bs, timing):
+            """Software pipeline over independent batches: the all-gather of batch i + 1 is in flight while phase B of
+            batch i runs (two send buffers; each gather has its own output).  Same work per batch as step()."""
+            total, pending = 0, None
+            for i, b in enumerate(bs):
+                t_a = time.perf_counter()
+                mine = phase_a(b, timing, i & 1)
+                t_x = time.perf_counter()
+                nxt = exchange_start(mine)
+                if timing:
+                    phase_ms[0] += (t_x - t_a) * 1e3; phase_ms[1] += (time.perf_counter() - t_x) * 1e3
+                if pending is not None:
+                    total += phase_b(pending, timing)
+                pending = nxt
+            if pending is not None:
+                total += phase_b(pending, timing)
+            return total
 
     if not args.per_instance:
         for b in batches:
             params_on_device(b)
         torch.cuda.synchronize()
-    for b in batches[:args.warmup]:
-        step(b, False)
+    overlap = world > 1 and not args.no_overlap
+    if overlap:
+        run_pipelined(batches[:args.warmup], False)
+    else:
+        for b in batches[:args.warmup]:
+            step(b, False)
     kstats.clear(); lat_ms.clear()
     barrier()
     t0 = time.perf_counter()
     local_rows = 0
-    for b in batches[args.warmup:]:
-        local_rows += step(b, True)
+    if overlap:
+        local_rows = run_pipelined(batches[args.warmup:], True)
+    else:
+        for b in batches[args.warmup:]:
+            local_rows += step(b, True)
     barrier()
     elapsed = time.perf_counter() - t0
 
@@ -460,6 +499,7 @@ def main():
                        "mode": "per-instance" if args.per_instance else "batched",
                        "triples_per_gpu": n_local, "sharding": "hash(subject) mod N, all-gatherv of constant-pattern bindings" if world > 1 else "none",
                        "sharded_result_check": shard_check,
+                       "exchange_overlapped_with_next_step": bool(world > 1 and not args.no_overlap),
                        "rank0_phase_ms_per_step": ({"constant_patterns": round(phase_ms[0] / args.steps, 3), "exchange": round(phase_ms[1] / args.steps, 3),
                                                     "join_pipeline": round(phase_ms[2] / args.steps, 3)} if world > 1 else None),
                        "queries_per_s": round(n_q / elapsed, 2), "bindings": total_rows,
