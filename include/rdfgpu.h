@@ -301,7 +301,13 @@ enum {
                                   through the inner paths of any graph while keeping the first path's graph (join_type = 1 =
                                   allow_cross_graph_paths).  A null start / end is an execution error, as in the reference. */
 };
-enum { RDFGPU_SORT_BY_ID = 0, RDFGPU_SORT_BY_TERM = 1 };
+enum { RDFGPU_SORT_BY_ID = 0, RDFGPU_SORT_BY_TERM = 1,
+       RDFGPU_SORT_BY_DOUBLE = 2 /* ENC_SORT of a numeric value: the sortable encoding orders numerics by Double::from(Numeric)
+                                    (lib/encoding/src/sortable_term/builder.rs:36-39, lib/model/src/xsd/double.rs:92-102) in IEEE
+                                    total order (-0 < +0, NaN last); unbound and non-numeric values sort first (the `xsd:double(...)`
+                                    cast of BSBM explore Q10's ORDER BY yields an error = null for them).  Exact for Q10, whose
+                                    prices are xsd:double literals; a decimal's cast goes through its lexical form in the
+                                    reference and through the Decimal -> Double conversion here.                            */ };
 enum { RDFGPU_JOIN_INNER = 0, RDFGPU_JOIN_LEFT = 1 };
 #define RDFGPU_MAX_KEYS 4u
 #define RDFGPU_MAX_COLUMNS 16u

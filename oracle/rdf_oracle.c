@@ -894,6 +894,13 @@ static int exec_topk(const pctx* c, const rdfgpu_plan_node* nd, orc_table* out) 
       const u32 id = in.cols[nd->left_keys[i]][r];
       if (nd->right_keys[i] == RDFGPU_SORT_BY_ID) { rows[r].k[i] = id; continue; }
       const val v = enc_tv(c->s, id);   /* NULLS FIRST: tag 0 sorts before everything */
+      if (nd->right_keys[i] == RDFGPU_SORT_BY_DOUBLE) {   /* sortable_term/builder.rs:36-39: numerics order by Double::from(Numeric); f64 total order */
+        const int nk = num_kind(v.tag);
+        if (nk == NK_NONE) { rows[r].k[i] = 0; continue; }
+        double d = to_f64(&v, nk); u64 bits; memcpy(&bits, &d, 8);
+        rows[r].k[i] = (bits >> 63) ? ~bits : (bits | 0x8000000000000000ull);
+        continue;
+      }
       if (v.tag != RDFGPU_TV_NULL && v.tag != RDFGPU_TV_STRING && v.tag != RDFGPU_TV_NAMED_NODE && v.tag != RDFGPU_TV_BLANK_NODE) {
         free(rows); orc_table_free(&in); FAIL("TopK: sort by term over a typed value of tag %u", v.tag);
       }

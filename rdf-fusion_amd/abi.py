@@ -32,7 +32,7 @@ TVF_EMPTY_STRING = 1
 # plan nodes
 (NODE_DATA_SOURCE, NODE_FILTER, NODE_HASH_JOIN, NODE_CROSS_JOIN, NODE_NESTED_LOOP_JOIN,
  NODE_PROJECTION, NODE_TABLE, NODE_TOPK, NODE_UNION, NODE_CLOSURE) = range(1, 11)
-SORT_BY_ID, SORT_BY_TERM = 0, 1
+SORT_BY_ID, SORT_BY_TERM, SORT_BY_DOUBLE = 0, 1, 2
 JOIN_INNER, JOIN_LEFT = 0, 1
 MAX_KEYS = 4
 MAX_COLUMNS = 16

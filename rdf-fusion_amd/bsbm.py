@@ -337,7 +337,7 @@ def q1_instance(ds, rng):
     return int(types.min()), int(f[0]), int(f[1]), int(rng.integers(1, 501))
 
 
-def q10_plan(ds, product_id, country_id, max_days=3, after="2008-06-20T00:00:00"):
+def q10_plan(ds, product_id, country_id, max_days=3, after="2008-06-20T00:00:00", topk=False):
     """BSBM Explore Q10 below its DISTINCT / ORDER BY: six chained hash joins on ?offer / ?vendor with the FilterExecs
     `EBV(LEQ(ENC_TV(deliveryDays), 9:3))` and `EBV(GT(ENC_TV(date), 10:{value:6334951680000.0000000000000000,offset:}))`
     (BSBM Explore - Q10 (Execution Plan).snap:12-27; the dateTime literal is timeOnTimeline("2008-06-20T00:00:00") =
@@ -354,7 +354,10 @@ def q10_plan(ds, product_id, country_id, max_days=3, after="2008-06-20T00:00:00"
     node = pb.hash_join(node, pb.data_source(quad_pattern("offer", pr["bsbm:price"], "price")), on=[(0, 0)], projection=[0, 2])
     valid = pb.filter(pb.data_source(quad_pattern("offer", pr["bsbm:validTo"], "date")),
                       EBV(GT(ENC_TV(col(1)), date_time(*xsd.parse_date_time(after)))), projection=[0])
-    return pb.build(pb.hash_join(node, valid, on=[(0, 0)], projection=[0, 1]))
+    node = pb.hash_join(node, valid, on=[(0, 0)], projection=[0, 1])
+    if topk:   # DISTINCT + ORDER BY xsd:double(str(?price)), ?offer, ?price LIMIT 10  (Q10 (Execution Plan).snap:6-8)
+        node = pb.topk(node, keys=[(1, abi.SORT_BY_DOUBLE), (0, abi.SORT_BY_ID), (1, abi.SORT_BY_ID)], limit=10)
+    return pb.build(node)
 
 
 def q4_plan(ds, type_id, feature1, feature2, feature3, threshold1, threshold2, topk=False):

@@ -273,7 +273,7 @@ Plan* plan_compile(Store* store, const rdfgpu_plan_desc* d) {
         if (r.table_cols < 1 || r.table_cols > 1024) fail(RDFGPU_ERR_UNSUPPORTED, "node %u: TopK fetch = %u", i, r.table_cols);
         for (u32 k = 0; k < r.n_keys; k++) {
           if (r.left_keys[k] >= c.width) fail(RDFGPU_ERR_INVALID, "node %u: sort key column %u out of range", i, r.left_keys[k]);
-          if (r.right_keys[k] > RDFGPU_SORT_BY_TERM) fail(RDFGPU_ERR_INVALID, "node %u: unknown sort mode %u", i, r.right_keys[k]);
+          if (r.right_keys[k] > RDFGPU_SORT_BY_DOUBLE) fail(RDFGPU_ERR_INVALID, "node %u: unknown sort mode %u", i, r.right_keys[k]);
         }
         if (r.table_slot > c.width) fail(RDFGPU_ERR_INVALID, "node %u: group column out of range", i);
         load_projection(nd, d, c.width, "TopK");
@@ -752,7 +752,7 @@ DevTable Plan::exec_topk(NodeInfo& nd) {
   a.n_in_dev = in.n_dev; a.n_in_cap = in.cap;
   a.has_group = nd.d.table_slot != 0; a.group_col = a.has_group ? nd.d.table_slot - 1 : 0;
   a.n_keys = nd.d.n_keys;
-  for (u32 k = 0; k < a.n_keys; k++) { a.key_col[k] = nd.d.left_keys[k]; a.key_by_term[k] = nd.d.right_keys[k] == RDFGPU_SORT_BY_TERM; }
+  for (u32 k = 0; k < a.n_keys; k++) { a.key_col[k] = nd.d.left_keys[k]; a.key_by_term[k] = nd.d.right_keys[k]; }   // RDFGPU_SORT_BY_*
   a.k = nd.d.table_cols;
   a.tt = store->typed_table();
   u64* n_out = new_counter();
@@ -779,7 +779,7 @@ DevTable Plan::exec_topk(NodeInfo& nd) {
   const size_t tb = scan_temp_bytes(ng + 1);
   void* temp = scratch<unsigned char>(tb);
   u32 key_bytes = 4 * a.n_keys;
-  for (u32 k = 0; k < a.n_keys; k++) key_bytes += 16 * a.key_by_term[k];
+  for (u32 k = 0; k < a.n_keys; k++) key_bytes += a.key_by_term[k] ? 16 : 0;
   timed(KC_TOPK_HIST, 0, in.cap, in.n_dev, 4, nullptr, 0, 0, [&] { launch_topk_hist(a, stream); });
   exclusive_scan_u32(a.counts, a.offsets, ng + 1, temp, tb, stream);
   RDFGPU_HIP(hipMemcpyAsync(a.cursor, a.offsets, ng * sizeof(u32), hipMemcpyDeviceToDevice, stream));

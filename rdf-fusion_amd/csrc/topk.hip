@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 
 #include "join_device.hpp"
+#include "expr_device.hpp"
 
 namespace rdfgpu {
 
@@ -41,8 +42,15 @@ __global__ __launch_bounds__(256) void topk_scatter_kernel(const TopkArgs a) {
 // strings / IRIs / blank nodes of one kind); tag 0 (null / unbound) sorts first (NULLS FIRST)
 __device__ __forceinline__ u64 topk_key(const TopkArgs& a, u32 which, u32 row) {
   const u32 id = a.in[a.key_col[which]][row];
-  if (!a.key_by_term[which]) return id;
+  if (a.key_by_term[which] == RDFGPU_SORT_BY_ID) return id;
   if (id == 0 || id >= a.tt.n_ids) return 0;
+  if (a.key_by_term[which] == RDFGPU_SORT_BY_DOUBLE) {   // Double::from(Numeric) in IEEE total order; everything else first
+    const Val v = enc_tv(a.tt, id);
+    const int k = num_kind(v.tag);
+    if (k == NK_NONE) return 0;
+    const u64 bits = (u64)__double_as_longlong(to_f64(v, k));
+    return (bits >> 63) ? ~bits : (bits | 0x8000000000000000ull);
+  }
   const int4 raw = *reinterpret_cast<const int4*>(a.tt.tv + id);
   const u32 tag = (u32)raw.w & 0xff;
   if (tag != RDFGPU_TV_STRING && tag != RDFGPU_TV_NAMED_NODE && tag != RDFGPU_TV_BLANK_NODE && tag != RDFGPU_TV_NULL) *a.bad = 1u;

@@ -777,6 +777,17 @@ def test_topk_distinct_matches_oracle(torch_cuda):
         pb = PlanBuilder()                                                 # one key, by id
         run_both(gs, os_, pb.build(pb.topk(pb.table(0, 3), keys=[(2, abi.SORT_BY_ID)], limit=limit, group=0, projection=[0, 2])),
                  gpu_tables=[(ptrs, n)], cpu_tables=[tab])
+    # ORDER BY a numeric value (ENC_SORT of a numeric = Double::from(Numeric), total order; Q10's xsd:double(str(?price)))
+    import test_oracle_pyarrow as tp
+    tvn, decn, _ = tp.numeric_table(np.random.default_rng(6), 400)
+    gn, on_ = both_stores((np.zeros(0, np.uint32),) * 4, typed=tvn, decimals=decn)
+    for n, limit, n_groups in ((0, 5, 1), (5000, 40, 1), (60_000, 7, 500)):
+        tab = [rng.integers(1, n_groups + 1, n).astype(np.uint32), rng.integers(1, 50, n).astype(np.uint32), rng.integers(0, 402, n).astype(np.uint32)]
+        keep, ptrs = table_on_device(torch_cuda, tab)
+        for group in (None, 0):
+            pb = PlanBuilder()
+            run_both(gn, on_, pb.build(pb.topk(pb.table(0, 3), keys=[(2, abi.SORT_BY_DOUBLE), (1, abi.SORT_BY_ID), (2, abi.SORT_BY_ID)], limit=limit, group=group,
+                                               projection=[1, 2] if group is None else None)), gpu_tables=[(ptrs, n)], cpu_tables=[tab])
     # a numeric column cannot be ordered as a term here: refused loudly
     tv2 = tv.copy(); tv2["tag"][5] = abi.TV_INTEGER
     gs2, _ = both_stores((np.zeros(0, np.uint32),) * 4, typed=tv2)
@@ -1025,6 +1036,10 @@ def test_bsbm_q10_matches_oracle(bsbm_stores):
         plan, got = run_both(gs, os_, bsbm.q10_plan(ds, ds.product(i * 7), ds.country_base + i % ds.n_countries, max_days=9, after="2004-03-01T06:00:00"))
         total += plan.result_info()[0]
     plan, got = run_both(gs, os_, bsbm.q10_plan(ds, ds.product(1), ds.country_base))      # the query's own constants
+    # the whole query: + DISTINCT + ORDER BY xsd:double(str(?price)), ?offer, ?price LIMIT 10 (Q10 (Execution Plan).snap:6-8)
+    for i in range(6):
+        plan, got = run_both(gs, os_, bsbm.q10_plan(ds, ds.product(i * 7), ds.country_base + i % ds.n_countries, max_days=21, after="2001-03-01T06:00:00", topk=True))
+        assert plan.result_info()[0] <= 10
     assert total > 10
 
 

@@ -125,3 +125,58 @@ def test_acero_batched_q5_baseline_equals_oracle():
         batch = np.array([ds.product(i) for i in rng.choice(ds.n_products, batch_size, replace=False)], dtype=np.uint32)
         cols, n, _ = st.execute(bsbm.q5_batch_plan(ds), [[np.arange(1, batch_size + 1, dtype=np.uint32), batch]])
         np.testing.assert_array_equal(ku.multiset(ab.run(prep, batch)), ku.multiset(cols, n))
+
+
+def numeric_table(rng, n_ids):
+    """ids 1.. : int / integer / float / double / decimal values incl. -0.0, NaN, equal values of different kinds; a string and an IRI"""
+    import struct
+    tv = np.zeros(n_ids, dtype=TV_DTYPE)
+    dec, values = [], [None] * n_ids
+    specials = [0.0, -0.0, float("nan"), float("inf"), -float("inf"), 1.5, -1.5, 2.0]
+    for i in range(1, n_ids - 2):
+        kind = int(rng.integers(0, 5))
+        if kind == 0:
+            v = int(rng.integers(-50, 50)); tv["tag"][i], tv["lo"][i] = abi.TV_INT, v; values[i] = float(v)
+        elif kind == 1:
+            v = int(rng.integers(-10 ** 12, 10 ** 12)); tv["tag"][i], tv["lo"][i] = abi.TV_INTEGER, v; values[i] = float(v)
+        elif kind == 2:
+            v = np.float32(specials[int(rng.integers(0, 8))] if rng.random() < 0.4 else rng.normal() * 10)
+            tv["tag"][i], tv["lo"][i] = abi.TV_FLOAT, int(v.view(np.uint32)); values[i] = float(v)
+        elif kind == 3:
+            v = specials[int(rng.integers(0, 8))] if rng.random() < 0.4 else float(rng.normal() * 1000)
+            tv["tag"][i], tv["lo"][i] = abi.TV_DOUBLE, struct.unpack("<q", struct.pack("<d", v))[0]; values[i] = v
+        else:
+            q = int(rng.integers(-5000, 5000))                      # quarters: exact in binary
+            raw = q * 25 * 10 ** 16
+            tv["tag"][i], tv["lo"][i] = abi.TV_DECIMAL, len(dec)
+            dec.append([raw & ((1 << 64) - 1), (raw >> 64) & ((1 << 64) - 1)]); values[i] = q / 4
+    tv["tag"][n_ids - 2], tv["lo"][n_ids - 2] = abi.TV_STRING, 1
+    tv["tag"][n_ids - 1], tv["lo"][n_ids - 1] = abi.TV_NAMED_NODE, 2
+    return tv, np.array(dec, dtype=np.uint64).astype(np.int64).reshape(-1, 2), values
+
+
+def total_order_key(v):
+    import struct
+    if v is None:
+        return 0                                                    # unbound / not a number: first
+    bits = struct.unpack("<Q", struct.pack("<d", v))[0]
+    return (~bits) & ((1 << 64) - 1) if bits >> 63 else bits | (1 << 63)
+
+
+def test_topk_by_numeric_value_agrees_with_python_sorting():
+    """RDFGPU_SORT_BY_DOUBLE (ENC_SORT of a numeric: Double::from(Numeric), IEEE total order, everything else first) in
+    the oracle vs Python: mixed numeric kinds, -0.0 < +0.0, NaN last, ties broken by the next key."""
+    from rdf_fusion_amd.plan import PlanBuilder as PB
+    rng = np.random.default_rng(6)
+    tv, dec, values = numeric_table(rng, 400)
+    os_ = orc.OracleStore()
+    os_.set_typed_values(tv, dec)
+    for n, limit in ((0, 5), (3000, 40), (200, 300)):
+        price = rng.integers(0, 402, n).astype(np.uint32)                 # incl. unbound (0) and an id beyond the table
+        offer = rng.integers(1, 50, n).astype(np.uint32)
+        pb = PB()
+        desc = pb.build(pb.topk(pb.table(0, 2), keys=[(1, abi.SORT_BY_DOUBLE), (0, abi.SORT_BY_ID), (1, abi.SORT_BY_ID)], limit=limit))
+        cols, m, _ = os_.execute(desc, [[offer, price]])
+        key = lambda o, p: (total_order_key(values[p] if 0 < p < 400 else None), o, p)
+        exp = sorted(set(key(int(o), int(p)) for o, p in zip(offer, price)))[:limit]
+        assert [(int(o), int(p)) for o, p in zip(cols[0][:m], cols[1][:m])] == [(o, p) for _, o, p in exp]
