@@ -286,12 +286,16 @@ enum {
   RDFGPU_NODE_TOPK = 8,        /* The operators directly above the path in the reference's explore plans (SURVEY §8f-3,
                                   ..Q5 (Execution Plan).snap:5-9): AggregateExec(gby = sort keys, first_value) = DISTINCT,
                                   then SortExec TopK(fetch = k), optionally per group (a batch of queries in one tree).
-                                  left = input; n_keys sort keys (<= 3), all ascending, NULLS FIRST: left_keys[i] = column,
-                                  right_keys[i] = RDFGPU_SORT_BY_ID (the UInt32 id itself, `product@1 ASC`) or
+                                  left = input; n_keys sort keys (<= 4), all ascending, NULLS FIRST: left_keys[i] = column,
+                                  right_keys[i] = RDFGPU_SORT_BY_ID (the UInt32 id itself, `product@1 ASC`),
                                   RDFGPU_SORT_BY_TERM (ENC_SORT of the term: defined here for columns of one kind among
-                                  strings / IRIs / blank nodes, whose typed value carries the rank); table_cols = k;
-                                  table_slot = 1 + group column (0 = one group).  Rows equal on (group, keys) collapse to
-                                  one; every output column must be the group column or a key column.               */
+                                  strings / IRIs / blank nodes, whose typed value carries the rank) or
+                                  RDFGPU_SORT_BY_DOUBLE; table_cols = k; table_slot = 1 + group column (0 = one group).
+                                  Rows equal on (group, keys) collapse to one.  The reference's AggregateExec groups by the
+                                  sort expressions AND the raw columns (`gby=[ENC_SORT(..), product, productLabel]`), so two
+                                  terms that sort alike stay two rows: every output column must be the group column or a key
+                                  BY_ID — the host appends the remaining gby columns as trailing BY_ID keys (which also makes
+                                  the order among ties of the declared ORDER BY deterministic).                          */
   RDFGPU_NODE_UNION = 9,       /* UnionExec: the rows of `left` followed by the rows of `right` (bag union; both inputs have
                                   the same columns) — SPARQL UNION as planned in BSBM Explore - Q4 / Q11 (Execution Plan).snap;
                                   optional projection */

@@ -866,30 +866,30 @@ done:
 
 /* DISTINCT + TopK per group (..Q5 (Execution Plan).snap:5-9: AggregateExec gby = sort keys with first_value, then
    SortExec TopK(fetch)): sort rows by (group, keys), drop adjacent duplicates, keep the first k of every group. */
-typedef struct { u32 g; u64 k[3]; u64 row; } topk_row;
+typedef struct { u32 g; u64 k[4]; u64 row; } topk_row;
 static int topk_cmp(const void* a, const void* b) {
   const topk_row* x = (const topk_row*)a; const topk_row* y = (const topk_row*)b;
   if (x->g != y->g) return x->g < y->g ? -1 : 1;
-  for (int i = 0; i < 3; i++) if (x->k[i] != y->k[i]) return x->k[i] < y->k[i] ? -1 : 1;
+  for (int i = 0; i < 4; i++) if (x->k[i] != y->k[i]) return x->k[i] < y->k[i] ? -1 : 1;
   return 0;
 }
 static int exec_topk(const pctx* c, const rdfgpu_plan_node* nd, orc_table* out) {
   orc_table in; memset(&in, 0, sizeof in);
   if (exec_node(c, (u32)nd->left, &in)) return -1;
   const u32* proj; u32 np; if (out_width(c, nd, in.n_cols, &proj, &np)) { orc_table_free(&in); return -1; }
-  if (nd->n_keys < 1 || nd->n_keys > 3) { orc_table_free(&in); FAIL("TopK needs 1 to 3 sort keys"); }
+  if (nd->n_keys < 1 || nd->n_keys > 4) { orc_table_free(&in); FAIL("TopK needs 1 to 4 sort keys"); }
   const int has_group = nd->table_slot != 0; const u32 gcol = has_group ? nd->table_slot - 1 : 0;
   for (u32 i = 0; i < nd->n_keys; i++) if (nd->left_keys[i] >= in.n_cols) { orc_table_free(&in); FAIL("TopK: key column out of range"); }
   if (has_group && gcol >= in.n_cols) { orc_table_free(&in); FAIL("TopK: group column out of range"); }
   for (u32 q = 0; q < np; q++) {
     const u32 pc = proj ? proj[q] : q;
     int covered = has_group && pc == gcol;
-    for (u32 i = 0; i < nd->n_keys; i++) covered = covered || pc == nd->left_keys[i];
-    if (!covered) { orc_table_free(&in); FAIL("TopK: output column %u is neither the group nor a sort key", pc); }
+    for (u32 i = 0; i < nd->n_keys; i++) covered = covered || (pc == nd->left_keys[i] && nd->right_keys[i] == RDFGPU_SORT_BY_ID);
+    if (!covered) { orc_table_free(&in); FAIL("TopK: output column %u is neither the group nor a sort key by id", pc); }
   }
   topk_row* rows = (topk_row*)malloc((in.n_rows ? in.n_rows : 1) * sizeof(topk_row));
   for (u64 r = 0; r < in.n_rows; r++) {
-    rows[r].g = has_group ? in.cols[gcol][r] : 0; rows[r].row = r; rows[r].k[1] = 0; rows[r].k[2] = 0;
+    rows[r].g = has_group ? in.cols[gcol][r] : 0; rows[r].row = r; rows[r].k[1] = 0; rows[r].k[2] = 0; rows[r].k[3] = 0;
     for (u32 i = 0; i < nd->n_keys; i++) {
       const u32 id = in.cols[nd->left_keys[i]][r];
       if (nd->right_keys[i] == RDFGPU_SORT_BY_ID) { rows[r].k[i] = id; continue; }

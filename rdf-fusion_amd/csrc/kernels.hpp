@@ -222,7 +222,7 @@ struct TopkArgs {
   const u32* in[kMaxCols];
   const u64* n_in_dev; u64 n_in_cap;
   u32 has_group, group_col;
-  u32 n_keys, key_col[3], key_by_term[3];
+  u32 n_keys, key_col[4], key_by_term[4];   // key_by_term[i] = RDFGPU_SORT_BY_*
   u32 k, n_groups;            // rows kept per group; group ids are < n_groups
   TypedTable tt;
   u32* counts;                // [n_groups + 1], zeroed: rows per group

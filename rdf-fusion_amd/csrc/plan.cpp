@@ -269,7 +269,7 @@ Plan* plan_compile(Store* store, const rdfgpu_plan_desc* d) {
       }
       case RDFGPU_NODE_TOPK: {   // DISTINCT + TopK(fetch) per group, ..Q5 (Execution Plan).snap:5-9
         const NodeInfo& c = child(r.left, "input");
-        if (r.n_keys < 1 || r.n_keys > 3) fail(RDFGPU_ERR_UNSUPPORTED, "node %u: TopK with %u sort keys (1 to 3)", i, r.n_keys);
+        if (r.n_keys < 1 || r.n_keys > RDFGPU_MAX_KEYS) fail(RDFGPU_ERR_UNSUPPORTED, "node %u: TopK with %u sort keys (1 to %u)", i, r.n_keys, RDFGPU_MAX_KEYS);
         if (r.table_cols < 1 || r.table_cols > 1024) fail(RDFGPU_ERR_UNSUPPORTED, "node %u: TopK fetch = %u", i, r.table_cols);
         for (u32 k = 0; k < r.n_keys; k++) {
           if (r.left_keys[k] >= c.width) fail(RDFGPU_ERR_INVALID, "node %u: sort key column %u out of range", i, r.left_keys[k]);
@@ -279,8 +279,8 @@ Plan* plan_compile(Store* store, const rdfgpu_plan_desc* d) {
         load_projection(nd, d, c.width, "TopK");
         for (u32 q = 0; q < nd.n_proj; q++) {   // DISTINCT is over (group, keys): the output may not carry anything else
           bool covered = r.table_slot != 0 && nd.proj[q] == r.table_slot - 1;
-          for (u32 k = 0; k < r.n_keys; k++) covered = covered || nd.proj[q] == r.left_keys[k];
-          if (!covered) fail(RDFGPU_ERR_UNSUPPORTED, "node %u: TopK output column %u is neither the group nor a sort key", i, nd.proj[q]);
+          for (u32 k = 0; k < r.n_keys; k++) covered = covered || (nd.proj[q] == r.left_keys[k] && r.right_keys[k] == RDFGPU_SORT_BY_ID);
+          if (!covered) fail(RDFGPU_ERR_UNSUPPORTED, "node %u: TopK output column %u is neither the group nor a sort key by id", i, nd.proj[q]);
         }
         nd.width = nd.n_proj;
         break;

@@ -14,6 +14,8 @@
 
 namespace rdfgpu {
 
+constexpr int kTopkKeys = 4;   // = RDFGPU_MAX_KEYS
+
 __global__ __launch_bounds__(256) void topk_max_kernel(const u32* col, const u64* n_dev, u64 cap, u32* out_max) {
   const u64 n = live_rows(n_dev, cap);
   u32 hi = 0;
@@ -63,26 +65,53 @@ __global__ __launch_bounds__(256) void topk_select_kernel(const TopkArgs a) {
   if (g >= a.n_groups) return;   // whole waves leave together
   const u32 lane = threadIdx.x & 63;
   const u32 begin = a.offsets[g], end = a.offsets[g + 1];
-  u64 p1 = 0, p2 = 0, p3 = 0; bool have_prev = false;
+  u64 prev[kTopkKeys] = {0, 0, 0, 0}; bool have_prev = false;
   u32 cnt = 0;
+  auto less = [](const u64* x, const u64* y) {   // lexicographic over the key tuple
+    bool lt = false, decided = false;
+#pragma unroll
+    for (int i = 0; i < kTopkKeys; i++) if (!decided && x[i] != y[i]) { lt = x[i] < y[i]; decided = true; }
+    return lt;
+  };
+  auto same = [](const u64* x, const u64* y) {
+    bool eq = true;
+#pragma unroll
+    for (int i = 0; i < kTopkKeys; i++) eq = eq && x[i] == y[i];
+    return eq;
+  };
   for (u32 r = 0; r < a.k; r++) {
-    u64 b1 = ~0ull, b2 = ~0ull, b3 = ~0ull; u32 brow = kNil;
+    u64 best[kTopkKeys] = {~0ull, ~0ull, ~0ull, ~0ull}; u32 brow = kNil;
     for (u32 e = begin + lane; e < end; e += 64) {
       const u32 row = a.perm[e];
-      const u64 k1 = topk_key(a, 0, row), k2 = a.n_keys > 1 ? topk_key(a, 1, row) : 0ull, k3 = a.n_keys > 2 ? topk_key(a, 2, row) : 0ull;
-      const bool after_prev = !have_prev || k1 > p1 || (k1 == p1 && (k2 > p2 || (k2 == p2 && k3 > p3)));
-      const bool better = brow == kNil || k1 < b1 || (k1 == b1 && (k2 < b2 || (k2 == b2 && k3 < b3)));
-      if (after_prev && better) { b1 = k1; b2 = k2; b3 = k3; brow = row; }
+      u64 cur[kTopkKeys];
+#pragma unroll
+      for (int i = 0; i < kTopkKeys; i++) cur[i] = (u32)i < a.n_keys ? topk_key(a, (u32)i, row) : 0ull;
+      const bool after_prev = !have_prev || less(prev, cur);
+      const bool better = brow == kNil || less(cur, best);
+      if (after_prev && better) {
+#pragma unroll
+        for (int i = 0; i < kTopkKeys; i++) best[i] = cur[i];
+        brow = row;
+      }
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
-      const u64 o1 = __shfl_xor(b1, d, 64), o2 = __shfl_xor(b2, d, 64), o3 = __shfl_xor(b3, d, 64); const u32 orow = __shfl_xor(brow, d, 64);
-      const bool take = orow != kNil && (brow == kNil || o1 < b1 || (o1 == b1 && (o2 < b2 || (o2 == b2 && (o3 < b3 || (o3 == b3 && orow < brow))))));
-      if (take) { b1 = o1; b2 = o2; b3 = o3; brow = orow; }
+      u64 other[kTopkKeys];
+#pragma unroll
+      for (int i = 0; i < kTopkKeys; i++) other[i] = __shfl_xor(best[i], d, 64);
+      const u32 orow = __shfl_xor(brow, d, 64);
+      const bool take = orow != kNil && (brow == kNil || less(other, best) || (same(other, best) && orow < brow));
+      if (take) {
+#pragma unroll
+        for (int i = 0; i < kTopkKeys; i++) best[i] = other[i];
+        brow = orow;
+      }
     }
     if (brow == kNil) break;        // wave-uniform after the reduction
     if (lane == 0) a.picked[(u64)g * a.k + r] = brow;
-    p1 = b1; p2 = b2; p3 = b3; have_prev = true; cnt++;
+#pragma unroll
+    for (int i = 0; i < kTopkKeys; i++) prev[i] = best[i];
+    have_prev = true; cnt++;
   }
   if (lane == 0) a.out_counts[g] = cnt;
 }

@@ -359,14 +359,23 @@ class PlanBuilder:
         n.n_proj = abi.NO_PROJECTION
         return self._push(n, n_cols)
 
-    def topk(self, left, keys, limit, group=None, projection=None):
+    def topk(self, left, keys, limit, group=None, projection=None, tie_break=True):
         """DISTINCT + ORDER BY keys ASC LIMIT `limit` (per `group` column if given) — the AggregateExec(first_value) +
         SortExec TopK(fetch) pair above the path in the reference's explore plans.  keys = [(column, abi.SORT_BY_ID |
-        abi.SORT_BY_TERM), ...] (at most 3)."""
+        abi.SORT_BY_TERM | abi.SORT_BY_DOUBLE), ...].  The AggregateExec groups by the sort expressions AND the raw output
+        columns, so (`tie_break`) every output column that is not yet a key by id is appended as one: at most 4 keys."""
+        keys = [(int(c), int(how)) for c, how in keys]
+        out_cols = list(range(self.width[left])) if projection is None else [int(c) for c in projection]
+        if tie_break:
+            for c in out_cols:
+                if (group is None or c != int(group)) and (c, abi.SORT_BY_ID) not in keys:
+                    keys.append((c, abi.SORT_BY_ID))
+        if len(keys) > 4:
+            raise ValueError("TopK: more than 4 sort keys (ORDER BY keys + output columns)")
         n = abi.PlanNode(kind=abi.NODE_TOPK, left=left, right=-1, n_keys=len(keys), table_cols=int(limit),
                          table_slot=0 if group is None else int(group) + 1)
         for i, (c, how) in enumerate(keys):
-            n.left_keys[i], n.right_keys[i] = int(c), int(how)
+            n.left_keys[i], n.right_keys[i] = c, how
         return self._push(n, self._proj(n, projection, self.width[left]))
 
     def union(self, left, right, projection=None):

@@ -78,8 +78,33 @@ def table_on_device(torch, cols):
 
 
 class Gen:
-    def __init__(self, rng, pb):
-        self.rng, self.pb = rng, pb
+    def __init__(self, rng, pb, oracle_run=None):
+        """oracle_run(description) -> (columns, rows): when given, a join whose inputs would produce more than MAX_JOIN_ROWS
+        rows (joins on a 3-valued graph column cascade into billions) is replaced by its left input"""
+        self.rng, self.pb, self.oracle_run = rng, pb, oracle_run
+
+    MAX_JOIN_ROWS = 200_000
+
+    def join_rows(self, l, r, on):
+        """exact size of the inner equi-join of two sub-plans on `on` (before any residual filter); None = unknown"""
+        if self.oracle_run is None:
+            return None
+        try:
+            (lc, nl), (rc, nr) = self.oracle_run(self.pb.build(l)), self.oracle_run(self.pb.build(r))
+        except RuntimeError:                                  # a sub-plan the oracle refuses (the whole plan will be refused too)
+            return None
+        if nl == 0 or nr == 0:
+            return 0
+        if not on:
+            return nl * nr
+        def keyed(cols, n, idx):
+            k = np.zeros(n, dtype=np.uint64); ok = np.ones(n, dtype=bool)
+            for c in idx:
+                k = k * np.uint64(1 << 20) + cols[c][:n].astype(np.uint64); ok &= cols[c][:n] != 0
+            return np.unique(k[ok], return_counts=True)
+        (ku_l, cl), (ku_r, cr) = keyed(lc, nl, [a for a, _ in on]), keyed(rc, nr, [b for _, b in on])
+        common, il, ir = np.intersect1d(ku_l, ku_r, return_indices=True)
+        return int((cl[il].astype(np.int64) * cr[ir].astype(np.int64)).sum()) + nl      # + the unmatched rows a left join keeps
 
     def r(self, n):
         return int(self.rng.integers(0, n))
@@ -157,6 +182,9 @@ class Gen:
             wl, wr = pb.width[l], pb.width[r]
             on = [(self.r(wl), self.r(wr)) for _ in range(1 if self.r(4) else 2)]
             w = wl + wr
+            size = self.join_rows(l, r, on)
+            if size is not None and size > self.MAX_JOIN_ROWS:
+                return l
             return pb.hash_join(l, r, on=on, join_type=abi.JOIN_LEFT if self.r(4) == 0 else abi.JOIN_INNER,
                                 filter=self.expr(w) if self.r(4) == 0 else None, projection=self.projection(w, 6) if self.r(3) else None)
         if k == 9:
@@ -172,11 +200,18 @@ class Gen:
             c = self.node(depth - 1)
             w = pb.width[c]
             k1, k2 = self.r(w), self.r(w)
-            return pb.topk(c, keys=[(k1, abi.SORT_BY_ID), (k2, abi.SORT_BY_ID)], limit=1 + self.r(6), group=None, projection=[k1, k2])
+            modes = [abi.SORT_BY_ID, abi.SORT_BY_ID, abi.SORT_BY_DOUBLE, abi.SORT_BY_TERM]      # BY_TERM over mixed kinds: refused by both sides
+            keys = [(k1, modes[self.r(4)]), (k2, modes[self.r(3)])]      # the builder appends the output columns as id keys (<= 4 in all)
+            return pb.topk(c, keys=keys, limit=1 + self.r(6), group=None, projection=[k1, k2])
         l, r = self.leaf(), self.leaf()                                                  # cross / nested-loop joins: leaves only (size)
         if k == 12:
-            return pb.cross_join(pb.filter(l, ID_EQ(col(0), lit_id(1 + self.r(20)))), r)
+            fl = pb.filter(l, ID_EQ(col(0), lit_id(1 + self.r(20))))
+            size = self.join_rows(fl, r, [])
+            return l if size is not None and size > self.MAX_JOIN_ROWS else pb.cross_join(fl, r)
         w = pb.width[l] + pb.width[r]
+        size = self.join_rows(l, r, [])
+        if size is not None and size > 20 * self.MAX_JOIN_ROWS:                          # the nested loop visits every pair
+            return l
         return pb.nested_loop_join(pb.filter(l, ID_NEQ(col(0), lit_id(3))), pb.filter(r, ID_EQ(col(0), lit_id(1 + self.r(20)))),
                                    join_type=abi.JOIN_LEFT if self.r(2) else abi.JOIN_INNER, filter=self.expr(w), projection=self.projection(w, 6))
 
@@ -196,7 +231,8 @@ def test_random_operator_trees(torch_cuda, seed, size):
     ran = skipped = rows_total = errors = 0
     for it in range(150 if size == "small" else 60):
         pb = PlanBuilder()
-        root = Gen(rng, pb).node((3 if size == "small" else 2) + (it % 3 == 0))
+        sizer = (lambda d: (lambda c, n, _: (c, n))(*os_.execute(d, [T0, T1]))) if size == "small" else None
+        root = Gen(rng, pb, sizer).node((3 if size == "small" else 2) + (it % 3 == 0))
         desc = pb.build(root)
         used = sorted({int(n.table_slot) for n in pb.nodes if n.kind == abi.NODE_TABLE})
         bound = [(slot, [(p0, n0), (p1, n1)][slot]) for slot in used]

@@ -800,7 +800,7 @@ def test_topk_distinct_matches_oracle(torch_cuda):
         plan.execute()
     pb = PlanBuilder()
     with pytest.raises(rf.RdfGpuError):          # an output column outside (group, keys) would make DISTINCT ambiguous
-        gs.plan(pb.build(pb.topk(pb.table(0, 3), keys=[(1, abi.SORT_BY_TERM)], limit=3, group=0)))
+        gs.plan(pb.build(pb.topk(pb.table(0, 3), keys=[(1, abi.SORT_BY_TERM)], limit=3, group=0, tie_break=False)))
 
 
 def test_bsbm_q5_whole_query_on_device(bsbm_stores, torch_cuda):
