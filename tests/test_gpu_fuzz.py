@@ -216,7 +216,17 @@ class Gen:
                                    join_type=abi.JOIN_LEFT if self.r(2) else abi.JOIN_INNER, filter=self.expr(w), projection=self.projection(w, 6))
 
 
-@pytest.mark.parametrize("seed,size", [(s, "small") for s in range(12)] + [(s, "large") for s in range(100, 106)])
+def _seeds():
+    """default: 12 small + 6 large stores; RDFGPU_FUZZ_SEEDS="200-260" hunts with other seeds (small and large each)"""
+    import os
+    extra = os.environ.get("RDFGPU_FUZZ_SEEDS")
+    if extra:
+        a, b = (int(x) for x in extra.split("-"))
+        return [(s, "small") for s in range(a, b)] + [(s, "large") for s in range(a, b, 2)]
+    return [(s, "small") for s in range(12)] + [(s, "large") for s in range(100, 106)]
+
+
+@pytest.mark.parametrize("seed,size", _seeds())
 def test_random_operator_trees(torch_cuda, seed, size):
     # small: 4000 quads over 64 ids (LDS-table joins, everything tiny, many plans); large: 120 k quads over 6000 ids
     # (HBM hash / direct-address / CSR tables cached on store slices, index joins, fused chains on re-execution)
