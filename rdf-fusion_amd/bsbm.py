@@ -246,15 +246,14 @@ def _window(sim, orig, w):
 def _q5_batch_constants(pb, ds, params):
     """C(inst, X, prodFeature, origProperty1, origProperty2): the three constant-subject patterns of every instance
     of PARAMS(inst, X).  `PARAMS JOIN (?s p ?v) ON X = ?s` is what B separate `<X> p ?v` scans return, tagged with
-    the instance; the instance's constants then meet on inst (B x ~19 rows)."""
+    the instance.  The three patterns share the subject, so after the first join the other two are look-ups by X on
+    rows that already carry it (inner joins commute: the same C as joining three per-instance tables on inst) — index
+    joins on the store's predicate slices, fused into one kernel on re-execution."""
     pr = ds.pred
-
-    def const(pname):
-        scan = pb.data_source(quad_pattern("s", pr[pname], "v"))              # (s, v)
-        return pb.hash_join(params, scan, on=[(1, 0)], projection=[0, 1, 3])  # (inst, X, v)
-    F, O1, O2 = const("bsbm:productFeature"), const("bsbm:productPropertyNumeric1"), const("bsbm:productPropertyNumeric2")
-    c = pb.hash_join(F, O1, on=[(0, 0)], projection=[0, 1, 2, 5])
-    return pb.hash_join(c, O2, on=[(0, 0)], projection=[0, 1, 2, 3, 6])
+    scan = lambda pname: pb.data_source(quad_pattern("s", pr[pname], "v"))           # (s, v)
+    c = pb.hash_join(params, scan("bsbm:productFeature"), on=[(1, 0)], projection=[0, 1, 3])             # (inst, X, f)
+    c = pb.hash_join(c, scan("bsbm:productPropertyNumeric1"), on=[(1, 0)], projection=[0, 1, 2, 4])      # + orig1
+    return pb.hash_join(c, scan("bsbm:productPropertyNumeric2"), on=[(1, 0)], projection=[0, 1, 2, 3, 5])  # + orig2
 
 
 def q5_batch_const_plan(ds):
