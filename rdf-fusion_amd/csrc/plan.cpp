@@ -1018,8 +1018,14 @@ DevTable Plan::exec_join(NodeInfo& nd) {
     return true;
   };
   bool lf = !left_join && fusable(nd.d.left), rf = fusable(nd.d.right);
+  // the inputs are sub-plans of their own: a chain request pending for THIS join must not keep the joins below from
+  // planning theirs (the batched Q5 has two: the constants' look-ups by X, and window 1 / window 2 / label above the
+  // candidate join)
+  ChainRequest* const for_this_join = pending_chain;
+  pending_chain = nullptr;
   DevTable L = lf ? exec_node((u32)nodes[nd.d.left].d.left) : exec_node((u32)nd.d.left);
   DevTable R = rf ? exec_node((u32)nodes[nd.d.right].d.left) : exec_node((u32)nd.d.right);
+  pending_chain = for_this_join;
   const NodeInfo* post = nullptr;   // a build-side FilterExec kept as a conjunct of the join filter (see below)
   if (lf || rf) {
     // `col <=|!=> literal` over a store slice: if the join builds on that slice (index join through the slice's cached
