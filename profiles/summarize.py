@@ -2,6 +2,7 @@
 
   python profiles/summarize.py stats <dir with *_kernel_stats.csv> <out.csv>
   python profiles/summarize.py pmc   <fetch dir> <write dir> <out.json>
+  python profiles/summarize.py counters <out.json> <kernel substring> <dir> [<dir> ...]
 
 The pmc form reads *_counter_collection.csv of two separate passes (FETCH_SIZE and WRITE_SIZE cannot share a
 pass on gfx950) and writes, per kernel: dispatches, median/max raw counter values in KB, and `hbm_bytes_per_launch`
@@ -37,6 +38,19 @@ def main():
     if sys.argv[1] == "stats":
         src = glob.glob(os.path.join(sys.argv[2], "**", "*kernel_stats.csv"), recursive=True)
         shutil.copy(src[0], sys.argv[3])
+        return
+    if sys.argv[1] == "counters":   # every counter found in the given pass directories, median per dispatch, for kernels matching the substring
+        out, want = {}, sys.argv[3]
+        for d in sys.argv[4:]:
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                per = defaultdict(lambda: defaultdict(list))
+                for r in csv.DictReader(open(f)):
+                    if want in r["Kernel_Name"]:
+                        per[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+                for k, cs in per.items():
+                    for c, v in cs.items():
+                        out.setdefault(k, {})[c] = {"dispatches": len(v), "median": statistics.median(v)}
+        json.dump(out, open(sys.argv[2], "w"), indent=1, sort_keys=True)
         return
     fetch, write = pmc_values(sys.argv[2], "FETCH_SIZE"), pmc_values(sys.argv[3], "WRITE_SIZE")
     res = {}
