@@ -759,7 +759,10 @@ typedef struct {
 } pctx;
 
 static int out_width(const pctx* c, const rdfgpu_plan_node* nd, u32 full, const u32** proj, u32* np) {
-  if (nd->n_proj == RDFGPU_NO_PROJECTION) { *proj = NULL; *np = full; return 0; }
+  if (nd->n_proj == RDFGPU_NO_PROJECTION) {
+    if (full > RDFGPU_MAX_COLUMNS) FAIL("too many columns");   /* orc_table holds RDFGPU_MAX_COLUMNS */
+    *proj = NULL; *np = full; return 0;
+  }
   if ((u64)nd->proj_off + nd->n_proj > c->d->n_pool) FAIL("projection out of pool range");
   *proj = c->d->pool + nd->proj_off; *np = nd->n_proj;
   for (u32 i = 0; i < *np; i++) if ((*proj)[i] >= full) FAIL("projection column out of range");
