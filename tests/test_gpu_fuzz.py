@@ -238,7 +238,7 @@ def test_random_operator_trees(torch_cuda, seed, size):
     T1 = [rng.integers(0, N_SUBJ, n1).astype(np.uint32) for _ in range(2)]
     k0, p0 = table_on_device(torch_cuda, T0)
     k1, p1 = table_on_device(torch_cuda, T1)
-    ran = skipped = rows_total = errors = 0
+    ran = skipped = rows_total = errors = mutated = 0
     for it in range(150 if size == "small" else 60):
         pb = PlanBuilder()
         sizer = (lambda d: (lambda c, n, _: (c, n))(*os_.execute(d, [T0, T1]))) if size == "small" else None
@@ -275,6 +275,20 @@ def test_random_operator_trees(torch_cuda, seed, size):
                 got = plan.execute().fetch()
                 assert plan.result_info()[0] == n_exp, (seed, it, fresh, rep)
                 np.testing.assert_array_equal(ku.multiset(got, n_exp), want, err_msg=f"seed {seed} plan {it} fresh {fresh} rep {rep}")
+            if fresh == 1 and it % 10 == 9:
+                # the store changes under a compiled plan (cached slice tables, located ranges, range indexes and verdict
+                # tables belong to a store version): the same plan object must answer for the new contents
+                k = 60 if size == "small" else 600
+                add = [rng.choice([0, 0, 7], k).astype(np.uint32), rng.integers(1, N_SUBJ + 1, k).astype(np.uint32),
+                       rng.choice(PREDS, k).astype(np.uint32), rng.integers(1, N_IDS, k).astype(np.uint32)]
+                assert gs.extend(*add) == os_.extend(*add)
+                drop = [c[: k // 2] for c in add]
+                assert gs.remove(*drop) == os_.remove(*drop)
+                exp2, n2, _ = os_.execute(desc, [T0, T1])
+                got = plan.execute().fetch()
+                assert plan.result_info()[0] == n2, (seed, it, "after mutation")
+                np.testing.assert_array_equal(ku.multiset(got, n2), ku.multiset(exp2, n2), err_msg=f"seed {seed} plan {it} after store mutation")
+                mutated += 1
             plan.close()
         ran += 1
         rows_total += n_exp
