@@ -239,7 +239,7 @@ __device__ __forceinline__ bool load_keys(const u32* const* key_cols, u32 n_keys
 constexpr int kResolveUnroll = 4;
 
 template <int FS, int PFS, int ITEMS, int MODE, bool CHAIN>
-__global__ __launch_bounds__(kLdsBlock) void lds_join_kernel(const LdsJoinArgs a) {
+__global__ __launch_bounds__(kLdsBlock) __attribute__((amdgpu_waves_per_eu(4))) void lds_join_kernel(const LdsJoinArgs a) {
   constexpr bool GLOBAL = MODE != kJoinTableLds;      // the table lives in HBM / L2
   constexpr bool DIRECT = MODE == kJoinTableDirect;   // direct-address table: row = direct[key - direct_min]
   constexpr bool CSR = MODE == kJoinTableCsr;         // rows of key k: csr_rows[csr_off[k - min] .. csr_off[k - min + 1])
@@ -319,6 +319,8 @@ __global__ __launch_bounds__(kLdsBlock) void lds_join_kernel(const LdsJoinArgs a
   };
 
   Keys key[ITEMS]; u32 h[ITEMS]; uint2 s[ITEMS]; bool walking[ITEMS]; u32 pend[ITEMS];
+  bool exact[ITEMS];     // range-index mode: the row's candidate range is exactly the first stage's window (integer operands)
+  bool q_exact = true;   // wave-uniform: every candidate in the queue comes from such a row => the first stage pass can be skipped
   u64 tile = blockIdx.x;
   bool tile_loaded = false, exhausted = false;   // wave-uniform
   for (;;) {
@@ -347,6 +349,7 @@ __global__ __launch_bounds__(kLdsBlock) void lds_join_kernel(const LdsJoinArgs a
             s[k] = make_uint2(0u, 0u);
             if (walking[k] && h[k] < a.direct_n) { s[k].x = a.csr_off[h[k]]; s[k].y = a.csr_off[h[k] + 1]; }
             if constexpr (CHAIN) {
+              exact[k] = false;
               if (a.range_vals != nullptr && walking[k] && s[k].x < s[k].y) {
                 // the group is ordered by the first stage's value: keep only [lower_bound(lo), upper_bound(hi)) of it,
                 // lo / hi = the integer interval the stage's window allows for this probe row (a superset is enough:
@@ -387,6 +390,7 @@ __global__ __launch_bounds__(kLdsBlock) void lds_join_kernel(const LdsJoinArgs a
                   e = empty ? s[k].x : s[k].y;
                   while (b < e) { const u32 mid = b + ((e - b) >> 1); if (a.range_vals[mid] <= hi_b) b = mid + 1; else e = mid; }  // upper_bound(hi)
                   s[k].x = first; s[k].y = b;
+                  exact[k] = true;
                 }
               }
             }
@@ -435,6 +439,7 @@ __global__ __launch_bounds__(kLdsBlock) void lds_join_kernel(const LdsJoinArgs a
           if (found == 0) break;
           const u32 n_found = (u32)__popcll(found);
           if (qn + n_found > qcap) { pend[k] = hit; full = true; break; }
+          if constexpr (CSR && CHAIN) q_exact = q_exact && !__any(hit != kNil && !exact[k]);
           if (hit != kNil) wq[qn + lane_prefix(found)] = make_uint2(hit, j);
           qn += n_found;
         }
@@ -502,6 +507,8 @@ __global__ __launch_bounds__(kLdsBlock) void lds_join_kernel(const LdsJoinArgs a
       // stage (a numeric window keeps ~10 %) leaves the later stages a tenth of the candidates, packed into full waves.
       for (u32 t = 0; t < a.n_chain; t++) {
         const ChainStage& st = a.chain[t];
+        // range-index mode: the candidates were cut out of their groups by exactly this stage's window — nothing to re-check
+        if (t == 0 && a.range_link != nullptr && st.val != nullptr && q_exact) continue;
         u32 kept = 0;
         for (u32 g0 = 0; g0 < qn; g0 += 64 * kResolveUnroll) {
           uint2 m[kResolveUnroll]; bool ok[kResolveUnroll], slow[kResolveUnroll]; u32 r[kResolveUnroll];
@@ -595,6 +602,7 @@ __global__ __launch_bounds__(kLdsBlock) void lds_join_kernel(const LdsJoinArgs a
     b = __shfl(b, 0, 64);
     write_out(b);
     qn = 0;
+    q_exact = true;
   }
 
   // what is still queued leaves with one reservation for the whole workgroup
