@@ -236,10 +236,12 @@ __device__ __forceinline__ bool load_keys(const u32* const* key_cols, u32 n_keys
 // between the base join and the last stage is materialised.  In range-index mode the fill expands, per probe row,
 // only the value interval of its key's group that the first stage's window allows, and candidates carry index
 // positions (see bcol).
-constexpr int kResolveUnroll = 4;
 
 template <int FS, int PFS, int ITEMS, int MODE, bool CHAIN>
-__global__ __launch_bounds__(kLdsBlock) __attribute__((amdgpu_waves_per_eu(4))) void lds_join_kernel(const LdsJoinArgs a) {
+__global__ __launch_bounds__(kLdsBlock) __attribute__((amdgpu_waves_per_eu(ITEMS == 1 ? 5 : 4))) void lds_join_kernel(const LdsJoinArgs a) {
+  // candidates taken out of the queue per lane and resolve round: four keep more gathers in flight; the one-row-per-lane
+  // variant takes two and fits 5 waves/SIMD without spills (95 VGPRs)
+  constexpr int kResolveUnroll = ITEMS == 1 ? 2 : 4;
   constexpr bool GLOBAL = MODE != kJoinTableLds;      // the table lives in HBM / L2
   constexpr bool DIRECT = MODE == kJoinTableDirect;   // direct-address table: row = direct[key - direct_min]
   constexpr bool CSR = MODE == kJoinTableCsr;         // rows of key k: csr_rows[csr_off[k - min] .. csr_off[k - min + 1])
