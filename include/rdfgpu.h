@@ -426,6 +426,50 @@ int rdfgpu_plan_enable_kernel_timing(rdfgpu_plan* plan, int on);
 int rdfgpu_plan_kernel_stats(rdfgpu_plan* plan, rdfgpu_kernel_stat* out, uint32_t cap, uint32_t* n);
 
 /* ------------------------------------------------------------------------------------ */
+/* 4b. Engine options                                                                    */
+/*     the session-level knobs of this path: the counterpart of DataFusion's SessionConfig */
+/*     / ConfigOptions the reference threads through planning (lib/rdf-fusion/src/store.rs */
+/*     :101-103, bench/src/environment.rs:71-87).  Every physical rewrite / table form /   */
+/*     speculation mode can be switched off; results never depend on them (tested).       */
+/* ------------------------------------------------------------------------------------ */
+/*
+ * Defaults are taken ONCE per process (first store creation) from the environment variables RDFGPU_<NAME>
+ * (e.g. RDFGPU_NO_CHAIN_FUSION=1); after that the environment is never consulted again.  A store copies the
+ * process defaults when it is created, a plan copies its store's options when it is compiled; the two setters
+ * change one store (plans compiled later) or one plan (its later executions).  Nothing on the execute path reads
+ * the environment.
+ */
+enum {
+  RDFGPU_OPT_FORCE_GENERIC_VM = 0,      /* every FILTER / join filter through the stack VM (no specialised kernels)   */
+  RDFGPU_OPT_NO_JOIN_REORDER,           /* keep (A x B) JOIN C as written                                             */
+  RDFGPU_OPT_NO_SPECULATION,            /* size every operator exactly (one host sync per join)                       */
+  RDFGPU_OPT_NO_FIRST_RUN_SPECULATION,  /* speculate only from a previous execution's cardinalities                   */
+  RDFGPU_OPT_NO_STRING_VERDICTS,        /* REGEX / CONTAINS / .. per row instead of per distinct term                 */
+  RDFGPU_OPT_NO_TABLE_CACHE,            /* join tables are built inside every execution, like HashJoinExec(CollectLeft)
+                                           does per query; nothing is kept on the store between executions            */
+  RDFGPU_OPT_NO_INDEX_JOIN,             /* never build on a store slice just because it is one                        */
+  RDFGPU_OPT_NO_CHAIN_FUSION,           /* run follow-up look-up joins as separate operators                          */
+  RDFGPU_OPT_NO_VALUE_TABLES,           /* no decoded integer tables next to direct tables                            */
+  RDFGPU_OPT_NO_RANGE_INDEX,            /* no value-ordered CSR groups                                                */
+  RDFGPU_OPT_NO_FILTER_FUSION,          /* materialise FilterExec children of joins                                   */
+  RDFGPU_OPT_NO_LDS_JOIN,               /* chained HBM hash join (count / scan / write) for every HashJoinExec         */
+  RDFGPU_OPT_NO_GLOBAL_TABLE_JOIN,      /* the fused join kernel only for builds that fit LDS                         */
+  RDFGPU_OPT_NO_DIRECT_TABLE,           /* no direct-address / CSR tables for dense keys                              */
+  RDFGPU_OPT_NO_BAND_JOIN,              /* no key-partitioned band join for fused look-up chains over small groups    */
+  RDFGPU_OPT_NO_PARTITIONED_JOIN,       /* no radix-partitioned LDS hash join for large non-cached build sides        */
+  RDFGPU_OPT_LDS_MAX_BUILD,             /* value: largest build side (rows) joined through a per-workgroup LDS table  */
+  RDFGPU_OPT_CSR_ROW_LANES_LOG2,        /* value + 1: lanes sharing one probe row of a CSR join (0 = automatic)        */
+  RDFGPU_OPT_JOIN_WAVE_Q,               /* value: entries of a wave's candidate queue (0 = automatic)                  */
+  RDFGPU_OPT_PARTITION_MIN_BUILD,       /* value: smallest non-cached build side (rows) that is radix-partitioned     */
+  RDFGPU_OPT__COUNT
+};
+int rdfgpu_store_set_option(rdfgpu_store* store, uint32_t option, uint64_t value);
+int rdfgpu_store_get_option(const rdfgpu_store* store, uint32_t option, uint64_t* value);
+int rdfgpu_plan_set_option(rdfgpu_plan* plan, uint32_t option, uint64_t value);
+/* "NO_CHAIN_FUSION" for RDFGPU_OPT_NO_CHAIN_FUSION (the environment variable is RDFGPU_ + this); NULL if out of range. */
+const char* rdfgpu_option_name(uint32_t option);
+
+/* ------------------------------------------------------------------------------------ */
 /* 5. Host logic of the scan planner (no device access)                                  */
 /* ------------------------------------------------------------------------------------ */
 /*

@@ -40,6 +40,13 @@ NO_PROJECTION = 0xFFFFFFFF
 
 OP_EQ, OP_GT, OP_GTEQ, OP_LT, OP_LTEQ = range(5)
 
+# engine options (include/rdfgpu.h section 4b); the environment variable of option X is RDFGPU_X, read once per process
+OPTION_NAMES = ["FORCE_GENERIC_VM", "NO_JOIN_REORDER", "NO_SPECULATION", "NO_FIRST_RUN_SPECULATION", "NO_STRING_VERDICTS",
+                "NO_TABLE_CACHE", "NO_INDEX_JOIN", "NO_CHAIN_FUSION", "NO_VALUE_TABLES", "NO_RANGE_INDEX", "NO_FILTER_FUSION",
+                "NO_LDS_JOIN", "NO_GLOBAL_TABLE_JOIN", "NO_DIRECT_TABLE", "NO_BAND_JOIN", "NO_PARTITIONED_JOIN",
+                "LDS_MAX_BUILD", "CSR_ROW_LANES_LOG2", "JOIN_WAVE_Q", "PARTITION_MIN_BUILD"]
+OPTIONS = {name: i for i, name in enumerate(OPTION_NAMES)}
+
 
 class Config(C.Structure):
     _fields_ = [("device", C.c_int32), ("batch_size", C.c_uint32), ("flags", C.c_uint32),
@@ -131,6 +138,7 @@ EXPORTED_SYMBOLS = [
     "rdfgpu_plan_result_info", "rdfgpu_plan_result_device", "rdfgpu_plan_fetch", "rdfgpu_plan_next",
     "rdfgpu_plan_rewind", "rdfgpu_plan_metrics", "rdfgpu_plan_selected_index", "rdfgpu_plan_stream",
     "rdfgpu_plan_enable_kernel_timing", "rdfgpu_plan_kernel_stats",
+    "rdfgpu_store_set_option", "rdfgpu_store_get_option", "rdfgpu_plan_set_option", "rdfgpu_option_name",
     "rdfgpu_scan_score", "rdfgpu_choose_index", "rdfgpu_predicate_and",
     "rdfgpu_pushdown_to_scan_predicate", "rdfgpu_regex_check",
 ]

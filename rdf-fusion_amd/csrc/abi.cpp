@@ -1,6 +1,8 @@
 // abi.cpp — the extern "C" boundary of include/rdfgpu.h.  No exception crosses it.
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
+#include <shared_mutex>
 #include <string>
 
 #include "host_logic.hpp"
@@ -94,6 +96,29 @@ int rdfgpu_store_read_index(const rdfgpu_store* store, uint32_t components, uint
   for (int k = 0; k < 4; k++) if (dst[k] && m) RDFGPU_HIP(hipMemcpy(dst[k], ix.col[k], m * 4, hipMemcpyDeviceToHost));
   ABI_END
 }
+
+// ---- engine options --------------------------------------------------------------------------------
+int rdfgpu_store_set_option(rdfgpu_store* store, uint32_t option, uint64_t value) {
+  ABI_BEGIN
+  if (option >= RDFGPU_OPT__COUNT) fail(RDFGPU_ERR_INVALID, "unknown engine option %u", option);
+  Store* st = S(store);
+  std::unique_lock<std::shared_mutex> lock(st->mu);   // no plan of this store is executing
+  st->opt.v[option] = value;
+  ABI_END
+}
+int rdfgpu_store_get_option(const rdfgpu_store* store, uint32_t option, uint64_t* value) {
+  ABI_BEGIN
+  if (option >= RDFGPU_OPT__COUNT || !value) fail(RDFGPU_ERR_INVALID, "unknown engine option %u", option);
+  *value = S(store)->opt.v[option];
+  ABI_END
+}
+int rdfgpu_plan_set_option(rdfgpu_plan* plan, uint32_t option, uint64_t value) {
+  ABI_BEGIN
+  if (option >= RDFGPU_OPT__COUNT) fail(RDFGPU_ERR_INVALID, "unknown engine option %u", option);
+  P(plan)->opt.v[option] = value;   // one in-flight call per handle: not concurrent with an execute of this plan
+  ABI_END
+}
+const char* rdfgpu_option_name(uint32_t option) { return engine_option_name(option); }
 
 // ---- plans ---------------------------------------------------------------------------------------
 int rdfgpu_plan_compile(rdfgpu_store* store, const rdfgpu_plan_desc* desc, rdfgpu_plan** out) {

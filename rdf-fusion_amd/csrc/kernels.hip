@@ -511,8 +511,7 @@ void launch_gjoin_build(const LdsJoinArgs& a, hipStream_t s) {
 // the per-workgroup LDS build), else 1 (many short workgroups; an HBM table has no per-workgroup build to
 // amortise and its probes are latency chains that want parallelism).
 int lds_join_items(u64 n_probe_cap, bool global) {
-  static const u64 min_global = [] { const char* e = std::getenv("RDFGPU_JOIN_ITEMS4_MIN_GLOBAL"); return e ? std::strtoull(e, nullptr, 10) : (4ull << 20); }();
-  static const u64 min_lds = [] { const char* e = std::getenv("RDFGPU_JOIN_ITEMS4_MIN_LDS"); return e ? std::strtoull(e, nullptr, 10) : (1ull << 20); }();
+  constexpr u64 min_global = 4ull << 20, min_lds = 1ull << 20;   // measured cross-over points
   return n_probe_cap >= (global ? min_global : min_lds) ? 4 : 1;
 }
 int lds_join_mode(const LdsJoinArgs& a) { return a.csr_off ? kJoinTableCsr : a.direct ? kJoinTableDirect : a.gslots ? kJoinTableHash : kJoinTableLds; }
@@ -526,11 +525,9 @@ void launch_lds_join(const LdsJoinArgs& a, hipStream_t s) {
   const u32 rl = mode == kJoinTableCsr ? a.row_lanes_log2 : 0u;
   if (rl > 6) fail(RDFGPU_ERR_INVALID, "lds join: %u lanes per row", 1u << rl);
   // enough workgroups to cover all 256 CUs; each builds its LDS copy once and strides over the tiles
-  static const u64 wg_cap = [] { const char* e = std::getenv("RDFGPU_JOIN_MAX_WG"); return e ? std::strtoull(e, nullptr, 10) : 0ull; }();
   // HBM table: no per-workgroup build, so one tile per workgroup and let the hardware overlap them.  LDS
   // table: the build is repeated per workgroup, so cap the grid by what that costs (tiny tables: no cap).
   u64 max_wg = global ? (1ull << 22) : tbl_lds > 64 * 1024 ? 256 : tbl_lds > 32 * 1024 ? 512 : 1024;
-  if (wg_cap) max_wg = wg_cap;
   const int items = lds_join_items(a.n_probe_cap << rl, global);
   const u64 rows = ((u64)kLdsBlock * items) >> rl;
   const u64 n_tiles = (a.n_probe_cap + rows - 1) / rows;

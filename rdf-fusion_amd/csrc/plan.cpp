@@ -9,6 +9,7 @@
 //                           semantics from lib/logical/src/join/rewrite.rs:71-221
 #include "plan.hpp"
 
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
@@ -70,8 +71,8 @@ u32 check_program(const rdfgpu_expr_node* p, u32 n, u32 n_cols, u32 n_regexes = 
   return st[0];
 }
 
-int detect_shape(const ExprProgram& pr) {
-  if (std::getenv("RDFGPU_FORCE_GENERIC_VM")) return 0;
+int detect_shape(const ExprProgram& pr, bool force_vm) {
+  if (force_vm) return 0;
   const rdfgpu_expr_node* e = pr.nodes;
   if (pr.n == 3 && e[0].op == RDFGPU_EX_COLUMN && e[1].op == RDFGPU_EX_LIT_ID && (e[2].op == RDFGPU_EX_ID_EQ || e[2].op == RDFGPU_EX_ID_NEQ)) return 1;
   if (pr.n == 5 && e[0].op == RDFGPU_EX_COLUMN && e[1].op == RDFGPU_EX_ENC_TV && e[2].op == RDFGPU_EX_LIT_TV && is_cmp(e[3].op) && e[4].op == RDFGPU_EX_EBV) return 2;
@@ -85,9 +86,9 @@ int detect_shape(const ExprProgram& pr) {
 // Join-filter specialisation: 3 = the BSBM Q5 "window" shape
 //   EBV(cmp(ENC_TV(x), ADD|SUB(ENC_TV(y), lit))) AND EBV(cmp(ENC_TV(x'), ADD|SUB(ENC_TV(y'), lit')))
 // (Q5 (Execution Plan).snap:10,12), 1 = generic VM, 0 = no filter.
-int detect_join_filter_shape(const ExprProgram& pr) {
+int detect_join_filter_shape(const ExprProgram& pr, bool force_vm) {
   if (pr.n == 0) return 0;
-  if (std::getenv("RDFGPU_FORCE_GENERIC_VM")) return 1;
+  if (force_vm) return 1;
   const rdfgpu_expr_node* e = pr.nodes;
   auto half = [&](u32 o) {
     return e[o].op == RDFGPU_EX_COLUMN && e[o + 1].op == RDFGPU_EX_ENC_TV && e[o + 2].op == RDFGPU_EX_COLUMN &&
@@ -137,6 +138,7 @@ Plan* plan_compile(Store* store, const rdfgpu_plan_desc* d) {
   if (d->root >= d->n_nodes) fail(RDFGPU_ERR_INVALID, "plan_compile: root %u out of range", d->root);
   std::unique_ptr<Plan> plan(new Plan());
   plan->store = store;
+  plan->opt = store->opt;
   store->retain();
   plan->root = d->root;
   plan->nodes.resize(d->n_nodes);
@@ -222,7 +224,7 @@ Plan* plan_compile(Store* store, const rdfgpu_plan_desc* d) {
         const NodeInfo& c = child(r.left, "input");
         load_program(nd, d, c.width, "FilterExec", plan->regex_dev);
         load_projection(nd, d, c.width, "FilterExec");
-        nd.shape = detect_shape(nd.prog);
+        nd.shape = detect_shape(nd.prog, plan->opt.on(RDFGPU_OPT_FORCE_GENERIC_VM));
         break;
       }
       case RDFGPU_NODE_PROJECTION: {
@@ -243,7 +245,7 @@ Plan* plan_compile(Store* store, const rdfgpu_plan_desc* d) {
         if (l.width + rr.width > 2u * kMaxCols) fail(RDFGPU_ERR_UNSUPPORTED, "node %u: too many columns", i);
         load_program(nd, d, l.width + rr.width, "join filter", plan->regex_dev);
         load_projection(nd, d, l.width + rr.width, "join");
-        nd.shape = detect_join_filter_shape(nd.prog);
+        nd.shape = detect_join_filter_shape(nd.prog, plan->opt.on(RDFGPU_OPT_FORCE_GENERIC_VM));
         if (l.width > (u32)kMaxCols || rr.width > (u32)kMaxCols) fail(RDFGPU_ERR_UNSUPPORTED, "node %u: too many columns", i);
         break;
       }
@@ -294,7 +296,7 @@ Plan* plan_compile(Store* store, const rdfgpu_plan_desc* d) {
   //     (A x B) JOIN C ON a = c1 AND b = c2          (Q5 (Execution Plan).snap:18-26: label x features(X))
   // is the join graph A - C - B; it runs as  A JOIN (B JOIN C ON b = c2) ON a = c1  without ever
   // materialising |A| x |B| rows.  Column order [A, B, C] is preserved, so filter and projection stay valid.
-  if (!std::getenv("RDFGPU_NO_JOIN_REORDER")) {
+  if (!plan->opt.on(RDFGPU_OPT_NO_JOIN_REORDER)) {
     const u32 n0 = (u32)plan->nodes.size();
     std::vector<u32> refs(n0, 0);
     for (u32 i = 0; i < n0; i++) {
@@ -498,7 +500,7 @@ void Plan::execute() {
 
   spec_checks.clear();
   memo.assign(nodes.size(), DevTable{}); memo_valid.assign(nodes.size(), 0);
-  speculative = allow_speculation && !std::getenv("RDFGPU_NO_SPECULATION");
+  speculative = allow_speculation && !opt.on(RDFGPU_OPT_NO_SPECULATION);
 
   // K1: locate every data source's range in one launch, one host round trip for all of them.  The ranges
   // depend only on the plan's constants and the store's content: a re-execution on an unchanged store
@@ -708,7 +710,7 @@ DevTable Plan::apply_filter(NodeInfo& nd, const DevTable& in) {
     key.append(rx.pattern ? std::string(rx.pattern, rx.pattern_len) : std::string());
     const u64 n_ids = std::min<u64>(store->n_ids, store->n_str_ids);
     unsigned char* verdict = nullptr;
-    if (!std::getenv("RDFGPU_NO_STRING_VERDICTS") && n_ids > 0) {
+    if (!opt.on(RDFGPU_OPT_NO_STRING_VERDICTS) && n_ids > 0) {
       std::unique_lock<std::mutex> building(store->slice_build_mu);
       { std::lock_guard<std::mutex> l(store->slice_mu); auto it = store->string_verdicts.find(key); if (it != store->string_verdicts.end()) verdict = it->second; }
       if (!verdict && in.cap * 4 >= n_ids) {
@@ -805,7 +807,7 @@ DevTable Plan::exec_topk(NodeInfo& nd) {
 bool Plan::choose_build_left(const NodeInfo& nd, const DevTable& L, const DevTable& R, bool left_join, bool lf, bool rf, bool lpost, bool rpost) const {
   if (left_join) return true;
   const bool smaller_left = L.cap <= R.cap;
-  if (nd.d.kind != RDFGPU_NODE_HASH_JOIN || std::getenv("RDFGPU_NO_TABLE_CACHE") || std::getenv("RDFGPU_NO_INDEX_JOIN")) return smaller_left;
+  if (nd.d.kind != RDFGPU_NODE_HASH_JOIN || opt.on(RDFGPU_OPT_NO_TABLE_CACHE) || opt.on(RDFGPU_OPT_NO_INDEX_JOIN)) return smaller_left;
   // (a slice under a `col <=|!=> literal` FilterExec still counts: that filter can run as a conjunct of the join filter)
   const bool ls = L.stable_id != 0 && L.n_dev == nullptr && (!lf || lpost), rs = R.stable_id != 0 && R.n_dev == nullptr && (!rf || rpost);
   if (!ls && !rs) return smaller_left;
@@ -836,7 +838,7 @@ bool Plan::choose_build_left(const NodeInfo& nd, const DevTable& L, const DevTab
 // slice with a cached DIRECT-address table and whose other input is a hash join consumed only here.  Only tried on
 // speculative re-executions (cardinalities and tables known from the first run).
 bool Plan::plan_chain(NodeInfo& top, ChainRequest& req) {
-  if (!speculative || !top.has_last || std::getenv("RDFGPU_NO_CHAIN_FUSION") || std::getenv("RDFGPU_NO_TABLE_CACHE")) return false;
+  if (!speculative || !top.has_last || opt.on(RDFGPU_OPT_NO_CHAIN_FUSION) || opt.on(RDFGPU_OPT_NO_TABLE_CACHE)) return false;
   req.top = &top;
   std::vector<ChainLink> down;
   NodeInfo* cur = &top;
@@ -915,7 +917,7 @@ bool Plan::apply_chain(const ChainRequest& req, NodeInfo& base, const DevTable& 
     // integer window whose x operand is a column of this stage's slice and whose y operands are base columns: use the
     // slice's decoded value table (built once per store version, kept with the direct table)
     if (st.fs == 3 && st.f[0].src == 2u + (u32)t && st.f[2].src == st.f[0].src && st.f[2].ptr == st.f[0].ptr && st.f[1].src <= 1 && st.f[3].src <= 1 &&
-        !std::getenv("RDFGPU_NO_VALUE_TABLES")) {
+        !opt.on(RDFGPU_OPT_NO_VALUE_TABLES)) {
       SliceTable* tab = const_cast<SliceTable*>(ln.table);
       std::unique_lock<std::mutex> building(store->slice_build_mu);
       SliceTable::ValueColumn* vc = nullptr;
@@ -951,7 +953,7 @@ bool Plan::apply_chain(const ChainRequest& req, NodeInfo& base, const DevTable& 
     auto range_op = [](u8 op) { return op == RDFGPU_EX_GT || op == RDFGPU_EX_LT || op == RDFGPU_EX_GEQ || op == RDFGPU_EX_LEQ; };
     const DevTable& B = build_left ? L : R;
     if (a.csr_off && cur_build_table && s0.val && s0.fs == 3 && s0.key.src == 1 && s0.f[1].src == 0 && s0.f[3].src == 0 &&
-        range_op(s0.l0.cmp_op) && range_op(s0.l1.cmp_op) && !std::getenv("RDFGPU_NO_RANGE_INDEX")) {
+        range_op(s0.l0.cmp_op) && range_op(s0.l1.cmp_op) && !opt.on(RDFGPU_OPT_NO_RANGE_INDEX)) {
       SliceTable* tab = cur_build_table;
       std::unique_lock<std::mutex> building(store->slice_build_mu);
       SliceTable::RangeIndex* ri = nullptr;
@@ -1011,7 +1013,7 @@ DevTable Plan::exec_join(NodeInfo& nd) {
   // Pipeline fusion: a FilterExec child (identity projection, consumed by this join only) is not
   // materialised when it ends up on the probe side of the LDS join — its predicate runs inside the probe.
   auto fusable = [&](int32_t ci) {
-    if (nd.d.kind != RDFGPU_NODE_HASH_JOIN || std::getenv("RDFGPU_NO_FILTER_FUSION") || std::getenv("RDFGPU_NO_LDS_JOIN")) return false;
+    if (nd.d.kind != RDFGPU_NODE_HASH_JOIN || opt.on(RDFGPU_OPT_NO_FILTER_FUSION) || opt.on(RDFGPU_OPT_NO_LDS_JOIN)) return false;
     const NodeInfo& c = nodes[ci];
     if (c.d.kind != RDFGPU_NODE_FILTER || c.prog.n == 0 || c.refs != 1 || c.n_proj != nodes[c.d.left].width) return false;
     for (u32 k = 0; k < c.n_proj; k++) if (c.proj[k] != k) return false;
@@ -1032,11 +1034,11 @@ DevTable Plan::exec_join(NodeInfo& nd) {
     // table) the FilterExec is neither materialised nor fused into the probe — it becomes one more conjunct of the
     // join filter, evaluated on the candidate pairs
     auto postable = [&](bool has, int32_t ci, const DevTable& in) {
-      return has && nodes[ci].shape == 1 && in.stable_id != 0 && in.n_dev == nullptr && in.cap > 1024 && nd.d.n_keys == 1 && !std::getenv("RDFGPU_NO_INDEX_JOIN");
+      return has && nodes[ci].shape == 1 && in.stable_id != 0 && in.n_dev == nullptr && in.cap > 1024 && nd.d.n_keys == 1 && !opt.on(RDFGPU_OPT_NO_INDEX_JOIN);
     };
     const bool lpost = postable(lf, nd.d.left, L), rpost = postable(rf, nd.d.right, R);
     const bool build_left = choose_build_left(nd, L, R, left_join, lf, rf, lpost, rpost);
-    const bool lds = ((build_left ? L.cap : R.cap) <= kLdsJoinMaxBuild || !std::getenv("RDFGPU_NO_GLOBAL_TABLE_JOIN")) && L.cap && R.cap;
+    const bool lds = ((build_left ? L.cap : R.cap) <= kLdsJoinMaxBuild || !opt.on(RDFGPU_OPT_NO_GLOBAL_TABLE_JOIN)) && L.cap && R.cap;
     if (lds && lf && build_left && lpost) { post = &nodes[nd.d.left]; lf = false; }
     else if (lds && rf && !build_left && rpost) { post = &nodes[nd.d.right]; rf = false; }
     // a fused filter survives only on the probe side of the LDS join; anything else is materialised now
@@ -1068,9 +1070,9 @@ DevTable Plan::exec_join(NodeInfo& nd) {
   // HashJoinExec / NestedLoopJoinExec
   if (L.cap == 0 || (R.cap == 0 && !left_join)) { t.cap = 0; return t; }
   const bool hash = nd.d.kind == RDFGPU_NODE_HASH_JOIN;
-  if (hash && !std::getenv("RDFGPU_NO_LDS_JOIN")) {
+  if (hash && !opt.on(RDFGPU_OPT_NO_LDS_JOIN)) {
     const bool build_left = choose_build_left(nd, L, R, left_join, lf, rf);
-    if ((build_left ? L.cap : R.cap) <= kLdsJoinMaxBuild || !std::getenv("RDFGPU_NO_GLOBAL_TABLE_JOIN")) {
+    if ((build_left ? L.cap : R.cap) <= kLdsJoinMaxBuild || !opt.on(RDFGPU_OPT_NO_GLOBAL_TABLE_JOIN)) {
       const NodeInfo* pf = lf ? &nodes[nd.d.left] : rf ? &nodes[nd.d.right] : nullptr;
       if (post && build_left != (post == &nodes[nd.d.left])) fail(RDFGPU_ERR_DEVICE, "join: build side changed under a residual filter");
       return exec_lds_join(nd, L, R, build_left, pf, post);
@@ -1171,7 +1173,7 @@ DevTable Plan::exec_lds_join(NodeInfo& nd, const DevTable& L, const DevTable& R,
   while (slots < 2 * B.cap) slots <<= 1;
   // LDS copy per workgroup vs ONE table in HBM/L2: the LDS form pays the build once per workgroup and, above
   // ~16 KiB of table, costs occupancy (a 128 KiB table = one workgroup per CU = latency-bound probes).
-  static const u64 lds_limit = [] { const char* e = std::getenv("RDFGPU_LDS_MAX_BUILD"); const u64 v = e ? std::strtoull(e, nullptr, 10) : 1024; return v > kLdsJoinMaxBuild ? (u64)kLdsJoinMaxBuild : v; }();
+  const u64 lds_limit = std::min<u64>(opt.v[RDFGPU_OPT_LDS_MAX_BUILD], kLdsJoinMaxBuild);
   const bool global_table = B.cap > lds_limit;
   // Every lane of a wave waits for the longest chain among its 64 probes, so short chains matter more than a
   // small table: LDS tables get load <= 0.25 and at least 2048 slots (16 KiB), HBM tables under 1 MiB load <= 0.125.
@@ -1182,7 +1184,7 @@ DevTable Plan::exec_lds_join(NodeInfo& nd, const DevTable& L, const DevTable& R,
   // same for every plan until the store changes: it is built once per store version and kept on the store.
   bool build_now = false;
   if (global_table) {
-    const bool cacheable = B.stable_id != 0 && B.n_dev == nullptr && !std::getenv("RDFGPU_NO_TABLE_CACHE");
+    const bool cacheable = B.stable_id != 0 && B.n_dev == nullptr && !opt.on(RDFGPU_OPT_NO_TABLE_CACHE);
     if (cacheable) {
       SliceKey sk; sk.n_keys = a.n_keys; sk.rows = B.cap;
       for (u32 k = 0; k < a.n_keys; k++) sk.key[k] = a.build_key[k];
@@ -1191,7 +1193,7 @@ DevTable Plan::exec_lds_join(NodeInfo& nd, const DevTable& L, const DevTable& R,
       std::unique_lock<std::mutex> building(store->slice_build_mu);
       // Dense forms first (one single key over a dense id range): direct-address if the keys are unique, CSR if not.
       // Decided once per slice; costs a few small kernels and host syncs at that time, nothing afterwards.
-      if (!st->dense_tried && a.n_keys == 1 && !std::getenv("RDFGPU_NO_DIRECT_TABLE")) {
+      if (!st->dense_tried && a.n_keys == 1 && !opt.on(RDFGPU_OPT_NO_DIRECT_TABLE)) {
         u32* mm = reinterpret_cast<u32*>(new_counter());     // {min, max}
         u32* flags = reinterpret_cast<u32*>(new_counter());  // {duplicate seen, unsorted seen}
         const u32 init[2] = {0xFFFFFFFFu, 0u};
@@ -1251,7 +1253,7 @@ DevTable Plan::exec_lds_join(NodeInfo& nd, const DevTable& L, const DevTable& R,
         const bool tiny = P.cap < 4096;
         u32 rl = 0;
         while (rl < (tiny ? 6u : 3u) && ((tiny ? 2ull : 16ull) << rl) <= fan && (P.cap << (rl + 1)) <= (1ull << 25)) rl++;
-        if (const char* e = std::getenv("RDFGPU_CSR_ROW_LANES_LOG2")) rl = (u32)std::atoi(e) > 6 ? 6 : (u32)std::atoi(e);
+        if (opt.v[RDFGPU_OPT_CSR_ROW_LANES_LOG2]) rl = (u32)std::min<u64>(6, opt.v[RDFGPU_OPT_CSR_ROW_LANES_LOG2] - 1);
         a.row_lanes_log2 = rl;
       } else if (st->direct) {
         a.direct = st->direct; a.direct_min = st->kmin; a.direct_n = st->kn;
@@ -1281,7 +1283,7 @@ DevTable Plan::exec_lds_join(NodeInfo& nd, const DevTable& L, const DevTable& R,
     // Sized from the matches a wave can expect out of one tile (64 x rows-per-lane probe rows), which is what a
     // workgroup of an HBM-table join sees in its whole life; "expected" = the previous execution's cardinality
     // when known, else one match per probe row.  A direct-address table has at most one match per row.
-    static const u32 q_env = [] { const char* e = std::getenv("RDFGPU_JOIN_WAVE_Q"); return e ? (u32)std::strtoul(e, nullptr, 10) : 0u; }();
+    const u32 q_env = (u32)opt.v[RDFGPU_OPT_JOIN_WAVE_Q];
     const u64 per_tile = 64ull * (u64)lds_join_items(P.cap << a.row_lanes_log2, global_table);
     const u64 expect = nd.has_last ? nd.last_rows : P.cap;
     u64 want = a.direct ? per_tile : (expect * per_tile * 3 / 2) / (P.cap ? P.cap : 1);
@@ -1348,7 +1350,7 @@ DevTable Plan::exec_lds_join(NodeInfo& nd, const DevTable& L, const DevTable& R,
   // about its mean rows per key, a hash table is assumed unique-ish — so the join can run without a host round
   // trip as well; the overflow flag at the end of the plan catches a wrong guess (exact re-run).
   u64 first_guess = 0;
-  if (speculative && !nd.has_last && !left_join && !std::getenv("RDFGPU_NO_FIRST_RUN_SPECULATION")) {
+  if (speculative && !nd.has_last && !left_join && !opt.on(RDFGPU_OPT_NO_FIRST_RUN_SPECULATION)) {
     if (a.direct) first_guess = P.cap;
     else if (a.csr_off) first_guess = 2 * P.cap * ((B.cap + a.direct_n - 1) / (a.direct_n ? a.direct_n : 1)) + 1024;
     else first_guess = P.cap + 1024;

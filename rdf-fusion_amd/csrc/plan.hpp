@@ -75,6 +75,7 @@ struct PendingLaunch {
 
 struct Plan {
   Store* store = nullptr;
+  EngineOptions opt;              // copied from the store at compile time (rdfgpu_plan_set_option changes this copy)
   std::vector<NodeInfo> nodes;
   std::vector<SourceInfo> sources;
   std::vector<u32> pool;          // IN-set ids of residual predicates (host copy)

@@ -1,6 +1,8 @@
 // store.cpp — see store.hpp.  Index build = device radix sort of three permutations + dedupe.
 #include "store.hpp"
 
+#include <cstdlib>
+#include <string>
 #include <vector>
 
 #include "kernels.hpp"
@@ -54,6 +56,32 @@ void DevicePool::trim() {
   std::lock_guard<std::mutex> g(mu_);
   for (auto& kv : free_) (void)hipFree(kv.second);
   free_.clear();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Engine options: names, and the process defaults (environment read once, here and nowhere else)
+// ------------------------------------------------------------------------------------------------
+static const char* const kOptionNames[RDFGPU_OPT__COUNT] = {
+    "FORCE_GENERIC_VM", "NO_JOIN_REORDER", "NO_SPECULATION", "NO_FIRST_RUN_SPECULATION", "NO_STRING_VERDICTS",
+    "NO_TABLE_CACHE", "NO_INDEX_JOIN", "NO_CHAIN_FUSION", "NO_VALUE_TABLES", "NO_RANGE_INDEX", "NO_FILTER_FUSION",
+    "NO_LDS_JOIN", "NO_GLOBAL_TABLE_JOIN", "NO_DIRECT_TABLE", "NO_BAND_JOIN", "NO_PARTITIONED_JOIN",
+    "LDS_MAX_BUILD", "CSR_ROW_LANES_LOG2", "JOIN_WAVE_Q", "PARTITION_MIN_BUILD"};
+const char* engine_option_name(u32 option) { return option < RDFGPU_OPT__COUNT ? kOptionNames[option] : nullptr; }
+const EngineOptions& default_engine_options() {
+  static const EngineOptions defaults = [] {
+    EngineOptions o;
+    o.v[RDFGPU_OPT_LDS_MAX_BUILD] = 1024;
+    o.v[RDFGPU_OPT_PARTITION_MIN_BUILD] = 1ull << 16;
+    for (u32 i = 0; i < RDFGPU_OPT__COUNT; i++) {
+      const std::string name = std::string("RDFGPU_") + kOptionNames[i];
+      if (const char* e = std::getenv(name.c_str())) {
+        const bool is_value = i >= RDFGPU_OPT_LDS_MAX_BUILD;
+        o.v[i] = is_value ? std::strtoull(e, nullptr, 10) + (i == RDFGPU_OPT_CSR_ROW_LANES_LOG2 ? 1 : 0) : 1;
+      }
+    }
+    return o;
+  }();
+  return defaults;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -47,6 +47,15 @@ struct ExecContext {
   ~ExecContext();
 };
 
+// Engine options (include/rdfgpu.h section 4b): process defaults are read from the environment exactly once; a store
+// copies the defaults at creation, a plan copies its store's at compile time.  The execute path reads only these copies.
+struct EngineOptions {
+  u64 v[RDFGPU_OPT__COUNT] = {};
+  bool on(int o) const { return v[o] != 0; }
+};
+const EngineOptions& default_engine_options();
+const char* engine_option_name(u32 option);
+
 struct Permutation {
   u32* col[4] = {nullptr, nullptr, nullptr, nullptr};  // index-order columns (flat, sorted, unique)
   u64 n = 0;
@@ -83,6 +92,7 @@ struct SliceKey {
 struct Store {
   int device = 0;
   u32 batch_size = 8192;
+  EngineOptions opt = default_engine_options();
   Permutation idx[RDFGPU_N_INDEXES];
   // typed-value side table (object_id_mapping.rs:376-399), 16 B per id
   rdfgpu_typed_value* tv = nullptr; u64 n_ids = 0;

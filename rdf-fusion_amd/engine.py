@@ -73,6 +73,11 @@ def load_library():
     lib.rdfgpu_plan_stream.argtypes = [vp, C.POINTER(vp)]
     lib.rdfgpu_plan_enable_kernel_timing.argtypes = [vp, C.c_int]
     lib.rdfgpu_plan_kernel_stats.argtypes = [vp, C.POINTER(abi.KernelStat), C.c_uint32, u32p]
+    lib.rdfgpu_store_set_option.argtypes = [vp, C.c_uint32, C.c_uint64]
+    lib.rdfgpu_store_get_option.argtypes = [vp, C.c_uint32, u64p]
+    lib.rdfgpu_plan_set_option.argtypes = [vp, C.c_uint32, C.c_uint64]
+    lib.rdfgpu_option_name.argtypes = [C.c_uint32]
+    lib.rdfgpu_option_name.restype = C.c_char_p
     lib.rdfgpu_scan_score.argtypes = [C.POINTER(abi.ScanInstruction)]
     lib.rdfgpu_scan_score.restype = C.c_uint64
     lib.rdfgpu_choose_index.argtypes = [C.POINTER(abi.ScanInstruction), C.c_uint32]
@@ -251,6 +256,17 @@ class GpuQuadStore:
         _check(self._lib.rdfgpu_store_read_index(self._h, components, *ptrs, n.value, C.byref(n)))
         return cols
 
+    def set_option(self, name, value=1):
+        """Engine option of this store (plans compiled afterwards copy it); `name` as in abi.OPTION_NAMES, with or
+        without the RDFGPU_ prefix of its environment variable."""
+        _check(self._lib.rdfgpu_store_set_option(self._h, abi.OPTIONS[name.replace("RDFGPU_", "", 1)], int(value)))
+        return self
+
+    def get_option(self, name):
+        v = C.c_uint64()
+        _check(self._lib.rdfgpu_store_get_option(self._h, abi.OPTIONS[name.replace("RDFGPU_", "", 1)], C.byref(v)))
+        return v.value
+
     def plan(self, description):
         return GpuPlan(self, description)
 
@@ -322,6 +338,11 @@ class GpuPlan:
         m = abi.Metrics()
         _check(self._lib.rdfgpu_plan_metrics(self._h, C.byref(m)))
         return m
+
+    def set_option(self, name, value=1):
+        """Engine option of this plan only (its later executions)."""
+        _check(self._lib.rdfgpu_plan_set_option(self._h, abi.OPTIONS[name.replace("RDFGPU_", "", 1)], int(value)))
+        return self
 
     def enable_kernel_timing(self, on=True):
         _check(self._lib.rdfgpu_plan_enable_kernel_timing(self._h, int(on)))

@@ -32,7 +32,7 @@ print("root", root)
 exp, n_exp, _ = os_.execute(desc, [T0, T1]); want = ku.multiset(exp, n_exp)
 used = sorted({int(n.table_slot) for n in pb.nodes if n.kind == abi.NODE_TABLE})
 for toggle in (None, "RDFGPU_NO_SPECULATION", "RDFGPU_NO_CHAIN_FUSION", "RDFGPU_NO_TABLE_CACHE", "RDFGPU_NO_INDEX_JOIN", "RDFGPU_NO_LDS_JOIN", "RDFGPU_NO_FILTER_FUSION", "RDFGPU_NO_DIRECT_TABLE", "RDFGPU_FORCE_GENERIC_VM", "RDFGPU_NO_JOIN_REORDER", "RDFGPU_NO_FIRST_RUN_SPECULATION"):
-    if toggle: os.environ[toggle] = "1"
+    if toggle: gs.set_option(toggle, 1)
     plan = gs.plan(desc)
     for slot in used: plan.bind_table(slot, *[(p0, n0), (p1, n1)][slot])
     res = []
@@ -41,4 +41,4 @@ for toggle in (None, "RDFGPU_NO_SPECULATION", "RDFGPU_NO_CHAIN_FUSION", "RDFGPU_
         ok = n == n_exp and np.array_equal(ku.multiset(got, n), want)
         res.append("ok" if ok else "BAD(%d vs %d)" % (n, n_exp))
     print("%-32s %s" % (toggle, res))
-    if toggle: del os.environ[toggle]
+    if toggle: gs.set_option(toggle, 0)

@@ -43,11 +43,11 @@ for pattern, flags in (("^GraduateStudent1", ""), ("student[0-9]*7$", "i"), ("."
     base = checksum(plan.fetch())
     kern = sorted(plan.kernel_stats(), key=lambda k: -k[2])[:4]
     for toggle in ("RDFGPU_NO_INDEX_JOIN", "RDFGPU_NO_DIRECT_TABLE", "RDFGPU_NO_LDS_JOIN"):
-        os.environ[toggle] = "1"
+        st.set_option(toggle, 1)
         alt = st.plan(desc).execute()
         assert checksum(alt.fetch()) == base, (pattern, toggle)
         alt.close()
-        del os.environ[toggle]
+        st.set_option(toggle, 0)
     got = plan.fetch()
     sel = np.random.default_rng(0).choice(len(got[0]), min(len(got[0]), 200_000), replace=False) if len(got[0]) else np.zeros(0, np.int64)
     for pname, a, b in (("ub:advisor", 0, 1), ("ub:teacherOf", 1, 2), ("ub:takesCourse", 0, 2)):

@@ -110,3 +110,29 @@ def test_product_package_does_not_import_the_oracle():
             if f.endswith((".py", ".cpp", ".hpp", ".hip", ".h")) or f == "Makefile":
                 text = open(os.path.join(dirpath, f), errors="replace").read()
                 assert "oracle" not in text.lower(), f"{f} mentions the oracle: the product path must not use it"
+
+
+def test_engine_option_names_match_the_header():
+    """include/rdfgpu.h section 4b: option ids, their names and the Python mirror agree; no device needed."""
+    import re
+    lib = rf.load_library()
+    header = open(os.path.join(ROOT, "include", "rdfgpu.h")).read()
+    declared = re.findall(r"RDFGPU_OPT_([A-Z0-9_]+?)(?: = 0)?,", header)
+    assert declared == abi.OPTION_NAMES
+    for i, name in enumerate(abi.OPTION_NAMES):
+        assert lib.rdfgpu_option_name(i).decode() == name
+    assert lib.rdfgpu_option_name(len(abi.OPTION_NAMES)) is None
+
+
+def test_environment_is_read_once_not_on_the_execute_path():
+    """the RDFGPU_* toggles are process defaults (store.cpp: default_engine_options), copied into the
+    store and the plan; nothing that compiles or executes a plan may call getenv."""
+    csrc = os.path.join(ROOT, "rdf-fusion_amd", "csrc")
+    for name in sorted(os.listdir(csrc)):
+        if not name.endswith((".cpp", ".hpp", ".hip")):
+            continue
+        text = open(os.path.join(csrc, name)).read()
+        if name == "store.cpp":
+            assert text.count("getenv") == 1
+        else:
+            assert "getenv" not in text, name

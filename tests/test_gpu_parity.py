@@ -521,11 +521,9 @@ def test_regex_filter_matches_oracle(torch_cuda, monkeypatch):
         p1 = gs.plan(desc); p1.bind_table(0, ptrs, len(ids)); p1.enable_kernel_timing(True)
         a_rows = np.sort(p1.execute().fetch()[0])
         assert any("filter_kernel<3>" in k[0] for k in p1.kernel_stats()) or ENGINE_TOGGLED
-        monkeypatch.setenv("RDFGPU_NO_STRING_VERDICTS", "1")
-        p2 = gs.plan(desc); p2.bind_table(0, ptrs, len(ids)); p2.enable_kernel_timing(True)
+        p2 = gs.plan(desc).set_option("NO_STRING_VERDICTS"); p2.bind_table(0, ptrs, len(ids)); p2.enable_kernel_timing(True)
         b_rows = np.sort(p2.execute().fetch()[0])
         assert not any("filter_kernel<3>" in k[0] for k in p2.kernel_stats())
-        monkeypatch.delenv("RDFGPU_NO_STRING_VERDICTS")
         np.testing.assert_array_equal(a_rows, b_rows)
     # an independent spot check of the device against Python's `re` (not via the oracle)
     for pat, py in (("(ab|cd)+e", "(ab|cd)+e"), ("^k.*x$", "^k.*x\\Z"), ("[^a]b", "[^a]b")):
@@ -680,11 +678,11 @@ def test_fused_lookup_chain_equals_unfused(bsbm_stores, torch_cuda, monkeypatch)
         names = [k[0] for k in plan.kernel_stats()]
         fused_seen = fused_seen or any("lds_join_kernel" in n and n.endswith("true>") for n in names)
         if it == 3:
-            monkeypatch.setenv("RDFGPU_NO_CHAIN_FUSION", "1")
+            plan.set_option("NO_CHAIN_FUSION", 1)
             plain = plan.execute().fetch()
             assert not any("lds_join_kernel" in k[0] and k[0].endswith("true>") for k in plan.kernel_stats())
             np.testing.assert_array_equal(ku.multiset(plain), ku.multiset(got))
-            monkeypatch.delenv("RDFGPU_NO_CHAIN_FUSION")
+            plan.set_option("NO_CHAIN_FUSION", 0)
     assert fused_seen or ENGINE_TOGGLED, "the lookup chain was never fused"
     # the store changes under the compiled plan: every cached table / value table / range index must be rebuilt
     extra_p = rng.choice(ds.n_products, 300, replace=False)
@@ -707,14 +705,17 @@ def test_fused_lookup_chain_equals_unfused(bsbm_stores, torch_cuda, monkeypatch)
 
 TOGGLES = ["RDFGPU_NO_CHAIN_FUSION", "RDFGPU_NO_INDEX_JOIN", "RDFGPU_NO_TABLE_CACHE", "RDFGPU_NO_SPECULATION",
            "RDFGPU_NO_FIRST_RUN_SPECULATION", "RDFGPU_NO_DIRECT_TABLE", "RDFGPU_FORCE_GENERIC_VM", "RDFGPU_NO_LDS_JOIN",
-           "RDFGPU_NO_GLOBAL_TABLE_JOIN", "RDFGPU_NO_FILTER_FUSION", "RDFGPU_NO_VALUE_TABLES", "RDFGPU_NO_RANGE_INDEX"]
+           "RDFGPU_NO_GLOBAL_TABLE_JOIN", "RDFGPU_NO_FILTER_FUSION", "RDFGPU_NO_VALUE_TABLES", "RDFGPU_NO_RANGE_INDEX",
+           "RDFGPU_NO_BAND_JOIN", "RDFGPU_NO_PARTITIONED_JOIN", "RDFGPU_NO_JOIN_REORDER", "RDFGPU_NO_STRING_VERDICTS"]
 
 
 @pytest.mark.parametrize("toggle", TOGGLES)
-def test_engine_toggles_do_not_change_results(bsbm_stores, torch_cuda, monkeypatch, toggle):
+def test_engine_toggles_do_not_change_results(bsbm_stores, torch_cuda, request, toggle):
     """Every physical rewrite / table form / speculation mode can be switched off; the bindings must not notice."""
     ds, gs, os_ = bsbm_stores
-    monkeypatch.setenv(toggle, "1")
+    before = gs.get_option(toggle)
+    gs.set_option(toggle, 1)            # plans compiled from here on copy it (the environment is only read once per process)
+    request.addfinalizer(lambda: gs.set_option(toggle, before))
     rng = np.random.default_rng(len(toggle))
     for x in rng.choice(ds.n_products, 3, replace=False):
         run_both(gs, os_, bsbm.q5_plan(ds, ds.product(int(x))))
@@ -1125,12 +1126,15 @@ def test_subject_hash_shard_keeps_the_index_join_path(torch_cuda, world):
         np.testing.assert_array_equal(ku.multiset(list(np.concatenate(union).T)), ku.multiset(exp_all, n_all))
 
 
-def test_generic_vm_equals_specialised_kernels(bsbm_stores, monkeypatch):
+def test_generic_vm_equals_specialised_kernels(bsbm_stores):
     ds, gs, os_ = bsbm_stores
     desc = bsbm.q5_plan(ds, ds.product(17))
     a = gs.plan(desc).execute().fetch()
-    monkeypatch.setenv("RDFGPU_FORCE_GENERIC_VM", "1")
-    b = gs.plan(desc).execute().fetch()
+    gs.set_option("FORCE_GENERIC_VM", 1)
+    try:
+        b = gs.plan(desc).execute().fetch()
+    finally:
+        gs.set_option("FORCE_GENERIC_VM", 0)
     np.testing.assert_array_equal(ku.multiset(a), ku.multiset(b))
 
 
