@@ -13,19 +13,23 @@
 // stage value tables); 107 M candidate pairs of a 262 144-instance BSBM Q5 batch cost 3.7 ms that way, 22x the
 // compulsory bytes in L2 misses.  Both sides of the base join are partitioned by the key instead — the build side IS
 // partitioned already (a CSR table = rows grouped by key), the probe side is radix-sorted by key per execution — and
-// one wave owns one key: the group's entries are decoded ONCE (stage look-ups, decoded window operands), the key's
-// probe rows are decoded ONCE (window bounds as biased 32-bit intervals), and the |group| x |rows| pair tests are
-// register compares (two unsigned range checks and one id compare per pair), 64 probe rows per wave-instruction.
-// Survivors are 1 bit per pair in HBM; a device scan over the per-key counts places every key's output; a second pass
-// expands the bits into rows.  No atomics, no candidate queue, deterministic output order.
+// every key's group meets the key's probe rows in 64 x 64 blocks, one wave per block: the group's entries are decoded
+// ONCE per execution (stage look-ups, decoded window operands), the probe rows are decoded ONCE (window bounds as
+// biased 32-bit intervals), and the pair tests are register compares (two unsigned range checks and one id compare per
+// pair), 64 probe rows per wave-instruction, the entry operands arriving through the scalar cache.
+// Survivors are 1 bit per pair in HBM; a device scan over the per-block counts places every block's output; a second
+// pass expands the bits into rows.  No atomics, no candidate queue, deterministic output order.
 //
-//   band_keys_kernel    sort key of every probe row (key - kmin; kn = "joins nothing")            -> rocPRIM radix sort
+//   band_entries_kernel per build row, in CSR order: the pair test's operands (16 B) and the entry's output values
+//   band_decode_kernel  per probe row, in row order: sort key (key - kmin; kn = "joins nothing"), window bounds (checked
+//                       i64 -> biased u32 interval), id operand                                    -> rocPRIM radix sort
 //   band_bounds_kernel  poff[k] = first sorted position with key >= k (one pass, gaps filled)
-//   band_blocks_kernel  blocks (64 entries x 64 rows) per key -> exclusive scan = first block of a key
-//   band_decode_kernel  per sorted probe row: window bounds (checked i64 -> biased u32 interval), id operand, row id
-//   band_mask_kernel    per key: the pair tests, 1 bit per pair, count per key                       (dominant)
-//   band_emit_kernel    per key: bits -> output rows at koff[k] + running count
+//   band_blocks_kernel  blocks (64 entries x 64 rows) per key -> exclusive scan = first block of a key -> band_desc_kernel
+//   band_mask_kernel    per block: the pair tests, 1 bit per pair, count per block
+//   band_slow_kernel    rows whose operands are not all xsd:integer: full semantics (exits at once if there are none)
+//   band_emit_kernel    per block: bits -> output rows at the block's scanned offset, coalesced
 #include <hip/hip_runtime.h>
+#include <cstring>
 #include <rocprim/rocprim.hpp>
 
 #include "join_device.hpp"
@@ -35,14 +39,6 @@ namespace rdfgpu {
 constexpr u32 kBandInvalidLo = 0xFFFFFFFFu;   // a row / window that nothing can pass: (x - 0xFFFFFFFF) <= 0 never holds for x < 2^32 - 1
 
 // ---- partition of the probe side by key ----------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void band_keys_kernel(const u32* key_col, const u64* n_dev, u64 cap, u32 kmin, u32 kn, u32* skey, u32* sval) {
-  const u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= cap) return;
-  const u64 n = live_rows(n_dev, cap);
-  u32 k = kn;
-  if (j < n) { const u32 v = key_col[j]; const u32 d = v - kmin; if (v != 0 && d < kn) k = d; }   // null keys never join
-  skey[j] = k; sval[j] = (u32)j;
-}
 // poff[k] = number of sorted rows with key < k, for k = 0 .. kn (kn + 1 entries): every position whose key differs
 // from its predecessor's fills the keys in between.
 __global__ __launch_bounds__(256) void band_bounds_kernel(const u32* skey_sorted, u64 n, u32 kn, u32* poff) {
@@ -101,11 +97,16 @@ __device__ __forceinline__ uint2 band_interval(long long lo, long long hi, long 
   const u32 hi_b = dh >= 0xFFFFFFF0ull ? 0xFFFFFFF0u : (u32)dh + 1u;
   return make_uint2(lo_b, hi_b - lo_b);
 }
-__global__ __launch_bounds__(256) void band_decode_kernel(const LdsJoinArgs a, const BandArgs b) {
-  const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= b.n_sorted) return;
-  if (b.skey[i] >= a.direct_n) return;                 // beyond the last joining row: never read
-  const u32 j = b.perm[i];
+// One pass over the probe side in ROW order (coalesced column reads): the sort key of every row (key - kmin; kn =
+// joins nothing) and, for the rows that can join, the decoded windows + the id operand of the base join's filter.
+__global__ __launch_bounds__(256) void band_decode_kernel(const BandArgs b) {
+  const u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= b.n_probe_cap) return;
+  const u64 n = live_rows(b.n_probe_dev, b.n_probe_cap);
+  u32 k = b.kn;
+  if (j < n) { const u32 v = b.probe_key[j]; const u32 d = v - b.kmin; if (v != 0 && d < b.kn) k = d; }   // null keys never join
+  b.skey_in[j] = k; b.sval_in[j] = (u32)j;
+  if (k == b.kn) return;
   uint4 rec = make_uint4(1u, 0u, 1u, 0u);              // no window: entries carry x_b = 1 (0 when the entry is dead)
   u32 flags = 0;
 #pragma unroll
@@ -114,51 +115,69 @@ __global__ __launch_bounds__(256) void band_decode_kernel(const LdsJoinArgs a, c
     const BandWin& bw = b.win[w];
     long long lo, hi;
     uint2 iv = make_uint2(kBandInvalidLo, 0u);
-    if (band_window_of(a.tt, bw, bw.y0[j], bw.y1[j], lo, hi)) iv = band_interval(lo, hi, bw.vbase);
+    if (band_window_of(b.tt, bw, bw.y0[j], bw.y1[j], lo, hi)) iv = band_interval(lo, hi, bw.vbase);
     else flags |= 1u;                                  // slow row: full semantics per pair
     if (w == 0) { rec.x = iv.x; rec.y = iv.y; } else { rec.z = iv.x; rec.w = iv.y; }
   }
   u32 x = 0;
   if (b.has_neq) { x = b.neq_probe[j]; if (x == 0) { rec.x = kBandInvalidLo; rec.y = 0u; flags = 2u; } }   // null => the comparison is not `true`
-  if (flags & 1u) { rec.x = kBandInvalidLo; rec.y = 0u; }   // the fast test must not pass a slow row
-  b.prec[i] = rec;
-  b.paux[i] = make_uint4(x, j, flags, 0u);
+  if (flags & 1u) { rec.x = kBandInvalidLo; rec.y = 0u; atomicAdd(b.slow_rows, 1u); }   // the register test must not pass a slow row
+  u32 rv[kBandMaxRowCols] = {0u, 0u};
+#pragma unroll
+  for (u32 u = 0; u < kBandMaxRowCols; u++) if (u < b.n_row_cols) rv[u] = b.row_col[u][j];
+  b.rec[2 * j] = rec;
+  b.rec[2 * j + 1] = make_uint4(x, flags, rv[0], rv[1]);
+}
+// The records in sorted order: the one random access per probe row (32 contiguous bytes); everything downstream streams.
+__global__ __launch_bounds__(256) void band_rows_kernel(const BandArgs b) {
+  const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= b.n_probe_cap || i >= b.poff[b.kn]) return;   // rows that join nothing sort to the end
+  const u32 j = b.perm[i];
+  b.rec_s[i] = b.rec[2 * (u64)j];
+  b.aux_s[i] = b.rec[2 * (u64)j + 1];
 }
 
 // ---- per group entry: the chain's look-ups, once ------------------------------------------------------------------
 struct BandEntry { u32 brow, r0, r1, r2, xb0, xb1, nq; bool ok; };
-__device__ __forceinline__ BandEntry band_entry(const LdsJoinArgs& a, const BandArgs& b, u32 pos, bool live) {
+__device__ __forceinline__ BandEntry band_entry(const BandArgs& b, u32 pos, bool live) {
   BandEntry e;
-  e.brow = live ? (a.csr_rows ? a.csr_rows[pos] : pos) : 0u;
+  e.brow = live ? (b.csr_rows ? b.csr_rows[pos] : pos) : 0u;
   e.ok = live;
+  // every look-up is issued on its own (none waits for another's verdict): one L2 round trip for all stages
   u32 r[kMaxChain] = {kNil, kNil, kNil};
 #pragma unroll
   for (u32 t = 0; t < (u32)kMaxChain; t++) {
-    if (t >= a.n_chain) continue;
-    const ChainStage& st = a.chain[t];
-    const u32 key = st.key.ptr[e.brow];               // key.src == 1: a build column (host-checked)
+    if (t >= b.n_stages) continue;
+    const BandStage& st = b.stage[t];
+    const u32 key = st.key_col[e.brow];
     const u32 d = key - st.kmin;
-    const bool in = e.ok && key != 0 && d < st.kn;    // null keys never join
-    r[t] = st.direct[in ? d : 0u];
-    r[t] = in ? r[t] : kNil;
-    e.ok = e.ok && r[t] != kNil;                      // inner join: an entry without a stage row joins nothing
+    const bool in = live && key != 0 && d < st.kn;    // null keys never join
+    const u32 row = st.direct[in ? d : 0u];
+    r[t] = in ? row : kNil;
   }
-  e.r0 = r[0]; e.r1 = r[1]; e.r2 = r[2];
-  u32 xb[2] = {1u, 1u};
+  long long xv[2] = {0, 0}; bool xin[2] = {true, true};
 #pragma unroll
   for (u32 w = 0; w < 2; w++) {
     if (w >= b.n_win) continue;
     const BandWin& bw = b.win[w];
     const u32 key = bw.key_col[e.brow];
     const u32 d = key - bw.vkmin;
-    const bool in = e.ok && key != 0 && d < bw.vkn;
-    const long long x = bw.val[in ? d : 0u];
-    xb[w] = (in && x != INT64_MIN) ? (u32)((unsigned long long)x - (unsigned long long)bw.vbase) + 1u : 0u;
+    xin[w] = live && key != 0 && d < bw.vkn;
+    xv[w] = bw.val[xin[w] ? d : 0u];
+  }
+#pragma unroll
+  for (u32 t = 0; t < (u32)kMaxChain; t++) if (t < b.n_stages) e.ok = e.ok && r[t] != kNil;   // inner join: no stage row, no match
+  e.r0 = r[0]; e.r1 = r[1]; e.r2 = r[2];
+  u32 xb[2] = {1u, 1u};
+#pragma unroll
+  for (u32 w = 0; w < 2; w++) {
+    if (w >= b.n_win) continue;
+    xb[w] = (xin[w] && xv[w] != INT64_MIN) ? (u32)((unsigned long long)xv[w] - (unsigned long long)b.win[w].vbase) + 1u : 0u;
     e.ok = e.ok && xb[w] != 0u;
   }
-  if (a.has_post) {   // the former build-side FilterExec `col <=|!=> literal` (host-checked: a build column)
-    const u32 v = a.cols[a.post.col][e.brow];
-    e.ok = e.ok && v != 0 && a.post.lit != 0 && ((v == a.post.lit) == (a.post.is_eq != 0));
+  if (b.has_post) {   // the former build-side FilterExec `col <=|!=> literal`
+    const u32 v = b.post_col[e.brow];
+    e.ok = e.ok && v != 0 && b.post_lit != 0 && ((v == b.post_lit) == (b.post_is_eq != 0));
   }
   e.nq = 0;
   if (b.has_neq) { e.nq = b.neq_build[e.brow]; e.ok = e.ok && e.nq != 0; }
@@ -167,139 +186,253 @@ __device__ __forceinline__ BandEntry band_entry(const LdsJoinArgs& a, const Band
   return e;
 }
 
-// ---- the pair tests: one wave per key ------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void band_mask_kernel(const LdsJoinArgs a, const BandArgs b) {
-  const u32 lane = threadIdx.x & 63;
-  const u32 k = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (threadIdx.x >> 6));
-  if (k >= a.direct_n) return;
-  const u32 e0 = a.csr_off[k], e1 = a.csr_off[k + 1], p0 = b.poff[k], p1 = b.poff[k + 1];
-  if (e0 >= e1 || p0 >= p1) { if (lane == 0) b.kcount[k] = 0; return; }
-  const u32 nrc = (p1 - p0 + 63) >> 6;
-  u32 blk = b.boff[k];
-  u32 total = 0;
-  for (u32 eb = e0; eb < e1; eb += 64) {
-    const u32 ne = e1 - eb < 64 ? e1 - eb : 64;       // wave-uniform
-    const BandEntry en = band_entry(a, b, eb + lane, lane < ne);
-    for (u32 rc = 0; rc < nrc; rc++, blk++) {
-      const u32 i = p0 + rc * 64 + lane;
-      const bool rlive = i < p1;
-      uint4 rec = make_uint4(kBandInvalidLo, 0u, 1u, 0u);
-      uint4 aux = make_uint4(0u, 0u, 0u, 0u);
-      if (rlive) { rec = b.prec[i]; aux = b.paux[i]; }
-      u32 m_lo = 0, m_hi = 0;
-      // lane = probe row; the entries of the chunk are broadcast one by one (v_readlane): per pair two unsigned range
-      // checks and one id compare, nothing is loaded inside the loop
-      auto test = [&](u32 e) {
-        const u32 x0 = __builtin_amdgcn_readlane(en.xb0, e), x1 = __builtin_amdgcn_readlane(en.xb1, e);
-        bool pass = (x0 - rec.x) <= rec.y && (x1 - rec.z) <= rec.w;
-        if (b.has_neq) { const u32 q = __builtin_amdgcn_readlane(en.nq, e); pass = pass && ((q == aux.x) == (b.neq_is_eq != 0)); }
-        return pass;
-      };
-      const u32 n_lo = ne < 32 ? ne : 32;
-      for (u32 e = 0; e < n_lo; e++) m_lo |= test(e) ? (1u << e) : 0u;
-      for (u32 e = 32; e < ne; e++) m_hi |= test(e) ? (1u << (e - 32)) : 0u;
-      if (__any((aux.z & 1u) != 0)) {
-        // rare: a probe row whose window operands are not all xsd:integer — the full typed-value semantics, pair by pair
-        for (u32 e = 0; e < ne; e++) {
-          const bool eok = __builtin_amdgcn_readlane((u32)en.ok, e) != 0;
-          const u32 brow = __builtin_amdgcn_readlane(en.brow, e);
-          const u32 r0 = __builtin_amdgcn_readlane(en.r0, e), r1 = __builtin_amdgcn_readlane(en.r1, e), r2 = __builtin_amdgcn_readlane(en.r2, e);
-          const u32 q = __builtin_amdgcn_readlane(en.nq, e);
-          if (!(aux.z & 1u) || !eok) continue;
-          bool pass = true;
+// The stage look-ups once per distinct key value (all stages keyed by the same build column): 32 B per key.
+__global__ __launch_bounds__(256) void band_pt_kernel(const BandArgs b) {
+  const u32 idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= b.pt_n) return;
+  const u32 key = b.pt_min + idx;
+  bool ok = key != 0;
+  u32 r[kMaxChain] = {kNil, kNil, kNil};
 #pragma unroll
-          for (u32 w = 0; w < 2; w++) {
-            if (w >= b.n_win) continue;
-            const u32 t = b.win[w].stage;
-            pass = pass && stage_filter_slow(a, a.chain[t], brow, aux.y, t == 0 ? r0 : t == 1 ? r1 : r2);
-          }
-          if (b.has_neq) pass = pass && ((q == aux.x) == (b.neq_is_eq != 0));
-          if (pass) { if (e < 32) m_lo |= 1u << e; else m_hi |= 1u << (e - 32); }
-        }
-      }
-      b.masks[(u64)blk * 64 + lane] = ((u64)m_hi << 32) | m_lo;
-      u32 c = (u32)__popc(m_lo) + (u32)__popc(m_hi);
-#pragma unroll
-      for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d, 64);
-      total += c;
-    }
+  for (u32 t = 0; t < (u32)kMaxChain; t++) {
+    if (t >= b.n_stages) continue;
+    const BandStage& st = b.stage[t];
+    const u32 d = key - st.kmin;
+    const bool in = key != 0 && d < st.kn;
+    const u32 row = st.direct[in ? d : 0u];
+    r[t] = in ? row : kNil;
+    ok = ok && r[t] != kNil;
   }
-  if (lane == 0) b.kcount[k] = total;
+  u32 xb[2] = {1u, 1u};
+#pragma unroll
+  for (u32 w = 0; w < 2; w++) {
+    if (w >= b.n_win) continue;
+    const BandWin& bw = b.win[w];
+    const u32 d = key - bw.vkmin;
+    const bool in = key != 0 && d < bw.vkn;
+    const long long x = bw.val[in ? d : 0u];
+    xb[w] = (in && x != INT64_MIN) ? (u32)((unsigned long long)x - (unsigned long long)bw.vbase) + 1u : 0u;
+    ok = ok && xb[w] != 0u;
+  }
+  u32 ov[kBandMaxSideCols] = {0u, 0u, 0u, 0u};
+#pragma unroll
+  for (u32 u = 0; u < kBandMaxSideCols; u++) {
+    if (u >= b.n_entry_cols || !ok) continue;
+    const ColRef c = b.entry_col[u];
+    if (c.src >= 2) ov[u] = c.ptr[c.src == 2 ? r[0] : c.src == 3 ? r[1] : r[2]];
+  }
+  b.pt[2 * (u64)idx] = make_uint4(ok ? xb[0] : 0u, xb[1], ok ? 1u : 0u, 0u);
+  b.pt[2 * (u64)idx + 1] = make_uint4(ov[0], ov[1], ov[2], ov[3]);
 }
-
-// ---- bits -> rows ----------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void band_emit_kernel(const LdsJoinArgs a, const BandArgs b) {
-  const u32 lane = threadIdx.x & 63;
-  const u32 k = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (threadIdx.x >> 6));
-  if (k == 0 && lane == 0) {   // the exact total, whether or not it fitted (like the fused join kernel's count)
-    const u64 total = b.koff[a.direct_n];
-    *a.n_out_dev = total;
-    if (total > a.out_cap) *a.overflow = 1u;
-  }
-  if (k >= a.direct_n) return;
-  if (b.kcount[k] == 0) return;
-  const u32 e0 = a.csr_off[k], e1 = a.csr_off[k + 1], p0 = b.poff[k], p1 = b.poff[k + 1];
-  const u32 nrc = (p1 - p0 + 63) >> 6;
-  u32 blk = b.boff[k];
-  u64 run = b.koff[k];
-  for (u32 eb = e0; eb < e1; eb += 64) {
-    const u32 ne = e1 - eb < 64 ? e1 - eb : 64;
-    const BandEntry en = band_entry(a, b, eb + lane, lane < ne);
-    // output columns that come from the build row or from a stage's row: one value per entry (lane = entry)
-    u32 ev[kBandMaxSideCols];
+// One pass over the build side in CSR order: what the pair test needs of every entry (16 B) and the entry's output values.
+__global__ __launch_bounds__(256) void band_entries_kernel(const BandArgs b) {
+  const u64 pos = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (pos >= b.n_entries) return;
+  if (b.pt == nullptr) {     // stages keyed by different columns: every entry does its own look-ups
+    const BandEntry en = band_entry(b, (u32)pos, true);
+    b.et[pos] = make_uint4(en.xb0, en.xb1, en.nq, en.ok ? 1u : 0u);
 #pragma unroll
     for (u32 u = 0; u < kBandMaxSideCols; u++) {
-      ev[u] = 0;
-      if (u < b.n_entry_cols && en.ok) {
-        const ColRef c = b.entry_col[u];
-        const u32 row = c.src == 1 ? en.brow : c.src == 2 ? en.r0 : c.src == 3 ? en.r1 : en.r2;
-        ev[u] = c.ptr[row];
-      }
+      if (u >= b.n_entry_cols) continue;
+      const ColRef c = b.entry_col[u];
+      const u32 row = c.src == 1 ? en.brow : c.src == 2 ? en.r0 : c.src == 3 ? en.r1 : en.r2;
+      b.eo[u][pos] = en.ok ? c.ptr[row] : 0u;
     }
-    for (u32 rc = 0; rc < nrc; rc++, blk++) {
-      const u32 i = p0 + rc * 64 + lane;
-      u64 mask = i < p1 ? b.masks[(u64)blk * 64 + lane] : 0ull;
-      const u32 cnt = (u32)__popcll(mask);
-      const u32 incl = wave_incl_scan(cnt);
-      const u32 tot = __shfl(incl, 63, 64);
-      if (tot == 0) continue;                                           // wave-uniform
-      u64 pos = run + (incl - cnt);
-      run += tot;
-      u32 rv[kBandMaxSideCols];                                         // output columns of the probe row (lane = row)
-      const u32 j = mask ? b.paux[i].y : 0u;
+    return;
+  }
+  const u32 brow = b.csr_rows ? b.csr_rows[pos] : (u32)pos;
+  const u32 key = b.pt_key_col[brow];
+  const u32 d = key - b.pt_min;
+  const bool in = key != 0 && d < b.pt_n;
+  const uint4 a0 = b.pt[2 * (u64)(in ? d : 0u)], a1 = b.pt[2 * (u64)(in ? d : 0u) + 1];
+  bool ok = in && a0.z != 0;
+  if (b.has_post) { const u32 v = b.post_col[brow]; ok = ok && v != 0 && b.post_lit != 0 && ((v == b.post_lit) == (b.post_is_eq != 0)); }
+  u32 nq = 0;
+  if (b.has_neq) { nq = b.neq_build[brow]; ok = ok && nq != 0; }
+  b.et[pos] = make_uint4(ok ? a0.x : 0u, a0.y, nq, ok ? 1u : 0u);
 #pragma unroll
-      for (u32 u = 0; u < kBandMaxSideCols; u++) { rv[u] = 0; if (u < b.n_row_cols && mask) rv[u] = b.row_col[u][j]; }
-      while (__any(mask != 0)) {
-        const bool has = mask != 0;
-        const u32 e = has ? (u32)__ffsll((long long)mask) - 1u : 0u;
-        mask &= mask - 1;
-        u32 ue = 0, ur = 0;
-        for (u32 oc = 0; oc < a.n_out_cols; oc++) {                     // wave-uniform schedule of the output columns
-          u32 v;
-          if (b.out_from_row[oc]) {
-            v = rv[0];
+  for (u32 u = 0; u < kBandMaxSideCols; u++) {
+    if (u >= b.n_entry_cols) continue;
+    const ColRef c = b.entry_col[u];
+    const u32 v = c.src == 1 ? c.ptr[brow] : (u == 0 ? a1.x : u == 1 ? a1.y : u == 2 ? a1.z : a1.w);
+    b.eo[u][pos] = ok ? v : 0u;
+  }
+}
+// Block descriptors: key k owns the blocks boff[k] .. boff[k + 1), entry chunk major.
+__global__ __launch_bounds__(256) void band_desc_kernel(const BandArgs b) {
+  const u32 k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= b.kn) return;
+  const u32 e0 = b.csr_off[k], e1 = b.csr_off[k + 1], p0 = b.poff[k], p1 = b.poff[k + 1];
+  if (e0 >= e1 || p0 >= p1) return;
+  u32 blk = b.boff[k];
+  for (u32 eb = e0; eb < e1; eb += 64)
+    for (u32 rb = p0; rb < p1; rb += 64, blk++)
+      if (blk < b.max_blocks) b.bdesc[blk] = make_uint4(eb, e1 - eb < 64 ? e1 - eb : 64, rb, p1 - rb < 64 ? p1 - rb : 64);
+}
+
+// ---- the pair tests: one wave per 64 x 64 block --------------------------------------------------------------------
+// lane = probe row (its decoded record in registers); the block's entries are wave-uniform: they stream through the
+// scalar cache (s_load_dwordx8 = two entries) and feed the vector compares as scalar operands — per pair two unsigned
+// range checks and one id compare, no vector memory and no LDS inside the loop.
+// NWIN = window stages (1..2; no window = one trivial window); NEQ = base filter: 0 none / 1 `!=` / 2 `=`.
+struct BandEntry8 { uint4 a[8]; };
+template <int NWIN, int NEQ>
+__global__ __launch_bounds__(256) void band_mask_kernel(const BandArgs b) {
+  const u32 lane = threadIdx.x & 63;
+  const u32 blk = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (threadIdx.x >> 6));
+  if (blk >= b.boff[b.kn] || blk >= b.max_blocks) return;
+  const uint4 d = b.bdesc[blk];
+  const u32 eb = __builtin_amdgcn_readfirstlane(d.x), ne = __builtin_amdgcn_readfirstlane(d.y);
+  const u32 rb = __builtin_amdgcn_readfirstlane(d.z), nr = __builtin_amdgcn_readfirstlane(d.w);
+  uint4 rec = make_uint4(kBandInvalidLo, 0u, 1u, 0u);
+  u32 x = 0;
+  if (lane < nr) { rec = b.rec_s[rb + lane]; if (NEQ) x = b.aux_s[rb + lane].x; }
+  const BandEntry8* __restrict__ p = reinterpret_cast<const BandEntry8*>(b.et + eb);   // the table is padded: reading past the group is harmless
+  u32 m[2] = {0u, 0u};
 #pragma unroll
-            for (u32 u = 1; u < kBandMaxSideCols; u++) v = ur == u ? rv[u] : v;
-            ur++;
-          } else {
-            u32 src = ev[0];
+  for (u32 h = 0; h < 2; h++) {
+    if (h * 32 >= ne) continue;                       // wave-uniform
+    u32 acc = 0;
+#pragma unroll 1
+    for (u32 g = 0; g < 4; g++) {
+      const BandEntry8 cur = p[h * 4 + g];
+      u32 part = 0;
 #pragma unroll
-            for (u32 u = 1; u < kBandMaxSideCols; u++) src = ue == u ? ev[u] : src;
-            v = __shfl(src, e, 64);
-            ue++;
-          }
-          if (has && pos < a.out_cap) a.out[oc][pos] = v;
+      for (u32 e = 0; e < 8; e++) {
+        const uint4 q = cur.a[e];
+        // branch-free on purpose (bitwise &, not &&): a short-circuit here becomes an exec-mask branch per pair
+        u32 pass = (u32)((q.x - rec.x) <= rec.y);
+        if (NWIN > 1) pass &= (u32)((q.y - rec.z) <= rec.w);
+        if (NEQ == 1) pass &= (u32)(q.z != x);
+        if (NEQ == 2) pass &= (u32)(q.z == x);
+        part |= pass << e;
+      }
+      acc |= part << (8 * g);
+    }
+    m[h] = acc;
+  }
+  // entries past the group's end belong to the next key: their bits do not count
+  const u64 live = ne >= 64 ? ~0ull : ((1ull << ne) - 1ull);
+  const u64 mask = ((((u64)m[1]) << 32) | m[0]) & live;
+  b.masks[(u64)blk * 64 + lane] = mask;
+  u32 c = (u32)__popcll(mask);
+#pragma unroll
+  for (int dd = 32; dd >= 1; dd >>= 1) c += __shfl_xor(c, dd, 64);
+  if (lane == 0) b.bcount[blk] = c;
+}
+
+// Rare: probe rows whose window operands are not all xsd:integer (or overflow i64) take the full typed-value semantics,
+// pair by pair (stage_filter_slow), and patch their bits and their block's count.  Runs after the mask kernel; exits at
+// once when the decode pass met no such row.
+__global__ __launch_bounds__(256) void band_slow_kernel(const LdsJoinArgs* ap, const BandArgs b) {
+  if (*b.slow_rows == 0) return;
+  const LdsJoinArgs& a = *ap;
+  const u32 lane = threadIdx.x & 63;
+  const u32 blk = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (threadIdx.x >> 6));
+  if (blk >= b.boff[b.kn] || blk >= b.max_blocks) return;
+  const uint4 d = b.bdesc[blk];
+  const u32 eb = d.x, ne = d.y, rb = d.z, nr = d.w;
+  u32 j = 0; uint4 aux = make_uint4(0u, 0u, 0u, 0u);
+  if (lane < nr) { j = b.perm[rb + lane]; aux = b.aux_s[rb + lane]; }
+  const bool slow = (aux.y & 1u) != 0;
+  if (!__any(slow)) return;
+  const BandEntry en = band_entry(b, eb + lane, lane < ne);
+  u32 m_lo = 0, m_hi = 0;
+  for (u32 e = 0; e < ne; e++) {
+    const bool eok = __builtin_amdgcn_readlane((u32)en.ok, e) != 0;
+    const u32 brow = __builtin_amdgcn_readlane(en.brow, e);
+    const u32 r0 = __builtin_amdgcn_readlane(en.r0, e), r1 = __builtin_amdgcn_readlane(en.r1, e), r2 = __builtin_amdgcn_readlane(en.r2, e);
+    const u32 q = __builtin_amdgcn_readlane(en.nq, e);
+    if (!slow || !eok) continue;
+    bool pass = true;
+    for (u32 w = 0; w < b.n_win; w++) {
+      const u32 t = b.win[w].stage;
+      pass = pass && stage_filter_slow(a, a.chain[t], brow, j, t == 0 ? r0 : t == 1 ? r1 : r2);
+    }
+    if (b.has_neq) pass = pass && ((q == aux.x) == (b.neq_is_eq != 0));
+    if (pass) { if (e < 32) m_lo |= 1u << e; else m_hi |= 1u << (e - 32); }
+  }
+  if (slow) b.masks[(u64)blk * 64 + lane] |= ((u64)m_hi << 32) | m_lo;
+  u32 c = (u32)__popc(m_lo) + (u32)__popc(m_hi);
+#pragma unroll
+  for (int dd = 32; dd >= 1; dd >>= 1) c += __shfl_xor(c, dd, 64);
+  if (lane == 0 && c) b.bcount[blk] += c;
+}
+
+// ---- bits -> rows: one wave per block --------------------------------------------------------------------------------
+// Every lane (= probe row) lists its surviving entries in LDS at its prefix position, then the wave writes the block's
+// output rows 64 at a time — consecutive rows, every column one coalesced 256-byte store — fetching each value from the
+// owning lane's registers (ds_bpermute).
+constexpr u32 kBandList = 1024;   // survivors listed at a time: a block with more is emitted 16 rows at a time (16 x 64 <= 1024)
+__global__ __launch_bounds__(256) void band_emit_kernel(const BandArgs b) {
+  __shared__ unsigned short list[4][kBandList];
+  const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const u32 blk = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + wave);
+  const u32 n_blocks = b.boff[b.kn] < b.max_blocks ? b.boff[b.kn] : b.max_blocks;
+  if (blk == 0 && lane == 0) {   // the exact total, whether or not it fitted (like the fused join kernel's count)
+    const u64 total = b.bofs[b.max_blocks];
+    *b.n_out_dev = total;
+    if (total > b.out_cap) *b.overflow = 1u;
+  }
+  if (blk >= n_blocks) return;
+  const u32 tot = __builtin_amdgcn_readfirstlane(b.bcount[blk]);
+  if (tot == 0) return;
+  const uint4 d = b.bdesc[blk];
+  const u32 eb = __builtin_amdgcn_readfirstlane(d.x), ne = __builtin_amdgcn_readfirstlane(d.y);
+  const u32 rb = __builtin_amdgcn_readfirstlane(d.z), nr = __builtin_amdgcn_readfirstlane(d.w);
+  u64 run = b.bofs[blk];
+  const u64 mask_all = lane < nr ? b.masks[(u64)blk * 64 + lane] : 0ull;
+  u32 ev[kBandMaxSideCols], rv[kBandMaxRowCols];   // output values of the entry (lane = entry) / of the probe row (lane = row)
+  {
+    uint4 aux = make_uint4(0u, 0u, 0u, 0u);
+    if (lane < nr) aux = b.aux_s[rb + lane];
+    rv[0] = aux.z; rv[1] = aux.w;
+  }
+#pragma unroll
+  for (u32 u = 0; u < kBandMaxSideCols; u++) { ev[u] = 0; if (u < b.n_entry_cols && lane < ne) ev[u] = b.eo[u][eb + lane]; }
+  const u32 step = tot <= kBandList ? 64u : 16u;   // rows listed per round (wave-uniform)
+  for (u32 r0 = 0; r0 < nr; r0 += step) {
+    u64 mask = (lane >= r0 && lane < r0 + step) ? mask_all : 0ull;
+    const u32 cnt = (u32)__popcll(mask);
+    const u32 incl = wave_incl_scan(cnt);
+    const u32 n_round = __shfl(incl, 63, 64);
+    if (n_round == 0) continue;                                         // wave-uniform
+    u32 at = incl - cnt;
+    while (mask) {                                                      // this lane's survivors, in entry order
+      const u32 e = (u32)__ffsll((long long)mask) - 1u;
+      mask &= mask - 1;
+      list[wave][at++] = (unsigned short)((lane << 6) | e);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    for (u32 t0 = 0; t0 < n_round; t0 += 64) {
+      const u32 idx = t0 + lane;
+      const bool valid = idx < n_round;
+      const u32 pr = valid ? (u32)list[wave][idx] : 0u;
+      const u32 r = pr >> 6, e = pr & 63u;
+      const u64 pos = run + idx;
+      u32 ue = 0, ur = 0;
+      for (u32 oc = 0; oc < b.n_out_cols; oc++) {                       // wave-uniform schedule of the output columns
+        u32 v;
+        if (b.out_from_row[oc]) { v = __shfl(ur == 0 ? rv[0] : rv[1], r, 64); ur++; }
+        else {
+          u32 src = ev[0];
+#pragma unroll
+          for (u32 u = 1; u < kBandMaxSideCols; u++) src = ue == u ? ev[u] : src;
+          v = __shfl(src, e, 64);
+          ue++;
         }
-        pos += has ? 1u : 0u;
+        if (valid && pos < b.out_cap) b.out[oc][pos] = v;
       }
     }
+    run += n_round;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");              // the list is free again
   }
 }
 
 // ---- host side -------------------------------------------------------------------------------------------------------
 static inline dim3 grid256(u64 n) { const u64 g = (n + 255) / 256; return dim3((unsigned)(g ? g : 1)); }
-void launch_band_keys(const u32* key_col, const u64* n_dev, u64 cap, u32 kmin, u32 kn, u32* skey, u32* sval, hipStream_t s) {
-  if (cap) hipLaunchKernelGGL(band_keys_kernel, grid256(cap), dim3(256), 0, s, key_col, n_dev, cap, kmin, kn, skey, sval);
+void launch_band_decode(const BandArgs& b, hipStream_t s) {
+  if (b.n_probe_cap) hipLaunchKernelGGL(band_decode_kernel, grid256(b.n_probe_cap), dim3(256), 0, s, b);
 }
 void launch_band_bounds(const u32* skey_sorted, u64 n, u32 kn, u32* poff, hipStream_t s) {
   hipLaunchKernelGGL(band_bounds_kernel, grid256(n + 1), dim3(256), 0, s, skey_sorted, n, kn, poff);
@@ -307,14 +440,33 @@ void launch_band_bounds(const u32* skey_sorted, u64 n, u32 kn, u32* poff, hipStr
 void launch_band_blocks(const u32* csr_off, const u32* poff, u32 kn, u32* nblk, hipStream_t s) {
   hipLaunchKernelGGL(band_blocks_kernel, grid256((u64)kn + 1), dim3(256), 0, s, csr_off, poff, kn, nblk);
 }
-void launch_band_decode(const LdsJoinArgs& a, const BandArgs& b, hipStream_t s) {
-  if (b.n_sorted) hipLaunchKernelGGL(band_decode_kernel, grid256(b.n_sorted), dim3(256), 0, s, a, b);
+void launch_band_pt(const BandArgs& b, hipStream_t s) {
+  if (b.pt && b.pt_n) hipLaunchKernelGGL(band_pt_kernel, grid256(b.pt_n), dim3(256), 0, s, b);
 }
-void launch_band_mask(const LdsJoinArgs& a, const BandArgs& b, hipStream_t s) {
-  hipLaunchKernelGGL(band_mask_kernel, dim3((a.direct_n + 3) / 4), dim3(256), 0, s, a, b);
+void launch_band_rows(const BandArgs& b, hipStream_t s) {
+  if (b.n_probe_cap) hipLaunchKernelGGL(band_rows_kernel, grid256(b.n_probe_cap), dim3(256), 0, s, b);
 }
-void launch_band_emit(const LdsJoinArgs& a, const BandArgs& b, hipStream_t s) {
-  hipLaunchKernelGGL(band_emit_kernel, dim3((a.direct_n + 3) / 4), dim3(256), 0, s, a, b);
+void launch_band_entries(const BandArgs& b, hipStream_t s) {
+  if (b.n_entries) hipLaunchKernelGGL(band_entries_kernel, grid256(b.n_entries), dim3(256), 0, s, b);
+}
+void launch_band_desc(const BandArgs& b, hipStream_t s) {
+  hipLaunchKernelGGL(band_desc_kernel, grid256(b.kn), dim3(256), 0, s, b);
+}
+template <int NWIN> static void launch_band_mask_w(const BandArgs& b, dim3 g, hipStream_t s) {
+  const int neq = b.has_neq ? (b.neq_is_eq ? 2 : 1) : 0;
+  if (neq == 0) hipLaunchKernelGGL((band_mask_kernel<NWIN, 0>), g, dim3(256), 0, s, b);
+  else if (neq == 1) hipLaunchKernelGGL((band_mask_kernel<NWIN, 1>), g, dim3(256), 0, s, b);
+  else hipLaunchKernelGGL((band_mask_kernel<NWIN, 2>), g, dim3(256), 0, s, b);
+}
+void launch_band_mask(const BandArgs& b, hipStream_t s) {
+  const dim3 g((b.max_blocks + 3) / 4);           // the number of blocks lives on the device: surplus waves leave at once
+  if (b.n_win == 2) launch_band_mask_w<2>(b, g, s); else launch_band_mask_w<1>(b, g, s);   // no window = one trivial window
+}
+void launch_band_slow(const LdsJoinArgs* a_dev, const BandArgs& b, hipStream_t s) {
+  hipLaunchKernelGGL(band_slow_kernel, dim3((b.max_blocks + 3) / 4), dim3(256), 0, s, a_dev, b);
+}
+void launch_band_emit(const BandArgs& b, hipStream_t s) {
+  hipLaunchKernelGGL(band_emit_kernel, dim3((b.max_blocks + 3) / 4), dim3(256), 0, s, b);
 }
 
 // rocPRIM radix sort of (u32 key, u32 value) pairs on the low `bits` bits: the partition pass of the probe side

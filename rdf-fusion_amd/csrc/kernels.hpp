@@ -199,6 +199,69 @@ struct LdsJoinArgs {
   u32 has_post; IdFilter post;
 };
 void launch_lds_join(const LdsJoinArgs& a, hipStream_t s);
+
+// ---- key-partitioned band join (band_join.hip): the fused chain over a CSR join with small groups, group by group ----
+constexpr u32 kBandMaxSideCols = 4;   // output columns taken from the group entry; from the probe row: kBandMaxRowCols
+constexpr u32 kBandMaxRowCols = 2;    // (they travel inside the row's 32-byte record)
+constexpr u32 kBandMaxGroup = 512;    // largest CSR group (rows of one key) the path accepts: 8 chunks of 64 entries
+struct BandWin {              // one integer window stage: lo(row) <= x(entry) <= hi(row)
+  const u32* key_col;         // build column holding the stage's key
+  const long long* val; u32 vkmin, vkn;   // x = val[key - vkmin] (INT64_MIN = no row)
+  long long vbase;            // bias of the 32-bit intervals: stored x = x - vbase + 1
+  const u32* y0; const u32* y1;   // probe columns of the two halves
+  TvLiteral l0, l1;
+  u32 stage, pad;             // index into LdsJoinArgs::chain (full-semantics path)
+};
+struct BandStage { const u32* key_col; const u32* direct; u32 kmin, kn; };   // look-up of a build column in a slice's direct table
+// Everything the band kernels need, and nothing else (the fused join kernel's argument block is 1.6 KB: passed by value it
+// costs 118 spilled SGPRs in the pair-test loop).
+struct BandArgs {
+  // the CSR table of the build side and the probe side's key column
+  const u32* csr_off; const u32* csr_rows; u32 kmin, kn;
+  const u32* probe_key; const u64* n_probe_dev; u64 n_probe_cap;
+  // what a group entry (a build row) is checked against, once per entry
+  u32 n_stages, n_win; BandStage stage[kMaxChain]; BandWin win[2];
+  u32 has_post, post_lit, post_is_eq, has_neq; const u32* post_col;
+  const u32* neq_build; const u32* neq_probe; u32 neq_is_eq, pad0;   // base join filter `build col <ID_EQ|ID_NEQ> probe col`
+  TypedTable tt;
+  // when every stage hangs off the SAME build column (the usual star: ?product), the stage look-ups are done once per
+  // distinct key value (pt: {x0_b, x1_b, joins, 0, stage-sourced output values 0..3}, 32 B per key of [pt_min, pt_min + pt_n))
+  // and an entry fetches its key's record with one gather; pt == null: every entry does its own look-ups
+  uint4* pt; u32 pt_min, pt_n; const u32* pt_key_col; u32 pt_out_slot[kBandMaxSideCols];
+  // the build side's groups, decoded once per execution in CSR order (entry = position in the CSR row list)
+  uint4* et;                  // per entry {x0_b, x1_b, id operand, 1 = the entry can join}: what the pair test reads
+  u32* eo[kBandMaxSideCols];  // per entry: its output values (one array per entry column)
+  u64 n_entries;              // = build rows
+  // the probe side, decoded in row order and radix-sorted by key - kmin (kn = joins nothing)
+  u32* skey_in; u32* sval_in; const u32* skey; const u32* perm;
+  uint4* rec;                 // per probe row (row order), 2 x uint4: {lo0, w0, lo1, w1} {id operand, flags (1 = full semantics), output value 0, 1}
+  uint4* rec_s; uint4* aux_s; // the same two halves in sorted order (what the block kernels stream)
+  u32* poff; u32* boff;       // [kn + 1]: first sorted row / first 64x64 block of every key
+  uint4* bdesc;               // per block {first entry, entries (<= 64), first sorted row, rows (<= 64)}
+  u64* masks;                 // 64 x u64 per block: bit e of lane r = (entry e, row r) joins
+  u32* bcount; u32* bofs;     // per block (+ 1): output rows / their exclusive scan
+  u32 max_blocks, pad2;
+  u32* slow_rows;             // number of probe rows that need the full typed-value semantics (usually 0)
+  // output
+  u32 n_out_cols, n_entry_cols, n_row_cols, pad1;
+  u32* out[kMaxCols]; u64 out_cap; u64* n_out_dev; u32* overflow;
+  ColRef entry_col[kBandMaxSideCols]; const u32* row_col[kBandMaxSideCols];
+  u8 out_from_row[kMaxCols];  // per output column: 1 = next row column, 0 = next entry column
+};
+void launch_band_pt(const BandArgs& b, hipStream_t s);
+void launch_band_entries(const BandArgs& b, hipStream_t s);
+void launch_band_rows(const BandArgs& b, hipStream_t s);      // records into sorted order
+void launch_band_desc(const BandArgs& b, hipStream_t s);
+void launch_band_decode(const BandArgs& b, hipStream_t s);   // + sort keys
+void launch_band_bounds(const u32* skey_sorted, u64 n, u32 kn, u32* poff, hipStream_t s);
+void launch_band_blocks(const u32* csr_off, const u32* poff, u32 kn, u32* nblk, hipStream_t s);
+void launch_band_mask(const BandArgs& b, hipStream_t s);
+void launch_band_slow(const LdsJoinArgs* a_dev, const BandArgs& b, hipStream_t s);   // patches masks / counts of the rare slow rows
+void launch_band_emit(const BandArgs& b, hipStream_t s);
+size_t sort_u32_temp_bytes(u64 n, u32 bits);
+void sort_pairs_u32_u32(const u32* kin, u32* kout, const u32* vin, u32* vout, u64 n, u32 bits, void* temp, size_t temp_bytes, hipStream_t s);
+void launch_val_minmax(const long long* val, u64 n, long long* out_minmax /* preset {INT64_MAX, INT64_MIN + 1} */, hipStream_t s);
+void launch_csr_max_group(const u32* off, u32 kn, u32* out_dev /* zeroed */, hipStream_t s);
 void launch_gjoin_build(const LdsJoinArgs& a, hipStream_t s);   // fills a.gslots (memset to 0xFF first)
 int lds_join_items(u64 n_probe_cap, bool global);   // rows per lane of the instantiation that will be launched: 4 / 1
 enum { kJoinTableLds = 0, kJoinTableHash = 1, kJoinTableDirect = 2, kJoinTableCsr = 3 };   // lds_join_kernel's MODE

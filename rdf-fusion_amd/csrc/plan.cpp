@@ -402,7 +402,10 @@ const char* kernel_class_name(int kc) {
       "void rdfgpu::nlj_kernel<true>", "rocprim device scan", "rdfgpu::gjoin_build_kernel", "rdfgpu::gdirect_build_kernel",
       "rdfgpu::minmax_u32_kernel", "rdfgpu::csr_hist_kernel", "rdfgpu::csr_scatter_kernel",
       "rdfgpu::topk_max_kernel", "rdfgpu::topk_hist_kernel", "rdfgpu::topk_scatter_kernel", "rdfgpu::topk_select_kernel",
-      "rdfgpu::topk_write_kernel", "void rdfgpu::filter_kernel<3>", "rdfgpu::regex_verdict_kernel", "rdfgpu::union_kernel"};
+      "rdfgpu::topk_write_kernel", "void rdfgpu::filter_kernel<3>", "rdfgpu::regex_verdict_kernel", "rdfgpu::union_kernel",
+      "rdfgpu::band_slow_kernel", "rocprim radix sort", "rdfgpu::band_bounds_kernel", "rdfgpu::band_blocks_kernel",
+      "rdfgpu::band_decode_kernel", "void rdfgpu::band_mask_kernel", "rdfgpu::band_emit_kernel", "rdfgpu::band_entries_kernel",
+      "rdfgpu::band_desc_kernel", "rdfgpu::band_pt_kernel", "rdfgpu::band_rows_kernel"};
   if (kc < KC_LDS_JOIN0) return fixed[kc];
   static std::string names[192];
   static std::once_flag once;
@@ -491,6 +494,7 @@ void Plan::execute() {
   metrics = rdfgpu_metrics{};
   counters_used = 0;
   progs_used = 0;
+  arg_slots_used = 0;
   events_used = 2;   // events 0/1 bracket the whole execute
   pending.clear();
   host_valid = false; cursor = 0; executed = false;
@@ -870,7 +874,7 @@ bool Plan::plan_chain(NodeInfo& top, ChainRequest& req) {
 
 // Resolves the chain against the base join's inputs; false (nothing changed in `a` that matters) if some column cannot
 // be addressed the way the kernel needs.
-bool Plan::apply_chain(const ChainRequest& req, NodeInfo& base, const DevTable& L, const DevTable& R, bool build_left, LdsJoinArgs& a, u64& stage_bytes) {
+bool Plan::apply_chain(const ChainRequest& req, NodeInfo& base, const DevTable& L, const DevTable& R, bool build_left, LdsJoinArgs& a, u64& stage_bytes, BandArgs* band, bool* use_band) {
   std::vector<ColRef> cur(base.n_proj);
   for (u32 k = 0; k < base.n_proj; k++) {
     const u32 c = base.proj[k];
@@ -878,6 +882,7 @@ bool Plan::apply_chain(const ChainRequest& req, NodeInfo& base, const DevTable& 
     cur[k] = ColRef{from_left ? L.cols[c] : R.cols[c - L.n_cols], (from_left == build_left) ? 1u : 0u, 0u};
   }
   ChainStage stages[kMaxChain];
+  const SliceTable::ValueColumn* stage_vc[kMaxChain] = {nullptr, nullptr, nullptr};
   stage_bytes = 0;
   for (size_t t = 0; t < req.links.size(); t++) {
     const ChainLink& ln = req.links[t];
@@ -933,10 +938,21 @@ bool Plan::apply_chain(const ChainRequest& req, NodeInfo& base, const DevTable& 
         RDFGPU_HIP(hipMemcpyAsync(&is_bad, bad, sizeof(u32), hipMemcpyDeviceToHost, stream));
         RDFGPU_HIP(hipStreamSynchronize(stream)); metrics.host_syncs++;
         if (is_bad) { RDFGPU_HIP(hipFree(val)); val = nullptr; }
-        tab->values.push_back(SliceTable::ValueColumn{st.f[0].ptr, val, val != nullptr});
+        SliceTable::ValueColumn fresh{st.f[0].ptr, val, val != nullptr};
+        if (val) {   // value range: the bias of the band join's 32-bit window intervals
+          long long* mm = reinterpret_cast<long long*>(new_counter()); (void)new_counter();
+          const long long init[2] = {INT64_MAX, INT64_MIN + 1};
+          RDFGPU_HIP(hipMemcpyAsync(mm, init, sizeof init, hipMemcpyHostToDevice, stream));
+          launch_val_minmax(val, tab->kn, mm, stream);
+          long long got[2];
+          RDFGPU_HIP(hipMemcpyAsync(got, mm, sizeof got, hipMemcpyDeviceToHost, stream));
+          RDFGPU_HIP(hipStreamSynchronize(stream)); metrics.host_syncs++;
+          fresh.vmin = got[0]; fresh.vmax = got[1];
+        }
+        tab->values.push_back(fresh);
         vc = &tab->values.back();
       }
-      if (vc->usable) st.val = vc->val;
+      if (vc->usable) { st.val = vc->val; stage_vc[t] = vc; }
     }
     std::vector<ColRef> next(N.n_proj);
     for (u32 k = 0; k < N.n_proj; k++) next[k] = resolve(N.proj[k]);
@@ -945,10 +961,63 @@ bool Plan::apply_chain(const ChainRequest& req, NodeInfo& base, const DevTable& 
     stage_bytes += base.last_rows * (8ull + 4ull * n_fcols);   // per candidate: key + table slot + filter operands (estimate)
   }
   if (cur.size() != req.top->n_proj || cur.size() > (size_t)kMaxCols) return false;
+  // Band join (band_join.hip): when the groups of the CSR base are small, every stage hangs off a BUILD column and the
+  // stage filters are integer windows between a stage value and probe columns, the chain runs group by group — both
+  // sides partitioned by the key, the pair tests in registers — instead of probe row by probe row.
+  *use_band = false;
+  if (band && a.csr_off && cur_build_table && !opt.on(RDFGPU_OPT_NO_BAND_JOIN) && arg_slots_used < ExecContext::kArgSlots) {
+    const DevTable& B = build_left ? L : R; const DevTable& Pp = build_left ? R : L;
+    auto from_build = [&](u32 c) { return (c < L.n_cols) == build_left; };
+    auto range_op = [](u8 op) { return op == RDFGPU_EX_GT || op == RDFGPU_EX_LT || op == RDFGPU_EX_GEQ || op == RDFGPU_EX_LEQ; };
+    BandArgs b{};
+    bool ok = a.n_keys == 1 && (a.has_filter == 0 || a.has_filter == 2) && a.has_probe_filter == 0 && a.visited == nullptr;
+    if (ok && a.has_filter == 2) {
+      const bool ab = from_build(a.idp.a), bb = from_build(a.idp.b);
+      ok = ab != bb;
+      if (ok) { b.has_neq = 1; b.neq_is_eq = a.idp.is_eq; b.neq_build = a.cols[ab ? a.idp.a : a.idp.b]; b.neq_probe = a.cols[ab ? a.idp.b : a.idp.a]; }
+    }
+    if (ok && a.has_post) {
+      ok = from_build(a.post.col);
+      b.has_post = 1; b.post_col = a.cols[a.post.col]; b.post_lit = a.post.lit; b.post_is_eq = a.post.is_eq;
+    }
+    b.n_stages = (u32)req.links.size();
+    for (size_t t = 0; ok && t < req.links.size(); t++) {
+      const ChainStage& st = stages[t];
+      ok = st.key.src == 1 && (st.fs == 0 || st.fs == 3);
+      if (!ok) break;
+      b.stage[t] = BandStage{st.key.ptr, st.direct, st.kmin, st.kn};
+      if (st.fs == 0) continue;
+      const SliceTable::ValueColumn* vc = stage_vc[t];
+      ok = st.val != nullptr && vc && b.n_win < 2 && st.f[1].src == 0 && st.f[3].src == 0 && range_op(st.l0.cmp_op) && range_op(st.l1.cmp_op) &&
+           vc->vmin <= vc->vmax && (unsigned long long)(vc->vmax - vc->vmin) < 0xFFFFFFE0ull;
+      if (!ok) break;
+      BandWin& w = b.win[b.n_win++];
+      w.key_col = st.key.ptr; w.val = st.val; w.vkmin = st.kmin; w.vkn = st.kn; w.vbase = vc->vmin;
+      w.y0 = st.f[1].ptr; w.y1 = st.f[3].ptr; w.l0 = st.l0; w.l1 = st.l1; w.stage = (u32)t;
+    }
+    for (size_t k = 0; ok && k < cur.size(); k++) {
+      if (cur[k].src == 0) { ok = b.n_row_cols < kBandMaxRowCols; if (ok) { b.out_from_row[k] = 1; b.row_col[b.n_row_cols++] = cur[k].ptr; } }
+      else { ok = b.n_entry_cols < kBandMaxSideCols; if (ok) { b.out_from_row[k] = 0; b.entry_col[b.n_entry_cols++] = cur[k]; } }
+    }
+    if (ok) {   // group sizes: the largest decides (one wave joins a whole group), measured once per table
+      SliceTable* tab = cur_build_table;
+      std::unique_lock<std::mutex> building(store->slice_build_mu);
+      if (tab->csr_max_group == 0) {
+        u32* mx = reinterpret_cast<u32*>(new_counter());
+        launch_csr_max_group(a.csr_off, a.direct_n, mx, stream);
+        u32 got = 0;
+        RDFGPU_HIP(hipMemcpyAsync(&got, mx, sizeof got, hipMemcpyDeviceToHost, stream));
+        RDFGPU_HIP(hipStreamSynchronize(stream)); metrics.host_syncs++;
+        tab->csr_max_group = got ? got : 1;
+      }
+      ok = tab->csr_max_group <= kBandMaxGroup && B.cap >= 4ull * a.direct_n && Pp.cap * 4 >= a.direct_n && Pp.cap < (1ull << 31);
+    }
+    if (ok) { *band = b; *use_band = true; }
+  }
   // Range index: a CSR base whose first stage is an integer window (GT / LT / GEQ / LEQ) between the stage's decoded
   // value and probe-side columns expands, per probe row, only the part of the key's group whose value can pass —
   // the group is kept sorted by that value (built once per store version, kept with the CSR table).
-  {
+  if (!*use_band) {
     const ChainStage& s0 = stages[0];
     auto range_op = [](u8 op) { return op == RDFGPU_EX_GT || op == RDFGPU_EX_LT || op == RDFGPU_EX_GEQ || op == RDFGPU_EX_LEQ; };
     const DevTable& B = build_left ? L : R;
@@ -1360,8 +1429,9 @@ DevTable Plan::exec_lds_join(NodeInfo& nd, const DevTable& L, const DevTable& R,
     // phase: the output is then the TOP node's, sized from the top node's history
     NodeInfo* size_node = &nd;
     u64 stage_bytes = 0;
+    BandArgs band{}; bool use_band = false;
     if (pending_chain && pending_chain->base == &nd && !pending_chain->consumed && global_table && !left_join && !probe_filter && nd.shape != 1 &&
-        apply_chain(*pending_chain, nd, L, R, build_left, a, stage_bytes)) {
+        apply_chain(*pending_chain, nd, L, R, build_left, a, stage_bytes, &band, &use_band)) {
       pending_chain->consumed = true;
       size_node = pending_chain->top;
       t.n_cols = a.n_out_cols;
@@ -1372,6 +1442,8 @@ DevTable Plan::exec_lds_join(NodeInfo& nd, const DevTable& L, const DevTable& R,
     a.out_cap = spec_cap;
     for (u32 c = 0; c < a.n_out_cols; c++) { a.out[c] = scratch<u32>(spec_cap + tail); t.cols[c] = a.out[c]; }
     if (left_join) RDFGPU_HIP(hipMemsetAsync(a.visited, 0, L.cap, stream));
+    if (use_band) exec_band_join(a, band, B, P, 4ull * (1 + build_payload), 4ull * probe_cols);
+    else
     timed(lds_join_class(a.has_filter, a.has_probe_filter, lds_join_items(P.cap << a.row_lanes_log2, global_table), lds_join_mode(a), chained),
           (global_table ? 0 : fixed) + stage_bytes, P.cap, P.n_dev,
           4ull * probe_cols + 8, n_out, 0, 4ull * a.n_out_cols, [&] { launch_lds_join(a, stream); });
@@ -1419,6 +1491,88 @@ DevTable Plan::exec_lds_join(NodeInfo& nd, const DevTable& L, const DevTable& R,
   timed(KC_LEFT_TAIL, 0, L.cap, L.n_dev, 1, nullptr, 0, 0, [&] { launch_join_left_unmatched(ja, stream); });
   t.n_dev = n_out;
   return t;
+}
+
+// The fused chain as a key-partitioned band join (band_join.hip).  `a` is complete (chain, output columns, out_cap,
+// counters); everything allocated here is scratch of this execution.  Bytes recorded per kernel = what that kernel has
+// to move once (compulsory): decode reads the probe columns and writes the records, the mask kernel reads the records
+// and the group entries with their stage look-ups and writes one bit per pair, the emit kernel reads the bits and
+// writes the output.
+void Plan::exec_band_join(LdsJoinArgs& a, BandArgs& b, const DevTable& B, const DevTable& P, u64 build_bytes_per_row, u64 probe_bytes_per_row) {
+  const u32 kn = a.direct_n;
+  const u64 np = P.cap, nb = B.cap;
+  b.csr_off = a.csr_off; b.csr_rows = a.csr_rows; b.kmin = a.direct_min; b.kn = kn;
+  b.probe_key = a.probe_key[0]; b.n_probe_dev = P.n_dev; b.n_probe_cap = np;
+  b.tt = a.tt;
+  b.n_out_cols = a.n_out_cols; b.out_cap = a.out_cap; b.n_out_dev = a.n_out_dev; b.overflow = a.overflow;
+  for (u32 c = 0; c < a.n_out_cols; c++) b.out[c] = a.out[c];
+  u32 bits = 1;
+  while ((1ull << bits) <= kn) bits++;            // keys 0 .. kn (kn = joins nothing)
+  b.skey_in = scratch<u32>(np); b.sval_in = scratch<u32>(np);
+  u32* skey = scratch<u32>(np); u32* perm = scratch<u32>(np);
+  b.skey = skey; b.perm = perm;
+  b.rec = scratch<uint4>(2 * np); b.rec_s = scratch<uint4>(np); b.aux_s = scratch<uint4>(np);
+  b.slow_rows = reinterpret_cast<u32*>(new_counter());
+  const size_t stb = sort_u32_temp_bytes(np, bits);
+  void* stemp = scratch<unsigned char>(stb);
+  u64 entry_bytes = build_bytes_per_row + (a.csr_rows ? 4 : 0) + (a.has_post ? 4 : 0);
+  for (u32 t = 0; t < a.n_chain; t++) entry_bytes += 4 + (a.chain[t].val ? 8 : 0);
+  // stages all keyed by one build column: their look-ups once per distinct key value instead of once per entry
+  {
+    const u32* kc = a.n_chain ? b.stage[0].key_col : nullptr;
+    bool same = kc != nullptr;
+    u64 lo = ~0ull, hi = 0;
+    for (u32 t = 0; t < b.n_stages; t++) { same = same && b.stage[t].key_col == kc; lo = std::min<u64>(lo, b.stage[t].kmin); hi = std::max<u64>(hi, (u64)b.stage[t].kmin + b.stage[t].kn); }
+    for (u32 w = 0; w < b.n_win; w++) same = same && b.win[w].key_col == kc;
+    if (same && hi > lo && hi - lo <= (64ull << 20) && hi - lo <= 8 * nb + 1024) {
+      b.pt_min = (u32)lo; b.pt_n = (u32)(hi - lo); b.pt_key_col = kc;
+      b.pt = scratch<uint4>(2ull * b.pt_n);
+      timed(KC_BAND_PT, 0, b.pt_n, nullptr, 4ull * b.n_stages + 8ull * b.n_win + 4ull * b.n_entry_cols + 32, nullptr, 0, 0, [&] { launch_band_pt(b, stream); });
+    }
+  }
+  // the build side, once: per row its columns + stage look-ups read, 16 B of operands + the output values written
+  b.n_entries = nb;
+  b.et = scratch<uint4>(nb + 64);                  // padded: the pair test reads whole groups of 8 entries
+  for (u32 u = 0; u < b.n_entry_cols; u++) b.eo[u] = scratch<u32>(nb);
+  timed(KC_BAND_ENTRIES, 0, nb, B.n_dev, entry_bytes + 4ull * b.n_entry_cols + 16 + 4ull * b.n_entry_cols, nullptr, 0, 0, [&] { launch_band_entries(b, stream); });
+  // per probe row: key + the window operands + the id operand read, 24 B of record + 8 B of sort pair written
+  timed(KC_BAND_DECODE, 0, np, P.n_dev, 4 + 4ull * (b.n_win + b.has_neq) + 9ull * b.n_win + 24 + 8, nullptr, 0, 0, [&] { launch_band_decode(b, stream); });
+  // the partition pass: in the time, not in the algorithmic bytes
+  timed(KC_RADIX_SORT, 0, np, nullptr, 0, nullptr, 0, 0, [&] { sort_pairs_u32_u32(b.skey_in, skey, b.sval_in, perm, np, bits, stemp, stb, stream); });
+  b.poff = scratch<u32>((u64)kn + 2);
+  u32* nblk = scratch<u32>((u64)kn + 1);
+  b.boff = scratch<u32>((u64)kn + 1);
+  // blocks: sum over keys of ceil(E/64) * ceil(R/64) <= cmax * (rows / 64) + sum of ceil(E/64) over the keys
+  const u64 cmax = (cur_build_table->csr_max_group + 63) / 64;
+  const u64 max_blocks = cmax * (np / 64 + 1) + nb / 64 + kn + 1;
+  if (max_blocks >= (1ull << 31)) fail(RDFGPU_ERR_UNSUPPORTED, "band join of %llu blocks", (unsigned long long)max_blocks);
+  b.max_blocks = (u32)max_blocks;
+  b.bdesc = scratch<uint4>(max_blocks);
+  b.masks = scratch<u64>(max_blocks * 64);
+  b.bcount = scratch<u32>(max_blocks + 1); b.bofs = scratch<u32>(max_blocks + 1);
+  const size_t tb = scan_temp_bytes(std::max<u64>((u64)kn + 1, max_blocks + 1));
+  void* temp = scratch<unsigned char>(tb);
+  RDFGPU_HIP(hipMemsetAsync(b.bcount, 0, (max_blocks + 1) * sizeof(u32), stream));
+  timed(KC_BAND_BOUNDS, 0, np, nullptr, 4, nullptr, 0, 0, [&] { launch_band_bounds(skey, np, kn, b.poff, stream); });
+  timed(KC_BAND_BLOCKS, 12ull * kn, 0, nullptr, 0, nullptr, 0, 0, [&] { launch_band_blocks(a.csr_off, b.poff, kn, nblk, stream); });
+  timed(KC_DEVICE_SCAN, 0, (u64)kn + 1, nullptr, 8, nullptr, 0, 0, [&] { exclusive_scan_u32(nblk, b.boff, (u64)kn + 1, temp, tb, stream); });
+  timed(KC_BAND_DESC, 12ull * kn, 0, nullptr, 0, nullptr, 0, 0, [&] { launch_band_desc(b, stream); });
+  timed(KC_BAND_ROWS, 0, np, P.n_dev, 4 + 32 + 32, nullptr, 0, 0, [&] { launch_band_rows(b, stream); });
+  // per probe row 4 (sorted position) + 24 (record) read, per entry 16 B read, per pair one bit written; the pair count
+  // is not known on the host
+  timed(KC_BAND_MASK, 16ull * nb, np, P.n_dev, 4 + 24, nullptr, 0, 0, [&] { launch_band_mask(b, stream); });
+  {
+    // the full-semantics pass needs the chain's literals and columns: the fused join kernel's argument block, by pointer
+    static_assert(sizeof(LdsJoinArgs) <= ExecContext::kArgBytes, "argument staging slot too small");
+    const u32 slot = arg_slots_used++;
+    LdsJoinArgs* a_host = reinterpret_cast<LdsJoinArgs*>(ctx->args_host + (size_t)slot * ExecContext::kArgBytes);
+    LdsJoinArgs* a_dev = reinterpret_cast<LdsJoinArgs*>(ctx->args_dev + (size_t)slot * ExecContext::kArgBytes);
+    *a_host = a;
+    RDFGPU_HIP(hipMemcpyAsync(a_dev, a_host, sizeof(LdsJoinArgs), hipMemcpyHostToDevice, stream));
+    timed(KC_BAND_SLOW, 0, 0, nullptr, 0, nullptr, 0, 0, [&] { launch_band_slow(a_dev, b, stream); });
+  }
+  timed(KC_DEVICE_SCAN, 0, max_blocks + 1, nullptr, 8, nullptr, 0, 0, [&] { exclusive_scan_u32(b.bcount, b.bofs, max_blocks + 1, temp, tb, stream); });
+  timed(KC_BAND_EMIT, 4ull * b.n_entry_cols * nb, np, P.n_dev, 4 + 4ull * b.n_row_cols, a.n_out_dev, 0, 4ull * a.n_out_cols, [&] { launch_band_emit(b, stream); });
 }
 
 void Plan::ensure_host_copy() {

@@ -50,6 +50,7 @@ enum KernelClass {
   KC_GDIRECT_BUILD, KC_MINMAX, KC_CSR_HIST, KC_CSR_SCATTER,
   KC_TOPK_MAX, KC_TOPK_HIST, KC_TOPK_SCATTER, KC_TOPK_SELECT, KC_TOPK_WRITE,
   KC_FILTER_VERDICT, KC_REGEX_VERDICTS, KC_UNION,
+  KC_BAND_SLOW, KC_RADIX_SORT, KC_BAND_BOUNDS, KC_BAND_BLOCKS, KC_BAND_DECODE, KC_BAND_MASK, KC_BAND_EMIT, KC_BAND_ENTRIES, KC_BAND_DESC, KC_BAND_PT, KC_BAND_ROWS,
   KC_LDS_JOIN0,                      // 192 names: lds_join_kernel<FS in {0..3}, PFS in {0,1,2}, ITEMS in {4,1}, MODE in {0,1,2,3}, CHAIN>
   KC__N = KC_LDS_JOIN0 + 192
 };
@@ -92,6 +93,7 @@ struct Plan {
   u64* counters = nullptr;        // device u64 slots for operator output counts
   u32 counters_used = 0;
   u32 progs_used = 0;
+  u32 arg_slots_used = 0;
   DevTable result; u64 result_rows = 0; bool executed = false;
   rdfgpu_metrics metrics{};
   bool timing = false;
@@ -120,7 +122,8 @@ struct Plan {
   DevTable apply_filter(NodeInfo& nd, const DevTable& in);
   DevTable exec_lds_join(NodeInfo& nd, const DevTable& L, const DevTable& R, bool build_left, const NodeInfo* probe_filter, const NodeInfo* post_filter = nullptr);
   bool plan_chain(NodeInfo& top, ChainRequest& req);
-  bool apply_chain(const ChainRequest& req, NodeInfo& base, const DevTable& L, const DevTable& R, bool build_left, LdsJoinArgs& a, u64& stage_bytes);
+  bool apply_chain(const ChainRequest& req, NodeInfo& base, const DevTable& L, const DevTable& R, bool build_left, LdsJoinArgs& a, u64& stage_bytes, BandArgs* band, bool* use_band);
+  void exec_band_join(LdsJoinArgs& a, BandArgs& b, const DevTable& B, const DevTable& P, u64 build_bytes_per_row, u64 probe_bytes_per_row);
   bool choose_build_left(const NodeInfo& nd, const DevTable& L, const DevTable& R, bool left_join, bool lf, bool rf, bool lpost = false, bool rpost = false) const;
   void release_intermediates();
   template <class T> T* scratch(u64 n);

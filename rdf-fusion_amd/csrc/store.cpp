@@ -129,6 +129,8 @@ ExecContext::~ExecContext() {
   if (counters_host) (void)hipHostFree(counters_host);
   if (progs_dev) (void)hipFree(progs_dev);
   if (progs_host) (void)hipHostFree(progs_host);
+  if (args_dev) (void)hipFree(args_dev);
+  if (args_host) (void)hipHostFree(args_host);
   if (jobs_dev) (void)hipFree(jobs_dev);
   if (lohi_dev) (void)hipFree(lohi_dev);
   if (jobs_host) (void)hipHostFree(jobs_host);
@@ -149,6 +151,8 @@ ExecContext* Store::acquire_context(u32 n_sources) {
     RDFGPU_HIP(hipHostMalloc((void**)&c->counters_host, 256 * sizeof(u64), hipHostMallocDefault));
     RDFGPU_HIP(hipMalloc((void**)&c->progs_dev, ExecContext::kProgSlots * sizeof(ExprProgram)));
     RDFGPU_HIP(hipHostMalloc((void**)&c->progs_host, ExecContext::kProgSlots * sizeof(ExprProgram), hipHostMallocDefault));
+    RDFGPU_HIP(hipMalloc((void**)&c->args_dev, (size_t)ExecContext::kArgSlots * ExecContext::kArgBytes));
+    RDFGPU_HIP(hipHostMalloc((void**)&c->args_host, (size_t)ExecContext::kArgSlots * ExecContext::kArgBytes, hipHostMallocDefault));
   }
   const u32 need = n_sources ? n_sources : 1;
   if (c->job_cap < need) {

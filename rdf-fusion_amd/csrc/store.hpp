@@ -43,6 +43,8 @@ struct ExecContext {
   void* jobs_host = nullptr; u64* lohi_host = nullptr;   // pinned staging
   static constexpr u32 kProgSlots = 16;
   ExprProgram* progs_dev = nullptr; ExprProgram* progs_host = nullptr;   // VM programs of fused kernels
+  static constexpr u32 kArgSlots = 4, kArgBytes = 4096;
+  unsigned char* args_dev = nullptr; unsigned char* args_host = nullptr;  // kernel argument blocks handed over by pointer (pinned staging)
   hipEvent_t event(u32 i);
   ~ExecContext();
 };
@@ -69,10 +71,11 @@ struct SliceTable {
   bool dense_tried = false, dense_failed = false;
   u32* direct = nullptr; u32 kmin = 0, kn = 0;      // row = direct[key - kmin]
   u32* csr_off = nullptr; u32* csr_rows = nullptr;  // rows of key k: csr_rows[csr_off[k - kmin] .. csr_off[k - kmin + 1]); null rows = identity
+  u32 csr_max_group = 0;                            // rows of the largest group (decides whether groups are joined whole, band_join.hip)
   void* slots = nullptr; u32 mask = 0;              // {key0,row} open-addressing table (uint2[mask + 1])
   // decoded payload columns of a direct table: val[key - kmin] = the xsd:integer value of that row's `col` (INT64_MIN =
   // no row); usable == false when some value is not an xsd:integer (then the generic path is the only one)
-  struct ValueColumn { const u32* col; long long* val; bool usable; };
+  struct ValueColumn { const u32* col; long long* val; bool usable; long long vmin = 0, vmax = -1; };   // vmin > vmax: no value at all
   std::vector<ValueColumn> values;
   // a CSR table's groups re-ordered by a decoded value of ANOTHER slice (reached through `link_col`, a column of this
   // slice holding that slice's key): rows[p] / vals[p] for every CSR position p, ascending by value inside each group

@@ -664,7 +664,7 @@ def test_fused_lookup_chain_equals_unfused(bsbm_stores, torch_cuda, monkeypatch)
     desc = bsbm.q5_batch_plan(ds)
     plan = gs.plan(desc)
     rng = np.random.default_rng(77)
-    fused_seen = False
+    fused_seen = band_seen = False
     for it in range(4):
         batch = 150 + 40 * it
         prods = np.array([ds.product(i) for i in rng.choice(ds.n_products, batch, replace=False)], dtype=np.uint32)
@@ -677,6 +677,7 @@ def test_fused_lookup_chain_equals_unfused(bsbm_stores, torch_cuda, monkeypatch)
         np.testing.assert_array_equal(ku.multiset(got), ku.multiset(exp, n_exp))
         names = [k[0] for k in plan.kernel_stats()]
         fused_seen = fused_seen or any("lds_join_kernel" in n and n.endswith("true>") for n in names)
+        band_seen = band_seen or any("band_mask_kernel" in n for n in names)
         if it == 3:
             plan.set_option("NO_CHAIN_FUSION", 1)
             plain = plan.execute().fetch()
@@ -684,6 +685,7 @@ def test_fused_lookup_chain_equals_unfused(bsbm_stores, torch_cuda, monkeypatch)
             np.testing.assert_array_equal(ku.multiset(plain), ku.multiset(got))
             plan.set_option("NO_CHAIN_FUSION", 0)
     assert fused_seen or ENGINE_TOGGLED, "the lookup chain was never fused"
+    assert band_seen or ENGINE_TOGGLED, "the candidate join's chain never ran as a band join"
     # the store changes under the compiled plan: every cached table / value table / range index must be rebuilt
     extra_p = rng.choice(ds.n_products, 300, replace=False)
     g2 = np.zeros(600, np.uint32)
@@ -904,6 +906,125 @@ def test_fused_chain_with_mixed_numeric_kinds(torch_cuda):
         run_both(gs, os_, bsbm.q5_plan(ds, int(x)))
 
 
+def _band_store(rng, n_prod, n_feat, fan, missing=0.1):
+    """(product, pF, feature) with `fan` features per product, (product, pV1 / pV2, integer literal), (product, pL, label);
+    ids: predicates 1..4, features, products, integer literals -500 .. 2499 (3000), a zoo of other kinds, labels."""
+    pF, pV1, pV2, pL = 1, 2, 3, 4
+    feat0 = 10
+    prod0 = feat0 + n_feat
+    int0 = prod0 + n_prod
+    n_int = 3000
+    zoo0 = int0 + n_int
+    zoo = [(abi.TV_DOUBLE, np.float64(700.5).view(np.int64)), (abi.TV_DOUBLE, np.float64("nan").view(np.int64)), (abi.TV_INTEGER, 2 ** 63 - 1),
+           (abi.TV_INTEGER, -2 ** 63), (abi.TV_INTEGER, 2 ** 63 - 100), (abi.TV_NAMED_NODE, 5), (abi.TV_INT, 900), (abi.TV_FLOAT, int(np.array([1200.0], np.float32).view(np.uint32)[0])),
+           (abi.TV_STRING, 3), (abi.TV_BOOLEAN, 1)]
+    lab0 = zoo0 + len(zoo)
+    n_ids = lab0 + n_prod
+    tv = np.zeros(n_ids, dtype=TV_DTYPE)
+    tv["tag"][1:] = abi.TV_NAMED_NODE
+    tv["lo"][1:] = np.arange(1, n_ids)
+    tv["tag"][int0:int0 + n_int] = abi.TV_INTEGER
+    tv["lo"][int0:int0 + n_int] = np.arange(n_int) - 500
+    for i, (tag, lo) in enumerate(zoo):
+        tv["tag"][zoo0 + i] = tag; tv["lo"][zoo0 + i] = lo
+    tv["tag"][lab0:] = abi.TV_STRING
+    tv["lo"][lab0:] = np.arange(n_prod)
+    prod = np.arange(prod0, prod0 + n_prod, dtype=np.uint32)
+    S, Pc, O = [], [], []
+    def emit(s, p, o):
+        S.append(np.asarray(s, np.uint32)); Pc.append(np.full(len(s), p, np.uint32)); O.append(np.asarray(o, np.uint32))
+    f = rng.integers(fan[0], fan[1] + 1, n_prod)
+    # skewed features: a few hot ones (groups of a few hundred rows = several 64-entry chunks) and a long tail, some never used
+    feat = feat0 + np.minimum((rng.random(int(f.sum())) ** 1.3 * n_feat).astype(np.int64), n_feat - 1)
+    emit(np.repeat(prod, f), pF, feat)
+    for pv in (pV1, pV2):
+        keep = rng.random(n_prod) >= missing                       # products without the value: no stage row
+        emit(prod[keep], pv, int0 + rng.integers(0, n_int, int(keep.sum())))
+    keep = rng.random(n_prod) >= missing / 2
+    emit(prod[keep], pL, lab0 + np.arange(n_prod)[keep])
+    s, p, o = np.concatenate(S), np.concatenate(Pc), np.concatenate(O)
+    ids = dict(pF=pF, pV1=pV1, pV2=pV2, pL=pL, feat0=feat0, n_feat=n_feat, prod0=prod0, n_prod=n_prod, int0=int0, n_int=n_int, zoo0=zoo0, n_zoo=len(zoo))
+    return (np.zeros(len(s), np.uint32), s, p, o), tv, ids
+
+
+@pytest.mark.parametrize("shape", ["two_windows_neq", "one_window", "lookups_only", "leq_geq_eq"])
+def test_band_join_matches_oracle(torch_cuda, shape):
+    """The key-partitioned band join (band_join.hip) = the fused look-up chain, group by group: bound table T(inst, X, f,
+    y1, y2) JOIN (product pF f) ON f [product != X] JOIN (product pV1 v1) ON product [window(v1; y1)] JOIN pV2 [window(v2; y2)]
+    JOIN (product pL label), against the oracle's operator-at-a-time answer.  Groups of 1 .. ~350 entries (up to six
+    64-entry chunks), keys without probe rows, probe rows without a group, null keys and null operands, products
+    without a stage row, windows that are empty / overflow i64 / have operands of other kinds (the full-semantics
+    path), and the same plan with the band join switched off."""
+    rng = np.random.default_rng(5)
+    quads, tv, ids = _band_store(rng, n_prod=6000, n_feat=220, fan=(1, 6))
+    gs, os_ = both_stores(quads, typed=tv)
+    n = 9000
+    inst = np.arange(1, n + 1, dtype=np.uint32)
+    X = (ids["prod0"] + rng.integers(0, ids["n_prod"], n)).astype(np.uint32)
+    X[rng.random(n) < 0.02] = 0                                     # unbound: `product != X` is not true
+    f = (ids["feat0"] + rng.integers(-3, ids["n_feat"] + 3, n)).astype(np.uint32)   # some ids that are no feature at all
+    f[rng.random(n) < 0.02] = 0                                     # null key: never joins
+    def operand():
+        y = (ids["int0"] + rng.integers(0, ids["n_int"], n)).astype(np.uint32)
+        odd = rng.random(n) < 0.06                                  # other kinds, i64 edges, NaN: the full semantics decide
+        y[odd] = (ids["zoo0"] + rng.integers(0, ids["n_zoo"], int(odd.sum()))).astype(np.uint32)
+        y[rng.random(n) < 0.01] = 0
+        return y
+    T = [inst, X, f, operand(), operand()]
+    keep, ptrs = table_on_device(torch_cuda, T)
+    pb = PlanBuilder()
+    t = pb.table(0, 5)
+    scan = lambda p, v: pb.data_source(quad_pattern("product", ids[p], v))
+    win = lambda x, y, w, lo_op=GT, hi_op=LT: AND(EBV(hi_op(ENC_TV(col(x)), ADD(ENC_TV(col(y)), integer(w)))), EBV(lo_op(ENC_TV(col(x)), SUB(ENC_TV(col(y)), integer(w)))))
+    if shape == "lookups_only":
+        node = pb.hash_join(t, scan("pF", "f"), on=[(2, 1)], projection=[0, 5, 3, 4])                       # (inst, product, y1, y2)
+        node = pb.hash_join(node, scan("pV1", "v1"), on=[(1, 0)], projection=[0, 1, 5])                    # + v1
+        node = pb.hash_join(node, scan("pL", "label"), on=[(1, 0)], projection=[0, 1, 2, 4])
+    else:
+        node = pb.hash_join(t, scan("pF", "f"), on=[(2, 1)], filter=ID_NEQ(col(5), col(1)) if shape == "two_windows_neq" else None, projection=[0, 5, 3, 4])
+        if shape == "leq_geq_eq":
+            node = pb.hash_join(node, scan("pV1", "v1"), on=[(1, 0)], filter=win(5, 2, 300, GEQ, LEQ), projection=[0, 1, 2, 3])
+            # an `=` half is no interval: this stage keeps the chain off the band path (and must still be right)
+            node = pb.hash_join(node, scan("pV2", "v2"), on=[(1, 0)], filter=AND(EBV(EQ(ENC_TV(col(5)), ADD(ENC_TV(col(3)), integer(0)))), EBV(GT(ENC_TV(col(5)), SUB(ENC_TV(col(3)), integer(9))))), projection=[0, 1, 5])
+        else:
+            node = pb.hash_join(node, scan("pV1", "v1"), on=[(1, 0)], filter=win(5, 2, 400), projection=[0, 1, 2, 3])
+            if shape == "two_windows_neq":
+                node = pb.hash_join(node, scan("pV2", "v2"), on=[(1, 0)], filter=win(5, 3, 900), projection=[0, 1, 2, 3])
+            node = pb.hash_join(node, scan("pL", "label"), on=[(1, 0)], projection=[0, 1, 5])
+    desc = pb.build(node)
+    exp, n_exp, _ = os_.execute(desc, [T])
+    assert n_exp > (10 if shape == "leq_geq_eq" else 1000)
+    want = ku.multiset(exp, n_exp)
+    plan = gs.plan(desc)
+    plan.bind_table(0, ptrs, n)
+    seen = set()
+    for rep in range(4):                                            # fusion needs the cardinalities of a first execution
+        plan.enable_kernel_timing(True)
+        got = plan.execute().fetch()
+        assert plan.result_info()[0] == n_exp
+        np.testing.assert_array_equal(ku.multiset(got, n_exp), want, err_msg=f"{shape} rep {rep}")
+        seen |= {k[0] for k in plan.kernel_stats()}
+    if shape != "leq_geq_eq" and not ENGINE_TOGGLED:
+        assert any("band_mask_kernel" in k for k in seen) and any("band_emit_kernel" in k for k in seen), seen
+    plan.set_option("NO_BAND_JOIN", 1)
+    got = plan.execute().fetch()
+    assert not any("band_" in k[0] for k in plan.kernel_stats())
+    np.testing.assert_array_equal(ku.multiset(got, n_exp), want)
+    plan.set_option("NO_BAND_JOIN", 0)
+    # the parameters change (fewer rows, other keys), the plan stays: sizes are speculative, results exact
+    m = 2500
+    T2 = [c[:m].copy() for c in T]
+    T2[2] = (ids["feat0"] + rng.integers(0, 12, m)).astype(np.uint32)   # every row on a hot feature: many rows per key
+    keep2, ptrs2 = table_on_device(torch_cuda, T2)
+    plan.bind_table(0, ptrs2, m)
+    exp2, n2, _ = os_.execute(desc, [T2])
+    for rep in range(2):
+        got = plan.execute().fetch()
+        assert plan.result_info()[0] == n2
+        np.testing.assert_array_equal(ku.multiset(got, n2), ku.multiset(exp2, n2))
+    del keep, keep2
+
+
 @pytest.mark.parametrize("cross", [False, True])
 @pytest.mark.parametrize("n,n_nodes,n_graphs", [(0, 5, 1), (1, 1, 1), (3, 3, 1), (300, 40, 2), (2000, 900, 4), (60_000, 120_000, 3), (5000, 5000, 700)])
 def test_closure_matches_oracle(torch_cuda, cross, n, n_nodes, n_graphs):
@@ -1120,7 +1241,8 @@ def test_subject_hash_shard_keeps_the_index_join_path(torch_cuda, world):
             got = plan.execute().fetch()
         exp, n_exp, _ = os_.execute(desc, [c_tab])
         np.testing.assert_array_equal(ku.multiset(got), ku.multiset(exp, n_exp))
-        assert any("lds_join_kernel" in k[0] and k[0].endswith("true>") for k in plan.kernel_stats()) or ENGINE_TOGGLED
+        # the fused chain: as a band join over the shard's CSR groups, or inside the candidate join's resolve phase
+        assert any(("lds_join_kernel" in k[0] and k[0].endswith("true>")) or "band_mask_kernel" in k[0] for k in plan.kernel_stats()) or ENGINE_TOGGLED
         union.append(ku.multiset(got))
     if world == 2:
         np.testing.assert_array_equal(ku.multiset(list(np.concatenate(union).T)), ku.multiset(exp_all, n_all))
