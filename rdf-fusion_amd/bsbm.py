@@ -212,7 +212,7 @@ def generate(n_products, seed=None, offers_per_product=20, reviews_per_product=1
 # --------------------------------------------------------------------------------------------------
 # The reference's physical plans (bench/tests/plans/snapshots/*.snap)
 # --------------------------------------------------------------------------------------------------
-def q5_plan(ds, product_id, w1=120, w2=170, topk=False):
+def q5_plan(ds, product_id, w1=120, w2=170, topk=False, builder=False):
     """BSBM Explore Q5 ("similar products"), 7 triple patterns, as planned by the reference:
     J3(J2(J1(label x features(X), productFeature), numeric1), numeric2) — Q5 (Execution Plan).snap:10-30.
     Output: (product, productLabel) bindings before DISTINCT / ORDER BY / LIMIT."""
@@ -234,6 +234,8 @@ def q5_plan(ds, product_id, w1=120, w2=170, topk=False):
         flt = AND(EBV(LT(ENC_TV(col(4)), ADD(ENC_TV(col(2)), integer(w)))),
                   EBV(GT(ENC_TV(col(4)), SUB(ENC_TV(col(2)), integer(w)))))
         node = pb.hash_join(cx, sim, on=[(0, 0)], filter=flt, projection=[0, 1])
+    if builder:              # (PlanBuilder, root) for plan display: plan.explain
+        return pb, node
     return pb.build(q5_topk(pb, node, False) if topk else node)
 
 
@@ -300,7 +302,7 @@ def q5_topk(pb_or_desc_builder, node, batched):
     return pb.topk(node, keys=[(1, abi.SORT_BY_TERM), (0, abi.SORT_BY_ID)], limit=5)
 
 
-def q1_plan(ds, type_id, feature1, feature2, threshold):
+def q1_plan(ds, type_id, feature1, feature2, threshold, builder=False):
     """BSBM Explore Q1: four chained single-key hash joins on ?product and the numeric FILTER
     (Q1 (Execution Plan).snap:10-19).  Output: (product, label)."""
     pr = ds.pred
@@ -314,6 +316,8 @@ def q1_plan(ds, type_id, feature1, feature2, threshold):
     num = pb.data_source(quad_pattern("product", pr["bsbm:productPropertyNumeric1"], "value1"))
     flt = pb.filter(num, EBV(GT(ENC_TV(col(1)), integer(threshold))), projection=[0])
     j = pb.hash_join(j, flt, on=[(0, 0)], projection=[0, 1])
+    if builder:
+        return pb, j
     return pb.build(j)
 
 

@@ -261,6 +261,8 @@ class PlanDescription:
 class PlanBuilder:
     def __init__(self):
         self.nodes, self.exprs, self.pool, self.width = [], [], [], []
+        self.names = []          # per node: the names of its output columns (variables), for plan display
+        self.patterns = []       # per node: the quad pattern of a DataSourceExec (four MemIndexScanInstructions) or None
         self.regexes = []
         self._regex_keys = []
         self.vars = {}
@@ -309,32 +311,38 @@ class PlanBuilder:
         self.pool.extend(int(c) for c in projection)
         return len(projection)
 
-    def _push(self, node, width):
+    def _push(self, node, width, names=None, pattern=None):
         self.nodes.append(node)
         self.width.append(width)
+        self.names.append(list(names) if names is not None else [f"c{i}" for i in range(width)])
+        self.patterns.append(pattern)
+        assert len(self.names[-1]) == width
         return len(self.nodes) - 1
+
+    def _projected(self, full_names, projection):
+        return list(full_names) if projection is None else [full_names[int(c)] for c in projection]
 
     # -- operators -----------------------------------------------------------------------------
     def data_source(self, instructions):
         """DataSourceExec(MemQuadPatternDataSource): four instructions in G,S,P,O order."""
         n = abi.PlanNode(kind=abi.NODE_DATA_SOURCE, left=-1, right=-1)
-        seen, width = set(), 0
+        seen, width = [], 0
         for i, ins in enumerate(instructions):
             n.scan[i] = self._instr(ins)
             if ins.kind == abi.SCAN and ins.var not in seen:
-                seen.add(ins.var)
+                seen.append(ins.var)
                 width += 1
         n.n_proj = abi.NO_PROJECTION
-        return self._push(n, width)
+        return self._push(n, width, seen, list(instructions))
 
     def filter(self, child, predicate, projection=None):
         n = abi.PlanNode(kind=abi.NODE_FILTER, left=child, right=-1)
         self._expr(n, predicate)
-        return self._push(n, self._proj(n, projection, self.width[child]))
+        return self._push(n, self._proj(n, projection, self.width[child]), self._projected(self.names[child], projection))
 
     def projection(self, child, columns):
         n = abi.PlanNode(kind=abi.NODE_PROJECTION, left=child, right=-1)
-        return self._push(n, self._proj(n, columns, self.width[child]))
+        return self._push(n, self._proj(n, columns, self.width[child]), self._projected(self.names[child], columns))
 
     def hash_join(self, left, right, on, join_type=abi.JOIN_INNER, filter=None, projection=None):
         n = abi.PlanNode(kind=abi.NODE_HASH_JOIN, left=left, right=right, join_type=join_type)
@@ -342,22 +350,24 @@ class PlanBuilder:
         for k, (l, r) in enumerate(on):
             n.left_keys[k], n.right_keys[k] = l, r
         self._expr(n, filter)
-        return self._push(n, self._proj(n, projection, self.width[left] + self.width[right]))
+        return self._push(n, self._proj(n, projection, self.width[left] + self.width[right]),
+                          self._projected(self.names[left] + self.names[right], projection))
 
     def cross_join(self, left, right):
         n = abi.PlanNode(kind=abi.NODE_CROSS_JOIN, left=left, right=right, join_type=abi.JOIN_INNER)
         n.n_proj = abi.NO_PROJECTION
-        return self._push(n, self.width[left] + self.width[right])
+        return self._push(n, self.width[left] + self.width[right], self.names[left] + self.names[right])
 
     def nested_loop_join(self, left, right, join_type=abi.JOIN_INNER, filter=None, projection=None):
         n = abi.PlanNode(kind=abi.NODE_NESTED_LOOP_JOIN, left=left, right=right, join_type=join_type)
         self._expr(n, filter)
-        return self._push(n, self._proj(n, projection, self.width[left] + self.width[right]))
+        return self._push(n, self._proj(n, projection, self.width[left] + self.width[right]),
+                          self._projected(self.names[left] + self.names[right], projection))
 
-    def table(self, slot, n_cols):
+    def table(self, slot, n_cols, names=None):
         n = abi.PlanNode(kind=abi.NODE_TABLE, left=-1, right=-1, table_slot=slot, table_cols=n_cols)
         n.n_proj = abi.NO_PROJECTION
-        return self._push(n, n_cols)
+        return self._push(n, n_cols, names)
 
     def topk(self, left, keys, limit, group=None, projection=None, tie_break=True):
         """DISTINCT + ORDER BY keys ASC LIMIT `limit` (per `group` column if given) — the AggregateExec(first_value) +
@@ -376,21 +386,166 @@ class PlanBuilder:
                          table_slot=0 if group is None else int(group) + 1)
         for i, (c, how) in enumerate(keys):
             n.left_keys[i], n.right_keys[i] = c, how
-        return self._push(n, self._proj(n, projection, self.width[left]))
+        return self._push(n, self._proj(n, projection, self.width[left]), self._projected(self.names[left], projection))
 
     def union(self, left, right, projection=None):
         """UnionExec: bag union of two inputs with the same columns (SPARQL UNION; Q4 (Execution Plan).snap:11)."""
         if self.width[left] != self.width[right]:
             raise ValueError("UNION inputs differ in width")
         n = abi.PlanNode(kind=abi.NODE_UNION, left=left, right=right)
-        return self._push(n, self._proj(n, projection, self.width[left]))
+        return self._push(n, self._proj(n, projection, self.width[left]), self._projected(self.names[left], projection))
 
     def closure(self, left, allow_cross_graph_paths=False):
         """KleenePlusClosureExec over inner paths (graph, start, end) — the `+` of a SPARQL property path."""
         if self.width[left] != 3:
             raise ValueError("inner paths are (graph, start, end)")
         n = abi.PlanNode(kind=abi.NODE_CLOSURE, left=left, right=-1, join_type=1 if allow_cross_graph_paths else 0)
-        return self._push(n, self._proj(n, None, 3))
+        return self._push(n, self._proj(n, None, 3), self.names[left])
 
     def build(self, root):
         return PlanDescription(self.nodes, self.exprs, self.pool, root, list(self.width), list(self.regexes))
+
+
+    # -- SparqlJoinNode lowering ------------------------------------------------------------------
+    def sparql_join(self, left, right, join_type=abi.JOIN_INNER, filter=None):
+        """SparqlJoinLoweringRule (lib/logical/src/join/rewrite.rs:71-221) for inputs whose shared variables are
+        non-nullable (object-id columns of quad patterns): no shared variable => CrossJoinExec (inner, :74-96) or a
+        left join without keys and without a filter (what DataFusion plans as NestedLoopJoinExec, ..Q2 (Execution
+        Plan).snap:6-8); otherwise an equi-join on ALL shared variables (:126-168, NullEqualsNothing :89) whose output
+        is the left fields followed by the right fields not already present (join/logical.rs:251-279).  Nullable shared
+        variables (IS_COMPATIBLE + COALESCE, :183-221, :327-345) are outside this path."""
+        ln, rn = self.names[left], self.names[right]
+        shared = [v for v in ln if v in rn]
+        if not shared:
+            if join_type == abi.JOIN_INNER:
+                if filter is not None:
+                    return self.nested_loop_join(left, right, abi.JOIN_INNER, filter=filter)
+                return self.cross_join(left, right)
+            return self.nested_loop_join(left, right, abi.JOIN_LEFT, filter=filter)
+        on = [(ln.index(v), rn.index(v)) for v in shared]
+        keep = list(range(len(ln))) + [len(ln) + i for i, v in enumerate(rn) if v not in ln]
+        return self.hash_join(left, right, on, join_type=join_type, filter=filter, projection=keep)
+
+
+# ----------------------------------------------------------------------------------------------
+# plan display, in the reference's format (bench/tests/plans/snapshots/*.snap; DataSourceExec lines as
+# MemQuadPatternDataSource::fmt_as prints them, pattern_data_source.rs:80-105)
+# ----------------------------------------------------------------------------------------------
+_BIN = {abi.EX_GT: "GT", abi.EX_LT: "LT", abi.EX_GEQ: "GEQ", abi.EX_LEQ: "LEQ", abi.EX_EQ: "EQ", abi.EX_ADD: "ADD", abi.EX_SUB: "SUB",
+        abi.EX_IS_COMPATIBLE: "IS_COMPATIBLE"}
+_UN = {abi.EX_ENC_TV: "ENC_TV", abi.EX_EBV: "EBV", abi.EX_BOUND: "BOUND", abi.EX_BOOL_AS_TV: "BOOLEAN_AS_TERM"}
+
+
+def format_expr(nodes, names):
+    """A postfix program as DataFusion prints the PhysicalExpr tree (`EBV(GT(ENC_TV(value1@1), 9:136))`,
+    `product@0 != <object id>`, `.. AND ..`); object-id literals print as the snapshots mask them (<c>)."""
+    st = []
+    for n in nodes:
+        op, tag, u, lo = n.op, n.tag, n.u, n.lo
+        if op == abi.EX_COLUMN:
+            st.append(f"{names[u]}@{u}")
+        elif op == abi.EX_LIT_ID:
+            st.append("<c>")
+        elif op == abi.EX_LIT_TV:
+            st.append(f"{tag}:{lo}")
+        elif op == abi.EX_LIT_BOOL:
+            st.append({0: "false", 1: "true", 2: "NULL"}[u])
+        elif op in _UN:
+            st.append(f"{_UN[op]}({st.pop()})")
+        elif op in _BIN:
+            b, a = st.pop(), st.pop()
+            st.append(f"{_BIN[op]}({a}, {b})")
+        elif op in (abi.EX_ID_EQ, abi.EX_ID_NEQ, abi.EX_AND, abi.EX_OR):
+            b, a = st.pop(), st.pop()
+            st.append(f"{a} {({abi.EX_ID_EQ: '=', abi.EX_ID_NEQ: '!=', abi.EX_AND: 'AND', abi.EX_OR: 'OR'})[op]} {b}")
+        elif op == abi.EX_NOT:
+            st.append(f"NOT {st.pop()}")
+        else:
+            st.append(f"op{op}({st.pop()})")
+    assert len(st) == 1
+    return st[0]
+
+
+def explain(pb, root, choose_index=None):
+    """The operator tree under `root`, one line per operator, indented like DataFusion's `displayable(plan).indent()`.
+    `choose_index(instructions) -> abi.GSPO | GPOS | GOSP` names the index of a DataSourceExec (the library's
+    rdfgpu_choose_index; default: engine.choose_index)."""
+    if choose_index is None:
+        from .engine import choose_index as _ci
+        choose_index = lambda ins: _ci([PlanBuilder()._instr(i) for i in ins])
+    lines = []
+
+    def proj(i, full):
+        n = pb.nodes[i]
+        if n.n_proj == abi.NO_PROJECTION:
+            return ""
+        cols = [pb.pool[n.proj_off + q] for q in range(n.n_proj)]
+        return ", projection=[" + ", ".join(f"{full[c]}@{c}" for c in cols) + "]"
+
+    def term(ins):
+        if ins.kind == abi.SCAN:
+            return "?" + ins.var
+        return "<c>"
+
+    def walk(i, depth):
+        n = pb.nodes[i]
+        pad = "  " * depth
+        if n.kind == abi.NODE_DATA_SOURCE:
+            g, s_, p_, o_ = pb.patterns[i]
+            idx = abi.INDEX_NAMES[choose_index(pb.patterns[i])]
+            graph = f"graph=?{g.var}, " if g.kind == abi.SCAN else ""
+            lines.append(f"{pad}DataSourceExec: [{idx}] {graph}subject={term(s_)}, predicate={term(p_)}, object={term(o_)}")
+            return
+        if n.kind == abi.NODE_FILTER:
+            full = pb.names[n.left]
+            e = format_expr(pb.exprs[n.expr_off:n.expr_off + n.expr_len], full)
+            lines.append(f"{pad}FilterExec: {e}{proj(i, full)}")
+            walk(n.left, depth + 1)
+            return
+        if n.kind in (abi.NODE_HASH_JOIN, abi.NODE_NESTED_LOOP_JOIN):
+            ln, rn = pb.names[n.left], pb.names[n.right]
+            jt = "Inner" if n.join_type == abi.JOIN_INNER else "Left"
+            head = "HashJoinExec: mode=CollectLeft" if n.kind == abi.NODE_HASH_JOIN else "NestedLoopJoinExec:"
+            sep = ", " if n.kind == abi.NODE_HASH_JOIN else " "
+            text = f"{head}{sep}join_type={jt}"
+            if n.kind == abi.NODE_HASH_JOIN:
+                text += ", on=[" + ", ".join(f"({ln[n.left_keys[k]]}@{n.left_keys[k]}, {rn[n.right_keys[k]]}@{n.right_keys[k]})" for k in range(n.n_keys)) + "]"
+            if n.expr_len:
+                # DataFusion prints a JoinFilter over ITS OWN intermediate schema: only the referenced columns, numbered in
+                # order of first use, left side first (`simProperty2@1 .. origProperty2@0`)
+                ex = pb.exprs[n.expr_off:n.expr_off + n.expr_len]
+                used = sorted({e.u for e in ex if e.op == abi.EX_COLUMN})
+                renum = {c: k for k, c in enumerate(used)}
+                both = ln + rn
+                fake = [abi.ExprNode(e.op, e.tag, e.flags, 0, renum[e.u] if e.op == abi.EX_COLUMN else e.u, e.lo, e.hi) for e in ex]
+                text += ", filter=" + format_expr(fake, [both[c] for c in used])
+            lines.append(f"{pad}{text}{proj(i, ln + rn)}")
+            walk(n.left, depth + 1); walk(n.right, depth + 1)
+            return
+        if n.kind == abi.NODE_CROSS_JOIN:
+            lines.append(f"{pad}CrossJoinExec")
+            walk(n.left, depth + 1); walk(n.right, depth + 1)
+            return
+        if n.kind == abi.NODE_TABLE:
+            lines.append(f"{pad}BoundTableExec: slot={n.table_slot}, columns=[{', '.join(pb.names[i])}]")
+            return
+        name = {abi.NODE_PROJECTION: "ProjectionExec", abi.NODE_TOPK: "SortExec: TopK", abi.NODE_UNION: "UnionExec",
+                abi.NODE_CLOSURE: "KleenePlusClosureExec"}[n.kind]
+        lines.append(f"{pad}{name}")
+        walk(n.left, depth + 1)
+        if n.kind == abi.NODE_UNION:
+            walk(n.right, depth + 1)
+
+    walk(root, 0)
+    return lines
+
+
+def explain_logical_join(pb, node):
+    """The LOGICAL form of a join node produced by PlanBuilder.sparql_join, as DataFusion prints it in the reference's
+    join-lowering tests (lib/logical/src/join/rewrite.rs:411-437: `Cross Join: ` / `Left Join: `)."""
+    n = pb.nodes[node]
+    if n.kind == abi.NODE_CROSS_JOIN:
+        return "Cross Join: "
+    jt = "Inner" if n.join_type == abi.JOIN_INNER else "Left"
+    on = ", ".join(f"{pb.names[n.left][n.left_keys[k]]} = {pb.names[n.right][n.right_keys[k]]}" for k in range(n.n_keys)) if n.kind == abi.NODE_HASH_JOIN else ""
+    return f"{jt} Join: {on}"

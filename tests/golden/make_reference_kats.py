@@ -207,13 +207,98 @@ decimal_to_double_cases = [  # M/decimal.rs:1097-1117 (Double::from(Decimal)); t
     dict(raw=str(I128_MIN), value=-1.7014118346046924e20, tol=0.0),
 ]
 
+# Ordering of xsd values (PartialOrd) and their `=`: inputs and expected results of the reference's in-file tests.
+# Values: ["double", v] / ["float", v] with v a float or "NaN" / "INF" / "-INF" / "MAX" / "MIN"; ordering "Less" | "Equal" |
+# "Greater" | "None" (incomparable: GT / LT / EQ all yield the SPARQL error value).
+compare_cases = []
+for kind, src in (("double", "M/double.rs"), ("float", "M/float.rs")):
+    compare_cases += [
+        # fn eq(): assert_eq!(0, 0); assert_ne!(NAN, NAN); assert_eq!(-0., 0.)            (double.rs:283-288, float.rs eq)
+        dict(src=src + " eq", a=[kind, 0.0], b=[kind, 0.0], ordering="Equal"),
+        dict(src=src + " eq", a=[kind, "NaN"], b=[kind, "NaN"], ordering="None"),
+        dict(src=src + " eq", a=[kind, -0.0], b=[kind, 0.0], ordering="Equal"),
+        # fn cmp()                                                                          (double.rs:290-310, float.rs cmp)
+        dict(src=src + " cmp", a=[kind, 0.0], b=[kind, 0.0], ordering="Equal"),
+        dict(src=src + " cmp", a=[kind, "INF"], b=[kind, "MAX"], ordering="Greater"),
+        dict(src=src + " cmp", a=[kind, "-INF"], b=[kind, "MIN"], ordering="Less"),
+        dict(src=src + " cmp", a=[kind, "NaN"], b=[kind, 0.0], ordering="None"),
+        dict(src=src + " cmp", a=[kind, "NaN"], b=[kind, "NaN"], ordering="None"),
+        dict(src=src + " cmp", a=[kind, 0.0], b=[kind, -0.0], ordering="Equal"),
+    ]
+# testsuite/oxigraph-tests/sparql/cmp_langString.{rq,srx}: BIND(?a < ?b AS ?o) over ("a"@fr "b"@fr) and ("a"@en "b"@fr):
+# the first row binds ?o = true, the second leaves it unbound (language tags differ: the comparison is an error).
+# Strings are ["string", rank of the lexical form in str order, language id]: "a" < "b" => ranks 0 < 1; fr = 1, en = 2.
+compare_cases += [
+    dict(src="testsuite/oxigraph-tests/sparql/cmp_langString.srx result 1", a=["string", 0, 1], b=["string", 1, 1], ordering="Less"),
+    dict(src="testsuite/oxigraph-tests/sparql/cmp_langString.srx result 2", a=["string", 0, 2], b=["string", 1, 1], ordering="None"),
+]
+# Decimal -> Float (M/decimal.rs fn to_float: Float::from(Decimal)); compared as floats (numeric.rs:127-201: Float x Decimal => Float)
+decimal_to_float_cases = [
+    dict(raw=str(0), value=0.0, tol=0.0),
+    dict(raw=str(1 * E18), value=1.0, tol=0.0),
+    dict(raw=str(10 * E18), value=10.0, tol=0.0),
+    dict(raw=str(E18 // 10), value=0.1, tol=0.0),                      # assert_eq!(Float::from(Decimal "0.1"), Float::from(0.1))
+    # |x - 1.701412e20| < 1 in f32: floats are 1.76e13 apart there, so that is x == the f32 nearest to 1.701412e20
+    dict(raw=str(I128_MAX), value=1.701412e20, tol=0.0),
+    dict(raw=str(I128_MIN), value=-1.701412e20, tol=0.0),
+]
+# TypedValueEncodingField type ids (lib/encoding/src/typed_value/encoding.rs fn test_type_ids + the enum's declaration
+# order :248-268): the dense-union type id of every field round-trips; the ids are the typed-value tags of the ABI.
+type_id_cases = [["NamedNode", 1], ["BlankNode", 2], ["String", 3], ["Boolean", 4], ["Float", 5], ["Double", 6], ["Decimal", 7],
+                 ["Int", 8], ["Integer", 9], ["DateTime", 10], ["Time", 11], ["Date", 12], ["Duration", 13], ["OtherLiteral", 14], ["Null", 0]]
+# SparqlJoinLoweringRule (lib/logical/src/join/rewrite.rs:381-481, insta inline snapshots): joins of inputs WITHOUT shared
+# variables.  "plan" = the lowered logical plan as the reference prints it.
+join_lowering_cases = [
+    dict(src="L/join/rewrite.rs:397-417 join_non_overlapping_variables_produces_cross_join", left=["a"], right=["b"], join_type="Inner",
+         plan=["Cross Join: ", "  EmptyRelation: rows=0", "  EmptyRelation: rows=0"]),
+    dict(src="L/join/rewrite.rs:419-439 optional_non_overlapping_variables_produces_left_join_with_empty_filter", left=["a"], right=["b"],
+         join_type="Left", plan=["Left Join: ", "  EmptyRelation: rows=0", "  EmptyRelation: rows=0"]),
+]
+# bench/tests/plans/snapshots/r#mod__plans__bsbm_explore__BSBM Explore - Q{1,5} (Execution Plan).snap: the operator subtree
+# below the SortExec (the path this library executes), line for line; IRIs and the masked object id are written <c>, and the
+# `additional_filters=[DynamicFilter ...]` annotations (a run-time superset filter, never changes results) are dropped.
+plan_snapshot_cases = dict(
+    q5=dict(src="..Q5 (Execution Plan).snap:10-30", lines=[
+        "HashJoinExec: mode=CollectLeft, join_type=Inner, on=[(product@0, product@0)], filter=EBV(LT(ENC_TV(simProperty2@1), ADD(ENC_TV(origProperty2@0), 9:170))) AND EBV(GT(ENC_TV(simProperty2@1), SUB(ENC_TV(origProperty2@0), 9:170))), projection=[product@0, productLabel@1]",
+        "  CrossJoinExec",
+        "    HashJoinExec: mode=CollectLeft, join_type=Inner, on=[(product@0, product@0)], filter=EBV(LT(ENC_TV(simProperty1@1), ADD(ENC_TV(origProperty1@0), 9:120))) AND EBV(GT(ENC_TV(simProperty1@1), SUB(ENC_TV(origProperty1@0), 9:120))), projection=[product@0, productLabel@1]",
+        "      CrossJoinExec",
+        "        HashJoinExec: mode=CollectLeft, join_type=Inner, on=[(prodFeature@2, prodFeature@1), (product@0, product@0)], projection=[product@0, productLabel@1]",
+        "          CrossJoinExec",
+        "            FilterExec: product@0 != <c>",
+        "              DataSourceExec: [GPOS] subject=?product, predicate=<c>, object=?productLabel",
+        "            DataSourceExec: [GSPO] subject=<c>, predicate=<c>, object=?prodFeature",
+        "          FilterExec: product@0 != <c>",
+        "            DataSourceExec: [GPOS] subject=?product, predicate=<c>, object=?prodFeature",
+        "        DataSourceExec: [GSPO] subject=<c>, predicate=<c>, object=?origProperty1",
+        "      FilterExec: product@0 != <c>",
+        "        DataSourceExec: [GPOS] subject=?product, predicate=<c>, object=?simProperty1",
+        "    DataSourceExec: [GSPO] subject=<c>, predicate=<c>, object=?origProperty2",
+        "  FilterExec: product@0 != <c>",
+        "    DataSourceExec: [GPOS] subject=?product, predicate=<c>, object=?simProperty2",
+    ]),
+    q1=dict(src="..Q1 (Execution Plan).snap:10-19", lines=[
+        "HashJoinExec: mode=CollectLeft, join_type=Inner, on=[(product@0, product@0)], projection=[product@0, label@1]",
+        "  HashJoinExec: mode=CollectLeft, join_type=Inner, on=[(product@0, product@0)], projection=[product@0, label@1]",
+        "    HashJoinExec: mode=CollectLeft, join_type=Inner, on=[(product@0, product@0)], projection=[product@0, label@1]",
+        "      HashJoinExec: mode=CollectLeft, join_type=Inner, on=[(product@0, product@0)], projection=[product@0, label@1]",
+        "        DataSourceExec: [GPOS] subject=?product, predicate=<c>, object=?label",
+        "        DataSourceExec: [GPOS] subject=?product, predicate=<c>, object=<c>",
+        "      DataSourceExec: [GPOS] subject=?product, predicate=<c>, object=<c>",
+        "    DataSourceExec: [GPOS] subject=?product, predicate=<c>, object=<c>",
+        "  FilterExec: EBV(GT(ENC_TV(value1@1), 9:136)), projection=[product@0]",
+        "    DataSourceExec: [GPOS] subject=?product, predicate=<c>, object=?value1",
+    ]),
+)
+
 out = dict(
     _about="Known-answer vectors transcribed from the reference's unit tests (see make_reference_kats.py).",
     scan=scan_cases, remove=remove_cases, store=store_cases, predicate_and=predicate_and_cases,
     index_choice=index_choice_cases, score_order=score_order_cases, pushdown=pushdown_cases,
     pushdown_display=pushdown_display_cases, rowgroups=rowgroup_cases, dedupe=dedupe_cases,
     prune=prune_cases, find_range=find_range_cases, numeric_arith=numeric_arith_cases,
-    decimal_to_double=decimal_to_double_cases)
+    decimal_to_double=decimal_to_double_cases, compare=compare_cases, decimal_to_float=decimal_to_float_cases,
+    type_ids=type_id_cases, join_lowering=join_lowering_cases, plan_snapshots=plan_snapshot_cases)
 
 if __name__ == "__main__":
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "reference_kats.json")

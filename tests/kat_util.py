@@ -70,10 +70,18 @@ def multiset(cols, n_rows=None):
 
 
 def kat_literal(v):
-    """["int"|"integer"|"decimal"|"double", value] of reference_kats.json -> a typed-value literal expression"""
-    from rdf_fusion_amd.plan import int32, integer, decimal, double
-    kind, val = v
-    return {"int": int32, "integer": integer, "decimal": lambda r: decimal(int(r)), "double": double}[kind](int(val) if kind != "double" else val)
+    """["int"|"integer"|"decimal"|"double"|"float", value] or ["string", rank, language id] of reference_kats.json -> a
+    typed-value literal expression; "NaN" / "INF" / "-INF" / "MAX" / "MIN" name the IEEE specials of the kind"""
+    from rdf_fusion_amd import abi
+    from rdf_fusion_amd.plan import int32, integer, decimal, double, float32, lit_tv
+    kind, val = v[0], v[1]
+    if kind == "string":
+        return lit_tv(abi.TV_STRING, int(val), aux=int(v[2]))
+    if kind in ("double", "float"):
+        fi = np.finfo(np.float64 if kind == "double" else np.float32)
+        x = {"NaN": float("nan"), "INF": float("inf"), "-INF": float("-inf"), "MAX": float(fi.max), "MIN": float(fi.min)}.get(val, val)
+        return (double if kind == "double" else float32)(x)
+    return {"int": int32, "integer": integer, "decimal": lambda r: decimal(int(r))}[kind](int(val))
 
 
 def numeric_kat_plans(kats):
@@ -98,6 +106,18 @@ def numeric_kat_plans(kats):
         else:
             expr = AND(EBV(LT(x, double(c["value"] + c["tol"]))), EBV(GT(x, double(c["value"] - c["tol"]))))
         out.append((f'decimal->double {c["raw"]}', pb.build(pb.filter(pb.table(0, 1), expr)), 1))
+    for c in kats["decimal_to_float"]:       # Float x Decimal compares as floats (numeric.rs:127-201): Float::from(Decimal) == the f32
+        from rdf_fusion_amd.plan import float32
+        pb = PlanBuilder()
+        expr = EBV(EQ(kat_literal(["decimal", c["raw"]]), float32(c["value"])))
+        out.append((f'decimal->float {c["raw"]}', pb.build(pb.filter(pb.table(0, 1), expr)), 1))
+    # PartialOrd of two values: which of `<`, `=`, `>` is true — none of them when the values are incomparable (error)
+    for c in kats["compare"]:
+        truth = {"Less": (1, 0, 0), "Equal": (0, 1, 0), "Greater": (0, 0, 1), "None": (0, 0, 0)}[c["ordering"]]
+        for op, name, n in ((LT, "LT", truth[0]), (EQ, "EQ", truth[1]), (GT, "GT", truth[2])):
+            pb = PlanBuilder()
+            expr = EBV(op(kat_literal(c["a"]), kat_literal(c["b"])))
+            out.append((f'{c["src"]} {name} {c["a"]} {c["b"]}', pb.build(pb.filter(pb.table(0, 1), expr)), n))
     return out
 
 

@@ -145,6 +145,20 @@ def test_reference_numeric_kats(kats, torch_cuda):
         assert plan.execute().result_info()[0] == n_expected, name
 
 
+def test_reference_join_lowering_kats(kats, torch_cuda):
+    """lib/logical/src/join/rewrite.rs:381-481 on the device: no shared variable => every pair (inner) / every left row, unbound
+    on the right when the right input is empty (left); shared variables => equi-join on all of them."""
+    for case in kats["join_lowering"]:
+        pb = PlanBuilder()
+        node = pb.sparql_join(pb.table(0, 1, case["left"]), pb.table(1, 1, case["right"]), abi.JOIN_INNER if case["join_type"] == "Inner" else abi.JOIN_LEFT)
+        desc = pb.build(node)
+        a, b = np.array([5, 6, 7], np.uint32), np.array([8, 9], np.uint32)
+        for right in (b, b[:0]):
+            ka, pa = table_on_device(torch_cuda, [a]); kb, pb_ = table_on_device(torch_cuda, [right])
+            gs, os_ = both_stores((np.zeros(0, np.uint32),) * 4)
+            run_both(gs, os_, desc, gpu_tables=[(pa, 3), (pb_, len(right))], cpu_tables=[[a], [right]])
+
+
 # ---------------------------------------------------------------------------------------------------
 # index build, random scans
 # ---------------------------------------------------------------------------------------------------

@@ -1,5 +1,7 @@
 """Pins the CPU oracle against the reference's own known-answer vectors
 (tests/golden/reference_kats.json, transcribed from the reference's unit tests)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -153,3 +155,55 @@ def test_numeric_kats(kats):
     for name, desc, n_expected in ku.numeric_kat_plans(kats):
         _, n, _ = os_.execute(desc, [one])
         assert n == n_expected, name
+
+
+def test_typed_value_type_ids(kats):
+    """lib/encoding/src/typed_value/encoding.rs (test_type_ids + the enum order :248-268): the ABI's typed-value tags ARE
+    the dense-union type ids, and the oracle's."""
+    names = {"NamedNode": "TV_NAMED_NODE", "BlankNode": "TV_BLANK_NODE", "String": "TV_STRING", "Boolean": "TV_BOOLEAN", "Float": "TV_FLOAT",
+             "Double": "TV_DOUBLE", "Decimal": "TV_DECIMAL", "Int": "TV_INT", "Integer": "TV_INTEGER", "DateTime": "TV_DATE_TIME",
+             "Time": "TV_TIME", "Date": "TV_DATE", "Duration": "TV_DURATION", "OtherLiteral": "TV_OTHER", "Null": "TV_NULL"}
+    import re
+    header = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "rdfgpu.h")).read()
+    for field, type_id in kats["type_ids"]:
+        assert getattr(abi, names[field]) == type_id, field
+        m = re.search(r"RDFGPU_" + names[field] + r" = (\d+)", header)
+        assert m and int(m.group(1)) == type_id, field
+
+
+def test_join_lowering_kats(kats):
+    """SparqlJoinLoweringRule on inputs without shared variables (lib/logical/src/join/rewrite.rs:381-481): the lowered
+    plan as the reference prints it, and what it computes: every left row with every right row; a left join against an
+    empty right input keeps every left row once, unbound on the right."""
+    from rdf_fusion_amd.plan import PlanBuilder, explain_logical_join
+    for case in kats["join_lowering"]:
+        pb = PlanBuilder()
+        l = pb.table(0, len(case["left"]), case["left"]); r = pb.table(1, len(case["right"]), case["right"])
+        jt = abi.JOIN_INNER if case["join_type"] == "Inner" else abi.JOIN_LEFT
+        node = pb.sparql_join(l, r, jt)
+        assert [explain_logical_join(pb, node), "  EmptyRelation: rows=0", "  EmptyRelation: rows=0"] == case["plan"], case["src"]
+        desc = pb.build(node)
+        os_ = orc.OracleStore()
+        a, b = np.array([5, 6, 7], np.uint32), np.array([8, 9], np.uint32)
+        cols, n, _ = os_.execute(desc, [[a], [b]])
+        assert sorted(zip(cols[0][:n].tolist(), cols[1][:n].tolist())) == [(x, y) for x in (5, 6, 7) for y in (8, 9)], case["src"]
+        cols, n, _ = os_.execute(desc, [[a], [b[:0]]])     # the reference's test inputs: EmptyRelation rows=0
+        expect = [] if jt == abi.JOIN_INNER else [(5, 0), (6, 0), (7, 0)]
+        assert sorted(zip(cols[0][:n].tolist(), cols[1][:n].tolist())) == expect, case["src"]
+    # shared, non-nullable variables: an equi-join on all of them (join/rewrite.rs:126-168), left fields then the new right fields
+    pb = PlanBuilder()
+    node = pb.sparql_join(pb.table(0, 2, ["s", "x"]), pb.table(1, 3, ["x", "y", "s"]))
+    assert explain_logical_join(pb, node) == "Inner Join: s = s, x = x" and pb.names[node] == ["s", "x", "y"]
+
+
+def test_bsbm_plans_equal_the_reference_execution_plan_snapshots(kats):
+    """bsbm.q5_plan / q1_plan ARE the operator trees of bench/tests/plans/snapshots/..Q5 / Q1 (Execution Plan).snap below the
+    SortExec: node for node — operators, join keys, JoinFilters, projections, the index every DataSourceExec scans
+    (IndexPermutations::choose_index through the library's host logic)."""
+    from rdf_fusion_amd import bsbm
+    from rdf_fusion_amd.plan import explain
+    ds = bsbm.generate(300)
+    pb, root = bsbm.q5_plan(ds, ds.product(7), builder=True)
+    assert explain(pb, root) == kats["plan_snapshots"]["q5"]["lines"]
+    pb, root = bsbm.q1_plan(ds, ds.type_base, ds.feature_base + 3, ds.feature_base + 5, 136, builder=True)
+    assert explain(pb, root) == kats["plan_snapshots"]["q1"]["lines"]
