@@ -36,25 +36,34 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md); measured copy ceiling is 6290 GB/s
 
 
-def scan_roofline(rf, device, log2_rows=26, threshold=1000, reps=10):
+def scan_roofline(rf, device, log2_rows=26, threshold=1000, reps=10, distinct=2000):
     """BASELINE config 2 at a partition that cannot sit in the 256 MiB Infinity Cache: the Q1 numeric
     scan + FILTER (FilterExec: EBV(GT(ENC_TV(value1@1), 9:c)), projection=[product@0]) over ONE predicate
-    partition of 2^log2_rows triples.  Algorithmic bytes: 17·N + 4·σ·N."""
+    partition of 2^log2_rows triples whose objects are `distinct` different xsd:integer literals.
+    Bytes: the formula's 17 N + 4 sigma N counts 9 B of typed-value gather per row; with 2000 distinct
+    literals (BSBM's value range) the 32 KB table never leaves the caches, so the HBM-roofline fraction is quoted on
+    the STREAM bytes 8 N + 4 sigma N (two u32 columns read, survivors written); `distinct` >= 4 M makes the typed
+    table (16 B per id) larger than the 32 MiB of L2 — then the gathers are real traffic too."""
     from rdf_fusion_amd import abi
     from rdf_fusion_amd.engine import TV_DTYPE
     from rdf_fusion_amd.plan import PlanBuilder, quad_pattern, col, integer, ENC_TV, GT, EBV
     n = 1 << log2_rows
     rng = np.random.default_rng(7)
     pred, int_base = 1, 2
-    subj = np.arange(int_base + 2000, int_base + 2000 + n, dtype=np.uint32)
-    val = np.clip(np.rint(rng.normal(1000, 333, n)), 1, 2000).astype(np.uint32)
+    subj = np.arange(int_base + distinct, int_base + distinct + n, dtype=np.uint32)
+    if distinct == 2000:
+        val = np.clip(np.rint(rng.normal(1000, 333, n)), 1, 2000).astype(np.uint32)
+        values = np.arange(1, 2001)
+    else:                                    # uniform over a large dictionary; literal k carries the value k mod 2000 + 1
+        val = rng.integers(1, distinct + 1, n).astype(np.uint32)
+        values = (np.arange(distinct) % 2000) + 1
     obj = (int_base + val - 1).astype(np.uint32)
     store = rf.GpuQuadStore(device=device)
     store.extend(np.zeros(n, np.uint32), subj, np.full(n, pred, np.uint32), obj)
-    tv = np.zeros(int_base + 2000, dtype=TV_DTYPE)
+    tv = np.zeros(int_base + distinct, dtype=TV_DTYPE)
     tv["tag"][1:] = abi.TV_NAMED_NODE
     tv["tag"][int_base:] = abi.TV_INTEGER
-    tv["lo"][int_base:] = np.arange(1, 2001)
+    tv["lo"][int_base:] = values
     store.set_typed_values(tv)
     pb = PlanBuilder()
     src = pb.data_source(quad_pattern("product", pred, "value1"))
@@ -67,17 +76,25 @@ def scan_roofline(rf, device, log2_rows=26, threshold=1000, reps=10):
         for name, launches, ms, nbytes, nrows in plan.kernel_stats():
             if "filter_kernel" in name and (best is None or ms < best[1]):
                 best = (name, ms, nbytes)
-    expect = int((val > threshold).sum())
+    expect = int((values[val - 1] > threshold).sum())
     assert rows == expect, (rows, expect)          # full-size parity: exact count against numpy
     plan.close(); store.close()
     name, ms, nbytes = best
-    gbs = nbytes / (ms * 1e-3) / 1e9
-    return {"kernel": name, "rows": n, "selectivity": round(rows / n, 4), "best_us": round(ms * 1e3, 1),
-            "algorithmic_bytes": int(nbytes), "achieved": round(gbs, 1), "unit": "GB/s", "peak": HBM_PEAK_GBS,
-            "frac": round(gbs / HBM_PEAK_GBS, 4), "frac_of_measured_copy_ceiling": round(gbs / 6290.0, 4)}
+    stream = 8 * n + 4 * rows
+    gbs = stream / (ms * 1e-3) / 1e9
+    out = {"kernel": name, "rows": n, "distinct_literals": distinct, "selectivity": round(rows / n, 4), "best_us": round(ms * 1e3, 1),
+           "stream_bytes": int(stream), "achieved": round(gbs, 1), "unit": "GB/s", "peak": HBM_PEAK_GBS,
+           "frac": round(gbs / HBM_PEAK_GBS, 4), "frac_of_measured_copy_ceiling": round(gbs / 6290.0, 4),
+           "formula_bytes_17N_4sN": int(nbytes), "formula_GBps": round(nbytes / (ms * 1e-3) / 1e9, 1),
+           "note": "frac = (8 N + 4 sigma N) / time / 8 TB/s: the two streamed u32 columns + the survivors; the 9 B/row typed gather "
+                   "of the SURVEY formula is cache traffic at 2000 distinct literals and is NOT counted"}
+    t, src_ = pmc_traffic(name, None, None, key="scan_rows", value=n)
+    if t:
+        out["traffic"] = t; out["traffic_source"] = src_; out["traffic_frac"] = round(t / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+    return out
 
 
-def pmc_traffic(kernel, queries, products):
+def pmc_traffic(kernel, queries, products, key=None, value=None):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of THIS command (FETCH_SIZE and
     WRITE_SIZE in separate runs, gfx950 corrections applied by profiles/summarize.py) — counters cannot be read
     from inside the benchmark process, so the newest summary under profiles/ whose recorded workload (`_workload`)
@@ -92,8 +109,9 @@ def pmc_traffic(kernel, queries, products):
         except (OSError, ValueError):
             continue
         w = d.get("_workload") or {}
-        e = d.get(kernel)
-        if w.get("queries") == queries and w.get("products") == products and e and "hbm_bytes_per_launch" in e:
+        e = next((v for k, v in d.items() if k != "_workload" and k.startswith(kernel.split("(")[0])), None)
+        same = (w.get(key) == value) if key else (w.get("queries") == queries and w.get("products") == products)
+        if same and e and "hbm_bytes_per_launch" in e:
             return int(e["hbm_bytes_per_launch"]), os.path.relpath(f, ROOT)
     return None, None
 
@@ -113,6 +131,9 @@ def main():
     ap.add_argument("--no-overlap", action="store_true", help="N > 1: run exchange and join pipeline of a step back to back instead of pipelining steps")
     ap.add_argument("--no-scan", action="store_true", help="skip the scaled scan+FILTER roofline measurement")
     ap.add_argument("--scan-log2-rows", type=int, default=26)
+    ap.add_argument("--no-table-cache", action="store_true",
+                    help="the headline itself with RDFGPU_OPT_NO_TABLE_CACHE: every join table is built inside the timed step, like HashJoinExec(CollectLeft) per query")
+    ap.add_argument("--no-cold", action="store_true", help="skip the cold-start / no-table-cache side measurements")
     args = ap.parse_args()
 
     import threading
@@ -221,6 +242,8 @@ def main():
             f = lambda x: one(x, timing)
             return sum(pool.map(f, batch)) if pool else sum(f(x) for x in batch)
     elif world == 1:
+        if args.no_table_cache:
+            store.set_option("NO_TABLE_CACHE", 1)
         plan = store.plan(bsbm.q5_batch_plan(ds))           # compiled once; only the bound PARAMS change
 
         def step(batch, timing):
@@ -314,12 +337,17 @@ def main():
         for b in batches:
             params_on_device(b)
         torch.cuda.synchronize()
-    # The store's join tables (direct / CSR / value / range tables of the predicate slices) are built on first use and
-    # cached per store version, and a plan fuses its look-up chains from its second execution on: part of loading, done
-    # here so that the timed steps are steady state whatever --warmup is.
+    # Cold start: the FIRST execution of the batch on a fresh store version builds every join table of the predicate slices
+    # (direct / CSR / decoded-value tables, cached per store version) and sizes every operator exactly (one host sync per
+    # join); the second execution speculates from the first one's cardinalities and fuses the look-up chains.  Both are
+    # measured and reported (config.cold_ms / table_build_ms); the timed steps below are the steady state after them.
+    cold = None
     if not args.per_instance:
-        for _ in range(3):
-            step(batches[0], False)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter(); step(batches[0], False); torch.cuda.synchronize(); cold_ms = (time.perf_counter() - t1) * 1e3
+        t1 = time.perf_counter(); step(batches[0], False); torch.cuda.synchronize(); second_ms = (time.perf_counter() - t1) * 1e3
+        t1 = time.perf_counter(); step(batches[0], False); torch.cuda.synchronize(); third_ms = (time.perf_counter() - t1) * 1e3
+        cold = {"cold_ms": round(cold_ms, 3), "second_execution_ms": round(second_ms, 3), "third_execution_ms": round(third_ms, 3)}
     overlap = world > 1 and not args.no_overlap
     if overlap:
         run_pipelined(batches[:args.warmup], False)
@@ -374,25 +402,75 @@ def main():
         barrier()
 
     # ------------------------------------------------------------------ roofline of the dominant kernel
+    # ONE formula: frac = compulsory bytes of the kernel / its time / 8 TB/s, compulsory = every input the
+    # kernel has to read once + everything it has to write (recorded per launch next to the HIP-event time, plan.cpp
+    # `timed`); never the bytes of the un-fused logical plan.  `traffic` = PMC FETCH + WRITE of the same kernel (committed
+    # rocprofv3 passes), `traffic_over_compulsory` = how much of it is re-reads.
     roofline = None
+    pipeline = None
     if kstats:
         name, (launches, ms, nbytes, rows) = max(kstats.items(), key=lambda kv: kv[1][1])
         achieved = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
         # the committed counters are of a single-GPU batched run: quoted only for the workload they were collected on
         traffic, traffic_src = pmc_traffic(name, args.queries, args.products) if world == 1 and not args.per_instance else (None, None)
+        per_launch = nbytes / max(1, launches)
         roofline = {"bound": "hbm", "kernel": name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                     "traffic_GBps": (round(traffic / (ms * 1e-3 / max(1, launches)) / 1e9, 1) if traffic and ms > 0 else None),
                     "traffic_frac": (round(traffic / (ms * 1e-3 / max(1, launches)) / 1e9 / HBM_PEAK_GBS, 4) if traffic and ms > 0 else None),
-                    "note": "achieved = SURVEY 8d bytes of the LOGICAL operators this launch computes (all candidate pairs of the fused "
-                            "joins, as if each join materialised its output) / time: it can exceed the HBM peak, because the range "
-                            "index and the fusion skip most of those bytes; traffic / traffic_frac = PMC FETCH+WRITE bytes the kernel "
-                            "really moved (the kernel is latency-bound, not HBM-bound: DESIGN.md 6)",
+                    "traffic_over_compulsory": (round(traffic / per_launch, 2) if traffic and per_launch else None),
+                    "note": "achieved = compulsory bytes of this kernel (inputs once + output, per launch) / its HIP-event time; a pair-test "
+                            "kernel (band_mask_kernel) is bound by VALU compares over |group| x |rows| pairs, not by HBM: its fraction is "
+                            "low by construction (DESIGN.md 6)",
                     "launches": launches, "avg_us": round(ms * 1e3 / max(1, launches), 2),
-                    "algorithmic_bytes_per_launch": int(nbytes / max(1, launches))}
+                    "compulsory_bytes_per_launch": int(per_launch)}
+        if roofline["frac"] > 1.0:   # a join kernel whose recorded bytes are the SURVEY 8d formula of a logical join it short-cuts: not a roofline number
+            roofline["frac"] = None
+            roofline["note"] += "; INVALID here: the recorded bytes of this kernel are a logical-join formula, not compulsory bytes"
+        # the whole step as ONE fused operator: what HBM has to deliver at least (the store slices and the parameters
+        # read once, the bindings written once) over the device time of a step
+        if world == 1 and not args.per_instance:
+            pr = ds.pred
+            cnt = lambda pname: int((ds.p == pr[pname]).sum())
+            rows_out = total_rows / args.steps
+            in_bytes = 8 * Q + 8 * (cnt("bsbm:productFeature") + cnt("bsbm:productPropertyNumeric1") + cnt("bsbm:productPropertyNumeric2") + cnt("rdfs:label"))
+            out_bytes = 12 * rows_out
+            dev_ms = sum(v[1] for v in kstats.values()) / args.steps
+            pipeline = {"compulsory_bytes_per_step": int(in_bytes + out_bytes), "inputs_bytes": int(in_bytes), "output_bytes": int(out_bytes),
+                        "kernel_ms_per_step": round(dev_ms, 3),
+                        "achieved": round((in_bytes + out_bytes) / (dev_ms * 1e-3) / 1e9, 1), "unit": "GB/s", "peak": HBM_PEAK_GBS,
+                        "frac": round((in_bytes + out_bytes) / (dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                        "note": "PARAMS + the four predicate slices (two u32 columns each) read once + 3 u32 columns of bindings written, "
+                                "over the summed kernel time of a step: the fraction of the HBM roofline the WHOLE join pipeline reaches"}
     kernel_table = {k: {"launches": v[0], "total_ms": round(v[1], 3), "avg_us": round(v[1] * 1e3 / max(1, v[0]), 1),
-                        "algorithmic_GBps": round(v[2] / (v[1] * 1e-3) / 1e9, 1) if v[1] > 0 else None}
+                        "compulsory_GBps": round(v[2] / (v[1] * 1e-3) / 1e9, 1) if v[1] > 0 else None}
                     for k, v in sorted(kstats.items(), key=lambda kv: -kv[1][1])}
+
+    # ------------------------------------------------------------------ the same step without any cached table (N = 1)
+    # RDFGPU_OPT_NO_TABLE_CACHE: nothing survives an execution — every HashJoinExec builds its table inside the step, like
+    # the reference's HashJoinExec(CollectLeft) does per query (..Q5 (Execution Plan).snap:10-30).  Like for like with a
+    # per-query engine; the headline above is the steady state with the slices' tables cached per store version.
+    if world == 1 and not args.per_instance and not args.no_cold and not args.no_table_cache and cold is not None:
+        plan_nc = store.plan(bsbm.q5_batch_plan(ds)).set_option("NO_TABLE_CACHE", 1)
+        def step_nc(batch):
+            t, ptrs, n = params_on_device(batch)
+            plan_nc.bind_table(0, ptrs, n)
+            plan_nc.execute()
+            return plan_nc.result_info()[0]
+        step_nc(batches[0]); step_nc(batches[1 % len(batches)])
+        torch.cuda.synchronize()
+        n_nc = min(5, len(batches))
+        t1 = time.perf_counter()
+        rows_nc = sum(step_nc(b) for b in batches[-n_nc:])
+        torch.cuda.synchronize()
+        ms_nc = (time.perf_counter() - t1) * 1e3 / n_nc
+        plan_nc.close()
+        steady = elapsed * 1e3 / args.steps
+        cold["no_table_cache"] = {"ms_per_step": round(ms_nc, 3), "bindings_per_s": round(rows_nc / n_nc / (ms_nc * 1e-3), 2), "steps": n_nc,
+                                  "what": "every join table (hash / CSR / direct) built inside the timed step: HashJoinExec-style per-query builds"}
+        cold["table_build_ms"] = round(max(0.0, cold["cold_ms"] - cold["second_execution_ms"]), 3)
+        gain = ms_nc - steady
+        cold["steps_to_amortise"] = (round(cold["table_build_ms"] / gain, 2) if gain > 0 else None)
 
     # ------------------------------------------------------------------ single-instance latency + CPU baseline, rank 0, N=1
     cpu = None
@@ -504,7 +582,10 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"BSBM-shaped store, {args.products} products ({ds.n_triples} triples), Explore Q5 "
                                    f"(7 triple patterns -> scans, hash joins, FILTERs), {Q} instances per step, "
-                                   + ("one reference plan per instance" if args.per_instance else "batched into one operator tree (shared scans)"),
+                                   + ("one reference plan per instance" if args.per_instance else "batched into one operator tree (shared scans)")
+                                   + ("; every join table built inside the timed step (--no-table-cache)" if args.no_table_cache else
+                                      "; steady state: the join tables of the predicate slices are cached per store version (cold start and the "
+                                      "no-cache step are under config.cold_start)"),
                        "mode": "per-instance" if args.per_instance else "batched",
                        "triples_per_gpu": n_local, "sharding": "hash(subject) mod N, all-gatherv of constant-pattern bindings" if world > 1 else "none",
                        "sharded_result_check": shard_check,
@@ -515,18 +596,25 @@ def main():
                        "host_threads": args.threads if args.per_instance else 1,
                        "single_instance_latency_ms": single,
                        "median_query_latency_ms": round(float(np.median(lat_ms)), 3) if lat_ms else None,
-                       "load_seconds": round(load_s, 1)},
+                       "load_seconds": round(load_s, 1), "cold_start": cold},
             "roofline": roofline,
+            "pipeline_roofline": pipeline,
             "cpu_baseline": cpu,
             "kernels": kernel_table,
         }
-        if cpu and cpu.get("queries_per_s"):
-            out["config"]["speedup_vs_cpu_port"] = round((n_q / elapsed) / cpu["queries_per_s"], 1)
+        # like for like only: one query at a time on the GPU against the per-query CPU port; the batched tree against the
+        # batched columnar CPU engine
+        if cpu and cpu.get("queries_per_s") and single:
+            out["config"]["speedup_per_query_vs_cpu_port_1_core"] = round((1e3 / single) / cpu["queries_per_s"], 1)
+            if cpu.get("all_cores"):
+                out["config"]["speedup_per_query_vs_cpu_port_all_cores"] = round((1e3 / single) / cpu["all_cores"]["queries_per_s"], 1)
         if cpu and cpu.get("tuned_columnar"):
-            out["config"]["speedup_vs_tuned_columnar_cpu"] = round((n_q / elapsed) / cpu["tuned_columnar"]["queries_per_s"], 1)
+            out["config"]["speedup_batched_vs_batched_columnar_cpu"] = round((n_q / elapsed) / cpu["tuned_columnar"]["queries_per_s"], 1)
         if world == 1 and not args.no_scan:
             # the BGP scan + FILTER kernel on a partition larger than the Infinity Cache (BASELINE config 2)
             out["scan_roofline"] = scan_roofline(rf, local_rank, args.scan_log2_rows)
+            # the same scan over a dictionary whose typed-value table (16 B per id) does not fit the 32 MiB of L2
+            out["scan_roofline_large_dictionary"] = scan_roofline(rf, local_rank, args.scan_log2_rows, distinct=1 << 22)
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
