@@ -73,22 +73,25 @@ def scan_roofline(rf, device, log2_rows=26, threshold=1000, reps=10, distinct=20
     for _ in range(reps):
         plan.execute()
         rows, _ = plan.result_info()
-        for name, launches, ms, nbytes, nrows in plan.kernel_stats():
-            if "filter_kernel" in name and (best is None or ms < best[1]):
-                best = (name, ms, nbytes)
+        # the scan + FILTER is two streaming passes and a 16 K-element scan: their summed HIP-event time is the operator's
+        ks = [k for k in plan.kernel_stats() if "filter" in k[0] or "device scan" in k[0]]
+        ms = sum(k[2] for k in ks)
+        if best is None or ms < best[1]:
+            best = ("+".join(k[0].replace("void rdfgpu::", "").replace("rdfgpu::", "") for k in ks), ms, sum(k[3] for k in ks),
+                    {k[0]: round(k[2] * 1e3, 1) for k in ks})
     expect = int((values[val - 1] > threshold).sum())
     assert rows == expect, (rows, expect)          # full-size parity: exact count against numpy
     plan.close(); store.close()
-    name, ms, nbytes = best
+    name, ms, nbytes, parts = best
     stream = 8 * n + 4 * rows
     gbs = stream / (ms * 1e-3) / 1e9
-    out = {"kernel": name, "rows": n, "distinct_literals": distinct, "selectivity": round(rows / n, 4), "best_us": round(ms * 1e3, 1),
+    out = {"kernel": name, "kernel_us": parts, "rows": n, "distinct_literals": distinct, "selectivity": round(rows / n, 4), "best_us": round(ms * 1e3, 1),
            "stream_bytes": int(stream), "achieved": round(gbs, 1), "unit": "GB/s", "peak": HBM_PEAK_GBS,
            "frac": round(gbs / HBM_PEAK_GBS, 4), "frac_of_measured_copy_ceiling": round(gbs / 6290.0, 4),
            "formula_bytes_17N_4sN": int(nbytes), "formula_GBps": round(nbytes / (ms * 1e-3) / 1e9, 1),
            "note": "frac = (8 N + 4 sigma N) / time / 8 TB/s: the two streamed u32 columns + the survivors; the 9 B/row typed gather "
                    "of the SURVEY formula is cache traffic at 2000 distinct literals and is NOT counted"}
-    t, src_ = pmc_traffic(name, None, None, key="scan_rows", value=n)
+    t, src_ = pmc_traffic("void rdfgpu::filter_bits_kernel", None, None, key="scan_rows", value=n)
     if t:
         out["traffic"] = t; out["traffic_source"] = src_; out["traffic_frac"] = round(t / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
     return out

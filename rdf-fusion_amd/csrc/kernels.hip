@@ -267,11 +267,191 @@ void launch_regex_verdicts(const RegexProg* prog_dev, const TypedTable& tt, int6
   hipLaunchKernelGGL(regex_verdict_kernel, dim3((unsigned)((n_ids + 255) / 256)), dim3(256), 0, s, prog_dev, tt, rhs_lang, out, n_ids);
 }
 
-void launch_filter(const FilterArgs& a0, int shape, hipStream_t s) {
-  FilterArgs a = a0;
-  // rows per workgroup: enough workgroups to fill the chip (>= ~1024), few enough reservations
-  u64 iters = (a.n_in_cap + (u64)kTile * 1024 - 1) / ((u64)kTile * 1024);
-  a.iters = (u32)(iters < 1 ? 1 : iters > kFilterMaxIters ? kFilterMaxIters : iters);
+// Streaming form of the specialised FilterExec shapes (1: `col <=|!=> id`, 2: `EBV(cmp(ENC_TV(col), literal))`, 3: per-term
+// verdict byte) for at most two output columns whose pointers share the predicate column's 16-byte phase — a slice of
+// one permutation, the BGP-scan case.  Two passes, NO atomics: a same-address returning atomic per 4096-row tile retires
+// at ~88 per microsecond chip-wide, so the 16 384 tiles of a 2^26-row scan would spend 186 us on output reservations alone
+// (measured: a single-pass kernel with one reservation per tile took 230 us whatever its body did).
+//   pass 1  one verdict bit per row (2 bytes per 16 rows) + the tile's survivor count; reads the predicate column only
+//   scan    exclusive scan of the tile counts (rocPRIM, 16 K elements)
+//   pass 2  reads the bits and the output columns, writes the survivors at the tile's offset IN INDEX ORDER (the output
+//           keeps the order of the scanned permutation, like the reference's filter over sorted row groups)
+// One tile = 256 lanes x 4 rounds x 4 consecutive rows (one 16-byte load per column and round), all loads of a tile
+// requested before anything is waited for.  The argument block is ~230 bytes (the generic kernel's carries a 40-node
+// expression program by value: 73 spilled SGPRs).
+struct FilterStreamArgs {
+  const u32* pcol; const u32* proj[2]; u32* out[2];
+  u32 n_out_cols, head_skip;
+  const u64* n_in_dev; u64 n_in_cap; u64* n_out_dev;
+  TypedTable tt;
+  rdfgpu_expr_node lit; u32 op, id_lit, is_eq, pad;
+  const unsigned char* verdict; u64 n_verdict;
+  unsigned short* bits; u32* tile_count; u32* tile_off;   // pass 1 -> scan -> pass 2
+};
+constexpr int kStreamRounds = 4;
+template <int SHAPE>
+__device__ __forceinline__ bool stream_pred(const FilterStreamArgs& a, u32 v) {
+  if constexpr (SHAPE == 3) return v != 0 && v < a.n_verdict && a.verdict[v] == 1;
+  else if constexpr (SHAPE == 1) { if (v == 0 || a.id_lit == 0) return false; return (v == a.id_lit) == (a.is_eq != 0); }
+  else {
+    const Val x = enc_tv(a.tt, v);
+    const u8 op = (u8)a.op;
+    if (x.tag == RDFGPU_TV_INTEGER && a.lit.tag == RDFGPU_TV_INTEGER) {   // xsd:integer vs xsd:integer: plain i64 compare
+      const int64_t p = x.lo, q = a.lit.lo;
+      return op == RDFGPU_EX_GT ? p > q : op == RDFGPU_EX_LT ? p < q : op == RDFGPU_EX_GEQ ? p >= q
+           : op == RDFGPU_EX_LEQ ? p <= q : op == RDFGPU_EX_EQ ? p == q : p != q;
+    }
+    Val y = val_tv_null(); y.tag = a.lit.tag; y.flags = a.lit.flags; y.aux = a.lit.u; y.lo = a.lit.lo; y.hi = a.lit.hi;
+    const int o = tv_partial_cmp(x, y);
+    if (o == ORD_NONE) return false;
+    return op == RDFGPU_EX_GT ? o > 0 : op == RDFGPU_EX_LT ? o < 0 : op == RDFGPU_EX_GEQ ? o >= 0
+         : op == RDFGPU_EX_LEQ ? o <= 0 : op == RDFGPU_EX_EQ ? o == 0 : o != 0;
+  }
+}
+// the 16-byte group of rows v0 .. v0 + 3 (virtual numbering: row v lives at col[v - mis]), zero outside [mis, nv)
+__device__ __forceinline__ uint4 stream_load4(const u32* col, u64 v0, u64 mis, u64 nv) {
+  if (v0 >= mis && v0 + 4 <= nv) return *reinterpret_cast<const uint4*>(col + (v0 - mis));
+  u32 t[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+  for (int r = 0; r < 4; r++) if (v0 + r >= mis && v0 + r < nv) t[r] = col[v0 + r - mis];
+  return make_uint4(t[0], t[1], t[2], t[3]);
+}
+template <int SHAPE>
+__global__ __launch_bounds__(kBlock) void filter_bits_kernel(const FilterStreamArgs a) {
+  __shared__ u32 wave_tot[kBlock / 64];
+  const u64 n = live_rows(a.n_in_dev, a.n_in_cap);
+  const u64 mis = a.head_skip, nv = n + mis;
+  const u64 base = (u64)blockIdx.x * (kTile * kStreamRounds);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint4 pv[kStreamRounds];
+#pragma unroll
+  for (int it = 0; it < kStreamRounds; it++) pv[it] = stream_load4(a.pcol, base + (u64)it * kTile + (u64)threadIdx.x * 4, mis, nv);
+  u32 bits = 0;
+  if constexpr (SHAPE == 2) {
+    // xsd:integer value against an xsd:integer literal: one 16-byte gather, a tag test and an i64 compare per row, all 16
+    // gathers of the lane in flight together.  Any other kind is left "undecided" and goes, one row at a time, through
+    // the single copy of the full typed-value comparison below (promotion, decimals, strings, errors).
+    const bool lit_int = a.lit.tag == RDFGPU_TV_INTEGER;
+    const long long q = a.lit.lo;
+    const u8 op = (u8)a.op;
+    const u32 truth = op == RDFGPU_EX_GT ? 4u : op == RDFGPU_EX_LT ? 1u : op == RDFGPU_EX_GEQ ? 6u : op == RDFGPU_EX_LEQ ? 3u : op == RDFGPU_EX_EQ ? 2u : 5u;   // (less, equal, greater)
+    const int4* tv = reinterpret_cast<const int4*>(a.tt.tv);
+    const u64 n_ids = a.tt.n_ids;
+    int4 raw[kStreamRounds * 4];
+    u32 und = 0;
+#pragma unroll
+    for (int it = 0; it < kStreamRounds; it++) {
+      const u32 val[4] = {pv[it].x, pv[it].y, pv[it].z, pv[it].w};
+#pragma unroll
+      for (int r = 0; r < 4; r++) raw[it * 4 + r] = tv[val[r] < n_ids ? val[r] : 0u];   // id 0 = null: tag 0
+    }
+#pragma unroll
+    for (int it = 0; it < kStreamRounds; it++) {
+      const u64 v0 = base + (u64)it * kTile + (u64)threadIdx.x * 4;
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int4 x = raw[it * 4 + r];
+        const bool live = v0 + r >= mis && v0 + r < nv;
+        const u32 tag = (u32)x.w & 0xffu;
+        const long long p = (long long)(((u64)(u32)x.y << 32) | (u32)x.x);
+        const u32 c = p < q ? 1u : p > q ? 4u : 2u;
+        const bool fast = lit_int && tag == RDFGPU_TV_INTEGER;
+        bits |= (u32)(live && fast && (truth & c) != 0) << (it * 4 + r);
+        und |= (u32)(live && !fast && tag != RDFGPU_TV_NULL) << (it * 4 + r);          // null / unknown id: the error value, dropped
+      }
+    }
+    if (__any(und != 0)) {
+      for (int k = 0; k < kStreamRounds * 4; k++) {
+        if (!((und >> k) & 1u)) continue;
+        const uint4 g = pv[0];
+        (void)g;
+        u32 v = 0;
+#pragma unroll
+        for (int it = 0; it < kStreamRounds; it++) {
+          const u32 val[4] = {pv[it].x, pv[it].y, pv[it].z, pv[it].w};
+#pragma unroll
+          for (int r = 0; r < 4; r++) v = (it * 4 + r) == k ? val[r] : v;
+        }
+        bits |= (u32)stream_pred<2>(a, v) << k;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int it = 0; it < kStreamRounds; it++) {
+      const u64 v0 = base + (u64)it * kTile + (u64)threadIdx.x * 4;
+      const u32 val[4] = {pv[it].x, pv[it].y, pv[it].z, pv[it].w};
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const u64 v = v0 + r;
+        const bool keep = v >= mis && v < nv && stream_pred<SHAPE>(a, val[r]);
+        bits |= (u32)keep << (it * 4 + r);
+      }
+    }
+  }
+  a.bits[(u64)blockIdx.x * kBlock + threadIdx.x] = (unsigned short)bits;
+  u32 wsum = (u32)__popc(bits);
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) wsum += __shfl_xor(wsum, d, 64);
+  if (lane == 0) wave_tot[wave] = wsum;
+  __syncthreads();
+  if (threadIdx.x == 0) a.tile_count[blockIdx.x] = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+}
+template <int NOUT>
+__global__ __launch_bounds__(kBlock) void filter_write_kernel(const FilterStreamArgs a) {
+  __shared__ u32 rcnt[kStreamRounds][kBlock / 64];
+  const u64 n = live_rows(a.n_in_dev, a.n_in_cap);
+  const u64 mis = a.head_skip, nv = n + mis;
+  const u64 base = (u64)blockIdx.x * (kTile * kStreamRounds);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (blockIdx.x == 0 && threadIdx.x == 0) *a.n_out_dev = a.tile_off[gridDim.x];   // the total: the scan runs over tiles + 1 counts
+  // (offsets from per-64-tile sums kept by no-return atomics in pass 1, instead of the 12 us scan launch, were tried: the
+  //  atomics cost pass 1 18 us)
+  const u64 tile_base = a.tile_off[blockIdx.x];
+  if (NOUT == 0 || a.tile_count[blockIdx.x] == 0) return;                            // uniform per workgroup
+  const u32 bits = a.bits[(u64)blockIdx.x * kBlock + threadIdx.x];
+  uint4 ov[NOUT > 0 ? NOUT : 1][kStreamRounds];
+#pragma unroll
+  for (int c = 0; c < NOUT; c++) {
+#pragma unroll
+    for (int it = 0; it < kStreamRounds; it++) {
+      ov[c][it] = make_uint4(0u, 0u, 0u, 0u);
+      if (((bits >> (it * 4)) & 15u) != 0) ov[c][it] = stream_load4(a.proj[c], base + (u64)it * kTile + (u64)threadIdx.x * 4, mis, nv);
+    }
+  }
+  // index order inside the tile: row = base + it * 1024 + tid * 4 + r  =>  round-major, then wave, then lane, then r
+#pragma unroll
+  for (int it = 0; it < kStreamRounds; it++) {
+    u32 c = (u32)__popc((bits >> (it * 4)) & 15u);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d, 64);
+    if (lane == 0) rcnt[it][wave] = c;
+  }
+  __syncthreads();
+  u64 off = tile_base;
+#pragma unroll
+  for (int it = 0; it < kStreamRounds; it++) {
+    u64 woff = off;
+    for (int w = 0; w < wave; w++) woff += rcnt[it][w];
+    off += rcnt[it][0] + rcnt[it][1] + rcnt[it][2] + rcnt[it][3];
+    const u32 nib = (bits >> (it * 4)) & 15u;
+    const u32 mine = (u32)__popc(nib);
+    u32 incl = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const u32 t = __shfl_up(incl, d, 64); if (lane >= d) incl += t; }
+    u64 pos = woff + (incl - mine);
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      if (!((nib >> r) & 1u)) continue;
+#pragma unroll
+      for (int c = 0; c < NOUT; c++) {
+        const u32 val[4] = {ov[c][it].x, ov[c][it].y, ov[c][it].z, ov[c][it].w};
+        a.out[c][pos] = val[r];
+      }
+      pos++;
+    }
+  }
+}
+static void filter_alignment(FilterArgs& a, int shape) {
   // 16-byte loads need every column the predicate reads to share one misalignment (slices of one
   // permutation do; freshly allocated tables are aligned)
   a.head_skip = 0; a.vec_ok = 0;
@@ -284,6 +464,56 @@ void launch_filter(const FilterArgs& a0, int shape, hipStream_t s) {
     const uintptr_t p = reinterpret_cast<uintptr_t>(a.in[a.proj[c]]);
     if ((p & 3) != 0 || ((p >> 2) & 3) != a.head_skip) a.vec_proj_ok = 0;
   }
+}
+u64 filter_stream_tiles(const FilterArgs& a0) {
+  FilterArgs a = a0;
+  filter_alignment(a, 1);
+  const u64 tile = (u64)kTile * kStreamRounds;
+  return (a.n_in_cap + a.head_skip + tile - 1) / tile;
+}
+// the streaming form: a specialised shape, at most two output columns, every column in the predicate column's 16-byte phase
+bool filter_streams(const FilterArgs& a0, int shape) {
+  FilterArgs a = a0;
+  filter_alignment(a, shape);
+  // (below ~1 M rows one kernel with one reservation per 16 K rows is the shorter path: fewer launches)
+  return shape != 0 && a.vec_ok && a.vec_proj_ok && a.n_out_cols <= 2 && a.n_in_cap >= (1ull << 20);
+}
+static FilterStreamArgs stream_args(const FilterArgs& a0, int shape) {
+  FilterArgs a = a0;
+  filter_alignment(a, shape);
+  if (!a.stream_bits || !a.stream_counts || !a.stream_offs) fail(RDFGPU_ERR_INVALID, "streaming filter without its pass buffers");
+  FilterStreamArgs f{};
+  f.pcol = a.in[a.prog.nodes[0].u];
+  for (u32 c = 0; c < a.n_out_cols; c++) { f.proj[c] = a.in[a.proj[c]]; f.out[c] = a.out[c]; }
+  f.n_out_cols = a.n_out_cols; f.head_skip = a.head_skip;
+  f.n_in_dev = a.n_in_dev; f.n_in_cap = a.n_in_cap; f.n_out_dev = a.n_out_dev;
+  f.tt = a.tt; f.verdict = a.verdict; f.n_verdict = a.n_verdict;
+  f.bits = a.stream_bits; f.tile_count = a.stream_counts; f.tile_off = a.stream_offs;
+  if (shape == 1) { f.id_lit = a.prog.nodes[1].u; f.is_eq = a.prog.nodes[2].op == RDFGPU_EX_ID_EQ; }
+  if (shape == 2) { f.lit = a.prog.nodes[2]; f.op = a.prog.nodes[3].op; }
+  return f;
+}
+void launch_filter_bits(const FilterArgs& a, int shape, hipStream_t s) {     // pass 1 of the streaming form
+  const FilterStreamArgs f = stream_args(a, shape);
+  const dim3 sg((unsigned)filter_stream_tiles(a));
+  if (shape == 1) hipLaunchKernelGGL((filter_bits_kernel<1>), sg, dim3(kBlock), 0, s, f);
+  else if (shape == 2) hipLaunchKernelGGL((filter_bits_kernel<2>), sg, dim3(kBlock), 0, s, f);
+  else hipLaunchKernelGGL((filter_bits_kernel<3>), sg, dim3(kBlock), 0, s, f);
+}
+void launch_filter_write(const FilterArgs& a, int shape, hipStream_t s) {    // pass 2, after the scan of stream_counts into stream_offs
+  const FilterStreamArgs f = stream_args(a, shape);
+  const dim3 sg((unsigned)filter_stream_tiles(a));
+  if (a.n_out_cols == 0) hipLaunchKernelGGL((filter_write_kernel<0>), sg, dim3(kBlock), 0, s, f);
+  else if (a.n_out_cols == 1) hipLaunchKernelGGL((filter_write_kernel<1>), sg, dim3(kBlock), 0, s, f);
+  else hipLaunchKernelGGL((filter_write_kernel<2>), sg, dim3(kBlock), 0, s, f);
+}
+void launch_filter(const FilterArgs& a0, int shape, hipStream_t s) {
+  FilterArgs a = a0;
+  filter_alignment(a, shape);
+  if (filter_streams(a0, shape)) fail(RDFGPU_ERR_INVALID, "launch_filter: these arguments take the streaming form (launch_filter_bits / _write)");
+  // rows per workgroup: enough workgroups to fill the chip (>= ~1024), few enough reservations
+  u64 iters = (a.n_in_cap + (u64)kTile * 1024 - 1) / ((u64)kTile * 1024);
+  a.iters = (u32)(iters < 1 ? 1 : iters > kFilterMaxIters ? kFilterMaxIters : iters);
   const u64 chunk = (u64)kTile * a.iters;
   const u64 g = (a.n_in_cap + a.head_skip + chunk - 1) / chunk;
   const dim3 grid((unsigned)(g ? g : 1));

@@ -59,10 +59,16 @@ struct FilterArgs {
   TypedTable tt;
   ExprProgram prog;
   const unsigned char* verdict; u64 n_verdict;   // shape 3: per-id verdicts of a string predicate (0 false / 1 true / 2 error)
+  // streaming form (filter_streams): one verdict bit per row, tile counts (+ 1, the extra one zeroed), their scan, scan temp
+  unsigned short* stream_bits; u32* stream_counts; u32* stream_offs; void* stream_temp; size_t stream_temp_bytes;
 };
 // shape 0 = generic VM; 1 = `col <op> object-id literal` (ID_EQ / ID_NEQ); 2 = EBV(cmp(ENC_TV(col), literal));
 // 3 = EBV(REGEX | CONTAINS | STRSTARTS | STRENDS (ENC_TV(col), constant)) through a per-distinct-term verdict table
 void launch_filter(const FilterArgs& a, int shape, hipStream_t s);
+bool filter_streams(const FilterArgs& a, int shape);
+void launch_filter_bits(const FilterArgs& a, int shape, hipStream_t s);    // pass 1: verdict bits + tile counts
+void launch_filter_write(const FilterArgs& a, int shape, hipStream_t s);   // pass 2 (after the scan): ordered write
+u64 filter_stream_tiles(const FilterArgs& a);           // 4096-row tiles of the streaming form   // launch_filter will take the streaming kernel (filter_stream_kernel) for these arguments
 // Evaluates one string predicate for EVERY object id once (streaming through the string heap): out[id] = 0 / 1 / 2.
 void launch_regex_verdicts(const RegexProg* prog_dev, const TypedTable& tt, int64_t rhs_lang, unsigned char* out, u64 n_ids, hipStream_t s);
 

@@ -405,7 +405,9 @@ const char* kernel_class_name(int kc) {
       "rdfgpu::topk_write_kernel", "void rdfgpu::filter_kernel<3>", "rdfgpu::regex_verdict_kernel", "rdfgpu::union_kernel",
       "rdfgpu::band_slow_kernel", "rocprim radix sort", "rdfgpu::band_bounds_kernel", "rdfgpu::band_blocks_kernel",
       "rdfgpu::band_decode_kernel", "void rdfgpu::band_mask_kernel", "rdfgpu::band_emit_kernel", "rdfgpu::band_entries_kernel",
-      "rdfgpu::band_desc_kernel", "rdfgpu::band_pt_kernel", "rdfgpu::band_rows_kernel"};
+      "rdfgpu::band_desc_kernel", "rdfgpu::band_pt_kernel", "rdfgpu::band_rows_kernel",
+      "void rdfgpu::filter_bits_kernel<1>", "void rdfgpu::filter_bits_kernel<2>", "void rdfgpu::filter_bits_kernel<3>",
+      "void rdfgpu::filter_write_kernel"};
   if (kc < KC_LDS_JOIN0) return fixed[kc];
   static std::string names[192];
   static std::once_flag once;
@@ -735,6 +737,22 @@ DevTable Plan::apply_filter(NodeInfo& nd, const DevTable& in) {
     if (verdict) { a.verdict = verdict; a.n_verdict = n_ids; } else shape = 0;
   }
   // FilterExec bytes: 4·c_r·N + t·N + 4·c_w·σN with t = 9 B per typed gather (tag + i64); shape 3: t = 1 B
+  if (filter_streams(a, shape)) {   // two passes without atomics: verdict bits + tile counts, device scan, ordered write
+    const u64 tiles = filter_stream_tiles(a);
+    a.stream_bits = scratch<unsigned short>(tiles * 256);
+    a.stream_counts = scratch<u32>(tiles + 1); a.stream_offs = scratch<u32>(tiles + 1);
+    a.stream_temp_bytes = scan_temp_bytes(tiles + 1);
+    a.stream_temp = scratch<unsigned char>(a.stream_temp_bytes);
+    RDFGPU_HIP(hipMemsetAsync(a.stream_counts + tiles, 0, sizeof(u32), stream));
+    // compulsory bytes: pass 1 streams the predicate column (its typed-value gathers hit a table that is cache-resident or
+    // not: not counted) and writes one bit per row; pass 2 reads the bits and the output columns and writes the survivors
+    const int kc1 = shape == 1 ? KC_FILTER_BITS_ID : shape == 2 ? KC_FILTER_BITS_TV : KC_FILTER_BITS_VERDICT;
+    timed(kc1, tiles * 4, in.cap, in.n_dev, 4, nullptr, 0, 0, [&] { launch_filter_bits(a, shape, stream); });
+    timed(KC_DEVICE_SCAN, 0, tiles + 1, nullptr, 8, nullptr, 0, 0, [&] { exclusive_scan_u32(a.stream_counts, a.stream_offs, tiles + 1, a.stream_temp, a.stream_temp_bytes, stream); });
+    timed(KC_FILTER_WRITE, tiles * 8, in.cap, in.n_dev, 4ull * nd.n_proj, a.n_out_dev, 0, 4ull * nd.n_proj, [&] { launch_filter_write(a, shape, stream); });
+    t.cap = in.cap; t.n_dev = a.n_out_dev;
+    return t;
+  }
   const int kc = shape == 1 ? KC_FILTER_ID : shape == 2 ? KC_FILTER_TV : shape == 3 ? KC_FILTER_VERDICT : KC_FILTER_VM;
   timed(kc, 0, in.cap, in.n_dev, shape == 3 ? 4ull * nd.n_cols_read + 1 : 4ull * nd.n_cols_read + 9ull * nd.n_enc_tv, a.n_out_dev, 0, 4ull * nd.n_proj,
         [&] { launch_filter(a, shape, stream); });
