@@ -206,6 +206,20 @@ struct LdsJoinArgs {
 };
 void launch_lds_join(const LdsJoinArgs& a, hipStream_t s);
 
+// ---- radix-partitioned LDS hash join (part_join.hip): large build sides that are not cached store slices ----
+constexpr u32 kPartChunk = 2048;      // build rows per LDS table (a partition with more is joined chunk by chunk)
+constexpr u32 kPartSlots = 4096;      // slots of the LDS table: load <= 0.5, ~0.25 at the target partition size
+constexpr u32 kPartTargetRows = 1024; // build rows per partition aimed for
+struct PartArgs {
+  const uint4* bpart; const uint4* ppart;   // {row, key0, key1, -} records of the build / probe side, grouped by partition
+  const u32* bstart; const u32* pstart;     // [n_parts + 1] first record of every partition
+  u32 n_parts, chunk, tbl_mask, pad;
+};
+void launch_part_keys(const u32* k0, const u32* k1, u32 n_keys, const u64* n_dev, u64 cap, u32 bits, u32 n_parts, u32* skey, uint4* sval, hipStream_t s);
+size_t part_sort_temp_bytes(u64 n, u32 bits);
+void part_sort(const u32* kin, u32* kout, const uint4* vin, uint4* vout, u64 n, u32 bits, void* temp, size_t temp_bytes, hipStream_t s);
+void launch_part_join(const LdsJoinArgs& a, const PartArgs& pa, hipStream_t s);
+
 // ---- key-partitioned band join (band_join.hip): the fused chain over a CSR join with small groups, group by group ----
 constexpr u32 kBandMaxSideCols = 4;   // output columns taken from the group entry; from the probe row: kBandMaxRowCols
 constexpr u32 kBandMaxRowCols = 2;    // (they travel inside the row's 32-byte record)

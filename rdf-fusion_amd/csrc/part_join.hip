@@ -1,0 +1,219 @@
+// part_join.hip — radix-partitioned hash join with LDS-staged hash buckets: HashJoinExec(CollectLeft) for build sides
+// that are NOT a cached store slice (bound tables, join outputs, sparse or multi-column keys, every build when the
+// table cache is off) and are too large for one workgroup's LDS.
+//
+// Reference behaviour: SparqlJoinLoweringRule -> DataFusion Join -> HashJoinExec(CollectLeft), inner | left,
+// NullEqualsNothing (lib/logical/src/join/rewrite.rs:126-168, :89), residual JoinFilter, projection; the build happens
+// per query, inside the operator.
+//
+// Both sides are partitioned by the TOP bits of the key hash (rocPRIM radix sort of (partition, {row, key0, key1})
+// records: the records travel with the sort, so neither side is gathered afterwards) into partitions of ~1 K build rows;
+// one workgroup owns one partition at a time: it builds the partition's {key0, index} open-addressing table in LDS (the
+// LOW hash bits pick the slot; second key and row id in LDS next to it), streams the partition's probe records
+// (16-byte coalesced loads), and compacts the key-equal (build row, probe row) candidates with ballot + mbcnt into
+// wave-private LDS queues; a full queue runs the join filter on its candidates, reserves its output range with ONE
+// atomicAdd and writes consecutive rows (the resolve phase of the fused join kernel, join_device.hpp).
+// A partition with more build rows than a table holds (duplicate-heavy keys) is joined chunk by chunk: every chunk's
+// table meets all probe records of the partition.
+#include <hip/hip_runtime.h>
+#include <cstring>
+#include <rocprim/rocprim.hpp>
+
+#include "join_device.hpp"
+
+namespace rdfgpu {
+
+// sort key of a row = its partition (top `bits` bits of the key hash; n_parts = "joins nothing": null key / beyond the live rows)
+__global__ __launch_bounds__(256) void part_keys_kernel(const u32* k0, const u32* k1, u32 n_keys, const u64* n_dev, u64 cap, u32 bits, u32 n_parts,
+                                                         u32* skey, uint4* sval) {
+  const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= cap) return;
+  const u64 n = live_rows(n_dev, cap);
+  Keys key; key.k[0] = 0; key.k[1] = 0; key.k[2] = 0; key.k[3] = 0;
+  u32 pid = n_parts;
+  if (i < n) {
+    key.k[0] = k0[i]; key.k[1] = n_keys > 1 ? k1[i] : 0u;
+    const bool null_key = key.k[0] == 0 || (n_keys > 1 && key.k[1] == 0);   // NullEqualsNothing
+    if (!null_key) pid = bits ? hash_keys4(key, n_keys) >> (32 - bits) : 0u;
+  }
+  skey[i] = pid;
+  sval[i] = make_uint4((u32)i, key.k[0], key.k[1], 0u);
+}
+
+template <int FS>
+__global__ __launch_bounds__(kLdsBlock) __attribute__((amdgpu_waves_per_eu(4))) void part_join_kernel(const LdsJoinArgs a, const PartArgs pa) {
+  extern __shared__ __align__(16) unsigned char lds_raw[];
+  // dynamic LDS: [slots: tbl_mask + 1 x {key0, local index}] [k1: chunk] [rows: chunk] [8 wave queues]
+  uint2* slots = reinterpret_cast<uint2*>(lds_raw);
+  u32* k1s = reinterpret_cast<u32*>(slots + (pa.tbl_mask + 1u));
+  u32* rows = k1s + pa.chunk;
+  uint2* queues = reinterpret_cast<uint2*>(rows + pa.chunk);
+  __shared__ u32 wave_tot[kLdsBlock / 64];
+  __shared__ u64 wg_base;
+  const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const u32 qcap = a.wave_q;
+  uint2* wq = queues + (size_t)wave * qcap;
+  u32 qn = 0;   // candidates in this wave's queue (wave-uniform)
+
+  auto write_out = [&](u64 base) {   // queue entries -> consecutive output rows base .. base + qn
+    for (u32 oc0 = 0; oc0 < a.n_out_cols; oc0 += 4) {
+      const u32* src[4]; u32* dst[4]; bool from_build[4], on[4];
+#pragma unroll
+      for (u32 u = 0; u < 4; u++) {
+        on[u] = oc0 + u < a.n_out_cols;
+        const u32 c = a.proj[on[u] ? oc0 + u : oc0];
+        from_build[u] = (c < a.n_left_cols) == (a.build_is_left != 0);
+        src[u] = a.cols[c];
+        dst[u] = a.out[on[u] ? oc0 + u : oc0];
+      }
+      for (u32 e = lane; e < qn; e += 64) {
+        const uint2 m = wq[e];
+        const u64 pos = base + e;
+        if (pos >= a.out_cap) continue;
+        u32 v[4];
+#pragma unroll
+        for (u32 u = 0; u < 4; u++) if (on[u]) v[u] = src[u][from_build[u] ? m.x : m.y];
+#pragma unroll
+        for (u32 u = 0; u < 4; u++) if (on[u]) dst[u][pos] = v[u];
+      }
+    }
+    if (a.visited) for (u32 e = lane; e < qn; e += 64) a.visited[wq[e].x] = 1;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  };
+  auto resolve = [&]() {   // join filter over the queued candidates, survivors compacted in place
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if (FS == 0) return;
+    u32 kept = 0;
+    for (u32 g0 = 0; g0 < qn; g0 += 64) {
+      const u32 e = g0 + lane;
+      uint2 m = make_uint2(0u, 0u);
+      bool ok = e < qn, slow = false;
+      if (ok) { m = wq[e]; ok = ljoin_filter_fast<FS>(a, m.x, m.y, slow); }
+      if constexpr (FS == 1 || FS == 3) { if (slow) ok = ljoin_filter_slow<FS>(a, m.x, m.y); }
+      const unsigned long long mask = __ballot(ok);
+      if (ok) wq[kept + lane_prefix(mask)] = m;   // kept + prefix <= e: never ahead of an unread entry of a later round
+      kept += (u32)__popcll(mask);
+    }
+    qn = kept;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  };
+  auto flush = [&]() {     // one reservation for the wave's queue
+    resolve();
+    unsigned long long b = 0;
+    if (lane == 0 && qn) {
+      b = atomicAdd((unsigned long long*)a.n_out_dev, (unsigned long long)qn);
+      if (b + qn > a.out_cap) *a.overflow = 1u;
+    }
+    b = __shfl(b, 0, 64);
+    write_out(b);
+    qn = 0;
+  };
+
+  for (u32 p = blockIdx.x; p < pa.n_parts; p += gridDim.x) {
+    const u32 bs = pa.bstart[p], be = pa.bstart[p + 1], ps = pa.pstart[p], pe = pa.pstart[p + 1];
+    if (bs >= be || ps >= pe) continue;              // uniform per workgroup
+    for (u32 cb = bs; cb < be; cb += pa.chunk) {
+      const u32 nb = be - cb < pa.chunk ? be - cb : pa.chunk;
+      __syncthreads();                               // every wave is done with the previous table
+      for (u32 s = tid; s <= pa.tbl_mask; s += kLdsBlock) slots[s] = make_uint2(0u, kNil);
+      __syncthreads();
+      for (u32 i = tid; i < nb; i += kLdsBlock) {
+        const uint4 r = pa.bpart[cb + i];            // {row, key0, key1, -}
+        k1s[i] = r.z; rows[i] = r.x;
+        Keys key; key.k[0] = r.y; key.k[1] = r.z; key.k[2] = 0; key.k[3] = 0;
+        u32 h = hash_keys4(key, a.n_keys) & pa.tbl_mask;
+        for (;;) {
+          if (atomicCAS(&slots[h].y, kNil, i) == kNil) { slots[h].x = r.y; break; }
+          h = (h + 1) & pa.tbl_mask;
+        }
+      }
+      __syncthreads();
+      const u32 n_probe = pe - ps;
+      for (u32 t0 = 0; t0 < n_probe; t0 += kLdsBlock) {   // uniform trip count per workgroup
+        const u32 t = t0 + tid;
+        const bool live = t < n_probe;
+        uint4 r = make_uint4(0u, 0u, 0u, 0u);
+        if (live) r = pa.ppart[ps + t];
+        Keys key; key.k[0] = r.y; key.k[1] = r.z; key.k[2] = 0; key.k[3] = 0;
+        u32 h = hash_keys4(key, a.n_keys) & pa.tbl_mask;
+        bool walking = live;
+        for (;;) {
+          u32 hit = kNil;
+          while (walking) {
+            const uint2 c = slots[h];
+            if (c.y == kNil) { walking = false; break; }
+            h = (h + 1) & pa.tbl_mask;
+            if (c.x != r.y) continue;
+            if (a.n_keys > 1 && k1s[c.y] != r.z) continue;
+            hit = rows[c.y];
+            break;
+          }
+          const unsigned long long found = __ballot(hit != kNil);
+          if (found == 0) break;
+          const u32 n_found = (u32)__popcll(found);
+          if (qn + n_found > qcap) flush();          // wave-uniform: the queue is empty afterwards and 64 <= qcap
+          if (hit != kNil) wq[qn + lane_prefix(found)] = make_uint2(hit, r.x);
+          qn += n_found;
+        }
+      }
+    }
+  }
+  // what is still queued leaves with one reservation for the whole workgroup
+  resolve();
+  if (lane == 0) wave_tot[wave] = qn;
+  __syncthreads();
+  if (tid == 0) {
+    u32 t = 0;
+    for (int w = 0; w < kLdsBlock / 64; w++) t += wave_tot[w];
+    u64 b = 0;
+    if (t) {
+      b = atomicAdd((unsigned long long*)a.n_out_dev, (unsigned long long)t);
+      if (b + t > a.out_cap) *a.overflow = 1u;
+    }
+    wg_base = b;
+  }
+  __syncthreads();
+  u64 out_base = wg_base;
+  for (u32 w = 0; w < wave; w++) out_base += wave_tot[w];
+  write_out(out_base);
+}
+
+// ---- host side -------------------------------------------------------------------------------------------------------
+void launch_part_keys(const u32* k0, const u32* k1, u32 n_keys, const u64* n_dev, u64 cap, u32 bits, u32 n_parts, u32* skey, uint4* sval, hipStream_t s) {
+  if (cap) hipLaunchKernelGGL(part_keys_kernel, dim3((unsigned)((cap + 255) / 256)), dim3(256), 0, s, k0, k1, n_keys, n_dev, cap, bits, n_parts, skey, sval);
+}
+size_t part_sort_temp_bytes(u64 n, u32 bits) {
+  size_t bytes = 0;
+  (void)rocprim::radix_sort_pairs(nullptr, bytes, (const u32*)nullptr, (u32*)nullptr, (const uint4*)nullptr, (uint4*)nullptr, (size_t)(n ? n : 1), 0, bits);
+  return bytes + 256;
+}
+void part_sort(const u32* kin, u32* kout, const uint4* vin, uint4* vout, u64 n, u32 bits, void* temp, size_t temp_bytes, hipStream_t s) {
+  if (!n) return;
+  RDFGPU_HIP(rocprim::radix_sort_pairs(temp, temp_bytes, kin, kout, vin, vout, (size_t)n, 0, bits, s));
+}
+size_t part_join_lds_bytes(const LdsJoinArgs& a, const PartArgs& pa) {
+  return (size_t)(pa.tbl_mask + 1) * sizeof(uint2) + 2ull * pa.chunk * sizeof(u32) + (size_t)(kLdsBlock / 64) * a.wave_q * sizeof(uint2);
+}
+template <int FS> static void launch_part_join_fs(const LdsJoinArgs& a, const PartArgs& pa, dim3 g, size_t lds, hipStream_t s) {
+  static std::once_flag attr_once;
+  std::call_once(attr_once, [] {
+    RDFGPU_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(part_join_kernel<FS>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
+  });
+  hipLaunchKernelGGL((part_join_kernel<FS>), g, dim3(kLdsBlock), lds, s, a, pa);
+}
+void launch_part_join(const LdsJoinArgs& a, const PartArgs& pa, hipStream_t s) {
+  const size_t lds = part_join_lds_bytes(a, pa);
+  if (lds > 152 * 1024 || a.wave_q < 64) fail(RDFGPU_ERR_INVALID, "partitioned join: %zu bytes of LDS", lds);
+  if (a.n_keys < 1 || a.n_keys > 2) fail(RDFGPU_ERR_INVALID, "partitioned join takes one or two key columns");
+  const u32 wgs = pa.n_parts < 8192 ? pa.n_parts : 8192;   // every workgroup strides over the partitions
+  const dim3 g(wgs ? wgs : 1);
+  switch (a.has_filter) {
+    case 0: return launch_part_join_fs<0>(a, pa, g, lds, s);
+    case 1: return launch_part_join_fs<1>(a, pa, g, lds, s);
+    case 2: return launch_part_join_fs<2>(a, pa, g, lds, s);
+    case 3: return launch_part_join_fs<3>(a, pa, g, lds, s);
+  }
+  fail(RDFGPU_ERR_INVALID, "partitioned join: bad filter shape %u", a.has_filter);
+}
+
+}  // namespace rdfgpu

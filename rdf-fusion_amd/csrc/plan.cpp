@@ -407,7 +407,7 @@ const char* kernel_class_name(int kc) {
       "rdfgpu::band_decode_kernel", "void rdfgpu::band_mask_kernel", "rdfgpu::band_emit_kernel", "rdfgpu::band_entries_kernel",
       "rdfgpu::band_desc_kernel", "rdfgpu::band_pt_kernel", "rdfgpu::band_rows_kernel",
       "void rdfgpu::filter_bits_kernel<1>", "void rdfgpu::filter_bits_kernel<2>", "void rdfgpu::filter_bits_kernel<3>",
-      "void rdfgpu::filter_write_kernel"};
+      "void rdfgpu::filter_write_kernel", "rdfgpu::part_keys_kernel", "void rdfgpu::part_join_kernel"};
   if (kc < KC_LDS_JOIN0) return fixed[kc];
   static std::string names[192];
   static std::once_flag once;
@@ -1258,6 +1258,7 @@ DevTable Plan::exec_lds_join(NodeInfo& nd, const DevTable& L, const DevTable& R,
   if (B.cap >= (1ull << 30)) fail(RDFGPU_ERR_UNSUPPORTED, "build side of %llu rows", (unsigned long long)B.cap);
   u32 slots = 64;
   while (slots < 2 * B.cap) slots <<= 1;
+  bool use_part = false; PartArgs part{};
   // LDS copy per workgroup vs ONE table in HBM/L2: the LDS form pays the build once per workgroup and, above
   // ~16 KiB of table, costs occupancy (a 128 KiB table = one workgroup per CU = latency-bound probes).
   const u64 lds_limit = std::min<u64>(opt.v[RDFGPU_OPT_LDS_MAX_BUILD], kLdsJoinMaxBuild);
@@ -1357,6 +1358,9 @@ DevTable Plan::exec_lds_join(NodeInfo& nd, const DevTable& L, const DevTable& R,
           }
         a.gslots = static_cast<uint2*>(st->slots);
       }
+    } else if (a.n_keys <= 2 && !probe_filter && !post_filter && !opt.on(RDFGPU_OPT_NO_PARTITIONED_JOIN) && B.cap >= opt.v[RDFGPU_OPT_PARTITION_MIN_BUILD] &&
+               B.cap < (1ull << 31) && P.cap < (1ull << 31)) {
+      use_part = true;     // radix-partition both sides; every partition's table is built in LDS (part_join.hip)
     } else {
       a.gslots = scratch<uint2>(slots);
       build_now = true;
@@ -1378,6 +1382,7 @@ DevTable Plan::exec_lds_join(NodeInfo& nd, const DevTable& L, const DevTable& R,
     while (q < want && q < 1024) q <<= 1;
     if (!global_table && (size_t)slots * sizeof(uint2) > 64 * 1024) q = 256;
     a.wave_q = q_env ? q_env : q;
+    if (use_part) a.wave_q = 256;
   }
   a.probe_col_base = build_left ? L.n_cols : 0;
   a.has_filter = (u32)nd.shape;   // 0 none / 1 generic VM / 3 window
@@ -1426,6 +1431,14 @@ DevTable Plan::exec_lds_join(NodeInfo& nd, const DevTable& L, const DevTable& R,
   // SURVEY §8d hash join: 4(k+p_b)N_b + 8N_b + 4(k+p_p)N_p + 8N_p + 4 c_o N_o  (the 8-byte slot lives in LDS here)
   const u64 fixed = (4ull * (a.n_keys + build_payload) + 8) * B.cap;
 
+  if (use_part) prepare_partitions(a, B, P, part);   // the build half of this HashJoinExec: inside the operator, every execution
+  // SURVEY 8d hash-join bytes of a partitioned join: both sides' key + payload columns and one 8-byte slot per row, the output;
+  // the partition passes are in the time of the operator, not in its bytes
+  const u64 part_fixed = (4ull * (a.n_keys + build_payload) + 8) * B.cap;
+  auto launch_join = [&](int kc_lds, u64 fixed_bytes, u64 out_bytes_per_row) {
+    if (use_part) timed(KC_PART_JOIN, part_fixed, P.cap, P.n_dev, 4ull * probe_cols + 8, n_out, 0, out_bytes_per_row, [&] { launch_part_join(a, part, stream); });
+    else timed(kc_lds, fixed_bytes, P.cap, P.n_dev, 4ull * probe_cols + 8, n_out, 0, out_bytes_per_row, [&] { launch_lds_join(a, stream); });
+  };
   if (build_now)   // build pass: keys read + one 8-byte slot written per build row
     timed(KC_GJOIN_BUILD, 0, B.cap, B.n_dev, 4ull * a.n_keys + 8, nullptr, 0, 0, [&] { launch_gjoin_build(a, stream); });
   // Speculative mode (re-execution of a plan whose previous run is known): the output is sized from the
@@ -1448,7 +1461,7 @@ DevTable Plan::exec_lds_join(NodeInfo& nd, const DevTable& L, const DevTable& R,
     NodeInfo* size_node = &nd;
     u64 stage_bytes = 0;
     BandArgs band{}; bool use_band = false;
-    if (pending_chain && pending_chain->base == &nd && !pending_chain->consumed && global_table && !left_join && !probe_filter && nd.shape != 1 &&
+    if (pending_chain && pending_chain->base == &nd && !pending_chain->consumed && global_table && !use_part && !left_join && !probe_filter && nd.shape != 1 &&
         apply_chain(*pending_chain, nd, L, R, build_left, a, stage_bytes, &band, &use_band)) {
       pending_chain->consumed = true;
       size_node = pending_chain->top;
@@ -1461,10 +1474,8 @@ DevTable Plan::exec_lds_join(NodeInfo& nd, const DevTable& L, const DevTable& R,
     for (u32 c = 0; c < a.n_out_cols; c++) { a.out[c] = scratch<u32>(spec_cap + tail); t.cols[c] = a.out[c]; }
     if (left_join) RDFGPU_HIP(hipMemsetAsync(a.visited, 0, L.cap, stream));
     if (use_band) exec_band_join(a, band, B, P, 4ull * (1 + build_payload), 4ull * probe_cols);
-    else
-    timed(lds_join_class(a.has_filter, a.has_probe_filter, lds_join_items(P.cap << a.row_lanes_log2, global_table), lds_join_mode(a), chained),
-          (global_table ? 0 : fixed) + stage_bytes, P.cap, P.n_dev,
-          4ull * probe_cols + 8, n_out, 0, 4ull * a.n_out_cols, [&] { launch_lds_join(a, stream); });
+    else launch_join(lds_join_class(a.has_filter, a.has_probe_filter, lds_join_items(P.cap << a.row_lanes_log2, global_table), use_part ? kJoinTableLds : lds_join_mode(a), chained),
+                     (global_table ? 0 : fixed) + stage_bytes, 4ull * a.n_out_cols);
     spec_checks.push_back({size_node, (u32)(n_out - counters), left_join});
     t.cap = spec_cap + tail; t.n_dev = n_out;
     if (left_join) {
@@ -1485,7 +1496,8 @@ DevTable Plan::exec_lds_join(NodeInfo& nd, const DevTable& L, const DevTable& R,
     a.out_cap = out_cap;
     for (u32 c = 0; c < nd.n_proj; c++) { a.out[c] = scratch<u32>(out_cap + tail); t.cols[c] = a.out[c]; }
     if (left_join) RDFGPU_HIP(hipMemsetAsync(a.visited, 0, L.cap, stream));
-    timed(lds_join_class(a.has_filter, a.has_probe_filter, lds_join_items(P.cap << a.row_lanes_log2, global_table), lds_join_mode(a)), global_table ? 0 : fixed, P.cap, P.n_dev, 4ull * probe_cols + 8, n_out, 0, 4ull * nd.n_proj, [&] { launch_lds_join(a, stream); });
+    launch_join(lds_join_class(a.has_filter, a.has_probe_filter, lds_join_items(P.cap << a.row_lanes_log2, global_table), use_part ? kJoinTableLds : lds_join_mode(a)),
+                global_table ? 0 : fixed, 4ull * nd.n_proj);
     const u32 i0 = (u32)(n_out - counters);
     RDFGPU_HIP(hipMemcpyAsync(ctx->counters_host + i0, counters + i0, 2 * sizeof(u64), hipMemcpyDeviceToHost, stream));
     RDFGPU_HIP(hipStreamSynchronize(stream)); metrics.host_syncs++;
@@ -1509,6 +1521,31 @@ DevTable Plan::exec_lds_join(NodeInfo& nd, const DevTable& L, const DevTable& R,
   timed(KC_LEFT_TAIL, 0, L.cap, L.n_dev, 1, nullptr, 0, 0, [&] { launch_join_left_unmatched(ja, stream); });
   t.n_dev = n_out;
   return t;
+}
+
+// Radix partitioning of both sides of a HashJoinExec by the top bits of the key hash (part_join.hip): per side one pass
+// that computes (partition, {row, key0, key1}) per row, one rocPRIM radix sort moving the 16-byte records, one pass that
+// finds the partition boundaries.  Rows with a null key (NullEqualsNothing) or beyond the live row count get the partition
+// "n_parts" and sort behind every real partition.
+void Plan::prepare_partitions(const LdsJoinArgs& a, const DevTable& B, const DevTable& P, PartArgs& pa) {
+  u32 bits = 0;
+  while (bits < 20 && (B.cap >> bits) > kPartTargetRows) bits++;
+  const u32 n_parts = 1u << bits;
+  pa.n_parts = n_parts; pa.chunk = kPartChunk; pa.tbl_mask = kPartSlots - 1;
+  auto side = [&](const DevTable& T, const u32* const* keys, const uint4*& recs, const u32*& start) {
+    const u64 n = T.cap;
+    u32* skey_in = scratch<u32>(n); u32* skey = scratch<u32>(n);
+    uint4* sval_in = scratch<uint4>(n); uint4* sval = scratch<uint4>(n);
+    u32* st = scratch<u32>((u64)n_parts + 2);
+    const size_t tb = part_sort_temp_bytes(n, bits + 1);
+    void* temp = scratch<unsigned char>(tb);
+    timed(KC_PART_KEYS, 0, n, T.n_dev, 0, nullptr, 0, 0, [&] { launch_part_keys(keys[0], a.n_keys > 1 ? keys[1] : nullptr, a.n_keys, T.n_dev, n, bits, n_parts, skey_in, sval_in, stream); });
+    timed(KC_RADIX_SORT, 0, n, nullptr, 0, nullptr, 0, 0, [&] { part_sort(skey_in, skey, sval_in, sval, n, bits + 1, temp, tb, stream); });
+    timed(KC_BAND_BOUNDS, 0, n, nullptr, 0, nullptr, 0, 0, [&] { launch_band_bounds(skey, n, n_parts, st, stream); });
+    recs = sval; start = st;
+  };
+  side(B, a.build_key, pa.bpart, pa.bstart);
+  side(P, a.probe_key, pa.ppart, pa.pstart);
 }
 
 // The fused chain as a key-partitioned band join (band_join.hip).  `a` is complete (chain, output columns, out_cap,

@@ -52,6 +52,7 @@ enum KernelClass {
   KC_FILTER_VERDICT, KC_REGEX_VERDICTS, KC_UNION,
   KC_BAND_SLOW, KC_RADIX_SORT, KC_BAND_BOUNDS, KC_BAND_BLOCKS, KC_BAND_DECODE, KC_BAND_MASK, KC_BAND_EMIT, KC_BAND_ENTRIES, KC_BAND_DESC, KC_BAND_PT, KC_BAND_ROWS,
   KC_FILTER_BITS_ID, KC_FILTER_BITS_TV, KC_FILTER_BITS_VERDICT, KC_FILTER_WRITE,
+  KC_PART_KEYS, KC_PART_JOIN,
   KC_LDS_JOIN0,                      // 192 names: lds_join_kernel<FS in {0..3}, PFS in {0,1,2}, ITEMS in {4,1}, MODE in {0,1,2,3}, CHAIN>
   KC__N = KC_LDS_JOIN0 + 192
 };
@@ -124,6 +125,7 @@ struct Plan {
   DevTable exec_lds_join(NodeInfo& nd, const DevTable& L, const DevTable& R, bool build_left, const NodeInfo* probe_filter, const NodeInfo* post_filter = nullptr);
   bool plan_chain(NodeInfo& top, ChainRequest& req);
   bool apply_chain(const ChainRequest& req, NodeInfo& base, const DevTable& L, const DevTable& R, bool build_left, LdsJoinArgs& a, u64& stage_bytes, BandArgs* band, bool* use_band);
+  void prepare_partitions(const LdsJoinArgs& a, const DevTable& B, const DevTable& P, PartArgs& pa);
   void exec_band_join(LdsJoinArgs& a, BandArgs& b, const DevTable& B, const DevTable& P, u64 build_bytes_per_row, u64 probe_bytes_per_row);
   bool choose_build_left(const NodeInfo& nd, const DevTable& L, const DevTable& R, bool left_join, bool lf, bool rf, bool lpost = false, bool rpost = false) const;
   void release_intermediates();

@@ -358,6 +358,62 @@ def test_hash_join_matches_oracle(torch_cuda, nl, nr, n_ids):
     del big
 
 
+@pytest.mark.parametrize("nb,npr,n_ids,min_build", [(3_000, 9_000, 700, 1000), (6_000, 2_000, 3, 1000), (70_000, 250_000, 30_000, None),
+                                                     (400_000, 1_500_000, 900_000, None), (2_500_000, 3_000_000, 4_000_000, None),
+                                                     (10_000_000, 12_000_000, 9_000_000, None)])
+def test_partitioned_join_matches_oracle(torch_cuda, nb, npr, n_ids, min_build):
+    """The radix-partitioned LDS hash join (part_join.hip): HashJoinExec(CollectLeft) over bound tables — builds that are no
+    cached store slice — from a few thousand to 10 M rows: sparse single keys and two-column keys, duplicate-heavy keys
+    (n_ids = 3: partitions far larger than one LDS table, joined chunk by chunk), null keys, inner / left, no filter /
+    id filter / typed filter, projections; against the oracle, and against the same plan with the path switched off."""
+    rng = np.random.default_rng(nb + npr)
+    tv, dec = typed_zoo()
+    gs, os_ = both_stores((np.zeros(0, np.uint32),) * 4, typed=tv, decimals=dec)
+    if min_build:
+        gs.set_option("PARTITION_MIN_BUILD", min_build)
+    n_tv = len(tv)
+    B = [rng.integers(1, n_ids + 1, nb).astype(np.uint32), rng.integers(1, max(2, n_ids // 50) + 1, nb).astype(np.uint32), rng.integers(1, n_tv, nb).astype(np.uint32)]
+    Pr = [rng.integers(1, n_ids + 1, npr).astype(np.uint32), rng.integers(1, max(2, n_ids // 50) + 1, npr).astype(np.uint32), rng.integers(1, n_tv, npr).astype(np.uint32)]
+    if n_ids > 3:
+        for t in (B, Pr):                     # unbound keys never join (NullEqualsNothing)
+            t[0][rng.random(len(t[0])) < 0.01] = 0
+            t[1][rng.random(len(t[1])) < 0.01] = 0
+    kb, pbp = table_on_device(torch_cuda, B)
+    kp, ppp = table_on_device(torch_cuda, Pr)
+    big = nb >= 2_000_000
+    shapes = [([(0, 0)], None, None, abi.JOIN_INNER),
+              ([(0, 0), (1, 1)], None, [0, 1, 2, 5], abi.JOIN_INNER),
+              ([(0, 0), (1, 1)], ID_NEQ(col(2), col(5)), [0, 2, 5], abi.JOIN_LEFT)]
+    if not big:
+        shapes += [([(1, 1)], AND(EBV(LT(ENC_TV(col(2)), ADD(ENC_TV(col(5)), integer(3)))), BOUND(col(0))), [0, 3, 2], abi.JOIN_INNER),
+                   ([(0, 0)], None, [1, 4], abi.JOIN_LEFT)]
+    if n_ids <= 3:                            # every key a heavy hitter: only the selective shapes keep the result small
+        shapes = [([(0, 0), (1, 1)], ID_EQ(col(2), col(5)), [0, 2], abi.JOIN_INNER), ([(0, 0), (1, 1)], ID_EQ(col(2), col(5)), [0, 2, 5], abi.JOIN_LEFT)]
+    seen = set()
+    for on, flt, proj, jt in shapes:
+        pb = PlanBuilder()
+        # DataFusion builds on the left input (CollectLeft): the larger-or-equal table goes right unless it is a left join
+        desc = pb.build(pb.hash_join(pb.table(0, 3), pb.table(1, 3), on=on, join_type=jt, filter=flt, projection=proj))
+        exp, n_exp, _ = os_.execute(desc, [B, Pr])
+        want = ku.multiset(exp, n_exp)
+        plan = gs.plan(desc)
+        plan.bind_table(0, pbp, nb); plan.bind_table(1, ppp, npr)
+        for rep in range(2):                  # exact sizing, then speculative sizing from the first run
+            plan.enable_kernel_timing(True)
+            got = plan.execute().fetch()
+            assert plan.result_info()[0] == n_exp, (on, jt, rep)
+            np.testing.assert_array_equal(ku.multiset(got, n_exp), want, err_msg=f"{on} {jt} rep {rep}")
+            seen |= {k[0] for k in plan.kernel_stats()}
+        if not big:
+            plan.set_option("NO_PARTITIONED_JOIN", 1)
+            got = plan.execute().fetch()
+            assert not any("part_join" in k[0] for k in plan.kernel_stats())
+            np.testing.assert_array_equal(ku.multiset(got, n_exp), want)
+        plan.close()
+    assert any("part_join_kernel" in k for k in seen) or ENGINE_TOGGLED, seen
+    del kb, kp
+
+
 def test_cross_and_nested_loop_join(torch_cuda):
     rng = np.random.default_rng(3)
     tv, dec = typed_zoo()
