@@ -23,21 +23,22 @@
 
 namespace rdfgpu {
 
-// sort key of a row = its partition (top `bits` bits of the key hash; n_parts = "joins nothing": null key / beyond the live rows)
+// sort key of a row = its partition (top `bits` bits of the key hash).  A row that joins nothing (null key / beyond the live
+// rows) rides in the last partition with row = kNil — the sort then needs exactly `bits` bits (16 bits = two radix passes)
 __global__ __launch_bounds__(256) void part_keys_kernel(const u32* k0, const u32* k1, u32 n_keys, const u64* n_dev, u64 cap, u32 bits, u32 n_parts,
                                                          u32* skey, uint4* sval) {
   const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= cap) return;
   const u64 n = live_rows(n_dev, cap);
   Keys key; key.k[0] = 0; key.k[1] = 0; key.k[2] = 0; key.k[3] = 0;
-  u32 pid = n_parts;
+  u32 pid = n_parts - 1, row = kNil;
   if (i < n) {
     key.k[0] = k0[i]; key.k[1] = n_keys > 1 ? k1[i] : 0u;
     const bool null_key = key.k[0] == 0 || (n_keys > 1 && key.k[1] == 0);   // NullEqualsNothing
-    if (!null_key) pid = bits ? hash_keys4(key, n_keys) >> (32 - bits) : 0u;
+    if (!null_key) { pid = bits ? hash_keys4(key, n_keys) >> (32 - bits) : 0u; row = (u32)i; }
   }
   skey[i] = pid;
-  sval[i] = make_uint4((u32)i, key.k[0], key.k[1], 0u);
+  sval[i] = make_uint4(row, key.k[0], key.k[1], 0u);
 }
 
 template <int FS>
@@ -120,6 +121,7 @@ __global__ __launch_bounds__(kLdsBlock) __attribute__((amdgpu_waves_per_eu(4))) 
       for (u32 i = tid; i < nb; i += kLdsBlock) {
         const uint4 r = pa.bpart[cb + i];            // {row, key0, key1, -}
         k1s[i] = r.z; rows[i] = r.x;
+        if (r.x == kNil) continue;                   // a row that joins nothing
         Keys key; key.k[0] = r.y; key.k[1] = r.z; key.k[2] = 0; key.k[3] = 0;
         u32 h = hash_keys4(key, a.n_keys) & pa.tbl_mask;
         for (;;) {
@@ -136,7 +138,7 @@ __global__ __launch_bounds__(kLdsBlock) __attribute__((amdgpu_waves_per_eu(4))) 
         if (live) r = pa.ppart[ps + t];
         Keys key; key.k[0] = r.y; key.k[1] = r.z; key.k[2] = 0; key.k[3] = 0;
         u32 h = hash_keys4(key, a.n_keys) & pa.tbl_mask;
-        bool walking = live;
+        bool walking = live && r.x != kNil;
         for (;;) {
           u32 hit = kNil;
           while (walking) {

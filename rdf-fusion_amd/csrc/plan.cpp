@@ -1525,11 +1525,11 @@ DevTable Plan::exec_lds_join(NodeInfo& nd, const DevTable& L, const DevTable& R,
 
 // Radix partitioning of both sides of a HashJoinExec by the top bits of the key hash (part_join.hip): per side one pass
 // that computes (partition, {row, key0, key1}) per row, one rocPRIM radix sort moving the 16-byte records, one pass that
-// finds the partition boundaries.  Rows with a null key (NullEqualsNothing) or beyond the live row count get the partition
-// "n_parts" and sort behind every real partition.
+// finds the partition boundaries.  Rows with a null key (NullEqualsNothing) or beyond the live row count ride in the last
+// partition, marked (row = kNil) so that the join skips them.
 void Plan::prepare_partitions(const LdsJoinArgs& a, const DevTable& B, const DevTable& P, PartArgs& pa) {
   u32 bits = 0;
-  while (bits < 20 && (B.cap >> bits) > kPartTargetRows) bits++;
+  while (bits < 16 && (B.cap >> bits) > kPartTargetRows) bits++;   // <= 16 bits = two radix passes; larger partitions are joined chunk by chunk
   const u32 n_parts = 1u << bits;
   pa.n_parts = n_parts; pa.chunk = kPartChunk; pa.tbl_mask = kPartSlots - 1;
   auto side = [&](const DevTable& T, const u32* const* keys, const uint4*& recs, const u32*& start) {
@@ -1537,10 +1537,10 @@ void Plan::prepare_partitions(const LdsJoinArgs& a, const DevTable& B, const Dev
     u32* skey_in = scratch<u32>(n); u32* skey = scratch<u32>(n);
     uint4* sval_in = scratch<uint4>(n); uint4* sval = scratch<uint4>(n);
     u32* st = scratch<u32>((u64)n_parts + 2);
-    const size_t tb = part_sort_temp_bytes(n, bits + 1);
+    const size_t tb = part_sort_temp_bytes(n, bits ? bits : 1);
     void* temp = scratch<unsigned char>(tb);
     timed(KC_PART_KEYS, 0, n, T.n_dev, 0, nullptr, 0, 0, [&] { launch_part_keys(keys[0], a.n_keys > 1 ? keys[1] : nullptr, a.n_keys, T.n_dev, n, bits, n_parts, skey_in, sval_in, stream); });
-    timed(KC_RADIX_SORT, 0, n, nullptr, 0, nullptr, 0, 0, [&] { part_sort(skey_in, skey, sval_in, sval, n, bits + 1, temp, tb, stream); });
+    timed(KC_RADIX_SORT, 0, n, nullptr, 0, nullptr, 0, 0, [&] { part_sort(skey_in, skey, sval_in, sval, n, bits ? bits : 1, temp, tb, stream); });
     timed(KC_BAND_BOUNDS, 0, n, nullptr, 0, nullptr, 0, 0, [&] { launch_band_bounds(skey, n, n_parts, st, stream); });
     recs = sval; start = st;
   };
