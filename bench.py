@@ -261,79 +261,77 @@ def main():
     else:
         plan_a = store.plan(bsbm.q5_batch_const_plan(ds))
         plan_b = store.plan(bsbm.q5_batch_plan(ds, tables=True))
-        ex = sharding.BatchExchange(Q, world)                # fixed-size, zero-padded exchange buffer (one all-gather per step)
-        buf_len = ex.buf_len
-        send_bufs = [torch.zeros(buf_len, dtype=torch.int32, device="cuda") for _ in range(2)]
+        # The exchange is part of the product: rdfgpu_exchange_allgatherv behind the C ABI (RCCL over xGMI, grouped send / recv,
+        # buffers sized from the exchanged row counts).  torch.distributed only carries the RCCL unique id, the barriers and the
+        # final reductions.  Two communicators: the gathered table of batch i stays valid while batch i + 1 is exchanged.
+        if rehearse:           # several ranks on ONE GPU (RCCL refuses that): the host-staged transport, gloo as the wire
+            def gloo_alltoallv(blocks):
+                got = [None] * world
+                dist.all_gather_object(got, [bytes(b) for b in blocks])
+                return [np.frombuffer(got[r][rank], dtype=np.uint8) for r in range(world)]
+            comms = [rf.Comm(rank, world, device=local_rank, host_alltoallv=gloo_alltoallv) for _ in range(2)]
+        else:
+            comms = []
+            for _ in range(2):
+                ids = [rf.Comm.unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(ids, src=0)
+                comms.append(rf.Comm(rank, world, device=local_rank, unique_id=ids[0]))
 
-        class _DevCol:
-            """A result column in HBM, as torch sees it (zero copy)."""
-            def __init__(self, ptr, n):
-                self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<i4", "data": (int(ptr), False), "version": 2}
-
-        def phase_a(batch, timing, slot):
+        def phase_a(batch, timing):
             """Phase A: the constant-subject patterns of the whole batch on the local shard, joined per instance:
-            C(inst, X, prodFeature, origProperty1, origProperty2) for the instances whose %Product% lives here, packed
-            into this step's fixed-size, zero-padded send buffer."""
+            C(inst, X, prodFeature, origProperty1, origProperty2) for the instances whose %Product% lives here — in HBM."""
             t, ptrs, n = params_on_device(batch)
-            mine = send_bufs[slot].zero_()
             plan_a.bind_table(0, ptrs, n)
             plan_a.enable_kernel_timing(timing)
             plan_a.execute()
             if timing:
                 account(plan_a)
-            cols, rows = plan_a.result_device()
-            ex.pack(mine, [torch.as_tensor(_DevCol(c, rows), device="cuda") if rows else None for c in cols], rows)
-            torch.cuda.current_stream().synchronize()
-            return mine
+            return plan_a.result_device()
 
-        def exchange_start(mine):
-            """ONE all-gather of the buffer holding C — a padding row has inst = 0 = null, and a null key never joins
-            (NullEqualsNothing), so the gathered buffer is bound as it is: no counts travel, nothing is unpacked on the
-            host.  Asynchronous: the collective runs on RCCL's stream while this rank computes."""
-            send = mine.to(xdev)
-            out = torch.empty(world * buf_len, dtype=torch.int32, device=send.device)
-            return dist.all_gather_into_tensor(out, send, async_op=True), out, send
-
-        def phase_b(pending, timing):
-            """Phase B: the batch's join / FILTER pipeline over the local shard of the product-side patterns, probing
-            with the gathered C."""
-            work, out, _send = pending
-            t_w = time.perf_counter()
-            work.wait()
-            keep = ex.unpack(out.to("cuda"))                  # (5, world * cap): one contiguous column per variable
-            rows_all = keep.shape[1]
-            plan_b.bind_table(0, [keep.data_ptr() + 4 * rows_all * k for k in range(ex.N_COLS)], rows_all)
-            torch.cuda.current_stream().synchronize()      # the table is complete before the plan's stream reads it
-            t_b = time.perf_counter()
+        def phase_b(tab, timing):
+            """Phase B: the batch's join / FILTER pipeline over the local shard of the product-side patterns, probing with
+            the gathered C (bound as it arrived: device columns owned by the communicator)."""
+            ptrs, rows_all = tab
+            plan_b.bind_table(0, ptrs, rows_all)
             plan_b.enable_kernel_timing(timing)
             plan_b.execute()
             rows, _ = plan_b.result_info()
             if timing:
                 account(plan_b)
-                phase_ms[1] += (t_b - t_w) * 1e3             # what is left of the exchange after the overlap + the table layout
-                phase_ms[2] += (time.perf_counter() - t_b) * 1e3
             return rows
 
         def step(batch, timing):
             """one batch, start to end (the sharded-result check; the timed loop pipelines the same three phases)"""
-            return phase_b(exchange_start(phase_a(batch, timing, 0)), timing)
+            ptrs, n = phase_a(batch, timing)
+            return phase_b(comms[0].allgatherv(ptrs, n), timing)
 
         def run_pipelined(bs, timing):
-            """Software pipeline over independent batches: the all-gather of batch i + 1 is in flight while phase B of
-            batch i runs (two send buffers; each gather has its own output).  Same work per batch as step()."""
+            """Software pipeline over independent batches: the all-gatherv of batch i + 1 (a host thread inside the library,
+            its own HIP stream) is in flight while phase B of batch i runs on the plan's stream.  Same work per batch as step()."""
             total, pending = 0, None
             for i, b in enumerate(bs):
                 t_a = time.perf_counter()
-                mine = phase_a(b, timing, i & 1)
+                ptrs, n = phase_a(b, timing)
                 t_x = time.perf_counter()
-                nxt = exchange_start(mine)
-                if timing:
-                    phase_ms[0] += (t_x - t_a) * 1e3; phase_ms[1] += (time.perf_counter() - t_x) * 1e3
+                box = {}
+                th = threading.Thread(target=lambda c=comms[i & 1], p=ptrs, r=n: box.update(tab=c.allgatherv(p, r)))
+                th.start()
+                t_b = time.perf_counter()
                 if pending is not None:
                     total += phase_b(pending, timing)
-                pending = nxt
+                t_w = time.perf_counter()
+                th.join()
+                if "tab" not in box:
+                    raise RuntimeError("the exchange thread failed")
+                pending = box["tab"]
+                if timing:
+                    phase_ms[0] += (t_x - t_a) * 1e3; phase_ms[2] += (t_w - t_b) * 1e3
+                    phase_ms[1] += (time.perf_counter() - t_w) * 1e3          # what the exchange costs beyond phase B
             if pending is not None:
+                t_b = time.perf_counter()
                 total += phase_b(pending, timing)
+                if timing:
+                    phase_ms[2] += (time.perf_counter() - t_b) * 1e3
             return total
 
     if not args.per_instance:
@@ -590,7 +588,7 @@ def main():
                                       "; steady state: the join tables of the predicate slices are cached per store version (cold start and the "
                                       "no-cache step are under config.cold_start)"),
                        "mode": "per-instance" if args.per_instance else "batched",
-                       "triples_per_gpu": n_local, "sharding": "hash(subject) mod N, all-gatherv of constant-pattern bindings" if world > 1 else "none",
+                       "triples_per_gpu": n_local, "sharding": "rdfgpu_shard_of(subject) over N ranks; rdfgpu_exchange_allgatherv (RCCL over xGMI, behind the C ABI) of the constant-pattern bindings" if world > 1 else "none",
                        "sharded_result_check": shard_check,
                        "exchange_overlapped_with_next_step": bool(world > 1 and not args.no_overlap),
                        "rank0_phase_ms_per_step": ({"constant_patterns": round(phase_ms[0] / args.steps, 3), "exchange": round(phase_ms[1] / args.steps, 3),

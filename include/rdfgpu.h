@@ -513,6 +513,40 @@ int rdfgpu_pushdown_to_scan_predicate(uint32_t op, uint32_t value, rdfgpu_predic
  */
 int rdfgpu_regex_check(const char* pattern, uint32_t pattern_len, const char* flags, uint32_t flags_len, uint32_t* positions);
 
+/* ------------------------------------------------------------------------------------ */
+/* 6. Multi-GPU exchange steps (one process per GPU; no reference counterpart) */
+/* ------------------------------------------------------------------------------------ */
+/*
+ * Triples are sharded by rdfgpu_shard_of(subject) over the ranks of a communicator; object ids are global and the typed-value
+ * table is replicated.  Joins on the shard key are local; the other two cases are one exchange step each, on binding tables
+ * that live in HBM (e.g. rdfgpu_plan_result_device of one plan -> rdfgpu_plan_bind_table of the next):
+ *   rdfgpu_exchange_allgatherv   every rank contributes its rows, every rank receives all ranks' rows (rank order)
+ *   rdfgpu_exchange_repartition  row i goes to rank rdfgpu_shard_of(cols[key_col][i]): re-shards a table by the key of the
+ *                                next join
+ * Row counts travel first, receive buffers are sized from them (nothing is padded or clipped).  Both calls are collective
+ * (every rank of the communicator calls them in the same order) and return when the received columns are complete; the
+ * columns belong to the communicator and stay valid until its next exchange.
+ * Transport: RCCL over xGMI (grouped ncclSend / ncclRecv, one pair per peer; the library dlopens librccl.so.1), or — for
+ * several ranks on one GPU and for tests — staging through host memory with the wire supplied by the caller.
+ */
+typedef struct rdfgpu_comm rdfgpu_comm;
+#define RDFGPU_COMM_ID_BYTES 128
+/* ncclGetUniqueId: called on one rank, the 128 bytes are handed to the others by the launcher (torchrun's store, MPI, a file). */
+int rdfgpu_comm_unique_id(uint8_t id[RDFGPU_COMM_ID_BYTES]);
+/* ncclCommInitRank on `device` (-1 = current). */
+int rdfgpu_comm_create(const uint8_t id[RDFGPU_COMM_ID_BYTES], uint32_t rank, uint32_t world, int32_t device, rdfgpu_comm** out);
+/* The caller's wire: an all-to-all of byte blocks in host memory — block p of `send` (send_bytes[p] bytes, blocks back to back)
+   goes to rank p, block p of `recv` (recv_bytes[p] bytes) comes from rank p; returns 0 on success. */
+typedef int (*rdfgpu_host_alltoallv_fn)(void* ctx, const void* send, const uint64_t* send_bytes, void* recv, const uint64_t* recv_bytes);
+int rdfgpu_comm_create_host(uint32_t rank, uint32_t world, int32_t device, rdfgpu_host_alltoallv_fn fn, void* ctx, rdfgpu_comm** out);
+void rdfgpu_comm_destroy(rdfgpu_comm* comm);
+int rdfgpu_exchange_allgatherv(rdfgpu_comm* comm, const uint32_t* const* cols, uint32_t n_cols, uint64_t n_rows,
+                               const uint32_t** out_cols, uint64_t* out_rows);
+int rdfgpu_exchange_repartition(rdfgpu_comm* comm, const uint32_t* const* cols, uint32_t n_cols, uint64_t n_rows, uint32_t key_col,
+                                const uint32_t** out_cols, uint64_t* out_rows);
+/* The shard of an object id among `world` ranks (host logic, no device access): the function triples are sharded by. */
+uint32_t rdfgpu_shard_of(uint32_t id, uint32_t world);
+
 #ifdef __cplusplus
 }
 #endif

@@ -141,4 +141,8 @@ EXPORTED_SYMBOLS = [
     "rdfgpu_store_set_option", "rdfgpu_store_get_option", "rdfgpu_plan_set_option", "rdfgpu_option_name",
     "rdfgpu_scan_score", "rdfgpu_choose_index", "rdfgpu_predicate_and",
     "rdfgpu_pushdown_to_scan_predicate", "rdfgpu_regex_check",
+    "rdfgpu_comm_unique_id", "rdfgpu_comm_create", "rdfgpu_comm_create_host", "rdfgpu_comm_destroy",
+    "rdfgpu_exchange_allgatherv", "rdfgpu_exchange_repartition", "rdfgpu_shard_of",
 ]
+COMM_ID_BYTES = 128
+HOST_ALLTOALLV_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64), C.c_void_p, C.POINTER(C.c_uint64))

@@ -5,6 +5,7 @@
 #include <shared_mutex>
 #include <string>
 
+#include "exchange.hpp"
 #include "host_logic.hpp"
 #include "plan.hpp"
 #include "regex_compile.hpp"
@@ -344,6 +345,39 @@ int rdfgpu_pushdown_to_scan_predicate(uint32_t op, uint32_t value, rdfgpu_predic
     if (r.kind == RDFGPU_PRED_IN) { out->from = out->to = r.ids[0]; out->n_ids = 1; }
     return 1;
   } catch (const Error& e) { set_last_error(e.what()); return e.status; }
+}
+
+// ---- multi-GPU exchange ----------------------------------------------------------------------------
+static Comm* CM(rdfgpu_comm* c) { if (!c) fail(RDFGPU_ERR_INVALID, "null communicator"); return reinterpret_cast<Comm*>(c); }
+int rdfgpu_comm_unique_id(uint8_t id[RDFGPU_COMM_ID_BYTES]) { ABI_BEGIN if (!id) fail(RDFGPU_ERR_INVALID, "null id"); comm_unique_id(id); ABI_END }
+int rdfgpu_comm_create(const uint8_t id[RDFGPU_COMM_ID_BYTES], uint32_t rank, uint32_t world, int32_t device, rdfgpu_comm** out) {
+  ABI_BEGIN
+  if (!id || !out) fail(RDFGPU_ERR_INVALID, "null pointer");
+  *out = reinterpret_cast<rdfgpu_comm*>(comm_create_rccl(id, rank, world, device));
+  ABI_END
+}
+int rdfgpu_comm_create_host(uint32_t rank, uint32_t world, int32_t device, rdfgpu_host_alltoallv_fn fn, void* ctx, rdfgpu_comm** out) {
+  ABI_BEGIN
+  if (!out) fail(RDFGPU_ERR_INVALID, "null out pointer");
+  *out = reinterpret_cast<rdfgpu_comm*>(comm_create_host(rank, world, device, fn, ctx));
+  ABI_END
+}
+void rdfgpu_comm_destroy(rdfgpu_comm* comm) { if (comm) comm_destroy(reinterpret_cast<Comm*>(comm)); }
+int rdfgpu_exchange_allgatherv(rdfgpu_comm* comm, const uint32_t* const* cols, uint32_t n_cols, uint64_t n_rows, const uint32_t** out_cols, uint64_t* out_rows) {
+  ABI_BEGIN
+  if (!cols || !out_cols || !out_rows) fail(RDFGPU_ERR_INVALID, "null pointer");
+  *out_rows = exchange_allgatherv(CM(comm), cols, n_cols, n_rows, out_cols);
+  ABI_END
+}
+int rdfgpu_exchange_repartition(rdfgpu_comm* comm, const uint32_t* const* cols, uint32_t n_cols, uint64_t n_rows, uint32_t key_col, const uint32_t** out_cols, uint64_t* out_rows) {
+  ABI_BEGIN
+  if (!cols || !out_cols || !out_rows) fail(RDFGPU_ERR_INVALID, "null pointer");
+  *out_rows = exchange_repartition(CM(comm), cols, n_cols, n_rows, key_col, out_cols);
+  ABI_END
+}
+uint32_t rdfgpu_shard_of(uint32_t id, uint32_t world) {
+  if (world == 0) return 0;
+  return (uint32_t)((((unsigned long long)id * 0x9E3779B97F4A7C15ull) >> 40) % world);
 }
 
 int rdfgpu_regex_check(const char* pattern, uint32_t pattern_len, const char* flags, uint32_t flags_len, uint32_t* positions) {

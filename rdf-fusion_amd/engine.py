@@ -78,6 +78,15 @@ def load_library():
     lib.rdfgpu_plan_set_option.argtypes = [vp, C.c_uint32, C.c_uint64]
     lib.rdfgpu_option_name.argtypes = [C.c_uint32]
     lib.rdfgpu_option_name.restype = C.c_char_p
+    lib.rdfgpu_comm_unique_id.argtypes = [C.c_void_p]
+    lib.rdfgpu_comm_create.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_int32, C.POINTER(vp)]
+    lib.rdfgpu_comm_create_host.argtypes = [C.c_uint32, C.c_uint32, C.c_int32, abi.HOST_ALLTOALLV_FN, C.c_void_p, C.POINTER(vp)]
+    lib.rdfgpu_comm_destroy.argtypes = [vp]
+    lib.rdfgpu_comm_destroy.restype = None
+    lib.rdfgpu_exchange_allgatherv.argtypes = [vp, C.POINTER(vp), C.c_uint32, C.c_uint64, C.POINTER(vp), u64p]
+    lib.rdfgpu_exchange_repartition.argtypes = [vp, C.POINTER(vp), C.c_uint32, C.c_uint64, C.c_uint32, C.POINTER(vp), u64p]
+    lib.rdfgpu_shard_of.argtypes = [C.c_uint32, C.c_uint32]
+    lib.rdfgpu_shard_of.restype = C.c_uint32
     lib.rdfgpu_scan_score.argtypes = [C.POINTER(abi.ScanInstruction)]
     lib.rdfgpu_scan_score.restype = C.c_uint64
     lib.rdfgpu_choose_index.argtypes = [C.POINTER(abi.ScanInstruction), C.c_uint32]
@@ -269,6 +278,87 @@ class GpuQuadStore:
 
     def plan(self, description):
         return GpuPlan(self, description)
+
+
+class Comm:
+    """A communicator of the multi-GPU exchange steps (include/rdfgpu.h section 6): one per process and GPU.
+    `unique_id` (bytes from Comm.unique_id() on one rank, shipped by the launcher) selects RCCL over xGMI;
+    `host_alltoallv(blocks) -> blocks` (a list of `world` uint8 arrays to send -> the list received) selects the
+    host-staged transport (several ranks on one GPU, tests)."""
+
+    def __init__(self, rank, world, device=-1, unique_id=None, host_alltoallv=None):
+        self._lib = load_library()
+        self._h = C.c_void_p()
+        self.rank, self.world = rank, world
+        if (unique_id is None) == (host_alltoallv is None):
+            raise ValueError("Comm: give either the RCCL unique id or a host all-to-all function")
+        if unique_id is not None:
+            buf = (C.c_uint8 * abi.COMM_ID_BYTES).from_buffer_copy(bytes(unique_id))
+            _check(self._lib.rdfgpu_comm_create(buf, rank, world, device, C.byref(self._h)))
+        else:
+            def wire(_ctx, send, send_bytes, recv, recv_bytes):
+                try:
+                    sb = [send_bytes[p] for p in range(world)]
+                    rb = [recv_bytes[p] for p in range(world)]
+                    blocks, at = [], 0
+                    for p in range(world):
+                        blocks.append(np.ctypeslib.as_array(C.cast(send + at, C.POINTER(C.c_uint8)), (sb[p],)).copy() if sb[p] else np.zeros(0, np.uint8))
+                        at += sb[p]
+                    got = host_alltoallv(blocks)
+                    at = 0
+                    for p in range(world):
+                        b = np.ascontiguousarray(got[p], dtype=np.uint8)
+                        if len(b) != rb[p]:
+                            return 1
+                        if rb[p]:
+                            C.memmove(recv + at, b.ctypes.data, rb[p])
+                        at += rb[p]
+                    return 0
+                except Exception:      # no exception may cross the C boundary
+                    import traceback
+                    traceback.print_exc()
+                    return 2
+            self._wire = abi.HOST_ALLTOALLV_FN(wire)      # keep the trampoline alive
+            _check(self._lib.rdfgpu_comm_create_host(rank, world, device, self._wire, None, C.byref(self._h)))
+
+    @staticmethod
+    def unique_id():
+        buf = (C.c_uint8 * abi.COMM_ID_BYTES)()
+        _check(load_library().rdfgpu_comm_unique_id(buf))
+        return bytes(buf)
+
+    def close(self):
+        if self._h:
+            self._lib.rdfgpu_comm_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _call(self, fn, device_ptrs, n_rows, *extra):
+        n_cols = len(device_ptrs)
+        cols = (C.c_void_p * n_cols)(*device_ptrs)
+        out = (C.c_void_p * n_cols)()
+        rows = C.c_uint64()
+        _check(fn(self._h, cols, n_cols, n_rows, *extra, out, C.byref(rows)))
+        return [out[i] or 0 for i in range(n_cols)], rows.value
+
+    def allgatherv(self, device_ptrs, n_rows):
+        """Every rank's rows to every rank (rank order): ([device pointers of the received columns], rows); the columns belong
+        to the communicator until its next exchange."""
+        return self._call(self._lib.rdfgpu_exchange_allgatherv, device_ptrs, n_rows)
+
+    def repartition(self, device_ptrs, n_rows, key_col):
+        """Row i goes to rank shard_of(cols[key_col][i]): the table re-sharded by the key of the next join."""
+        return self._call(self._lib.rdfgpu_exchange_repartition, device_ptrs, n_rows, C.c_uint32(key_col))
+
+
+def shard_of(object_id, world):
+    """rdfgpu_shard_of: the shard of an object id among `world` ranks."""
+    return int(load_library().rdfgpu_shard_of(int(object_id), int(world)))
 
 
 TV_DTYPE = np.dtype([("lo", "<i8"), ("aux", "<u4"), ("tag", "u1"), ("flags", "u1"), ("reserved", "<u2")])

@@ -251,3 +251,32 @@ def q9_optional_regex_plan(ds, pattern="^GraduateStudent1", flags=""):
     node = pb.hash_join(node, pb.data_source(quad_pattern("x", pr["ub:emailAddress"], "e")), on=[(0, 0)], join_type=abi.JOIN_LEFT,
                         projection=[0, 1, 2, 3, 5])
     return pb.build(node)
+
+
+def q9_sharded_stages(ds, pattern="^GraduateStudent1", flags=""):
+    """LUBM Q9 + REGEX + OPTIONAL over triples sharded by hash(subject) (rdfgpu_shard_of): the triangle student x -> advisor y ->
+    course z -> x joins on three different subjects, so the intermediate bindings are re-sharded by the key of the next
+    join (rdfgpu_exchange_repartition) three times.  Returns [(plan description, repartition column or None), ...]: stage k
+    reads the re-sharded output of stage k - 1 as bound table 0 (stage 0 reads no table); inner joins commute, so the
+    union of the ranks' last outputs is q9_optional_regex_plan's answer as a multiset.  Output: (x, y, z, name, email?)."""
+    pr, cl = ds.pred, ds.cls
+    stages = []
+    pb = PlanBuilder()          # local by x: (x advisor y) JOIN (x a Student)
+    node = pb.hash_join(pb.data_source(quad_pattern("x", pr["ub:advisor"], "y")),
+                        pb.data_source(quad_pattern("x", pr["rdf:type"], cl["ub:Student"])), on=[(0, 0)], projection=[0, 1])
+    stages.append((pb.build(node), 1))                                   # -> re-shard by y
+    pb = PlanBuilder()          # local by y: JOIN (y a Faculty) JOIN (y teacherOf z)
+    node = pb.hash_join(pb.table(0, 2, ["x", "y"]), pb.data_source(quad_pattern("y", pr["rdf:type"], cl["ub:Faculty"])), on=[(1, 0)], projection=[0, 1])
+    node = pb.hash_join(node, pb.data_source(quad_pattern("y", pr["ub:teacherOf"], "z")), on=[(1, 0)], projection=[0, 1, 3])
+    stages.append((pb.build(node), 2))                                   # -> re-shard by z
+    pb = PlanBuilder()          # local by z: JOIN (z a Course)
+    node = pb.hash_join(pb.table(0, 3, ["x", "y", "z"]), pb.data_source(quad_pattern("z", pr["rdf:type"], cl["ub:Course"])), on=[(2, 0)], projection=[0, 1, 2])
+    stages.append((pb.build(node), 0))                                   # -> re-shard by x
+    pb = PlanBuilder()          # local by x: closes the triangle with the two-key join, then name + REGEX, then the OPTIONAL
+    node = pb.hash_join(pb.table(0, 3, ["x", "y", "z"]), pb.data_source(quad_pattern("x", pr["ub:takesCourse"], "z")), on=[(0, 0), (2, 1)], projection=[0, 1, 2])
+    node = pb.hash_join(node, pb.data_source(quad_pattern("x", pr["ub:name"], "n")), on=[(0, 0)], projection=[0, 1, 2, 4])
+    node = pb.filter(node, EBV(REGEX(ENC_TV(col(3)), pattern, flags)))
+    node = pb.hash_join(node, pb.data_source(quad_pattern("x", pr["ub:emailAddress"], "e")), on=[(0, 0)], join_type=abi.JOIN_LEFT,
+                        projection=[0, 1, 2, 3, 5])
+    stages.append((pb.build(node), None))
+    return stages

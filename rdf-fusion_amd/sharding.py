@@ -67,7 +67,9 @@ def q5_local_plan(ds, product_id, w1=120, w2=170):
 
 def pack_record(feats, o1, o2):
     rec = np.zeros(RECORD, dtype=np.int32)
-    nf, n1, n2 = min(len(feats), MAX_FEATURES), min(len(o1), 2), min(len(o2), 2)
+    if len(feats) > MAX_FEATURES or len(o1) > 2 or len(o2) > 2:    # never clip silently: the batched flow (all-gatherv sized from counts) has no such limit
+        raise ValueError(f"fixed-size exchange record: {len(feats)} features / {len(o1)} / {len(o2)} values do not fit ({MAX_FEATURES} / 2 / 2)")
+    nf, n1, n2 = len(feats), len(o1), len(o2)
     rec[0], rec[1], rec[2] = nf, n1, n2
     rec[4:4 + nf] = np.asarray(feats[:nf], dtype=np.uint32).view(np.int32)
     rec[60:60 + n1] = np.asarray(o1[:n1], dtype=np.uint32).view(np.int32)
@@ -112,34 +114,51 @@ def run_q5_batch_sharded(ds, products, run_const, run_local, all_gather, pmap=No
     return sum(pmap(lambda i: run_local(q5_local_plan(ds, products[i]), list(tables[i])), range(len(products))))
 
 
-class BatchExchange:
-    """The exchange step of a graph-sharded BATCH of Q5 instances (bench.py --gpus N, tests/test_sharding_cpu.py):
-    every rank holds C(inst, X, prodFeature, origProperty1, origProperty2) — bsbm.q5_batch_const_plan — for the
-    instances whose %Product% is a subject of ITS shard; all ranks need all of it.  One fixed-size int32 buffer per
-    rank, zero padded, ONE all-gather: a padding row has inst = 0 = null, and a null key never joins
-    (NullEqualsNothing), so the gathered buffer is bound as it is — an all-gatherv without the count exchange.
-    Works on torch tensors of any device."""
-    N_COLS = 5
+# --------------------------------------------------------------------------------------------------
+# Staged execution over graph shards.  A "table" is whatever the executor and the exchange agree on: numpy columns with
+# the CPU oracle and torch.distributed (tests), (device pointers, rows) with the HIP library and rdfgpu_comm (bench.py).
+# --------------------------------------------------------------------------------------------------
+def run_q5_batch_sharded_tables(ds, params, execute, allgatherv):
+    """One graph-sharded step of a BATCH of BSBM Q5 instances (bench.py --gpus N):
+    phase A   C(inst, X, prodFeature, origProperty1, origProperty2) for the instances whose %Product% lives on THIS shard
+              (bsbm.q5_batch_const_plan over the local shard: all three constant-subject patterns share the subject);
+    exchange  all-gatherv of C — every rank needs every instance's constants; sizes come from the row counts, nothing padded;
+    phase B   the batch's join / FILTER pipeline over the local shard of the product-side patterns, probing with all of C.
+    `execute(desc, [table, ...]) -> table`, `allgatherv(table) -> table`.  Returns this rank's bindings."""
+    from . import bsbm
+    c_local = execute(bsbm.q5_batch_const_plan(ds), [params])
+    c_all = allgatherv(c_local)
+    return execute(bsbm.q5_batch_plan(ds, tables=True), [c_all])
 
-    def __init__(self, n_instances, world, fanout_max=28, fanout_mean=18.5):
-        # Hash sharding gives a rank Binomial(Q, 1/world) of a batch's instances: 10 % + 256 instances of head room is
-        # > 15 standard deviations at every batch size.  C holds U{9..28} rows per instance: small batches get the
-        # worst case, large ones the mean + 13 % (the sum of >= 4096 fan-outs is within 1 % of its mean).
-        # pack() refuses a table that does not fit.
-        self.world = world
-        self.inst_cap = min(n_instances, int(n_instances / world * 1.1) + 256)
-        per_inst = fanout_max if self.inst_cap <= 4096 else min(fanout_max, int(fanout_mean * 1.13) + 1)
-        self.cap = self.inst_cap * per_inst                  # rows per rank
-        self.buf_len = self.N_COLS * self.cap                # int32 elements per rank
 
-    def pack(self, buf, cols, rows):
-        """writes this rank's C (N_COLS int32 tensors of `rows` elements) into the zeroed send buffer, column-major"""
-        if rows > self.cap:
-            raise RuntimeError(f"exchange buffer too small: {rows} rows > {self.cap}")
-        for k in range(self.N_COLS):
-            if rows:
-                buf[k * self.cap:k * self.cap + rows] = cols[k]
+def run_stages(stages, execute, repartition):
+    """Plans chained through hash repartitions (lubm.q9_sharded_stages): stage k's output, re-sharded by `key column`, is
+    stage k + 1's bound table 0.  `repartition(table, key_col) -> table`."""
+    table = None
+    for desc, key_col in stages:
+        table = execute(desc, [] if table is None else [table])
+        if key_col is not None:
+            table = repartition(table, key_col)
+    return table
 
-    def unpack(self, gathered):
-        """(world * buf_len,) gathered buffer -> one contiguous (N_COLS, world * cap) tensor: a column per variable"""
-        return gathered.view(self.world, self.N_COLS, self.cap).permute(1, 0, 2).contiguous().view(self.N_COLS, self.world * self.cap)
+
+class NumpyExchange:
+    """The two exchange steps on numpy tables over a torch.distributed process group (gloo in the CPU tests): the
+    protocol of exchange.hip — counts first, then the rows, rank order — with pickled objects as the wire."""
+
+    def __init__(self, dist, world, rank):
+        self.dist, self.world, self.rank = dist, world, rank
+
+    def allgatherv(self, cols):
+        mine = [np.ascontiguousarray(c, dtype=np.uint32) for c in cols]
+        got = [None] * self.world
+        self.dist.all_gather_object(got, mine)
+        return [np.concatenate([g[k] for g in got]) for k in range(len(mine))]
+
+    def repartition(self, cols, key_col):
+        cols = [np.ascontiguousarray(c, dtype=np.uint32) for c in cols]
+        dest = shard_of(cols[key_col], self.world)
+        blocks = [[c[dest == d] for c in cols] for d in range(self.world)]
+        got = [None] * self.world
+        self.dist.all_gather_object(got, blocks)          # got[r][d] = what rank r sends to rank d
+        return [np.concatenate([got[r][self.rank][k] for r in range(self.world)]) for k in range(len(cols))]

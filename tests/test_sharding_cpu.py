@@ -117,12 +117,18 @@ def _batch_products(ds):
     return np.array([ds.product(int(i)) for i in rng.integers(0, ds.n_products, BATCH)], dtype=np.uint32)
 
 
+def _oracle_executor(st, ku):
+    def execute(desc, tables):
+        cols, n, _ = st.execute(desc, tables=tables)
+        return [np.ascontiguousarray(c[:n]) for c in cols]
+    return execute
+
+
 def _batch_worker(rank, world, port, q):
-    """bench.py's N > 1 step with the oracle as executor: phase A (three constant-subject plans over the local shard,
-    whole batch, one plan) -> BatchExchange.pack -> ONE all_gather_into_tensor -> unpack -> phase B over the local shard."""
+    """bench.py's N > 1 step with the oracle as executor and gloo as the wire: phase A over the local shard -> all-gatherv of
+    C (sized from the row counts) -> phase B over the local shard (sharding.run_q5_batch_sharded_tables)."""
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import torch
     import torch.distributed as dist
     from rdf_fusion_amd import bsbm, sharding
     from oracle import oracle as orc
@@ -137,36 +143,40 @@ def _batch_worker(rank, world, port, q):
         st.set_typed_values(ds.typed_values, ds.decimals)
         batch = _batch_products(ds)
         params = [np.arange(1, BATCH + 1, dtype=np.uint32), batch]
-        ex = sharding.BatchExchange(BATCH, world)
-        mine = torch.zeros(ex.buf_len, dtype=torch.int32)
-        cols, n, _ = st.execute(bsbm.q5_batch_const_plan(ds), tables=[params])
-        ex.pack(mine, [torch.from_numpy(np.ascontiguousarray(c[:n]).view(np.int32)) for c in cols], n)
-        out = torch.empty(world * ex.buf_len, dtype=torch.int32)
-        dist.all_gather_into_tensor(out, mine)
-        tab = [c.numpy().view(np.uint32) for c in ex.unpack(out)]
-        assert len(tab) == 5 and all(len(c) == world * ex.cap for c in tab)
-        cols, n, _ = st.execute(bsbm.q5_batch_plan(ds, tables=True), tables=[tab])
-        q.put((rank, n, ku.multiset(cols, n), int((tab[0] != 0).sum())))
+        ex = sharding.NumpyExchange(dist, world, rank)
+        seen = {}
+
+        def allgatherv(cols):
+            out = ex.allgatherv(cols)
+            seen["local"], seen["all"] = len(cols[0]), len(out[0])
+            return out
+        cols = sharding.run_q5_batch_sharded_tables(ds, params, _oracle_executor(st, ku), allgatherv)
+        q.put((rank, len(cols[0]), ku.multiset(cols), seen["local"], seen["all"]))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_sharded_q5_batch_exchange_equals_unsharded(world):
+def _spawn(target, world, timeout=300):
     import torch.multiprocessing as mp
-    from rdf_fusion_amd import bsbm
-    from oracle import oracle as orc
-    import kat_util as ku
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_batch_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=target, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    results = [q.get(timeout=240) for _ in range(world)]
+    results = [q.get(timeout=timeout) for _ in range(world)]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
+    return sorted(results, key=lambda r: r[0])
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_q5_batch_exchange_equals_unsharded(world):
+    from rdf_fusion_amd import bsbm
+    from oracle import oracle as orc
+    import kat_util as ku
+    results = _spawn(_batch_worker, world)
     ds = bsbm.generate(600)
     st = orc.OracleStore()
     st.extend(ds.g, ds.s, ds.p, ds.o)
@@ -178,29 +188,60 @@ def test_sharded_q5_batch_exchange_equals_unsharded(world):
     got = ku.multiset(list(got.T))
     assert sum(r[1] for r in results) == n > 0
     np.testing.assert_array_equal(got, expected)
-    # every rank saw the same gathered tables; the padding rows (inst = 0) joined with nothing
-    assert all(r[3] == results[0][3] for r in results) and results[0][3] > 0
+    # the all-gatherv delivered exactly the sum of the ranks' rows to every rank: nothing padded, nothing clipped
+    total = sum(r[3] for r in results)
+    assert total > 0 and all(r[4] == total for r in results)
 
 
-def test_batch_exchange_layout_and_overflow():
-    import torch
-    from rdf_fusion_amd import sharding
-    ex = sharding.BatchExchange(1000, 4)
-    assert ex.inst_cap == 531 and ex.cap == 531 * 28 and ex.buf_len == 5 * ex.cap
-    big = sharding.BatchExchange(262144, 8)
-    assert big.inst_cap == 36300 and big.cap == 36300 * 21                    # large batches: mean fan-out + margin, not the worst case
-    assert sharding.BatchExchange(10, 4).inst_cap == 10                       # never more than the batch itself
-    bufs = []
-    for r in range(4):
-        b = torch.zeros(ex.buf_len, dtype=torch.int32)
-        rows = 3 * r                                                           # ragged, including an empty table
-        ex.pack(b, [torch.full((rows,), 100 * r + k + 1, dtype=torch.int32) for k in range(5)], rows)
-        bufs.append(b)
-    t = ex.unpack(torch.cat(bufs))
-    assert t.shape == (5, 4 * ex.cap) and t.is_contiguous()
-    for r in range(4):
-        seg = t[:, r * ex.cap:(r + 1) * ex.cap]
-        for k in range(5):
-            assert seg[k, :3 * r].tolist() == [100 * r + k + 1] * (3 * r) and int(seg[k, 3 * r:].abs().sum()) == 0
-    with pytest.raises(RuntimeError, match="exchange buffer too small"):
-        ex.pack(torch.zeros(ex.buf_len, dtype=torch.int32), [torch.zeros(ex.cap + 1, dtype=torch.int32)] * 5, ex.cap + 1)
+# --------------------------------------------------------------------------- LUBM Q9: joins whose key is not the shard key
+def _q9_worker(rank, world, port, q):
+    """lubm.q9_sharded_stages with the oracle as executor: three hash repartitions (by advisor, by course, by student)
+    between four local plans; the triangle cannot be answered shard-locally."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+    from rdf_fusion_amd import lubm, sharding
+    from oracle import oracle as orc
+    import kat_util as ku
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ds = lubm.generate(2)
+        g, s, p, o = sharding.shard_dataset(ds, rank, world)
+        st = orc.OracleStore()
+        st.extend(g, s, p, o)
+        st.set_typed_values(ds.typed_values)
+        st.set_strings(ds.str_offsets, ds.str_heap)
+        ex = sharding.NumpyExchange(dist, world, rank)
+        moved = []
+
+        def repartition(cols, key_col):
+            out = ex.repartition(cols, key_col)
+            assert (sharding.shard_of(out[key_col], world) == rank).all()       # every row is where its key lives
+            moved.append((len(cols[0]), len(out[0])))
+            return out
+        cols = sharding.run_stages(lubm.q9_sharded_stages(ds, "^GraduateStudent1", ""), _oracle_executor(st, ku), repartition)
+        q.put((rank, len(cols[0]), ku.multiset(cols), moved))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_lubm_q9_with_repartitions_equals_unsharded(world):
+    from rdf_fusion_amd import lubm
+    from oracle import oracle as orc
+    import kat_util as ku
+    results = _spawn(_q9_worker, world)
+    ds = lubm.generate(2)
+    st = orc.OracleStore()
+    st.extend(ds.g, ds.s, ds.p, ds.o)
+    st.set_typed_values(ds.typed_values)
+    st.set_strings(ds.str_offsets, ds.str_heap)
+    cols, n, _ = st.execute(lubm.q9_optional_regex_plan(ds, "^GraduateStudent1", ""))
+    expected = ku.multiset(cols, n)
+    got = ku.multiset(list(np.concatenate([r[2] for r in results]).T))
+    assert sum(r[1] for r in results) == n > 0
+    np.testing.assert_array_equal(got, expected)
+    # a repartition moves rows, it neither drops nor invents any: per step, rows sent over all ranks == rows received
+    for step in range(3):
+        assert sum(r[3][step][0] for r in results) == sum(r[3][step][1] for r in results) > 0
