@@ -116,7 +116,7 @@ def run_q5_batch_sharded(ds, products, run_const, run_local, all_gather, pmap=No
 
 # --------------------------------------------------------------------------------------------------
 # Staged execution over graph shards.  A "table" is whatever the executor and the exchange agree on: numpy columns with
-# the CPU oracle and torch.distributed (tests), (device pointers, rows) with the HIP library and rdfgpu_comm (bench.py).
+# a CPU executor and torch.distributed (the CPU tests), (device pointers, rows) with the HIP library and rdfgpu_comm (bench.py).
 # --------------------------------------------------------------------------------------------------
 def run_q5_batch_sharded_tables(ds, params, execute, allgatherv):
     """One graph-sharded step of a BATCH of BSBM Q5 instances (bench.py --gpus N):
