@@ -409,6 +409,48 @@ int rdfgpu_plan_selected_index(const rdfgpu_plan* plan, uint32_t node, uint32_t*
 int rdfgpu_plan_stream(rdfgpu_plan* plan, void** hip_stream);
 
 /*
+ * Filter push-down into a DataSourceExec leaf.  When a subtree is NOT fused into one rdfgpu plan, DataFusion's physical
+ * filter push-down offers the leaf the filters above it (MemQuadPatternDataSource::try_pushdown_filters,
+ * lib/storage/src/memory/storage/pattern_data_source.rs:107-151): id-level comparisons of a bound variable with an object
+ * id, their conjunctions on one column, literal `true`, and DynamicFilterPhysicalExprs (predicate_pushdown.rs:62-157,
+ * 161-249).  A filter here is the MemStoragePredicateExpr the host already extracted (MemStoragePredicateExpr::try_from).
+ */
+enum { RDFGPU_PUSH_UNSUPPORTED = 0,  /* try_from returned None: answered PushedDown::No, nothing changes                  */
+       RDFGPU_PUSH_TRUE = 1,         /* literal true                                                                       */
+       RDFGPU_PUSH_BINARY = 2,       /* column <op> object id, op = RDFGPU_OP_*                                             */
+       RDFGPU_PUSH_BETWEEN = 3 };    /* from <= column <= to (what `>` AND `<=` on one column become, :189-249)             */
+typedef struct rdfgpu_pushdown_filter {
+  uint32_t kind;      /* RDFGPU_PUSH_*                                                        */
+  uint32_t var;       /* the variable slot of the column (rdfgpu_scan_instruction.var)        */
+  uint32_t op;        /* BINARY: RDFGPU_OP_EQ / GT / GTEQ / LT / LTEQ                         */
+  uint32_t value;     /* BINARY: the object id                                                */
+  uint32_t from, to;  /* BETWEEN, inclusive                                                   */
+} rdfgpu_pushdown_filter;
+/*
+ * try_pushdown_filters on DATA_SOURCE node `node` of a compiled plan: pushed[i] receives 1 (PushedDown::Yes) or 0.  Every
+ * supported filter is AND-ed into the instruction that binds its variable (MemIndexScanInstructions::apply_filter,
+ * scan_instructions.rs:101-133, through try_and_with :170-210) and the index is chosen again (apply_pushdown_filters ->
+ * try_find_better_index, pattern_data_source.rs:155-165, scan.rs:469-486).  The change is permanent for this plan.
+ * Errors like the reference: a filter on a variable the pattern does not bind, or one that cannot be combined
+ * (EqualTo), is RDFGPU_ERR_INVALID.
+ */
+int rdfgpu_plan_pushdown_filters(rdfgpu_plan* plan, uint32_t node, const rdfgpu_pushdown_filter* filters, uint32_t n, uint8_t* pushed);
+/*
+ * The CURRENT predicates of the leaf's dynamic filters — a HashJoinExec publishes its build side's key bounds when the
+ * build finishes; the scan reads them on its first next() (combine_instructions_with_dynamic_filters, scan.rs:241-261) and
+ * may switch index for them (collect_relevant_row_groups, scan.rs:217-239).  Applied on top of the static instructions by
+ * every execute until replaced; n = 0 clears.  Only BINARY / BETWEEN / TRUE kinds.
+ */
+int rdfgpu_plan_set_dynamic_filters(rdfgpu_plan* plan, uint32_t node, const rdfgpu_pushdown_filter* filters, uint32_t n);
+/*
+ * One level of the leaf as it will be scanned (after push-down / with the current dynamic filters): level 0..3 in G,S,P,O
+ * order; `*pred` as in rdfgpu_predicate (IN sets with one id: from = to = the id, n_ids = 1; larger sets: n_ids only).
+ * For plan display: "[GPOS] subject=?s, predicate=<p>, object=?o" + "object in (2..9)" (pattern_data_source.rs:192-234).
+ */
+struct rdfgpu_predicate;
+int rdfgpu_plan_source_predicate(const rdfgpu_plan* plan, uint32_t node, uint32_t level, struct rdfgpu_predicate* pred);
+
+/*
  * Per-kernel device timing of the last execute (HIP events on the plan's stream, around every
  * launch) with the algorithmic bytes each kernel class had to move (formulas: DESIGN.md,
  * from SURVEY.md §8d).  The equivalent of DataFusion's per-operator BaselineMetrics

@@ -104,6 +104,14 @@ class Predicate(C.Structure):
                 ("ids", C.POINTER(C.c_uint32)), ("n_ids", C.c_uint32), ("equal_to", C.c_uint32)]
 
 
+PUSH_UNSUPPORTED, PUSH_TRUE, PUSH_BINARY, PUSH_BETWEEN = range(4)
+
+
+class PushdownFilter(C.Structure):
+    _fields_ = [("kind", C.c_uint32), ("var", C.c_uint32), ("op", C.c_uint32), ("value", C.c_uint32),
+                ("from_", C.c_uint32), ("to", C.c_uint32)]
+
+
 class ArrowSchema(C.Structure):
     pass
 
@@ -138,6 +146,7 @@ EXPORTED_SYMBOLS = [
     "rdfgpu_plan_result_info", "rdfgpu_plan_result_device", "rdfgpu_plan_fetch", "rdfgpu_plan_next",
     "rdfgpu_plan_rewind", "rdfgpu_plan_metrics", "rdfgpu_plan_selected_index", "rdfgpu_plan_stream",
     "rdfgpu_plan_enable_kernel_timing", "rdfgpu_plan_kernel_stats",
+    "rdfgpu_plan_pushdown_filters", "rdfgpu_plan_set_dynamic_filters", "rdfgpu_plan_source_predicate",
     "rdfgpu_store_set_option", "rdfgpu_store_get_option", "rdfgpu_plan_set_option", "rdfgpu_option_name",
     "rdfgpu_scan_score", "rdfgpu_choose_index", "rdfgpu_predicate_and",
     "rdfgpu_pushdown_to_scan_predicate", "rdfgpu_regex_check",

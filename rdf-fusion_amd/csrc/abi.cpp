@@ -270,6 +270,32 @@ int rdfgpu_plan_selected_index(const rdfgpu_plan* plan, uint32_t node, uint32_t*
   if (components) *components = p->sources[p->nodes[node].source].components;
   ABI_END
 }
+int rdfgpu_plan_pushdown_filters(rdfgpu_plan* plan, uint32_t node, const rdfgpu_pushdown_filter* filters, uint32_t n, uint8_t* pushed) {
+  ABI_BEGIN
+  if (n && !filters) fail(RDFGPU_ERR_INVALID, "null filter array");
+  P(plan)->pushdown_filters(node, filters, n, pushed);
+  ABI_END
+}
+int rdfgpu_plan_set_dynamic_filters(rdfgpu_plan* plan, uint32_t node, const rdfgpu_pushdown_filter* filters, uint32_t n) {
+  ABI_BEGIN
+  if (n && !filters) fail(RDFGPU_ERR_INVALID, "null filter array");
+  P(plan)->set_dynamic_filters(node, filters, n);
+  ABI_END
+}
+int rdfgpu_plan_source_predicate(const rdfgpu_plan* plan, uint32_t node, uint32_t level, rdfgpu_predicate* pred) {
+  ABI_BEGIN
+  const Plan* p = reinterpret_cast<const Plan*>(plan);
+  if (!p || !pred) fail(RDFGPU_ERR_INVALID, "null pointer");
+  if (node >= p->nodes.size() || p->nodes[node].source < 0 || level > 3) fail(RDFGPU_ERR_INVALID, "node %u level %u is not a data-source level", node, level);
+  const SourceInfo& src = p->sources[p->nodes[node].source];
+  // the instructions as they will be scanned: in the chosen index's order; report by G,S,P,O level
+  ScanPredicate sp;
+  for (int k = 0; k < 4; k++) if ((u32)PERM[src.components][k] == level) sp = src.ix.in[k].pred;
+  std::memset(pred, 0, sizeof *pred);
+  pred->pred = sp.kind; pred->from = sp.from; pred->to = sp.to; pred->equal_to = sp.equal_to;
+  if (sp.kind == RDFGPU_PRED_IN) { pred->n_ids = (u32)sp.ids.size(); if (sp.ids.size() == 1) pred->from = pred->to = sp.ids[0]; }
+  ABI_END
+}
 int rdfgpu_plan_stream(rdfgpu_plan* plan, void** hip_stream) {
   ABI_BEGIN
   if (!hip_stream) fail(RDFGPU_ERR_INVALID, "null out pointer");

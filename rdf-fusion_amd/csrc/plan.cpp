@@ -203,18 +203,8 @@ Plan* plan_compile(Store* store, const rdfgpu_plan_desc* d) {
       case RDFGPU_NODE_DATA_SOURCE: {
         SourceInfo src;
         src.node = i;
-        const ScanInstructions gspo = make_gspo(r.scan, d->pool, d->n_pool);
-        src.components = choose_index(gspo, 0b111);
-        src.ix = reorder(gspo, src.components);
-        src.prune = plan_pruning(src.ix);
-        for (int k = 0; k < 4; k++) {   // bound variables in G,S,P,O order (patterns/mod.rs:68-107)
-          if (gspo.in[k].kind != RDFGPU_SCAN) continue;
-          for (int lvl = 0; lvl < 4; lvl++)
-            if (src.ix.in[lvl].kind == RDFGPU_SCAN && src.ix.in[lvl].var == gspo.in[k].var) src.out_level[src.n_out] = lvl;
-          src.n_out++;
-        }
-        for (int k = 0; k < 4; k++)
-          if (src.ix.in[k].pred.kind != RDFGPU_PRED_NONE && !(src.prune.dropped_mask & (1u << k))) src.has_residual = true;
+        src.gspo = make_gspo(r.scan, d->pool, d->n_pool);
+        plan->derive_source(src, src.gspo);
         nd.width = src.n_out;
         nd.source = (int)plan->sources.size();
         plan->sources.push_back(src);
@@ -367,18 +357,108 @@ Plan* plan_compile(Store* store, const rdfgpu_plan_desc* d) {
   plan->ctx = store->acquire_context((u32)plan->sources.size());
   plan->stream = plan->ctx->stream;
   plan->counters = plan->ctx->counters;
-  // IN sets of residual predicates live on the device for the plan's lifetime
-  for (SourceInfo& s : plan->sources)
+  plan->upload_pool();
+  return plan.release();
+}
+
+// The scan of a pattern from its G,S,P,O instructions: index choice (IndexPermutations::choose_index, permutations.rs:81-96),
+// the instructions in that index's order, the pruning levels and what they make redundant, the output columns in G,S,P,O
+// order of first binding (patterns/mod.rs:68-107).
+void Plan::derive_source(SourceInfo& src, const ScanInstructions& gspo) {
+  src.components = choose_index(gspo, 0b111);
+  src.ix = reorder(gspo, src.components);
+  src.prune = plan_pruning(src.ix);
+  src.n_out = 0; src.has_residual = false;
+  for (int k = 0; k < 4; k++) {
+    if (gspo.in[k].kind != RDFGPU_SCAN) continue;
+    bool first = true;
+    for (int j = 0; j < k; j++) if (gspo.in[j].kind == RDFGPU_SCAN && gspo.in[j].var == gspo.in[k].var) first = false;
+    if (!first) continue;
+    for (int lvl = 0; lvl < 4; lvl++)
+      if (src.ix.in[lvl].kind == RDFGPU_SCAN && src.ix.in[lvl].var == gspo.in[k].var) src.out_level[src.n_out] = lvl;
+    src.n_out++;
+  }
+  for (int k = 0; k < 4; k++)
+    if (src.ix.in[k].pred.kind != RDFGPU_PRED_NONE && !(src.prune.dropped_mask & (1u << k))) src.has_residual = true;
+}
+// IN sets of residual predicates live on the device: uploaded at compile time and again when push-down changed them
+void Plan::upload_pool() {
+  pool.clear();
+  for (SourceInfo& s : sources)
     for (int k = 0; k < 4; k++)
       if (s.ix.in[k].pred.kind == RDFGPU_PRED_IN && !(s.prune.dropped_mask & (1u << k))) {
-        s.ix.in[k].pred.from = (u32)plan->pool.size();
-        plan->pool.insert(plan->pool.end(), s.ix.in[k].pred.ids.begin(), s.ix.in[k].pred.ids.end());
+        s.ix.in[k].pred.from = (u32)pool.size();
+        pool.insert(pool.end(), s.ix.in[k].pred.ids.begin(), s.ix.in[k].pred.ids.end());
       }
-  if (!plan->pool.empty()) {
-    RDFGPU_HIP(hipMalloc((void**)&plan->pool_dev, plan->pool.size() * 4));
-    RDFGPU_HIP(hipMemcpy(plan->pool_dev, plan->pool.data(), plan->pool.size() * 4, hipMemcpyHostToDevice));
+  store->activate();
+  if (stream) RDFGPU_HIP(hipStreamSynchronize(stream));
+  if (pool_dev) { RDFGPU_HIP(hipFree(pool_dev)); pool_dev = nullptr; }
+  if (!pool.empty()) {
+    RDFGPU_HIP(hipMalloc((void**)&pool_dev, pool.size() * 4));
+    RDFGPU_HIP(hipMemcpy(pool_dev, pool.data(), pool.size() * 4, hipMemcpyHostToDevice));
   }
-  return plan.release();
+}
+
+namespace {
+// MemStoragePredicateExpr -> MemIndexScanPredicate (to_scan_predicate, predicate_pushdown.rs:120-157); false = `true` (no predicate)
+bool filter_to_predicate(const rdfgpu_pushdown_filter& f, ScanPredicate* out) {
+  if (f.kind == RDFGPU_PUSH_TRUE) return false;
+  if (f.kind == RDFGPU_PUSH_BINARY) { *out = pushdown_to_scan_predicate(f.op, f.value); return true; }
+  if (f.kind == RDFGPU_PUSH_BETWEEN) {
+    ScanPredicate p;
+    if (f.from > f.to) p.kind = RDFGPU_PRED_FALSE; else { p.kind = RDFGPU_PRED_BETWEEN; p.from = f.from; p.to = f.to; }
+    *out = p; return true;
+  }
+  fail(RDFGPU_ERR_INVALID, "push-down filter of kind %u", f.kind);
+}
+// MemIndexScanInstructions::apply_filter (scan_instructions.rs:101-133)
+void and_into_instructions(ScanInstructions& gspo, u32 var, const ScanPredicate& p) {
+  int at = -1;
+  for (int k = 0; k < 4 && at < 0; k++) if (gspo.in[k].kind == RDFGPU_SCAN && gspo.in[k].var == var) at = k;   // instructions_for_column: the first binding
+  if (at < 0) fail(RDFGPU_ERR_INVALID, "Could not find scan instruction for column: variable %u", var);
+  ScanPredicate combined = p;
+  if (gspo.in[at].pred.kind != RDFGPU_PRED_NONE && !predicate_and(gspo.in[at].pred, p, &combined))
+    fail(RDFGPU_ERR_INVALID, "Could not apply predicate to scan instruction.");
+  gspo.in[at].pred = combined;
+}
+}  // namespace
+
+void Plan::pushdown_filters(u32 node, const rdfgpu_pushdown_filter* filters, u32 n, u8* pushed) {
+  if (node >= nodes.size() || nodes[node].source < 0) fail(RDFGPU_ERR_INVALID, "node %u is not a data source", node);
+  SourceInfo& src = sources[nodes[node].source];
+  ScanInstructions gspo = src.gspo;
+  bool any = false;
+  for (u32 i = 0; i < n; i++) {
+    const bool yes = filters[i].kind != RDFGPU_PUSH_UNSUPPORTED;   // rewritten => PushedDown::Yes (pattern_data_source.rs:121-127)
+    if (pushed) pushed[i] = yes ? 1 : 0;
+    if (!yes) continue;
+    any = true;
+    ScanPredicate p;
+    if (filter_to_predicate(filters[i], &p)) and_into_instructions(gspo, filters[i].var, p);
+  }
+  if (!any) return;                       // "Don't create a new node if no filters were pushed down"
+  src.gspo = gspo;
+  derive_source(src, src.gspo);           // apply_pushdown_filters ends in try_find_better_index
+  src.dynamic_dirty = !src.dynamic.empty();
+  upload_pool();
+  located_version = ~0ull;                // the cached ranges belong to the old instructions
+  for (NodeInfo& nd : nodes) { nd.has_last = false; nd.last_rows = 0; }   // and so do the cardinalities
+}
+
+void Plan::set_dynamic_filters(u32 node, const rdfgpu_pushdown_filter* filters, u32 n) {
+  if (node >= nodes.size() || nodes[node].source < 0) fail(RDFGPU_ERR_INVALID, "node %u is not a data source", node);
+  SourceInfo& src = sources[nodes[node].source];
+  std::vector<std::pair<u32, ScanPredicate>> dyn;
+  for (u32 i = 0; i < n; i++) {
+    if (filters[i].kind == RDFGPU_PUSH_UNSUPPORTED) continue;      // `current_predicate_expr().ok()`: unsupported ones are skipped (scan.rs:246-249)
+    ScanPredicate p;
+    if (filter_to_predicate(filters[i], &p)) dyn.emplace_back(filters[i].var, p);
+  }
+  // validate now, against the static instructions, so that execute cannot fail on them
+  ScanInstructions probe = src.gspo;
+  for (auto& d : dyn) and_into_instructions(probe, d.first, d.second);
+  src.dynamic = dyn;
+  src.dynamic_dirty = true;
 }
 
 Plan::~Plan() {
@@ -508,6 +588,27 @@ void Plan::execute() {
   memo.assign(nodes.size(), DevTable{}); memo_valid.assign(nodes.size(), 0);
   speculative = allow_speculation && !opt.on(RDFGPU_OPT_NO_SPECULATION);
 
+  // Dynamic filters (scan.rs:217-261): the effective instructions of a leaf = its static ones AND the filters' current
+  // predicates, index re-chosen for them; derived when the filters changed, the ranges located again.
+  {
+    bool changed = false;
+    for (SourceInfo& s : sources) {
+      if (!s.dynamic_dirty) continue;
+      ScanInstructions eff = s.gspo;
+      for (auto& dflt : s.dynamic) and_into_instructions(eff, dflt.first, dflt.second);
+      derive_source(s, eff);
+      s.dynamic_dirty = false;
+      changed = true;
+    }
+    if (changed) {
+      lock.unlock();
+      upload_pool();
+      lock.lock();
+      located_version = ~0ull;
+      for (NodeInfo& nd : nodes) { nd.has_last = false; nd.last_rows = 0; }
+      speculative = false;
+    }
+  }
   // K1: locate every data source's range in one launch, one host round trip for all of them.  The ranges
   // depend only on the plan's constants and the store's content: a re-execution on an unchanged store
   // reuses them (no launch, no sync).

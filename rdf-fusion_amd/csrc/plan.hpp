@@ -19,6 +19,9 @@ struct SourceInfo {               // one DataSourceExec
   u32 n_out = 0;
   u32 out_level[4] = {};          // index level feeding output column k (G,S,P,O order of first binding)
   u64 lo = 0, hi = 0;             // located range of the last execution
+  ScanInstructions gspo;          // the pattern's instructions in G,S,P,O order, push-down filters folded in
+  std::vector<std::pair<u32, ScanPredicate>> dynamic;   // current dynamic filters: (variable slot, predicate)
+  bool dynamic_dirty = false;     // the effective instructions have to be derived again before the next execute
 };
 
 struct NodeInfo {
@@ -113,6 +116,10 @@ struct Plan {
 
   ~Plan();
   void execute();
+  void pushdown_filters(u32 node, const rdfgpu_pushdown_filter* filters, u32 n, u8* pushed);
+  void set_dynamic_filters(u32 node, const rdfgpu_pushdown_filter* filters, u32 n);
+  void derive_source(SourceInfo& src, const ScanInstructions& gspo);
+  void upload_pool();
   void ensure_host_copy();
 
  private:

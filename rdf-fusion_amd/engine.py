@@ -73,6 +73,9 @@ def load_library():
     lib.rdfgpu_plan_stream.argtypes = [vp, C.POINTER(vp)]
     lib.rdfgpu_plan_enable_kernel_timing.argtypes = [vp, C.c_int]
     lib.rdfgpu_plan_kernel_stats.argtypes = [vp, C.POINTER(abi.KernelStat), C.c_uint32, u32p]
+    lib.rdfgpu_plan_pushdown_filters.argtypes = [vp, C.c_uint32, C.POINTER(abi.PushdownFilter), C.c_uint32, C.POINTER(C.c_uint8)]
+    lib.rdfgpu_plan_set_dynamic_filters.argtypes = [vp, C.c_uint32, C.POINTER(abi.PushdownFilter), C.c_uint32]
+    lib.rdfgpu_plan_source_predicate.argtypes = [vp, C.c_uint32, C.c_uint32, C.POINTER(abi.Predicate)]
     lib.rdfgpu_store_set_option.argtypes = [vp, C.c_uint32, C.c_uint64]
     lib.rdfgpu_store_get_option.argtypes = [vp, C.c_uint32, u64p]
     lib.rdfgpu_plan_set_option.argtypes = [vp, C.c_uint32, C.c_uint64]
@@ -433,6 +436,50 @@ class GpuPlan:
         """Engine option of this plan only (its later executions)."""
         _check(self._lib.rdfgpu_plan_set_option(self._h, abi.OPTIONS[name.replace("RDFGPU_", "", 1)], int(value)))
         return self
+
+    @staticmethod
+    def _filters(filters):
+        """[("true",) | ("unsupported",) | ("binary", var_slot, abi.OP_*, object_id) | ("between", var_slot, from, to)] -> ctypes array"""
+        arr = (abi.PushdownFilter * max(1, len(filters)))()
+        for i, f in enumerate(filters):
+            if f[0] == "binary":
+                arr[i] = abi.PushdownFilter(abi.PUSH_BINARY, f[1], f[2], f[3], 0, 0)
+            elif f[0] == "between":
+                arr[i] = abi.PushdownFilter(abi.PUSH_BETWEEN, f[1], 0, 0, f[2], f[3])
+            elif f[0] == "true":
+                arr[i] = abi.PushdownFilter(abi.PUSH_TRUE, 0, 0, 0, 0, 0)
+            else:
+                arr[i] = abi.PushdownFilter(abi.PUSH_UNSUPPORTED, 0, 0, 0, 0, 0)
+        return arr
+
+    def pushdown_filters(self, node, filters):
+        """MemQuadPatternDataSource::try_pushdown_filters (pattern_data_source.rs:107-151) on a DataSourceExec node:
+        returns PushedDown::Yes / No per filter; the supported ones are folded into the scan, the index chosen again."""
+        arr = self._filters(filters)
+        pushed = (C.c_uint8 * max(1, len(filters)))()
+        _check(self._lib.rdfgpu_plan_pushdown_filters(self._h, node, arr, len(filters), pushed))
+        return [bool(pushed[i]) for i in range(len(filters))]
+
+    def set_dynamic_filters(self, node, filters):
+        """The current predicates of the node's dynamic filters (scan.rs:241-261), applied by every execute until replaced."""
+        _check(self._lib.rdfgpu_plan_set_dynamic_filters(self._h, node, self._filters(filters), len(filters)))
+        return self
+
+    def source_predicate(self, node, level):
+        """The predicate of G,S,P,O level `level` of a DataSourceExec node as it will be scanned, as a
+        plan.MemIndexScanPredicate (None = no predicate); repr() gives the reference's display (`in (2..9)`, `== 1`)."""
+        from .plan import MemIndexScanPredicate as P
+        s = abi.Predicate()
+        _check(self._lib.rdfgpu_plan_source_predicate(self._h, node, level, C.byref(s)))
+        if s.pred == abi.PRED_NONE:
+            return None
+        if s.pred == abi.PRED_FALSE:
+            return P.false()
+        if s.pred == abi.PRED_BETWEEN:
+            return P.between(s.from_, s.to)
+        if s.pred == abi.PRED_IN:
+            return P.in_([s.from_]) if s.n_ids == 1 else P(abi.PRED_IN, ids=list(range(s.n_ids)))
+        return P.equal_to(s.equal_to)
 
     def enable_kernel_timing(self, on=True):
         _check(self._lib.rdfgpu_plan_enable_kernel_timing(self._h, int(on)))

@@ -159,6 +159,100 @@ def test_reference_join_lowering_kats(kats, torch_cuda):
             run_both(gs, os_, desc, gpu_tables=[(pa, 3), (pb_, len(right))], cpu_tables=[[a], [right]])
 
 
+def test_reference_pushdown_and_dynamic_filter_kats(kats):
+    """Filter push-down INTO the DataSourceExec leaf: try_pushdown_filters with its display strings
+    (pattern_data_source.rs:192-234), test_dynamic_filters as the reference wrote it (static Between(2,3) on the scan, dynamic
+    Between(subject,1,2) arriving at execute time, scan.rs:617-672) and the index switch a dynamic filter causes (:674-729)."""
+    # --- pattern_data_source.rs: `?subject <http://example.com/test> ?object`, filters on object
+    for case in kats["pushdown_display"]:
+        gs = rf.GpuQuadStore(batch_size=10)
+        gs.extend(*ku.quad_columns([[0, 5, 7, v] for v in (1, 2, 5, 9, 10, 4000000000)]))
+        pb = PlanBuilder()
+        node = pb.data_source(quad_pattern("subject", 7, "object"))
+        plan = gs.plan(pb.build(node))
+        flt = case["filters"]
+        obj = pb.vars["object"]
+        if len(flt) == 1:
+            f = [("binary", obj, {"Eq": abi.OP_EQ, "Gt": abi.OP_GT, "GtEq": abi.OP_GTEQ, "Lt": abi.OP_LT, "LtEq": abi.OP_LTEQ}[flt[0][0]], flt[0][1])]
+        else:      # `object > a AND object < b` arrives as ONE Between (predicate_pushdown.rs:189-249; KAT A.4: > 123 AND <= 456 => Between(124, 456))
+            lo = max(v + 1 if op == "Gt" else v for op, v in flt if op in ("Gt", "GtEq"))
+            hi = min(v - 1 if op == "Lt" else v for op, v in flt if op in ("Lt", "LtEq"))
+            f = [("between", obj, lo, hi)]
+        assert plan.pushdown_filters(node, f + [("unsupported",)]) == [True, False]
+        assert abi.INDEX_NAMES[plan.selected_index(node)] == "GPOS"
+        assert repr(plan.source_predicate(node, 3)) == case["display"], case    # "object == 1" / "object in (2..9)" (pattern_data_source.rs:232)
+        got = plan.execute().fetch()
+        allv = np.array([1, 2, 5, 9, 10, 4000000000], dtype=np.int64)
+        keep = np.ones(len(allv), bool)
+        for op, v in flt:
+            keep &= {"Eq": allv == v, "Gt": allv > v, "GtEq": allv >= v, "Lt": allv < v, "LtEq": allv <= v}[op]
+        assert sorted(got[1].tolist()) == allv[keep].tolist(), case
+    # --- scan.rs test_dynamic_filters
+    gs = rf.GpuQuadStore(batch_size=100)
+    gs.extend(*ku.quad_columns([[0, 1, 10, 100], [0, 2, 10, 100], [0, 2, 10, 200], [0, 3, 10, 100]]))
+    pb = PlanBuilder()
+    node = pb.data_source([I.traverse(0), I.scan_with_predicate("subject", P.between(2, 3)), I.traverse(), I.traverse(200)])
+    plan = gs.plan(pb.build(node))
+    assert plan.execute().result_info()[0] == 1                     # only (0,2,10,200) has object 200 and subject in 2..3
+    plan.set_dynamic_filters(node, [("between", pb.vars["subject"], 1, 2)])
+    assert plan.execute().result_info()[0] == 1 and plan.fetch()[0].tolist() == [2]
+    assert repr(plan.source_predicate(node, 1)) == "== 2" or repr(plan.source_predicate(node, 1)) == "in (2..2)"
+    plan.set_dynamic_filters(node, [("between", pb.vars["subject"], 3, 9)])   # the filter moves: subject 3 has no object 200
+    assert plan.execute().result_info()[0] == 0
+    plan.set_dynamic_filters(node, [])
+    assert plan.execute().result_info()[0] == 1
+    # --- scan.rs test_collect_relevant_batches_dynamic_filters_choose_better_index
+    gs = rf.GpuQuadStore(batch_size=100)
+    gs.extend(*ku.quad_columns([[0, 1, 10, 100]]))
+    pb = PlanBuilder()
+    node = pb.data_source([I.traverse(0), I.scan("subject"), I.scan("predicate"), I.scan("object")])
+    plan = gs.plan(pb.build(node))
+    plan.execute()
+    assert abi.INDEX_NAMES[plan.selected_index(node)] == "GSPO"
+    plan.set_dynamic_filters(node, [("between", pb.vars["object"], 1, 200)])
+    got = plan.execute().fetch()
+    assert abi.INDEX_NAMES[plan.selected_index(node)] == "GOSP"     # "Switches to GOSP because the dynamic filter filters the object component"
+    assert [c.tolist() for c in got] == [[1], [10], [100]]         # columns stay in G,S,P,O order of the variables
+    # --- errors like the reference's: a filter on a variable the pattern does not bind
+    with pytest.raises(rf.RdfGpuError):
+        plan.pushdown_filters(node, [("binary", 77, abi.OP_EQ, 1)])
+
+
+def test_pushdown_equals_filter_above_the_scan(torch_cuda):
+    """try_pushdown_filters answers PushedDown::Yes: DataFusion then drops the FilterExec — the pushed-down scan must return
+    exactly what the scan followed by the filter returns (here: numpy on the unfiltered scan), whichever index it switches to."""
+    rng = np.random.default_rng(21)
+    g, s_, p, o = random_quads(rng, 60_000, 900, graphs=2)
+    gs, os_ = both_stores((g, s_, p, o))
+    for trial in range(40):
+        pb = PlanBuilder()
+        const_p = int(rng.choice(p))
+        shape = trial % 4
+        pat = [quad_pattern("s", const_p, "o"), quad_pattern("s", "p", "o", graph="all", graph_variable="g"),
+               quad_pattern(int(rng.choice(s_)), "p", "o"), quad_pattern("s", "p", int(rng.choice(o)), graph="all")][shape]
+        node = pb.data_source(pat)
+        desc = pb.build(node)
+        base_cols, n, _ = os_.execute(desc)
+        names = [v for v, _ in sorted(pb.vars.items(), key=lambda kv: kv[1]) if v in pb.names[node]]
+        names = pb.names[node]
+        var = names[int(rng.integers(0, len(names)))]
+        col_i = names.index(var)
+        lo, hi = sorted(int(x) for x in rng.integers(0, 900, 2))
+        kind = trial % 3
+        if kind == 0:
+            f, keep = [("between", pb.vars[var], lo, hi)], (base_cols[col_i][:n] >= lo) & (base_cols[col_i][:n] <= hi)
+        elif kind == 1:
+            f, keep = [("binary", pb.vars[var], abi.OP_GT, lo)], base_cols[col_i][:n] > lo
+        else:
+            f, keep = [("binary", pb.vars[var], abi.OP_EQ, hi), ("true",)], base_cols[col_i][:n] == hi
+        plan = gs.plan(desc)
+        assert all(plan.pushdown_filters(node, f))
+        got = plan.execute().fetch()
+        exp = [c[:n][keep] for c in base_cols]
+        np.testing.assert_array_equal(ku.multiset(got, plan.result_info()[0]), ku.multiset(exp, int(keep.sum())), err_msg=f"trial {trial}")
+        plan.close()
+
+
 # ---------------------------------------------------------------------------------------------------
 # index build, random scans
 # ---------------------------------------------------------------------------------------------------
