@@ -143,7 +143,7 @@ int rdfgpu_store_create(const rdfgpu_config* cfg, rdfgpu_store** out);
 void rdfgpu_store_destroy(rdfgpu_store* store);
 
 /*
- * QuadStorage::extend (lib/extensions/src/storage/quad_storage.rs:30; mem_storage.rs:95-102;
+ * QuadStorage::extend (lib/extensions/src/storage/quad_storage.rs:35; mem_storage.rs:95-102;
  * IndexPermutations::insert permutations.rs:102-118): merges `n` encoded quads (host
  * buffers, ids assigned by the host dictionary) into all three permutations; duplicates
  * are ignored.  `*inserted` receives the number of quads that were new.
@@ -154,12 +154,15 @@ int rdfgpu_store_extend(rdfgpu_store* store, const uint32_t* g, const uint32_t* 
 int rdfgpu_store_extend_device(rdfgpu_store* store, const uint32_t* g, const uint32_t* s,
                                const uint32_t* p, const uint32_t* o, uint64_t n,
                                uint64_t* inserted);
-/* QuadStorage::remove (quad_storage.rs:33; permutations.rs:120-128). */
+/* QuadStorage::remove (quad_storage.rs:38; permutations.rs:120-128). */
 int rdfgpu_store_remove(rdfgpu_store* store, const uint32_t* g, const uint32_t* s,
                         const uint32_t* p, const uint32_t* o, uint64_t n, uint64_t* removed);
-/* QuadStorage::clear (quad_storage.rs:60). */
+/* QuadStorage::clear (quad_storage.rs:56). */
 int rdfgpu_store_clear(rdfgpu_store* store);
-/* QuadStorage::len (quad_storage.rs:69). */
+/* QuadStorage::clear_graph (quad_storage.rs:59-62) and the quads of QuadStorage::drop_named_graph (:65-68): removes every quad
+   whose graph is `graph` (0 = the default graph; the registry of named graphs is the host dictionary's). */
+int rdfgpu_store_remove_graph(rdfgpu_store* store, uint32_t graph, uint64_t* removed);
+/* QuadStorage::len (quad_storage.rs:71). */
 int rdfgpu_store_len(const rdfgpu_store* store, uint64_t* out);
 
 /*
@@ -389,7 +392,9 @@ int rdfgpu_plan_execute(rdfgpu_plan* plan);
 
 /* Result shape (waits for the stream). */
 int rdfgpu_plan_result_info(rdfgpu_plan* plan, uint64_t* n_rows, uint32_t* n_cols);
-/* Device pointers of the result columns (valid until the next execute / destroy). */
+/* Device pointers of the result columns (valid until the next execute / destroy of THIS plan — also across mutations of the
+   store: an executed plan keeps the store generation its result may point into, and keeps showing the pre-mutation rows,
+   like the reference's plan keeps its snapshot, snapshot.rs:35-37). */
 int rdfgpu_plan_result_device(rdfgpu_plan* plan, const uint32_t** cols, uint32_t cap_cols);
 /* Copies the whole result to caller-owned host columns (each with room for n_rows). */
 int rdfgpu_plan_fetch(rdfgpu_plan* plan, uint32_t* const* host_cols, uint32_t n_cols);

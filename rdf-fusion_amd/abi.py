@@ -140,7 +140,7 @@ assert C.sizeof(ExprNode) == 24
 EXPORTED_SYMBOLS = [
     "rdfgpu_last_error", "rdfgpu_abi_version",
     "rdfgpu_store_create", "rdfgpu_store_destroy", "rdfgpu_store_extend", "rdfgpu_store_extend_device",
-    "rdfgpu_store_remove", "rdfgpu_store_clear", "rdfgpu_store_len", "rdfgpu_store_set_typed_values", "rdfgpu_store_set_strings",
+    "rdfgpu_store_remove", "rdfgpu_store_clear", "rdfgpu_store_remove_graph", "rdfgpu_store_len", "rdfgpu_store_set_typed_values", "rdfgpu_store_set_strings",
     "rdfgpu_store_read_index",
     "rdfgpu_plan_compile", "rdfgpu_plan_destroy", "rdfgpu_plan_bind_table", "rdfgpu_plan_execute",
     "rdfgpu_plan_result_info", "rdfgpu_plan_result_device", "rdfgpu_plan_fetch", "rdfgpu_plan_next",

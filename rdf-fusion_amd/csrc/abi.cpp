@@ -66,10 +66,18 @@ int rdfgpu_store_remove(rdfgpu_store* store, const uint32_t* g, const uint32_t* 
   ABI_END
 }
 int rdfgpu_store_clear(rdfgpu_store* store) { ABI_BEGIN S(store)->clear(); ABI_END }
+int rdfgpu_store_remove_graph(rdfgpu_store* store, uint32_t graph, uint64_t* removed) {
+  ABI_BEGIN
+  const u64 r = S(store)->remove_graph(graph);
+  if (removed) *removed = r;
+  ABI_END
+}
 int rdfgpu_store_len(const rdfgpu_store* store, uint64_t* out) {
   ABI_BEGIN
   if (!out) fail(RDFGPU_ERR_INVALID, "null out pointer");
-  *out = S(store)->idx[0].n;
+  Store* st = const_cast<Store*>(S(store));
+  std::shared_lock<std::shared_mutex> lock(st->mu);
+  *out = st->idx[0].n;
   ABI_END
 }
 int rdfgpu_store_set_strings(rdfgpu_store* store, const uint64_t* offsets, uint64_t n_ids, const uint8_t* heap, uint64_t heap_bytes) {
@@ -90,6 +98,7 @@ int rdfgpu_store_read_index(const rdfgpu_store* store, uint32_t components, uint
   const Store* st = S(store);
   if (components >= RDFGPU_N_INDEXES) fail(RDFGPU_ERR_INVALID, "bad index components %u", components);
   st->activate();
+  std::shared_lock<std::shared_mutex> lock(const_cast<Store*>(st)->mu);
   const Permutation& ix = st->idx[components];
   if (n) *n = ix.n;
   uint32_t* dst[4] = {c0, c1, c2, c3};

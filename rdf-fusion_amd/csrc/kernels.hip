@@ -931,7 +931,12 @@ __global__ void mark_removed_kernel(Ptr4 ix, u64 n_ix, Ptr4 rm, u64 n_rm, u32* k
   }
   if (a < n_ix && ix.p[0][a] == q[0] && ix.p[1][a] == q[1] && ix.p[2][a] == q[2] && ix.p[3][a] == q[3]) keep[a] = 0;
 }
+__global__ void mark_not_equal_kernel(const u32* col, u32 value, u32* keep, u64 n) {
+  u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) keep[i] = col[i] != value ? 1u : 0u;
+}
 static inline dim3 flat_grid(u64 n) { u64 g = (n + 255) / 256; return dim3((unsigned)(g ? g : 1)); }
+void launch_mark_not_equal(const u32* col, u32 value, u32* keep, u64 n, hipStream_t s) { if (n) hipLaunchKernelGGL(mark_not_equal_kernel, flat_grid(n), dim3(256), 0, s, col, value, keep, n); }
 void launch_fill_u32(u32* p, u32 v, u64 n, hipStream_t s) { if (n) hipLaunchKernelGGL(fill_u32_kernel, flat_grid(n), dim3(256), 0, s, p, v, n); }
 void launch_iota_u32(u32* p, u64 n, hipStream_t s) { if (n) hipLaunchKernelGGL(iota_u32_kernel, flat_grid(n), dim3(256), 0, s, p, n); }
 void launch_gather_u32(const u32* src, const u32* idx, u32* dst, u64 n, hipStream_t s) { if (n) hipLaunchKernelGGL(gather_u32_kernel, flat_grid(n), dim3(256), 0, s, src, idx, dst, n); }

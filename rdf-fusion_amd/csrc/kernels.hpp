@@ -327,6 +327,7 @@ void launch_topk_write(const TopkArgs& a, hipStream_t s);
 
 // ---- utilities ----
 void launch_fill_u32(u32* p, u32 v, u64 n, hipStream_t s);
+void launch_mark_not_equal(const u32* col, u32 value, u32* keep, u64 n, hipStream_t s);   // keep[i] = col[i] != value
 void launch_gather_u32(const u32* src, const u32* idx, u32* dst, u64 n, hipStream_t s);
 void launch_iota_u32(u32* p, u64 n, hipStream_t s);
 void launch_pack_key(const u32* hi, const u32* lo, const u32* idx /*nullable*/, u64* key, u64 n, hipStream_t s);

@@ -573,6 +573,7 @@ void Plan::execute() {
   std::shared_lock<std::shared_mutex> lock(store->mu);   // a plan holds the snapshot while it runs (snapshot.rs:35-37)
   RDFGPU_HIP(hipStreamSynchronize(stream));
   release_intermediates();
+  held = store->gen;         // ... and the generation it read until its next execute: the result may be zero-copy slices of it
   metrics = rdfgpu_metrics{};
   counters_used = 0;
   progs_used = 0;

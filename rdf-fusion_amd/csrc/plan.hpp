@@ -1,6 +1,7 @@
 // plan.hpp — compiled operator tree: DataSourceExec / FilterExec / HashJoinExec / CrossJoinExec /
 // NestedLoopJoinExec / ProjectionExec over HBM-resident binding tables.
 #pragma once
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -100,6 +101,7 @@ struct Plan {
   u32 progs_used = 0;
   u32 arg_slots_used = 0;
   DevTable result; u64 result_rows = 0; bool executed = false;
+  std::shared_ptr<IndexGeneration> held;   // the store generation the last execute ran against: zero-copy result slices point into it
   rdfgpu_metrics metrics{};
   bool timing = false;
   u64 located_version = ~0ull;    // store version the cached scan ranges belong to

@@ -106,6 +106,8 @@ Store* store_create(const rdfgpu_config* cfg) {
   Store* s = new Store();
   s->device = dev;
   s->batch_size = (cfg && cfg->batch_size) ? cfg->batch_size : 8192;
+  s->gen = std::make_shared<IndexGeneration>();
+  s->gen->device = dev;
   RDFGPU_HIP(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
   return s;
 }
@@ -206,7 +208,7 @@ Store::~Store() {
   drop_slice_tables();
   drop_string_verdicts();
   for (ExecContext* c : free_ctx) delete c;
-  for (auto& ix : idx) for (auto& c : ix.col) if (c) (void)hipFree(c);
+  gen.reset();     // the columns go when the last plan holding this generation lets go
   if (tv) (void)hipFree(tv);
   if (dec) (void)hipFree(dec);
   if (str_off) (void)hipFree(str_off);
@@ -214,12 +216,23 @@ Store::~Store() {
   if (stream) (void)hipStreamDestroy(stream);
 }
 
+IndexGeneration::~IndexGeneration() {
+  (void)hipSetDevice(device);
+  for (auto& ix : idx) for (auto& c : ix.col) if (c) (void)hipFree(c);
+}
+void Store::adopt(std::shared_ptr<IndexGeneration> fresh) {
+  version++;
+  drop_slice_tables();
+  gen = std::move(fresh);
+  for (u32 k = 0; k < RDFGPU_N_INDEXES; k++) idx[k] = gen->idx[k];
+}
+
 void Store::clear() {
   std::unique_lock<std::shared_mutex> lock(mu);
   activate();
-  version++;
-  drop_slice_tables();
-  for (auto& ix : idx) { for (auto& c : ix.col) { if (c) RDFGPU_HIP(hipFree(c)); c = nullptr; } ix.n = 0; }
+  auto fresh = std::make_shared<IndexGeneration>();
+  fresh->device = device;
+  adopt(fresh);
 }
 
 namespace {
@@ -232,7 +245,7 @@ struct Scratch {  // pool-backed temporaries released together
 }  // namespace
 
 // Sorted-unique compaction shared by extend / remove: keeps rows with flags[i] != 0.
-static u64 compact_columns(Store& st, Scratch& sc, u32* const src[4], const u32* flags, u64 n, u32* dst_out[4]) {
+static u64 compact_columns(Store& st, Scratch& sc, u32* const src[4], const u32* flags, u64 n, Permutation& dst) {
   hipStream_t s = st.stream;
   u32* excl = sc.get<u32>(n);
   const size_t tb = scan_temp_bytes(n);
@@ -246,12 +259,13 @@ static u64 compact_columns(Store& st, Scratch& sc, u32* const src[4], const u32*
   }
   const u64 total = (u64)last_excl + (last_flag ? 1 : 0);
   for (int k = 0; k < 4; k++) {
-    dst_out[k] = nullptr;
+    dst.col[k] = nullptr;     // (owned by the generation from the moment it exists: a later failure frees it)
     if (total) {
-      RDFGPU_HIP(hipMalloc((void**)&dst_out[k], total * sizeof(u32)));
-      launch_scatter_if(src[k], flags, excl, dst_out[k], n, s);
+      RDFGPU_HIP(hipMalloc((void**)&dst.col[k], total * sizeof(u32)));
+      launch_scatter_if(src[k], flags, excl, dst.col[k], n, s);
     }
   }
+  dst.n = total;
   RDFGPU_HIP(hipStreamSynchronize(s));
   return total;
 }
@@ -262,13 +276,13 @@ u64 Store::extend_device(const u32* g, const u32* s_, const u32* p, const u32* o
   std::unique_lock<std::shared_mutex> lock(mu);
   activate();
   if (n == 0) return 0;
-  version++;
-  drop_slice_tables();
   const u32* in[4] = {g, s_, p, o};
   hipStream_t s = stream;
   u64 inserted = 0;
+  auto fresh_gen = std::make_shared<IndexGeneration>();   // all three permutations first, swapped in only when complete
+  fresh_gen->device = device;
   for (u32 comp = 0; comp < RDFGPU_N_INDEXES; comp++) {
-    Permutation& ix = idx[comp];
+    const Permutation& ix = idx[comp];
     const u64 N = ix.n + n;
     if (N >= 0xFFFFFFFFull) fail(RDFGPU_ERR_UNSUPPORTED, "index would exceed 2^32-1 rows");
     Scratch sc(pool);
@@ -291,12 +305,11 @@ u64 Store::extend_device(const u32* g, const u32* s_, const u32* p, const u32* o
     for (int k = 0; k < 4; k++) { sorted[k] = sc.get<u32>(N); launch_gather_u32(cat[k], idx_a, sorted[k], N, s); }
     u32* flags = sc.get<u32>(N);
     launch_unique_flags(sorted[0], sorted[1], sorted[2], sorted[3], flags, N, s);
-    u32* fresh[4];
-    const u64 total = compact_columns(*this, sc, sorted, flags, N, fresh);
+    const u64 total = compact_columns(*this, sc, sorted, flags, N, fresh_gen->idx[comp]);
+    if (comp && total - ix.n != inserted) fail(RDFGPU_ERR_DEVICE, "extend: the permutations disagree on the number of new quads (%llu vs %llu)", (unsigned long long)(total - ix.n), (unsigned long long)inserted);
     inserted = total - ix.n;
-    for (int k = 0; k < 4; k++) { if (ix.col[k]) RDFGPU_HIP(hipFree(ix.col[k])); ix.col[k] = fresh[k]; }
-    ix.n = total;
   }
+  adopt(fresh_gen);
   pool.trim();  // the load path's big temporaries go back to the driver
   return inserted;
 }
@@ -323,13 +336,13 @@ u64 Store::remove_host(const u32* g, const u32* s_, const u32* p, const u32* o, 
   std::unique_lock<std::shared_mutex> lock(mu);
   activate();
   if (n == 0 || idx[0].n == 0) return 0;
-  version++;
-  drop_slice_tables();
   hipStream_t s = stream;
   const u32* h[4] = {g, s_, p, o};
   u64 removed = 0;
+  auto fresh_gen = std::make_shared<IndexGeneration>();
+  fresh_gen->device = device;
   for (u32 comp = 0; comp < RDFGPU_N_INDEXES; comp++) {
-    Permutation& ix = idx[comp];
+    const Permutation& ix = idx[comp];
     Scratch sc(pool);
     u32* rm[4];
     for (int k = 0; k < 4; k++) {
@@ -341,12 +354,35 @@ u64 Store::remove_host(const u32* g, const u32* s_, const u32* p, const u32* o, 
     const u32* ixc[4] = {ix.col[0], ix.col[1], ix.col[2], ix.col[3]};
     const u32* rmc[4] = {rm[0], rm[1], rm[2], rm[3]};
     launch_mark_removed(ixc, ix.n, rmc, n, keep, s);
-    u32* fresh[4];
-    const u64 total = compact_columns(*this, sc, ix.col, keep, ix.n, fresh);
+    const u64 total = compact_columns(*this, sc, ix.col, keep, ix.n, fresh_gen->idx[comp]);
+    if (comp && ix.n - total != removed) fail(RDFGPU_ERR_DEVICE, "remove: the permutations disagree on the number of removed quads");
     removed = ix.n - total;
-    for (int k = 0; k < 4; k++) { RDFGPU_HIP(hipFree(ix.col[k])); ix.col[k] = fresh[k]; }
-    ix.n = total;
   }
+  adopt(fresh_gen);
+  pool.trim();
+  return removed;
+}
+
+// QuadStorage::clear_graph / drop_named_graph (lib/extensions/src/storage/quad_storage.rs:59-68): every quad of one graph
+// (0 = the default graph).  The graph is level 0 of all three permutations: one compare per row, one compaction each.
+u64 Store::remove_graph(u32 graph) {
+  std::unique_lock<std::shared_mutex> lock(mu);
+  activate();
+  if (idx[0].n == 0) return 0;
+  hipStream_t s = stream;
+  u64 removed = 0;
+  auto fresh_gen = std::make_shared<IndexGeneration>();
+  fresh_gen->device = device;
+  for (u32 comp = 0; comp < RDFGPU_N_INDEXES; comp++) {
+    const Permutation& ix = idx[comp];
+    Scratch sc(pool);
+    u32* keep = sc.get<u32>(ix.n);
+    launch_mark_not_equal(ix.col[0], graph, keep, ix.n, s);
+    const u64 total = compact_columns(*this, sc, ix.col, keep, ix.n, fresh_gen->idx[comp]);
+    if (comp && ix.n - total != removed) fail(RDFGPU_ERR_DEVICE, "remove_graph: the permutations disagree on the number of removed quads");
+    removed = ix.n - total;
+  }
+  if (removed) adopt(fresh_gen);
   pool.trim();
   return removed;
 }

@@ -4,6 +4,7 @@
 #pragma once
 #include <atomic>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <shared_mutex>
 #include <string>
@@ -62,6 +63,16 @@ struct Permutation {
   u32* col[4] = {nullptr, nullptr, nullptr, nullptr};  // index-order columns (flat, sorted, unique)
   u64 n = 0;
 };
+// The three permutations of ONE store version.  The store holds the current generation; every executed plan holds the
+// generation it ran against until its next execute / destroy, so the zero-copy slices a result may consist of stay
+// valid — and keep showing the pre-mutation rows — while the store moves on (the reference's snapshot: a plan keeps
+// an Arc'ed read guard, snapshot.rs:35-37).  A mutation builds a complete new generation and swaps it in only when
+// all three permutations succeeded; on failure the store is unchanged and the partial generation frees itself.
+struct IndexGeneration {
+  Permutation idx[RDFGPU_N_INDEXES];
+  int device = 0;
+  ~IndexGeneration();
+};
 
 // Join table of one key-column slice of the store (a param-free triple-pattern scan joined on `n_keys` of its
 // columns).  The slice is the same on every execution of every plan until the store changes, so its table is built
@@ -96,7 +107,9 @@ struct Store {
   int device = 0;
   u32 batch_size = 8192;
   EngineOptions opt = default_engine_options();
-  Permutation idx[RDFGPU_N_INDEXES];
+  std::shared_ptr<IndexGeneration> gen;   // owns the columns `idx` points at
+  Permutation idx[RDFGPU_N_INDEXES];      // the current generation's permutations (same pointers as gen->idx)
+  void adopt(std::shared_ptr<IndexGeneration> fresh);   // swap in a complete generation (caller holds `mu` exclusively)
   // typed-value side table (object_id_mapping.rs:376-399), 16 B per id
   rdfgpu_typed_value* tv = nullptr; u64 n_ids = 0;
   int64_t* dec = nullptr; u64 n_dec = 0;
@@ -133,6 +146,7 @@ struct Store {
   u64 extend_device(const u32* g, const u32* s, const u32* p, const u32* o, u64 n);
   u64 extend_host(const u32* g, const u32* s, const u32* p, const u32* o, u64 n);
   u64 remove_host(const u32* g, const u32* s, const u32* p, const u32* o, u64 n);
+  u64 remove_graph(u32 graph);
   void clear();
   void set_typed_values(const rdfgpu_typed_value* v, u64 n_ids, const int64_t* dec, u64 n_dec);
   void set_strings(const u64* offsets, u64 n_ids, const unsigned char* heap_host, u64 heap_bytes);

@@ -54,6 +54,7 @@ def load_library():
     lib.rdfgpu_store_extend_device.argtypes = [vp, vp, vp, vp, vp, C.c_uint64, u64p]
     lib.rdfgpu_store_remove.argtypes = [vp, vp, vp, vp, vp, C.c_uint64, u64p]
     lib.rdfgpu_store_clear.argtypes = [vp]
+    lib.rdfgpu_store_remove_graph.argtypes = [vp, C.c_uint32, u64p]
     lib.rdfgpu_store_len.argtypes = [vp, u64p]
     lib.rdfgpu_store_set_typed_values.argtypes = [vp, vp, C.c_uint64, vp, C.c_uint64]
     lib.rdfgpu_store_set_strings.argtypes = [vp, vp, C.c_uint64, vp, C.c_uint64]
@@ -239,6 +240,12 @@ class GpuQuadStore:
 
     def clear(self):
         _check(self._lib.rdfgpu_store_clear(self._h))
+
+    def remove_graph(self, graph_id):
+        """QuadStorage::clear_graph / the quads of drop_named_graph: every quad of one graph (0 = default graph)."""
+        n = C.c_uint64()
+        _check(self._lib.rdfgpu_store_remove_graph(self._h, int(graph_id), C.byref(n)))
+        return n.value
 
     def __len__(self):
         n = C.c_uint64()

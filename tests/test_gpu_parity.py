@@ -1424,6 +1424,52 @@ def test_generic_vm_equals_specialised_kernels(bsbm_stores):
     np.testing.assert_array_equal(ku.multiset(a), ku.multiset(b))
 
 
+def test_result_keeps_its_snapshot_across_store_mutations(torch_cuda):
+    """a pure-scan result is zero-copy slices of the permutations; extend / remove / clear replace every column.
+    An executed plan keeps the generation it ran against: fetch, batches and the device pointers after the mutation still
+    show the pre-mutation rows (the reference's plan keeps its Arc'ed snapshot, snapshot.rs:35-37); the next execute sees
+    the new contents."""
+    rng = np.random.default_rng(3)
+    g, s_, p, o = random_quads(rng, 30_000, 500, graphs=1)
+    gs, os_ = both_stores((g, s_, p, o), batch=4096)
+    pb = PlanBuilder()
+    desc = pb.build(pb.data_source(quad_pattern("s", int(p[0]), "o")))
+    plan = gs.plan(desc).execute()
+    n_before, _ = plan.result_info()
+    before = ku.multiset(plan.fetch())
+    assert n_before > 100
+    add = random_quads(rng, 20_000, 500, graphs=1)
+    gs.extend(*add)                                              # frees and replaces every column of every permutation
+    np.testing.assert_array_equal(ku.multiset(plan.fetch()), before)
+    gs.remove(g[:5000], s_[:5000], p[:5000], o[:5000])
+    assert sum(len(b) for b in plan.batches()) == n_before
+    gs.clear()
+    np.testing.assert_array_equal(ku.multiset(plan.fetch()), before)
+    assert len(gs) == 0
+    assert plan.execute().result_info()[0] == 0                 # the next execute reads the current generation
+    plan.close()
+
+
+def test_remove_graph_matches_numpy(torch_cuda):
+    """QuadStorage::clear_graph / drop_named_graph (quad_storage.rs:59-68) through rdfgpu_store_remove_graph."""
+    rng = np.random.default_rng(9)
+    g, s_, p, o = random_quads(rng, 40_000, 300, graphs=4)
+    gs = rf.GpuQuadStore()
+    n0 = gs.extend(g, s_, p, o)
+    uniq = np.unique(np.stack([g, s_, p, o], axis=1), axis=0)
+    assert n0 == len(uniq)
+    for graph in (2, 0, 7):
+        expect = int((uniq[:, 0] == graph).sum())
+        assert gs.remove_graph(graph) == expect
+        uniq = uniq[uniq[:, 0] != graph]
+        assert len(gs) == len(uniq)
+        for comp in (abi.GSPO, abi.GPOS, abi.GOSP):
+            cols = gs.read_index(comp)
+            assert len(cols[0]) == len(uniq) and not (cols[0] == graph).any()
+    got = np.stack(gs.read_index(abi.GSPO), axis=1)
+    np.testing.assert_array_equal(got, uniq)
+
+
 def test_plan_is_reexecutable_and_sees_updates(bsbm_stores):
     ds, gs, os_ = bsbm_stores
     desc = bsbm.q1_scan_filter_plan(ds, 900)
