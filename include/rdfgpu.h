@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define RDFGPU_ABI_VERSION 1u
+#define RDFGPU_ABI_VERSION 2u
 
 /* ------------------------------------------------------------------------------------ */
 /* 0. Status codes                                                                       */
@@ -247,8 +247,10 @@ enum {
   RDFGPU_EX_REGEX = 23,       /* TV -> TV(boolean|null)  REGEX(value, <constant pattern>[, <constant flags>]),
                                  scalar/strings/regex.rs:47-141; `u` indexes rdfgpu_plan_desc.regexes.  The value
                                  must come from ENC_TV of a column; simple / language strings match, anything else is
-                                 the error value.  Patterns that are not plan constants (regex_variable.rq) and
-                                 syntax outside csrc/regex_compile.hpp's subset are RDFGPU_ERR_UNSUPPORTED.        */
+                                 the error value.  Syntax outside csrc/regex_compile.hpp's subset is RDFGPU_ERR_UNSUPPORTED at
+                                 compile time; `\d \w \s \b` are compiled with their ASCII members and a row whose subject
+                                 has a non-ASCII byte fails the execute with RDFGPU_ERR_UNSUPPORTED (the crate's Unicode tables
+                                 are not restated).  Per-row patterns: RDFGPU_EX_REGEX_VAR.                        */
   RDFGPU_EX_CONTAINS = 24,    /* TV -> TV(boolean|null)  CONTAINS(value, <constant string>), scalar/strings/contains.rs;
                                  `u` indexes rdfgpu_plan_desc.regexes (the entry's pattern is the needle, taken literally; its
                                  flags are ignored), `lo` = language id of the constant (0 = simple literal).  Argument
@@ -263,6 +265,13 @@ enum {
                                  string values; byte 0 = the empty tag, i.e. every literal without a language), 1 = the tag matches
                                  the range.  Named / blank nodes and null => error (lang.rs:50-52); a language id beyond the table
                                  => error.  At most 16384 language ids.                                                       */
+  RDFGPU_EX_REGEX_VAR = 28,   /* TV TV -> TV(boolean|null)  REGEX(value, ?pattern[, <constant flags>]) with a PER-ROW pattern
+                                 (regex.rs:59-76 compiles the pattern of every row; testsuite/oxigraph-tests/sparql/regex_variable.rq).
+                                 The second operand is the pattern's typed value (ENC_TV of its column): a simple literal, else the
+                                 error value.  The host announces the DISTINCT patterns that can occur: rdfgpu_plan_desc.regexes
+                                 [u .. u + lo), each with its object id (rdfgpu_regex.pattern_id) and the constant flags; they are
+                                 compiled at plan time and a row picks its program by the pattern's id.  A row whose pattern was not
+                                 announced fails the execute (RDFGPU_ERR_UNSUPPORTED), it is never answered as "no match".            */
   RDFGPU_EX__COUNT
 };
 
@@ -342,6 +351,8 @@ typedef struct rdfgpu_regex {             /* one constant REGEX pattern of the p
   const char* flags;                      /* SPARQL flags: any of s m i x q (regex.rs:107-141); may be NULL    */
   uint32_t pattern_len;
   uint32_t flags_len;
+  uint32_t pattern_id;                    /* RDFGPU_EX_REGEX_VAR entries: the object id of this pattern literal; else 0 */
+  uint32_t reserved;
 } rdfgpu_regex;
 
 typedef struct rdfgpu_plan_desc {

@@ -95,10 +95,16 @@ def _u32(a):
     return a, a.ctypes.data_as(C.c_void_p)
 
 
+class NeedsUnicodeTables(Exception):
+    """`\\d \\w \\s \\b` over a subject with non-ASCII characters: the restatement holds only their ASCII members."""
+
+
 def regex_is_match(pattern, flags, subject):
     """REGEX restatement (regex_oracle.c): True / False, or None for the error value."""
     p, f, s = (x.encode("utf-8") if isinstance(x, str) else bytes(x) for x in (pattern, flags, subject))
     r = lib().orc_regex_is_match(p, len(p), f, len(f), s, len(s))
+    if r == -2:
+        raise NeedsUnicodeTables(pattern)
     return None if r < 0 else bool(r)
 
 

@@ -657,6 +657,22 @@ static int eval_prog(const orc_store* s, const rdfgpu_expr_node* p, u32 n, const
         const rdfgpu_regex* rx = &g_regexes[e->u];
         int m = orc_regex_is_match(rx->pattern, rx->pattern_len, rx->flags ? rx->flags : "", rx->flags ? rx->flags_len : 0,
                                    s->heap + s->str_off[a.id], (size_t)(s->str_off[a.id + 1] - s->str_off[a.id]));
+        if (m == -2) FAIL("REGEX with \\d \\w \\s or \\b over a string with non-ASCII characters needs the regex crate's Unicode tables");
+        if (m >= 0) v = tv_bool(m);
+        break; }
+      case RDFGPU_EX_REGEX_VAR: {
+        /* regex.rs:59-76: the pattern is the row's second argument — a simple literal, compiled for this row */
+        if (sp < 2 || st[sp - 1].kind != 1 || st[sp - 2].kind != 1) FAIL("REGEX needs two typed values");
+        if (e->u >= g_n_regexes) FAIL("REGEX pattern table %u out of range", e->u);
+        val pat = st[--sp]; val a = st[--sp];
+        v = tv_null();
+        if (pat.tag != RDFGPU_TV_STRING || pat.aux != 0 || pat.id == 0 || pat.id >= s->n_str_ids) break;
+        if (a.tag != RDFGPU_TV_STRING || a.id == 0 || a.id >= s->n_str_ids) break;
+        const rdfgpu_regex* rx = &g_regexes[e->u];      /* the flags are the plan's constant third argument */
+        int m = orc_regex_is_match((const char*)(s->heap + s->str_off[pat.id]), (size_t)(s->str_off[pat.id + 1] - s->str_off[pat.id]),
+                                   rx->flags ? rx->flags : "", rx->flags ? rx->flags_len : 0,
+                                   s->heap + s->str_off[a.id], (size_t)(s->str_off[a.id + 1] - s->str_off[a.id]));
+        if (m == -2) FAIL("REGEX with \\d \\w \\s or \\b over a string with non-ASCII characters needs the regex crate's Unicode tables");
         if (m >= 0) v = tv_bool(m);
         break; }
       case RDFGPU_EX_CONTAINS: case RDFGPU_EX_STRSTARTS: case RDFGPU_EX_STRENDS: {

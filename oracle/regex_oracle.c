@@ -6,18 +6,21 @@
  * The `regex` crate itself (1.12.2, Cargo.lock:3834-3835) is a third-party dependency absent from /root/reference;
  * this restates its documented syntax for the subset the device supports and a little more (anchors anywhere):
  *   literals, `.`, `[...]`, `( )`, `(?: )`, `(?P<n> )`, `|`, `* + ? {m} {m,} {m,n}` (+ lazy suffix), `^ $ \A \z`,
- *   escaped punctuation, `\n \r \t \f \v \a \xHH`.
+ *   escaped punctuation, `\n \r \t \f \v \a \xHH`, the Perl classes `\d \w \s \D \W \S` (also inside `[...]`) and the word
+ *   boundaries `\b \B` with their ASCII members — the crate's Unicode classes agree with those on all-ASCII subjects; a
+ *   subject with a non-ASCII character then yields -2 ("needs the crate's Unicode tables") instead of a guess.
  * Deliberately a DIFFERENT algorithm from the device's bit-parallel Glushkov automaton over bytes: a Thompson
  * program (char / split / jmp / assert / match) run by a Pike VM over decoded CODE POINTS, so UTF-8 expansion,
  * follow-set or anchoring mistakes on the device side do not cancel out.  tests/ cross-check both against Python's
  * `re` as a third opinion.
- * Returns: 1 match, 0 no match, -1 = the error value (bad flag / unsupported or invalid pattern).
+ * Returns: 1 match, 0 no match, -1 = the error value (bad flag / unsupported or invalid pattern), -2 = not answerable
+ * without the Unicode tables (see above).
  */
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
 
-enum { I_CHAR, I_SPLIT, I_JMP, I_MATCH, I_BOL, I_EOL, I_BOT, I_EOT };
+enum { I_CHAR, I_SPLIT, I_JMP, I_MATCH, I_BOL, I_EOL, I_BOT, I_EOT, I_WB, I_NWB };
 typedef struct {
   int op;
   int x, y;            /* SPLIT: both targets; JMP: x */
@@ -33,6 +36,7 @@ typedef struct {
   int f_i, f_s, f_m, f_x;
   inst* prog; int n_inst, cap;
   int bad;
+  int ascii_only;      /* \d \w \s \b used: restated with their ASCII members; a non-ASCII subject is then "needs the Unicode tables" (-2) */
 } rx;
 
 static int emit(rx* r, int op) {
@@ -91,6 +95,24 @@ static int escape(rx* r, unsigned* out) {   /* after '\\' */
   }
 }
 
+/* `\d \w \s` / `\D \W \S` at p[i] (after the backslash): adds the ASCII members to `c`; 1 if consumed */
+static int perl_class(rx* r, inst* c) {
+  if (r->i >= r->n) return 0;
+  unsigned e = r->p[r->i];
+  uint64_t m[2] = {0, 0};
+#define M_ADD(ch) (m[(ch) >> 6] |= 1ull << ((ch) & 63))
+  if (e == 'd' || e == 'D') { for (unsigned k = '0'; k <= '9'; k++) M_ADD(k); }
+  else if (e == 'w' || e == 'W') { for (unsigned k = '0'; k <= '9'; k++) M_ADD(k); for (unsigned k = 'a'; k <= 'z'; k++) { M_ADD(k); M_ADD(k - 32); } M_ADD('_'); }
+  else if (e == 's' || e == 'S') { M_ADD('\t'); M_ADD('\n'); M_ADD('\v'); M_ADD('\f'); M_ADD('\r'); M_ADD(' '); }
+  else return 0;
+#undef M_ADD
+  r->i++;
+  r->ascii_only = 1;
+  const int neg = e == 'D' || e == 'W' || e == 'S';
+  for (unsigned k = 0; k < 0x80; k++) { const int in = (int)((m[k >> 6] >> (k & 63)) & 1); if (in != neg) set_add(c, k); }
+  return 1;
+}
+
 /* Fragments: the parser emits code for a sub-expression into [start, n_inst) and every fragment falls through at its
  * end, so concatenation is emission order; repetition and alternation copy / patch with relative fix-ups. */
 static int parse_alt(rx* r);
@@ -133,7 +155,7 @@ static int parse_class(rx* r) {
     if (ch == '[' || ch >= 0x80) return -1;
     if ((ch == '&' || ch == '~') && r->i + 1 < r->n && r->p[r->i + 1] == ch) return -1;
     r->i++;
-    if (ch == '\\' && escape(r, &ch)) return -1;
+    if (ch == '\\') { if (perl_class(r, &c)) continue; if (escape(r, &ch)) return -1; }
     unsigned hi = ch;
     if (r->i + 1 < r->n && r->p[r->i] == '-' && r->p[r->i + 1] != ']') {
       if (r->p[r->i + 1] == '-') return -1;
@@ -184,6 +206,8 @@ static int parse_atom(rx* r) {
     r->i++;
     if (r->i < r->n && r->p[r->i] == 'A') { r->i++; emit(r, I_BOT); return 0; }
     if (r->i < r->n && r->p[r->i] == 'z') { r->i++; emit(r, I_EOT); return 0; }
+    if (r->i < r->n && (r->p[r->i] == 'b' || r->p[r->i] == 'B')) { emit(r, r->p[r->i] == 'b' ? I_WB : I_NWB); r->i++; r->ascii_only = 1; return 0; }
+    { int id = emit(r, I_CHAR); inst c = r->prog[id]; if (perl_class(r, &c)) { fold(r, &c); r->prog[id] = c; return 0; } r->n_inst--; }
     unsigned b;
     if (escape(r, &b)) return -1;
     int id = emit(r, I_CHAR);
@@ -199,8 +223,6 @@ static int parse_atom(rx* r) {
   else { if (r->f_i) return -1; r->prog[id].extra[0] = cp; r->prog[id].n_extra = 1; }
   return 0;
 }
-
-static int is_assert(const rx* r, int start) { return r->n_inst == start + 1 && r->prog[start].op >= I_BOL; }
 
 static void wrap_star(rx* r, int start) {   /* L1: split L2, L3; L2: e; jmp L1; L3: */
   insert_at(r, start, I_SPLIT);
@@ -226,7 +248,6 @@ static int parse_repeat(rx* r) {
     if (r->i >= r->n) break;
     unsigned ch = r->p[r->i];
     if (ch != '*' && ch != '+' && ch != '?' && ch != '{') break;
-    if (is_assert(r, start)) return -1;
     if (ch == '{') {
       r->i++;
       unsigned lo = 0, hi = 0; int open = 0;
@@ -309,6 +330,11 @@ static void add_thread(const rx* r, tlist* l, int* mark, int gen, int pc, const 
     case I_EOT: if (i == len) add_thread(r, l, mark, gen, pc + 1, s, i, len); break;
     case I_BOL: if (i == 0 || s[i - 1] == '\n') add_thread(r, l, mark, gen, pc + 1, s, i, len); break;
     case I_EOL: if (i == len || s[i] == '\n') add_thread(r, l, mark, gen, pc + 1, s, i, len); break;
+    case I_WB: case I_NWB: {   /* ASCII word characters (the subject is all-ASCII when these occur) */
+      const int a = i > 0 && s[i - 1] < 0x80 && (s[i - 1] == '_' || (s[i - 1] >= '0' && s[i - 1] <= '9') || ((s[i - 1] | 32) >= 'a' && (s[i - 1] | 32) <= 'z'));
+      const int b = i < len && s[i] < 0x80 && (s[i] == '_' || (s[i] >= '0' && s[i] <= '9') || ((s[i] | 32) >= 'a' && (s[i] | 32) <= 'z'));
+      if ((a != b) == (in->op == I_WB)) add_thread(r, l, mark, gen, pc + 1, s, i, len);
+      break; }
     default: l->pc[l->n++] = pc;
   }
 }
@@ -348,6 +374,7 @@ int orc_regex_is_match(const char* pattern, size_t pattern_len, const char* flag
   uint32_t* cps = (uint32_t*)malloc((subject_len + 1) * sizeof(uint32_t));
   size_t len = 0, at = 0;
   while (at < subject_len) { if (decode(subject, subject_len, &at, &cps[len])) { free(cps); free(r.prog); return -1; } len++; }
+  if (r.ascii_only) for (size_t k = 0; k < len; k++) if (cps[k] >= 0x80) { free(cps); free(r.prog); return -2; }
 
   /* raw = successor pcs of the previous character; clist = their epsilon closure at this position */
   int* raw = (int*)malloc((size_t)r.n_inst * sizeof(int)); int n_raw = 0;

@@ -5,7 +5,7 @@ test-only CPU checker binding can describe a plan with the same structs.
 """
 import ctypes as C
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 # status codes
 OK, END = 0, 1
@@ -27,7 +27,7 @@ TVF_EMPTY_STRING = 1
 # expression ops
 (EX_COLUMN, EX_LIT_ID, EX_LIT_TV, EX_ENC_TV, EX_GT, EX_LT, EX_GEQ, EX_LEQ, EX_EQ, EX_ADD, EX_SUB,
  EX_EBV, EX_ID_EQ, EX_ID_NEQ, EX_AND, EX_OR, EX_NOT, EX_IS_COMPATIBLE, EX_BOUND, EX_BOOL_AS_TV,
- EX_LIT_BOOL, EX_NEQ, EX_REGEX, EX_CONTAINS, EX_STRSTARTS, EX_STRENDS, EX_LANG_IN) = range(1, 28)
+ EX_LIT_BOOL, EX_NEQ, EX_REGEX, EX_CONTAINS, EX_STRSTARTS, EX_STRENDS, EX_LANG_IN, EX_REGEX_VAR) = range(1, 29)
 
 # plan nodes
 (NODE_DATA_SOURCE, NODE_FILTER, NODE_HASH_JOIN, NODE_CROSS_JOIN, NODE_NESTED_LOOP_JOIN,
@@ -77,7 +77,8 @@ class PlanNode(C.Structure):
 
 
 class Regex(C.Structure):
-    _fields_ = [("pattern", C.c_char_p), ("flags", C.c_char_p), ("pattern_len", C.c_uint32), ("flags_len", C.c_uint32)]
+    _fields_ = [("pattern", C.c_char_p), ("flags", C.c_char_p), ("pattern_len", C.c_uint32), ("flags_len", C.c_uint32),
+                ("pattern_id", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class PlanDesc(C.Structure):

@@ -36,6 +36,8 @@ struct TypedTable {
   const uint64_t* str_off;       // lexical form of string id i: heap[str_off[i] .. str_off[i + 1]) (null: not installed)
   const uint8_t* heap;
   uint64_t n_str_ids;
+  uint32_t* rt_error;            // the executing plan's run-time error flags (null outside a plan): bit 0 a REGEX with a Perl
+                                 // class / word boundary met a non-ASCII subject, bit 1 a per-row REGEX pattern was not announced
 };
 
 // Value kinds on the evaluation stack.
@@ -246,6 +248,9 @@ __device__ __forceinline__ uint32_t tv_ebv(const Val& v) {
 // & byte_mask[byte].  Simple and language-tagged strings match; every other kind is the error value.
 // `rhs_lang` >= 0: CONTAINS / STRSTARTS / STRENDS argument compatibility (string_literal.rs:80-95) — the constant has no
 // language (0) or the value's; REGEX passes -1 (no such rule).
+// The error value with aux = kRegexNeedsUnicode: "a Perl class / word boundary met a non-ASCII subject" — a per-term
+// verdict pass (no plan to fail) records it as verdict 3; a row that actually reads such a verdict raises the run-time error.
+constexpr uint32_t kRegexNeedsUnicode = 0xFFFFFFFFu;
 __device__ __forceinline__ Val tv_regex(const RegexProg& p, const TypedTable& t, const Val& v, int64_t rhs_lang = -1) {
   if (v.tag != RDFGPU_TV_STRING || p.always_error || t.str_off == nullptr) return val_tv_null();
   if (rhs_lang > 0 && (int64_t)v.aux != rhs_lang) return val_tv_null();
@@ -253,25 +258,56 @@ __device__ __forceinline__ Val tv_regex(const RegexProg& p, const TypedTable& t,
   if (id == 0 || id >= t.n_str_ids) return val_tv_null();   // a string literal of the plan has no lexical form on the device
   const uint64_t b0 = t.str_off[id], len = t.str_off[id + 1] - b0;
   const uint8_t* s = t.heap + b0;
+  if (p.ascii_only) {   // `\d \w \s \b` are compiled with their ASCII members: exact on ASCII subjects only
+    bool non_ascii = false;
+    for (uint64_t i = 0; i < len; i++) non_ascii = non_ascii || s[i] >= 0x80;
+    if (non_ascii) {
+      if (t.rt_error) atomicOr(t.rt_error, 1u);
+      Val e = val_tv_null(); e.aux = kRegexNeedsUnicode; return e;
+    }
+  }
   auto start_ok = [&](uint64_t i) { return !p.anchor_start || i == 0 || (p.ml_start && s[i - 1] == '\n'); };
   auto end_ok = [&](uint64_t i) { return !p.anchor_end || i == len || (p.ml_end && s[i] == '\n'); };
-  if (p.nullable) {
-    if (!p.anchor_start && !p.anchor_end) return val_tv_bool(true);
-    for (uint64_t i = 0; i <= len; i++) if (start_ok(i) && end_ok(i)) return val_tv_bool(true);
+  if (!p.has_assert) {
+    if (p.nullable) {
+      if (!p.anchor_start && !p.anchor_end) return val_tv_bool(true);
+      for (uint64_t i = 0; i <= len; i++) if (start_ok(i) && end_ok(i)) return val_tv_bool(true);
+    }
+    uint64_t cur = 0;
+    for (uint64_t i = 0; i < len; i++) {
+      uint64_t nxt = start_ok(i) ? p.first : 0;
+      for (uint64_t c = cur; c; c &= c - 1) nxt |= p.follow[__builtin_ctzll(c)];
+      cur = nxt & p.byte_mask[s[i]];
+      if ((cur & p.last) && end_ok(i + 1)) return val_tv_bool(true);
+    }
+    return val_tv_bool(false);
   }
+  // with `\b` / `\B`: every crossing also looks at the word-boundary flag of the point it crosses (ASCII word characters)
+  auto isw = [](uint8_t c) { return (c >= '0' && c <= '9') || (c >= 'a' && c <= 'z') || (c >= 'A' && c <= 'Z') || c == '_'; };
+  auto bnd = [&](uint64_t i) { const bool a = i > 0 && isw(s[i - 1]), b = i < len && isw(s[i]); return a != b; };
+  for (uint64_t i = 0; i <= len; i++)
+    if (start_ok(i) && end_ok(i) && (p.nullable || (bnd(i) ? p.nullable_b : p.nullable_nb))) return val_tv_bool(true);
   uint64_t cur = 0;
   for (uint64_t i = 0; i < len; i++) {
-    uint64_t nxt = start_ok(i) ? p.first : 0;
-    for (uint64_t c = cur; c; c &= c - 1) nxt |= p.follow[__builtin_ctzll(c)];
+    const bool bi = bnd(i);
+    uint64_t nxt = start_ok(i) ? (p.first | (bi ? p.first_b : p.first_nb)) : 0;
+    for (uint64_t c = cur; c; c &= c - 1) { const int k = __builtin_ctzll(c); nxt |= p.follow[k] | (bi ? p.follow_b[k] : p.follow_nb[k]); }
     cur = nxt & p.byte_mask[s[i]];
-    if ((cur & p.last) && end_ok(i + 1)) return val_tv_bool(true);
+    if ((cur & (p.last | (bnd(i + 1) ? p.last_b : p.last_nb))) && end_ok(i + 1)) return val_tv_bool(true);
   }
   return val_tv_bool(false);
 }
+// REGEX(value, ?pattern): the pattern is a per-row simple literal (regex.rs:59-76, compiled per row there); here every
+// DISTINCT pattern the host announced was compiled at plan time and the row picks its program by the pattern's object id.
+// A pattern that was not announced raises the plan's run-time error (never answered as if it did not match).
+__device__ __forceinline__ Val tv_regex_var(const RegexProg* progs, uint32_t first, uint32_t count, const TypedTable& t, const Val& v, const Val& pat) {
+  if (pat.tag != RDFGPU_TV_STRING || pat.aux != 0) return val_tv_null();   // the pattern must be a simple literal
+  const uint32_t pid = (uint32_t)pat.hi;
+  for (uint32_t k = 0; k < count; k++) if (progs[first + k].pattern_id == pid) return tv_regex(progs[first + k], t, v);
+  if (t.rt_error) atomicOr(t.rt_error, 2u);
+  return val_tv_null();
+}
 
-// Evaluates `prog` for one row.  `col(c)` returns the u32 value of input column c.  The program was
-// type-checked on the host (plan compile), so the stack discipline is not re-checked here.
-// Returns the final value (BOOL for predicates).
 template <class ColFn>
 __device__ __forceinline__ Val eval_program(const ExprProgram& prog, const TypedTable& tt, ColFn col) {
   Val st[kMaxStack];
@@ -295,6 +331,7 @@ __device__ __forceinline__ Val eval_program(const ExprProgram& prog, const Typed
       case RDFGPU_EX_ADD: case RDFGPU_EX_SUB: { const Val b = st[--sp]; const Val a = st[--sp]; v = tv_arith(a, b, e.op == RDFGPU_EX_SUB); break; }
       case RDFGPU_EX_EBV: v = val_bool(tv_ebv(st[--sp])); break;
       case RDFGPU_EX_REGEX: v = tv_regex(prog.regex[e.u], tt, st[--sp]); break;
+      case RDFGPU_EX_REGEX_VAR: { const Val pat = st[--sp]; const Val val = st[--sp]; v = tv_regex_var(prog.regex, e.u, (uint32_t)e.lo, tt, val, pat); break; }
       case RDFGPU_EX_CONTAINS: case RDFGPU_EX_STRSTARTS: case RDFGPU_EX_STRENDS: v = tv_regex(prog.regex[e.u], tt, st[--sp], e.lo < 0 ? 0 : e.lo); break;
       case RDFGPU_EX_LANG_IN: {   // LANGMATCHES(LANG(v), range): one verdict bit per language id (bit 0 = no language)
         const Val a = st[--sp];

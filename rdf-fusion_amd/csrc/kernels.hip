@@ -141,7 +141,10 @@ void launch_scan_write(const ScanJob& job, const u32* block_offsets, hipStream_t
 template <int SHAPE>
 __device__ __forceinline__ bool filter_pred_value(const FilterArgs& a, u32 v) {
   if constexpr (SHAPE == 3) {  // string predicate, answered per distinct term beforehand: one byte gather (L2-resident table)
-    return v != 0 && v < a.n_verdict && a.verdict[v] == 1;
+    if (v == 0 || v >= a.n_verdict) return false;
+    const unsigned char verdict = a.verdict[v];
+    if (verdict == 3 && a.tt.rt_error) atomicOr(a.tt.rt_error, 1u);   // this row's string needs the Unicode tables: fail loudly
+    return verdict == 1;
   } else if constexpr (SHAPE == 1) {  // col <ID_EQ|ID_NEQ> object-id literal; null on either side => dropped
     const u32 lit = a.prog.nodes[1].u;
     if (v == 0 || lit == 0) return false;
@@ -260,7 +263,7 @@ __global__ __launch_bounds__(256) void regex_verdict_kernel(const RegexProg* pro
   if (id >= n_ids) return;
   const Val v = enc_tv(tt, (u32)id);
   const Val r = tv_regex(*prog, tt, v, rhs_lang);
-  out[id] = r.tag == RDFGPU_TV_BOOLEAN ? (unsigned char)(r.lo != 0) : (unsigned char)2;
+  out[id] = r.tag == RDFGPU_TV_BOOLEAN ? (unsigned char)(r.lo != 0) : r.aux == kRegexNeedsUnicode ? (unsigned char)3 : (unsigned char)2;   // 3: needs the Unicode tables
 }
 void launch_regex_verdicts(const RegexProg* prog_dev, const TypedTable& tt, int64_t rhs_lang, unsigned char* out, u64 n_ids, hipStream_t s) {
   if (!n_ids) return;
@@ -291,7 +294,12 @@ struct FilterStreamArgs {
 constexpr int kStreamRounds = 4;
 template <int SHAPE>
 __device__ __forceinline__ bool stream_pred(const FilterStreamArgs& a, u32 v) {
-  if constexpr (SHAPE == 3) return v != 0 && v < a.n_verdict && a.verdict[v] == 1;
+  if constexpr (SHAPE == 3) {
+    if (v == 0 || v >= a.n_verdict) return false;
+    const unsigned char verdict = a.verdict[v];
+    if (verdict == 3 && a.tt.rt_error) atomicOr(a.tt.rt_error, 1u);
+    return verdict == 1;
+  }
   else if constexpr (SHAPE == 1) { if (v == 0 || a.id_lit == 0) return false; return (v == a.id_lit) == (a.is_eq != 0); }
   else {
     const Val x = enc_tv(a.tt, v);

@@ -54,6 +54,9 @@ u32 check_program(const rdfgpu_expr_node* p, u32 n, u32 n_cols, u32 n_regexes = 
         // the lexical form lives in HBM under the value's object id: the operand has to be ENC_TV(column)
         if (i < 2 || p[i - 1].op != RDFGPU_EX_ENC_TV || p[i - 2].op != RDFGPU_EX_COLUMN) fail(RDFGPU_ERR_UNSUPPORTED, "REGEX / CONTAINS / STRSTARTS / STRENDS over anything but ENC_TV(column)");
         pop(VK_TV, "REGEX"); out = VK_TV; break;
+      case RDFGPU_EX_REGEX_VAR:
+        if (e.lo < 1 || (u64)e.u + (u64)e.lo > n_regexes) fail(RDFGPU_ERR_INVALID, "expression: REGEX pattern table %u .. +%lld out of range (%u patterns)", e.u, (long long)e.lo, n_regexes);
+        pop(VK_TV, "REGEX pattern"); pop(VK_TV, "REGEX"); out = VK_TV; break;
       case RDFGPU_EX_LANG_IN:
         if (e.u >= n_regexes) fail(RDFGPU_ERR_INVALID, "expression: language table %u out of range (%u tables)", e.u, n_regexes);
         pop(VK_TV, "LANGMATCHES(LANG())"); out = VK_TV; break;
@@ -150,6 +153,10 @@ Plan* plan_compile(Store* store, const rdfgpu_plan_desc* d) {
     std::vector<int> use(d->n_regexes, -1);
     for (u32 i = 0; i < d->n_exprs; i++) {
       const rdfgpu_expr_node& e = d->exprs[i];
+      if (e.op == RDFGPU_EX_REGEX_VAR) {   // a table of per-row patterns: entries u .. u + lo, all REGEX patterns
+        for (int64_t k = 0; k < e.lo && (u64)e.u + (u64)k < d->n_regexes; k++) use[e.u + k] = RDFGPU_EX_REGEX;
+        continue;
+      }
       if (e.op != RDFGPU_EX_REGEX && e.op != RDFGPU_EX_CONTAINS && e.op != RDFGPU_EX_STRSTARTS && e.op != RDFGPU_EX_STRENDS && e.op != RDFGPU_EX_LANG_IN) continue;
       if (e.u >= d->n_regexes) fail(RDFGPU_ERR_INVALID, "expression: string pattern %u out of range", e.u);
       if (use[e.u] >= 0 && use[e.u] != (int)e.op) fail(RDFGPU_ERR_INVALID, "string pattern %u is used by two different functions", e.u);
@@ -172,6 +179,7 @@ Plan* plan_compile(Store* store, const rdfgpu_plan_desc* d) {
       const size_t n_flags = literal ? 1 : (rx.flags ? rx.flags_len : 0);
       if (regex_compile(rx.pattern ? rx.pattern : "", rx.pattern_len, flags, n_flags, progs[r], why) != REGEX_OK)
         fail(RDFGPU_ERR_UNSUPPORTED, "string pattern %u: %s", r, why.c_str());
+      progs[r].pattern_id = rx.pattern_id;
       if (use[r] == RDFGPU_EX_STRSTARTS) progs[r].anchor_start = 1;
       if (use[r] == RDFGPU_EX_STRENDS) progs[r].anchor_end = 1;
     }
@@ -557,7 +565,7 @@ const ExprProgram* Plan::upload_program(const ExprProgram& p) {
   return ctx->progs_dev + slot;
 }
 u64* Plan::new_counter() {
-  if (counters_used >= 256) fail(RDFGPU_ERR_UNSUPPORTED, "plan needs more than 256 cardinality counters");
+  if (counters_used >= 255) fail(RDFGPU_ERR_UNSUPPORTED, "plan needs more than 255 cardinality counters");   // slot 255: run-time error flags
   return counters + counters_used++;
 }
 u64 Plan::read_u64(const u64* dev) {
@@ -641,6 +649,10 @@ void Plan::execute() {
   RDFGPU_HIP(hipEventRecord(ev_stop, stream));
   RDFGPU_HIP(hipStreamSynchronize(stream)); metrics.host_syncs++;
   RDFGPU_HIP(hipGetLastError());
+  if (const u32 rt = (u32)(ctx->counters_host[255] & 0xFFFFFFFFull)) {   // a row asked for something that is refused loudly, not answered differently
+    if (rt & 1u) fail(RDFGPU_ERR_UNSUPPORTED, "REGEX with \\d \\w \\s or \\b over a string with non-ASCII characters needs the regex crate's Unicode tables (not restated)");
+    fail(RDFGPU_ERR_UNSUPPORTED, "REGEX with a per-row pattern: a row's pattern literal was not announced in the plan's pattern table");
+  }
   // speculative joins: did every output fit the size taken from the previous run?
   bool spec_failed = false;
   for (const SpecCheck& c : spec_checks) {
@@ -804,7 +816,7 @@ DevTable Plan::apply_filter(NodeInfo& nd, const DevTable& in) {
   for (u32 c = 0; c < nd.n_proj; c++) { a.proj[c] = nd.proj[c]; a.out[c] = scratch<u32>(in.cap); t.cols[c] = a.out[c]; }
   a.n_in_dev = in.n_dev; a.n_in_cap = in.cap;
   a.n_out_dev = new_counter();
-  a.tt = store->typed_table();
+  a.tt = typed_table();
   a.prog = nd.prog;
   int shape = nd.shape;
   if (shape == 3) {
@@ -828,7 +840,8 @@ DevTable Plan::apply_filter(NodeInfo& nd, const DevTable& in) {
         { std::lock_guard<std::mutex> l(store->slice_mu); cache_it = store->string_verdicts.size() < 64; }
         if (cache_it) RDFGPU_HIP(hipMalloc((void**)&verdict, n_ids)); else verdict = scratch<unsigned char>(n_ids);
         const int64_t lang = e.op == RDFGPU_EX_REGEX ? -1 : (e.lo < 0 ? 0 : e.lo);
-        timed(KC_REGEX_VERDICTS, 0, n_ids, nullptr, 16 + 8 + 1, nullptr, 0, 0, [&] { launch_regex_verdicts(regex_dev + e.u, a.tt, lang, verdict, n_ids, stream); });
+        timed(KC_REGEX_VERDICTS, 0, n_ids, nullptr, 16 + 8 + 1, nullptr, 0, 0, [&] { TypedTable vt = a.tt; vt.rt_error = nullptr;   // a verdict pass covers the whole dictionary: what it cannot answer is verdict 3, an error only for a row that reads it
+                                                                                               launch_regex_verdicts(regex_dev + e.u, vt, lang, verdict, n_ids, stream); });
         if (cache_it) {
           RDFGPU_HIP(hipStreamSynchronize(stream)); metrics.host_syncs++;   // complete before other plans may see it
           std::lock_guard<std::mutex> l(store->slice_mu);
@@ -880,7 +893,7 @@ DevTable Plan::exec_topk(NodeInfo& nd) {
   a.n_keys = nd.d.n_keys;
   for (u32 k = 0; k < a.n_keys; k++) { a.key_col[k] = nd.d.left_keys[k]; a.key_by_term[k] = nd.d.right_keys[k]; }   // RDFGPU_SORT_BY_*
   a.k = nd.d.table_cols;
-  a.tt = store->typed_table();
+  a.tt = typed_table();
   u64* n_out = new_counter();
   u32* flags = reinterpret_cast<u32*>(new_counter());   // {largest group id, unsupported-kind flag}
   a.n_out_dev = n_out; a.bad = flags + 1;
@@ -1053,7 +1066,7 @@ bool Plan::apply_chain(const ChainRequest& req, NodeInfo& base, const DevTable& 
         RDFGPU_HIP(hipMalloc((void**)&val, (size_t)tab->kn * sizeof(long long)));
         u32* bad = reinterpret_cast<u32*>(new_counter());
         launch_fill_i64(val, INT64_MIN, tab->kn, stream);
-        launch_direct_values(ln.slice.cols[key_local], st.f[0].ptr, ln.slice.cap, tab->kmin, tab->kn, store->typed_table(), val, bad, stream);
+        launch_direct_values(ln.slice.cols[key_local], st.f[0].ptr, ln.slice.cap, tab->kmin, tab->kn, typed_table(), val, bad, stream);
         u32 is_bad = 0;
         RDFGPU_HIP(hipMemcpyAsync(&is_bad, bad, sizeof(u32), hipMemcpyDeviceToHost, stream));
         RDFGPU_HIP(hipStreamSynchronize(stream)); metrics.host_syncs++;
@@ -1277,7 +1290,7 @@ DevTable Plan::exec_join(NodeInfo& nd) {
   a.n_left_dev = L.n_dev; a.n_left_cap = L.cap; a.n_right_dev = R.n_dev; a.n_right_cap = R.cap;
   a.has_filter = nd.prog.n ? 1 : 0;
   a.prog = nd.prog;
-  a.tt = store->typed_table();
+  a.tt = typed_table();
   if (L.cap >= 0xFFFFFFF0ull) fail(RDFGPU_ERR_UNSUPPORTED, "build side of %llu rows", (unsigned long long)L.cap);
   if (left_join) { a.visited = scratch<u8>(L.cap); if (!hash) RDFGPU_HIP(hipMemsetAsync(a.visited, 0, L.cap, stream)); }
   if (hash) {
@@ -1509,7 +1522,7 @@ DevTable Plan::exec_lds_join(NodeInfo& nd, const DevTable& L, const DevTable& R,
     a.has_post = 1;
     a.post.col = (build_left ? 0 : L.n_cols) + e[0].u; a.post.lit = e[1].u; a.post.is_eq = e[2].op == RDFGPU_EX_ID_EQ;
   }
-  a.tt = store->typed_table();
+  a.tt = typed_table();
   if (left_join) a.visited = scratch<u8>(L.cap);
   u64* n_out = new_counter();
   u32* overflow = reinterpret_cast<u32*>(new_counter());

@@ -117,6 +117,8 @@ struct Plan {
   std::vector<std::vector<u32>> host_cols; bool host_valid = false; u64 cursor = 0;
 
   ~Plan();
+  // the store's typed-value table with this execution's run-time error word attached (the last counter slot)
+  TypedTable typed_table() const { TypedTable t = store->typed_table(); t.rt_error = reinterpret_cast<u32*>(counters + 255); return t; }
   void execute();
   void pushdown_filters(u32 node, const rdfgpu_pushdown_filter* filters, u32 n, u8* pushed);
   void set_dynamic_filters(u32 node, const rdfgpu_pushdown_filter* filters, u32 n);

@@ -8,9 +8,12 @@
 //   literals (any UTF-8), `.`, `[...]` / `[^...]` with ASCII members and ranges, `( )`, `(?: )`, `(?P<n> )`, `|`,
 //   `* + ? {m} {m,} {m,n}` (+ lazy suffix), escaped punctuation, `\n \r \t \f \v \xHH`, a leading `^` / `\A` and a
 //   trailing `$` / `\z` of a pattern without top-level alternation;
+//   `\d \w \s` and `\D \W \S` (also inside classes) and the word boundaries `\b \B` outside repetitions — with their
+//   ASCII members: on an all-ASCII subject that IS the crate's Unicode class; a subject with a non-ASCII byte raises the
+//   plan's run-time error (RegexProg::ascii_only) instead of being answered without the Unicode tables;
 //   flags: `i` (ASCII letters, incl. the two non-ASCII simple folds K <-> U+212A and s <-> U+017F), `s`, `m`, `x`, `q`.
-// Not supported: `\d \w \s \b` and `\p{..}` (Unicode tables), class set operations, inline flags, non-ASCII class
-// members, non-ASCII letters under `i`, anchors elsewhere, > 64 positions.
+// Not supported: `\p{..}` (Unicode tables), class set operations, inline flags, non-ASCII class members, non-ASCII
+// letters under `i`, anchors elsewhere, `\b` under a repetition, > 64 positions.
 #pragma once
 #include <cstdint>
 #include <cstring>
@@ -31,7 +34,7 @@ struct ByteSet {
   bool has(unsigned b) const { return (w[b >> 6] >> (b & 63)) & 1; }
 };
 
-enum Kind { EMPTY, LEAF, CAT, ALT, STAR, PLUS, OPT, A_START, A_END };
+enum Kind { EMPTY, LEAF, CAT, ALT, STAR, PLUS, OPT, A_START, A_END, A_WORDB, A_NWORDB };
 struct Node {
   Kind kind = EMPTY;
   ByteSet set;
@@ -60,6 +63,7 @@ inline NodeP bytes_seq(const unsigned char* b, size_t n) {
 struct Parser {
   const unsigned char* p; size_t n, i = 0;
   bool f_i = false, f_s = false, f_x = false;
+  bool ascii_only = false;          // a Perl class or a word boundary was used
   std::string err;
   bool fail(const char* m) { if (err.empty()) err = m; return false; }
   bool eof() const { return i >= n; }
@@ -96,6 +100,22 @@ struct Parser {
     if (len == 1) { ByteSet s; s.add(p[at]); return ascii_set_node(s); }
     if (f_i) { fail("non-ASCII literal under the `i` flag"); return nullptr; }
     return bytes_seq(p + at, len);
+  }
+
+  // `\d \w \s` / `\D \W \S` at p[i]: their ASCII members (the crate's Unicode classes restricted to ASCII)
+  bool perl_class(ByteSet& s) {
+    if (eof()) return false;
+    const unsigned e = p[i];
+    ByteSet m;
+    if (e == 'd' || e == 'D') m.add_range('0', '9');
+    else if (e == 'w' || e == 'W') { m.add_range('0', '9'); m.add_range('a', 'z'); m.add_range('A', 'Z'); m.add('_'); }
+    else if (e == 's' || e == 'S') { m.add('\t'); m.add('\n'); m.add('\v'); m.add('\f'); m.add('\r'); m.add(' '); }
+    else return false;
+    i++;
+    ascii_only = true;
+    if (e == 'D' || e == 'W' || e == 'S') { for (unsigned c = 0; c < 0x80; c++) if (!m.has(c)) s.add(c); }
+    else for (unsigned c = 0; c < 0x80; c++) if (m.has(c)) s.add(c);
+    return true;
   }
 
   // escape after '\\': returns a single byte value in `c` (is_byte) or fails
@@ -137,7 +157,10 @@ struct Parser {
       if (c >= 0x80) { fail("non-ASCII class member"); return nullptr; }
       if ((c == '&' || c == '-' || c == '~') && i + 1 < n && p[i + 1] == c && c != '-') { fail("class set operation"); return nullptr; }
       i++;
-      if (c == '\\') { if (!escape_byte(c)) return nullptr; }
+      if (c == '\\') {
+        if (perl_class(s)) continue;        // `[\d_-]`: a class inside the class (no range from / to it)
+        if (!escape_byte(c)) return nullptr;
+      }
       unsigned hi = c;
       if (!eof() && p[i] == '-' && i + 1 < n && p[i + 1] != ']') {   // range
         if (p[i + 1] == '-') { fail("class set operation"); return nullptr; }
@@ -192,6 +215,8 @@ struct Parser {
       i++;
       if (!eof() && p[i] == 'A') { i++; auto a = mk(A_START); a->set.add(1); return a; }   // set bit 1: not affected by `m`
       if (!eof() && p[i] == 'z') { i++; auto a = mk(A_END); a->set.add(1); return a; }
+      if (!eof() && (p[i] == 'b' || p[i] == 'B')) { const bool nb = p[i] == 'B'; i++; ascii_only = true; return mk(nb ? A_NWORDB : A_WORDB); }
+      { ByteSet ps_; if (perl_class(ps_)) return ascii_set_node(ps_); }
       unsigned b;
       if (!escape_byte(b)) return nullptr;
       ByteSet s; s.add(b);
@@ -225,7 +250,7 @@ struct Parser {
       if (eof()) break;
       const unsigned c = p[i];
       if (c != '*' && c != '+' && c != '?' && c != '{') break;
-      if (a->kind == A_START || a->kind == A_END) { fail("repeated anchor"); return nullptr; }
+      if (a->kind == A_START || a->kind == A_END || a->kind == A_WORDB || a->kind == A_NWORDB) { fail("repeated anchor"); return nullptr; }
       if (c == '{') {
         i++;
         unsigned lo = 0, hi = 0; bool open = false;
@@ -274,39 +299,67 @@ struct Parser {
   }
 };
 
-struct Info { bool nullable; uint64_t first, last; };
+// Glushkov sets with word-boundary conditions: index 0 = unconditional, 1 = only across a word boundary (`\b`), 2 = only
+// where there is none (`\B`).  A condition on `first` holds at the point before the position's character, on `last` at the
+// point after it, on `nullable` at the single point of the empty match.
+struct Info { bool nullable[3]; uint64_t first[3], last[3]; };
+inline int both(int a, int b) { return a == 0 ? b : b == 0 ? a : a == b ? a : -1; }   // -1: `\b` and `\B` at one point
 
 struct Builder {
-  RegexProg* out; uint32_t n_pos = 0; bool too_big = false; bool stray_anchor = false;
+  RegexProg* out; uint32_t n_pos = 0; bool too_big = false; bool stray_anchor = false; bool assert_in_loop = false;
+  uint64_t* fol(int c) { return c == 0 ? out->follow : c == 1 ? out->follow_b : out->follow_nb; }
+  void edges(const Info& a, const Info& b) {   // every last of a -> every first of b, conditions combined
+    for (int ca = 0; ca < 3; ca++) for (int cb = 0; cb < 3; cb++) {
+      const int c = both(ca, cb);
+      if (c < 0 || !a.last[ca] || !b.first[cb]) continue;
+      for (uint64_t l = a.last[ca]; l; l &= l - 1) fol(c)[__builtin_ctzll(l)] |= b.first[cb];
+    }
+  }
   Info build(const NodeP& a) {
+    Info z{{false, false, false}, {0, 0, 0}, {0, 0, 0}};
     switch (a->kind) {
-      case EMPTY: return {true, 0, 0};
-      case A_START: case A_END: stray_anchor = true; return {true, 0, 0};
+      case EMPTY: z.nullable[0] = true; return z;
+      case A_START: case A_END: stray_anchor = true; z.nullable[0] = true; return z;
+      case A_WORDB: z.nullable[1] = true; return z;
+      case A_NWORDB: z.nullable[2] = true; return z;
       case LEAF: {
-        if (n_pos >= 64) { too_big = true; return {false, 0, 0}; }
+        if (n_pos >= 64) { too_big = true; return z; }
         const uint32_t id = n_pos++;
         for (unsigned b = 0; b < 256; b++) if (a->set.has(b)) out->byte_mask[b] |= 1ull << id;
-        return {false, 1ull << id, 1ull << id};
+        z.first[0] = z.last[0] = 1ull << id;
+        return z;
       }
       case CAT: {
-        Info acc{true, 0, 0};
+        Info acc = z; acc.nullable[0] = true;
         for (const NodeP& k : a->kids) {
           const Info b = build(k);
-          for (uint64_t l = acc.last; l; l &= l - 1) out->follow[__builtin_ctzll(l)] |= b.first;
-          const Info r{acc.nullable && b.nullable, acc.first | (acc.nullable ? b.first : 0), b.last | (b.nullable ? acc.last : 0)};
+          edges(acc, b);
+          Info r = z;
+          for (int c = 0; c < 3; c++) { r.first[c] = acc.first[c]; r.last[c] = b.last[c]; }
+          for (int ca = 0; ca < 3; ca++) for (int cb = 0; cb < 3; cb++) {
+            const int c = both(ca, cb);
+            if (c < 0) continue;
+            if (acc.nullable[ca]) r.first[c] |= b.first[cb];
+            if (b.nullable[cb]) r.last[c] |= acc.last[ca];
+            if (acc.nullable[ca] && b.nullable[cb]) r.nullable[c] = true;
+          }
           acc = r;
         }
         return acc;
       }
       case ALT: {
-        Info acc{false, 0, 0};
-        for (const NodeP& k : a->kids) { const Info b = build(k); acc.nullable = acc.nullable || b.nullable; acc.first |= b.first; acc.last |= b.last; }
+        Info acc = z;
+        for (const NodeP& k : a->kids) { const Info b = build(k); for (int c = 0; c < 3; c++) { acc.nullable[c] = acc.nullable[c] || b.nullable[c]; acc.first[c] |= b.first[c]; acc.last[c] |= b.last[c]; } }
         return acc;
       }
       default: {   // STAR, PLUS, OPT
-        const Info b = build(a->kids[0]);
-        if (a->kind != OPT) for (uint64_t l = b.last; l; l &= l - 1) out->follow[__builtin_ctzll(l)] |= b.first;
-        return {a->kind == PLUS ? b.nullable : true, b.first, b.last};
+        Info b = build(a->kids[0]);
+        if (a->kind != OPT) {
+          if (b.nullable[1] || b.nullable[2]) assert_in_loop = true;   // (\b|x)*: an iteration that is only an assertion
+          edges(b, b);
+        }
+        if (a->kind != PLUS) b.nullable[0] = true;
+        return b;
       }
     }
   }
@@ -370,7 +423,14 @@ inline RegexStatus regex_compile(const char* pattern, size_t n, const char* flag
   const Info info = b.build(root);
   if (b.stray_anchor) { why = "anchor that is not the first / last element of the pattern"; return REGEX_UNSUPPORTED; }
   if (b.too_big) { why = "more than 64 positions"; return REGEX_UNSUPPORTED; }
-  out.first = info.first; out.last = info.last; out.nullable = info.nullable ? 1 : 0; out.n_pos = b.n_pos;
+  if (b.assert_in_loop) { why = "word boundary under a repetition"; return REGEX_UNSUPPORTED; }
+  out.first = info.first[0]; out.last = info.last[0]; out.nullable = info.nullable[0] ? 1 : 0; out.n_pos = b.n_pos;
+  out.first_b = info.first[1]; out.first_nb = info.first[2]; out.last_b = info.last[1]; out.last_nb = info.last[2];
+  out.nullable_b = info.nullable[1] ? 1 : 0; out.nullable_nb = info.nullable[2] ? 1 : 0;
+  out.ascii_only = ps.ascii_only ? 1 : 0;
+  uint64_t any = out.first_b | out.first_nb | out.last_b | out.last_nb;
+  for (int k = 0; k < 64; k++) any |= out.follow_b[k] | out.follow_nb[k];
+  out.has_assert = (any || out.nullable_b || out.nullable_nb) ? 1 : 0;
   return REGEX_OK;
 }
 

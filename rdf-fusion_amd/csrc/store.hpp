@@ -150,7 +150,7 @@ struct Store {
   void clear();
   void set_typed_values(const rdfgpu_typed_value* v, u64 n_ids, const int64_t* dec, u64 n_dec);
   void set_strings(const u64* offsets, u64 n_ids, const unsigned char* heap_host, u64 heap_bytes);
-  TypedTable typed_table() const { return TypedTable{tv, n_ids, dec, n_dec, str_off, heap, n_str_ids}; }
+  TypedTable typed_table() const { return TypedTable{tv, n_ids, dec, n_dec, str_off, heap, n_str_ids, nullptr}; }
 };
 
 Store* store_create(const rdfgpu_config* cfg);

@@ -192,6 +192,14 @@ def REGEX(e, pattern, flags=""):
     return Expr(e.nodes + [(abi.EX_REGEX, 0, 0, (enc(pattern), enc(flags), abi.EX_REGEX), 0, 0)])
 
 
+def REGEX_VAR(e, pattern_expr, patterns, flags=""):
+    """REGEX(value, ?pattern[, "flags"]) with a per-row pattern (regex.rs:59-76): `pattern_expr` = ENC_TV of the pattern column,
+    `patterns` = {object id: pattern text} of every distinct pattern literal that can occur (the host's dictionary knows them)."""
+    enc = lambda x: x.encode("utf-8") if isinstance(x, str) else bytes(x)
+    table = tuple((int(pid), enc(txt)) for pid, txt in sorted(patterns.items()))
+    return Expr(e.nodes + pattern_expr.nodes + [(abi.EX_REGEX_VAR, 0, 0, ("var", table, enc(flags)), 0, 0)])
+
+
 def _string_fn(op):
     def f(e, needle, language_id=0):
         """<fn>(value, "constant"[@lang]) — contains.rs / str_starts.rs / str_ends.rs; language_id = the constant's
@@ -247,8 +255,8 @@ class PlanDescription:
         self._nodes = (abi.PlanNode * max(1, len(nodes)))(*nodes)
         self._exprs = (abi.ExprNode * max(1, len(exprs)))(*exprs)
         self._pool = (C.c_uint32 * max(1, len(pool)))(*pool)
-        self._regex_bytes = [(bytes(p), bytes(f)) for p, f in regexes]      # keeps the char buffers alive
-        self._regexes = (abi.Regex * max(1, len(regexes)))(*[abi.Regex(p, f, len(p), len(f)) for p, f in self._regex_bytes])
+        self._regex_bytes = [(bytes(r[0]), bytes(r[1]), int(r[2]) if len(r) > 2 else 0) for r in regexes]      # keeps the char buffers alive
+        self._regexes = (abi.Regex * max(1, len(regexes)))(*[abi.Regex(p, f, len(p), len(f), pid, 0) for p, f, pid in self._regex_bytes])
         self.desc = abi.PlanDesc(self._nodes, len(nodes), root, self._exprs, len(exprs), self._pool,
                                  len(pool), 0, self._regexes, len(regexes), 0)
         self.root = root
@@ -295,7 +303,14 @@ class PlanBuilder:
             return
         node.expr_off, node.expr_len = len(self.exprs), len(e.nodes)
         for (op, tag, flags, u, lo, hi) in e.nodes:
-            if op in (abi.EX_REGEX, abi.EX_CONTAINS, abi.EX_STRSTARTS, abi.EX_STRENDS, abi.EX_LANG_IN):
+            if op == abi.EX_REGEX_VAR:
+                # one regex entry per announced pattern, contiguous: u = first entry, lo = count
+                _, table, fl = u
+                u, lo = len(self.regexes), len(table)
+                for pid, txt in table:
+                    self._regex_keys.append(("var", pid, txt, fl))
+                    self.regexes.append((txt, fl, pid))
+            elif op in (abi.EX_REGEX, abi.EX_CONTAINS, abi.EX_STRSTARTS, abi.EX_STRENDS, abi.EX_LANG_IN):
                 # u carries (pattern, flags, op): register the plan constant (one entry per function), keep its index
                 if u not in self._regex_keys:
                     self._regex_keys.append(u)

@@ -133,8 +133,10 @@ def _lit(ch):
     return ("\\" + ch) if ch in _META else ch
 
 
-def random_regex(rng, depth=0):
-    """Returns (pattern, flags, python_pattern, python_flags)."""
+def random_regex(rng, depth=0, perl=False):
+    """Returns (pattern, flags, python_pattern, python_flags).  `perl`: also draw `\\d \\w \\s \\D \\W \\S` (alone and inside
+    classes) and `\\b \\B` — restated / compiled with their ASCII members, so pair them with all-ASCII subjects
+    (python_flags then carries re.ASCII)."""
     import re
     flags = "".join(f for f in "ismx" if rng.random() < 0.25)
     # non-ASCII letters under `i` need the Unicode case-folding tables: outside the restated / supported subset
@@ -142,6 +144,16 @@ def random_regex(rng, depth=0):
 
     def atom(d):
         r = rng.random()
+        if perl and r < 0.25:
+            k = int(rng.integers(0, 10))
+            if k < 6:
+                c = ["\\d", "\\w", "\\s", "\\D", "\\W", "\\S"][k]
+                return c, c
+            if k < 8:
+                c = "[" + ("^" if rng.random() < 0.3 else "") + "".join(m for m in ["\\d", "\\s", "\\w", "x", "\\."] if rng.random() < 0.4) + "a]"
+                return c, c
+            c = "\\b" if k == 8 else "\\B"
+            return c + "a", c + "a"              # a repetition operator never lands on the assertion itself
         if r < 0.45:
             ch = letters[int(rng.integers(0, len(letters)))]
             if ch == "\n":
@@ -189,13 +201,15 @@ def random_regex(rng, depth=0):
 
     top_alt = rng.random() < 0.2
     pat, py = alt(depth) if top_alt else cat(depth)
+    if perl and not top_alt and rng.random() < 0.3:
+        pat, py = pat + "\\b", py + "\\b"
     if not top_alt:                       # anchors only around a pattern without top-level alternation
         multiline = "m" in flags
         if rng.random() < 0.3:
             pat, py = "^" + pat, "^" + py
         if rng.random() < 0.3:
             pat, py = pat + "$", py + ("$" if multiline else "\\Z")   # Python's bare $ also matches before a final \n
-    py_flags = 0
+    py_flags = re.ASCII if perl else 0
     for f, v in (("i", re.I), ("s", re.S), ("m", re.M), ("x", re.X)):
         if f in flags:
             py_flags |= v
@@ -207,9 +221,13 @@ def regex_needs_unicode_fold_care(pattern, flags):
     return "i" in flags and "[^" in pattern
 
 
-def random_subject(rng):
+ASCII_ALPHABET = [c for c in REGEX_ALPHABET if ord(c) < 0x80] + ["_", "7", "\t", "-"]
+
+
+def random_subject(rng, ascii_only=False):
     n = int(rng.integers(0, 9))
-    return "".join(REGEX_ALPHABET[int(rng.integers(0, len(REGEX_ALPHABET)))] for _ in range(n))
+    alphabet = ASCII_ALPHABET if ascii_only else REGEX_ALPHABET
+    return "".join(alphabet[int(rng.integers(0, len(alphabet)))] for _ in range(n))
 
 
 def string_dictionary(strings, n_other=5, lang_every=5, lang_id=7):

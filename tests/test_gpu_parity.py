@@ -12,7 +12,7 @@ from rdf_fusion_amd.engine import TV_DTYPE
 from rdf_fusion_amd.plan import (PlanBuilder, MemIndexScanInstruction as I, MemIndexScanPredicate as P,
                                  quad_pattern, col, lit_id, lit_tv, lit_bool, integer, int32, double, float32,
                                  decimal, boolean, ENC_TV, GT, LT, GEQ, LEQ, EQ, NEQ, ADD, SUB, EBV, ID_EQ,
-                                 ID_NEQ, AND, OR, NOT, IS_COMPATIBLE, BOUND, BOOLEAN_AS_TERM, REGEX, CONTAINS, STRSTARTS, STRENDS)
+                                 ID_NEQ, AND, OR, NOT, IS_COMPATIBLE, BOUND, BOOLEAN_AS_TERM, REGEX, REGEX_VAR, CONTAINS, STRSTARTS, STRENDS)
 from oracle import oracle as orc
 import kat_util as ku
 
@@ -735,6 +735,137 @@ def test_string_functions_match_oracle(torch_cuda):
         gs.plan(pb.build(pb.filter(pb.table(0, 2), EBV(CONTAINS(ENC_TV(col(0)), "y" * 65)))))
 
 
+def test_regex_perl_classes_and_word_boundaries(torch_cuda):
+    """`\\d \\w \\s \\D \\W \\S` (alone and inside classes) and `\\b \\B`: device automaton vs the oracle's Pike VM and vs
+    Python's `re` (re.ASCII) over an all-ASCII dictionary — both the per-term verdict table and the per-row VM."""
+    import re
+    rng = np.random.default_rng(123)
+    strings = [ku.random_subject(rng, ascii_only=True) for _ in range(1500)] + ["", "a", "foo", "a foo b", "afoo", "ab12", "GraduateStudent42 x"]
+    tv, offsets, heap = string_dictionary(strings)
+    gs, os_ = both_stores((np.zeros(0, np.uint32),) * 4, typed=tv)
+    gs.set_strings(offsets, heap)
+    os_.set_strings(offsets, heap)
+    ids = rng.integers(0, len(tv), 20_000).astype(np.uint32)
+    payload = np.arange(len(ids), dtype=np.uint32) + 1
+    keep, ptrs = table_on_device(torch_cuda, [ids, payload])
+    is_str = (ids >= 1) & (ids <= len(strings))
+    cases = [("\\d+", "", "\\d+", re.A), ("^\\w+$", "", "^\\w+\\Z", re.A), ("\\bfoo\\b", "", "\\bfoo\\b", re.A), ("\\Bfoo", "", "\\Bfoo", re.A),
+             ("[\\d\\s]x", "", "[\\d\\s]x", re.A), ("grad\\w*\\d{2}\\b", "i", "grad\\w*\\d{2}\\b", re.A | re.I), ("\\S\\s\\S", "", "\\S\\s\\S", re.A)]
+    while len(cases) < 130:
+        pat, flags, py, py_flags = ku.random_regex(rng, perl=True)
+        try:
+            rf.engine.regex_check(pat, flags)
+            rx = re.compile(py, py_flags)
+        except (rf.engine.RdfGpuError, re.error):
+            continue
+        cases.append((pat, flags, py, py_flags))
+    matched_some = 0
+    for k, (pat, flags, py, py_flags) in enumerate(cases):
+        pb = PlanBuilder()
+        desc = pb.build(pb.filter(pb.table(0, 2), EBV(REGEX(ENC_TV(col(0)), pat, flags)), projection=[1]))
+        plan, got = run_both(gs, os_, desc, gpu_tables=[(ptrs, len(ids))], cpu_tables=[[ids, payload]])
+        matched_some += plan.result_info()[0] > 0
+        rx = re.compile(py, py_flags)
+        if "\\B" not in pat:              # Python (< 3.14) never matches \B against the empty string
+            exp = np.array([bool(is_str[r]) and rx.search(strings[ids[r] - 1]) is not None for r in range(len(ids))])
+            np.testing.assert_array_equal(np.sort(got[0]), payload[exp], err_msg=repr((pat, flags)))
+        if k % 4 == 0:                    # the per-row VM path gives the same rows as the verdict table
+            p2 = gs.plan(desc).set_option("NO_STRING_VERDICTS"); p2.bind_table(0, ptrs, len(ids))
+            np.testing.assert_array_equal(np.sort(p2.execute().fetch()[0]), np.sort(got[0]))
+    assert matched_some > 60
+
+
+def test_regex_perl_class_over_non_ascii_subject_is_a_loud_error(torch_cuda):
+    """`\\d \\w \\s \\b` are compiled with their ASCII members (the crate's Unicode tables are not restated): a row whose
+    subject holds a non-ASCII character is refused at run time — never answered from the ASCII approximation; rows
+    that do not touch such a string are answered, and patterns without those classes stay exact on any subject."""
+    strings = ["abc 12", "caf\u00e9 12", "x"]
+    tv, offsets, heap = string_dictionary(strings, lang_every=100)
+    gs, os_ = both_stores((np.zeros(0, np.uint32),) * 4, typed=tv)
+    gs.set_strings(offsets, heap)
+    os_.set_strings(offsets, heap)
+    for option in (None, "NO_STRING_VERDICTS"):
+        for pat in ("\\d+", "\\bcaf", "[\\s]1"):
+            pb = PlanBuilder()
+            desc = pb.build(pb.filter(pb.table(0, 1), EBV(REGEX(ENC_TV(col(0)), pat, ""))))
+            ascii_rows = np.array([1, 3, 1, 0, 4], np.uint32)
+            keep, ptrs = table_on_device(torch_cuda, [ascii_rows])
+            plan = gs.plan(desc)
+            if option:
+                plan.set_option(option)
+            plan.bind_table(0, ptrs, len(ascii_rows))
+            got = plan.execute().fetch()
+            exp, n_exp, _ = os_.execute(desc, [[ascii_rows]])
+            np.testing.assert_array_equal(ku.multiset(got, plan.result_info()[0]), ku.multiset(exp, n_exp))
+            rows = np.array([1, 2, 3], np.uint32)
+            keep2, ptrs2 = table_on_device(torch_cuda, [rows])
+            plan.bind_table(0, ptrs2, len(rows))
+            with pytest.raises(rf.RdfGpuError, match="Unicode"):
+                plan.execute()
+            with pytest.raises(Exception, match="Unicode"):
+                os_.execute(desc, [[rows]])
+            plan.bind_table(0, ptrs, len(ascii_rows))          # the plan stays usable after the refusal
+            np.testing.assert_array_equal(ku.multiset(plan.execute().fetch(), n_exp), ku.multiset(exp, n_exp))
+        pb = PlanBuilder()
+        desc = pb.build(pb.filter(pb.table(0, 1), EBV(REGEX(ENC_TV(col(0)), "caf.", ""))))
+        rows = np.array([1, 2, 3], np.uint32)
+        keep2, ptrs2 = table_on_device(torch_cuda, [rows])
+        plan, got = run_both(gs, os_, desc, gpu_tables=[(ptrs2, 3)], cpu_tables=[[rows]])
+        assert got[0].tolist() == [2]
+
+
+def test_regex_variable_pattern_rq(torch_cuda):
+    """testsuite/oxigraph-tests/sparql/regex_variable.rq as written: `VALUES (?l ?r) { ("a" "^a$") ("b" "^a$") }
+    FILTER(REGEX(?l, ?r))` -> one solution, ?l = "a" (regex_variable.srx).  The pattern is a per-row value
+    (regex.rs:59-76): the host announces the distinct pattern literals, the row picks its program by object id."""
+    strings = ["a", "b", "^a$"]
+    tv, offsets, heap = string_dictionary(strings, lang_every=100)
+    gs, os_ = both_stores((np.zeros(0, np.uint32),) * 4, typed=tv)
+    gs.set_strings(offsets, heap)
+    os_.set_strings(offsets, heap)
+    l = np.array([1, 2], np.uint32); r = np.array([3, 3], np.uint32)
+    keep, ptrs = table_on_device(torch_cuda, [l, r])
+    pb = PlanBuilder()
+    desc = pb.build(pb.filter(pb.table(0, 2), EBV(REGEX_VAR(ENC_TV(col(0)), ENC_TV(col(1)), {3: "^a$"})), projection=[0]))
+    plan, got = run_both(gs, os_, desc, gpu_tables=[(ptrs, 2)], cpu_tables=[[l, r]])
+    assert got[0].tolist() == [1]                    # ?l = "a"
+
+
+def test_regex_variable_patterns_match_oracle(torch_cuda):
+    """Many distinct per-row patterns (incl. an invalid-flag program, a language-tagged "pattern" = error value, nulls and
+    non-strings); a pattern id the host did not announce is a loud run-time error, not a non-match."""
+    rng = np.random.default_rng(5)
+    patterns = ["^a", "b$", "a.c", "(ab|cd)+", "\\d", "^\\w+$", "x{2,}", "k", "[^a]b", "\\bfoo\\b"]
+    subjects = [ku.random_subject(rng, ascii_only=True) for _ in range(600)] + ["", "foo", "abc", "xx7"]
+    strings = subjects + patterns
+    tv, offsets, heap = string_dictionary(strings, lang_every=97)       # some subjects and one pattern carry a language tag
+    first_pat = 1 + len(subjects)
+    table = {first_pat + k: p for k, p in enumerate(patterns)}
+    gs, os_ = both_stores((np.zeros(0, np.uint32),) * 4, typed=tv)
+    gs.set_strings(offsets, heap)
+    os_.set_strings(offsets, heap)
+    n = 30_000
+    val = rng.integers(0, len(tv), n).astype(np.uint32)
+    pat = rng.integers(first_pat, first_pat + len(patterns), n).astype(np.uint32)
+    pat[rng.random(n) < 0.02] = 0                                       # unbound pattern
+    pat[rng.random(n) < 0.02] = len(tv) - 1                             # a non-string "pattern": the error value
+    payload = np.arange(n, dtype=np.uint32) + 1
+    keep, ptrs = table_on_device(torch_cuda, [val, pat, payload])
+    for flags in ("", "i", "s"):
+        for negate in (False, True):
+            e = EBV(REGEX_VAR(ENC_TV(col(0)), ENC_TV(col(1)), table, flags))
+            pb = PlanBuilder()
+            desc = pb.build(pb.filter(pb.table(0, 3), NOT(e) if negate else e, projection=[2]))
+            plan, got = run_both(gs, os_, desc, gpu_tables=[(ptrs, n)], cpu_tables=[[val, pat, payload]])
+            assert 0 < plan.result_info()[0] < n
+    partial = dict(list(table.items())[:-1])
+    pb = PlanBuilder()
+    desc = pb.build(pb.filter(pb.table(0, 3), EBV(REGEX_VAR(ENC_TV(col(0)), ENC_TV(col(1)), partial)), projection=[2]))
+    plan = gs.plan(desc); plan.bind_table(0, ptrs, n)
+    with pytest.raises(rf.RdfGpuError, match="announce"):
+        plan.execute()
+
+
 def test_regex_unsupported_is_refused_loudly(torch_cuda):
     tv, offsets, heap = string_dictionary(["abc"])
     gs, _ = both_stores((np.zeros(0, np.uint32),) * 4, typed=tv)
@@ -744,7 +875,7 @@ def test_regex_unsupported_is_refused_loudly(torch_cuda):
         gs.plan(desc)
     gs.set_strings(offsets, heap)
     gs.plan(desc)
-    for bad in ("\\d+", "(?i)a", "a|^b", "[é]"):
+    for bad in ("\\p{L}", "(?i)a", "a|^b", "[é]"):
         pb = PlanBuilder()
         with pytest.raises(rf.RdfGpuError):
             gs.plan(pb.build(pb.filter(pb.table(0, 1), EBV(REGEX(ENC_TV(col(0)), bad, "")))))

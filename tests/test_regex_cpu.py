@@ -26,6 +26,14 @@ KATS = [  # (pattern, flags, subject, expected)   None = the SPARQL error value
     ("(a|b)*c|d", "", "bbac", True), ("(a*)*b", "", "aaab", True), ("(a*)*b", "", "aaac", False), ("a|", "", "zzz", True),
     ("\\Aab\\z", "m", "ab", True), ("\\Aab\\z", "m", "x\nab", False), ("a\\.b", "", "a.b", True), ("a\\.b", "", "axb", False),
     ("(?P<n>ab)c", "", "zabc", True), ("a+?b", "", "aaab", True), ("\\x41", "", "A", True),
+    # Perl classes and word boundaries (ASCII members; exact on all-ASCII subjects)
+    ("\\d+", "", "ab12", True), ("\\d+", "", "abc", False), ("^\\w+$", "", "ab_1Z", True), ("^\\w+$", "", "ab-1", False),
+    ("\\s", "", "a\tb", True), ("\\s", "", "ab", False), ("\\D", "", "12", False), ("\\W", "", "a_b", False), ("\\W", "", "a b", True),
+    ("^\\S+$", "", "a\x0bb", False), ("[\\d\\s]x", "", " x", True), ("[^\\d]x", "", "1x", False), ("[^\\d]x", "", "ax", True),
+    ("\\bfoo\\b", "", "a foo b", True), ("\\bfoo\\b", "", "afoo", False), ("\\bfoo\\b", "", "foo", True), ("\\Bfoo", "", "afoo", True),
+    ("\\Bfoo", "", "foo", False), ("\\B", "", "", True), ("\\b", "", "", False), ("\\b", "", "a", True), ("a\\b|\\Bb", "", "ab", True), ("a\\b|\\Bb", "", "a-b", True), ("a\\B|\\Bb", "", "a-b", False),
+    ("(\\b|x)+a", "", "-a", True), ("\\w\\b\\w", "", "ab", False), ("^\\b", "", " a", False), ("\\b$", "", "a ", False), ("\\d", "i", "5", True),
+    ("grad\\w*\\d{2}\\b", "i", "GraduateStudent42 x", True),
 ]
 
 
@@ -50,11 +58,48 @@ def test_oracle_regex_agrees_with_python_re():
     assert checked > 15_000
 
 
+def test_oracle_perl_classes_agree_with_python_re():
+    """`\\d \\w \\s \\b` and their negations against Python's `re` with re.ASCII over all-ASCII subjects."""
+    rng = np.random.default_rng(77)
+    checked = 0
+    for _ in range(4000):
+        pat, flags, py, py_flags = ku.random_regex(rng, perl=True)
+        try:
+            rx = re.compile(py, py_flags)
+        except re.error:
+            continue
+        for _ in range(6):
+            s = ku.random_subject(rng, ascii_only=True)
+            if s == "" and "\\B" in pat:
+                continue                      # Python (< 3.14) never matches \B against the empty string; the regex crate does
+            assert orc.regex_is_match(pat, flags, s) == (rx.search(s) is not None), (pat, flags, s)
+            checked += 1
+    assert checked > 15_000
+
+
+def test_oracle_perl_classes_refuse_non_ascii_subjects():
+    for pat in ("\\d", "\\w+", "a\\b", "[\\s]"):
+        with pytest.raises(orc.NeedsUnicodeTables):
+            orc.regex_is_match(pat, "", "caf\u00e9 1")
+        assert orc.regex_is_match(pat, "", "cafe 1a") in (True, False)
+    assert orc.regex_is_match("é", "", "café") is True          # no Perl class: non-ASCII subjects stay exact
+
+
 def test_device_compiler_accepts_the_subset_and_refuses_the_rest():
     for pattern, flags, _, expected in KATS:
         if expected is None and flags != "z":
             continue
+        if pattern == "(\\b|x)+a":
+            with pytest.raises(engine.RdfGpuError, match="word boundary under a repetition"):
+                engine.regex_check(pattern, flags)       # a loop whose body can be just the assertion: outside the device subset
+            continue
         assert engine.regex_check(pattern, flags) >= 0
+    for _ in range(2000):
+        pat, flags, _, _ = ku.random_regex(np.random.default_rng(_), perl=True)
+        try:
+            assert 0 <= engine.regex_check(pat, flags) <= 64
+        except engine.RdfGpuError as e:
+            assert "64 positions" in str(e) or "word boundary under a repetition" in str(e) or ku.regex_needs_unicode_fold_care(pat, flags), (pat, flags, str(e))
     assert engine.regex_check("a", "z") == 0                     # invalid flag: a program that only yields the error value
     rng = np.random.default_rng(7)
     n_ok = 0
@@ -66,7 +111,7 @@ def test_device_compiler_accepts_the_subset_and_refuses_the_rest():
         except engine.RdfGpuError as e:
             assert "64 positions" in str(e) or ku.regex_needs_unicode_fold_care(pat, flags), (pat, flags, str(e))
     assert n_ok > 2000
-    for bad in ("\\d+", "\\w", "\\bfoo", "\\p{L}", "[[:alpha:]]", "[a&&b]", "(?i)a", "a|^b", "x^", "[é]", "a{", "*a", "(", "a)", "\\"):
+    for bad in ("\\p{L}", "\\pL", "[\\b]", "\\b*", "\\b+a", "\\<a", "[[:alpha:]]", "[a&&b]", "(?i)a", "a|^b", "x^", "[é]", "a{", "*a", "(", "a)", "\\"):
         with pytest.raises(engine.RdfGpuError):
             engine.regex_check(bad, "")
     with pytest.raises(engine.RdfGpuError):
