@@ -1,7 +1,7 @@
 """Turns rocprofv3 output directories into the small per-kernel summaries committed next to this file.
 
   python profiles/summarize.py stats <dir with *_kernel_stats.csv> <out.csv>
-  python profiles/summarize.py pmc   <fetch dir> <write dir> <out.json>
+  python profiles/summarize.py pmc   <fetch dir> <write dir> <out.json> [key=value ...]   (key=value -> "_workload", what bench.py matches on)
   python profiles/summarize.py counters <out.json> <kernel substring> <dir> [<dir> ...]
 
 The pmc form reads *_counter_collection.csv of two separate passes (FETCH_SIZE and WRITE_SIZE cannot share a
@@ -18,7 +18,7 @@ import statistics
 import sys
 from collections import defaultdict
 
-STREAMING = ("filter_kernel", "scan_count_kernel", "scan_write_kernel")   # 16-B-per-lane coalesced readers
+STREAMING = ("filter_kernel", "filter_bits_kernel", "filter_write_kernel", "scan_count_kernel", "scan_write_kernel")   # 16-B-per-lane coalesced readers
 
 
 def short(name):
@@ -60,6 +60,8 @@ def main():
         res[k] = {"dispatches": len(f), "FETCH_SIZE_KB_median": statistics.median(f), "FETCH_SIZE_KB_max": max(f),
                   "WRITE_SIZE_KB_median": statistics.median(w), "WRITE_SIZE_KB_max": max(w), "fetch_factor": factor,
                   "hbm_bytes_per_launch": int(1024 * (factor * statistics.median(f) + statistics.median(w)))}
+    if len(sys.argv) > 5:
+        res["_workload"] = {kv.split("=", 1)[0]: (int(kv.split("=", 1)[1]) if kv.split("=", 1)[1].lstrip("-").isdigit() else kv.split("=", 1)[1]) for kv in sys.argv[5:]}
     json.dump(res, open(sys.argv[4], "w"), indent=1, sort_keys=True)
 
 

@@ -47,6 +47,7 @@ __global__ __launch_bounds__(64) void locate_kernel(const LocateJob* jobs, u32 n
   if (j >= n_jobs) return;
   const LocateJob job = jobs[j];
   u64 lo = 0, hi = job.n;
+  u32 sorted_level = 0;                // the first level not pinned to one id: sorted within [lo, hi)
   for (u32 k = 0; k < job.n_levels && lo < hi; k++) {
     const u32* c = job.col[k];
     const u32 from = job.from[k], to = job.to[k];
@@ -54,9 +55,15 @@ __global__ __launch_bounds__(64) void locate_kernel(const LocateJob* jobs, u32 n
     const u64 nhi = wave_partition_point<true>(c, nlo, hi, to);     // upper_bound(to)
     lo = nlo; hi = nhi;
     if (from != to) break;            // below a proper range the inner levels are not contiguous (:240)
+    sorted_level = k + 1;
   }
   if (lo > hi) lo = hi;
-  if (threadIdx.x == 0) { lo_hi[2 * j] = lo; lo_hi[2 * j + 1] = hi; }
+  if (threadIdx.x == 0) {
+    lo_hi[kLocateWords * j] = lo; lo_hi[kLocateWords * j + 1] = hi;
+    const bool any = lo < hi && sorted_level < 4;
+    lo_hi[kLocateWords * j + 2] = ((u64)(any ? sorted_level : 4u) << 32) | (any ? job.col[sorted_level][lo] : 0u);
+    lo_hi[kLocateWords * j + 3] = any ? job.col[sorted_level][hi - 1] : 0u;
+  }
 }
 void launch_locate(const LocateJob* jobs_dev, u32 n_jobs, u64* lo_hi_dev, hipStream_t s) {
   if (!n_jobs) return;
@@ -300,6 +307,11 @@ __device__ __forceinline__ bool stream_pred(const FilterStreamArgs& a, u32 v) {
     if (verdict == 3 && a.tt.rt_error) atomicOr(a.tt.rt_error, 1u);
     return verdict == 1;
   }
+  else if constexpr (SHAPE == 4) {   // the comparison was answered once per id of the sorted slice's id range: one bit per id
+    const u32 d = v - a.id_lit;
+    if ((u64)d >= a.n_verdict) return false;
+    return (reinterpret_cast<const u32*>(a.verdict)[d >> 5] >> (d & 31u)) & 1u;
+  }
   else if constexpr (SHAPE == 1) { if (v == 0 || a.id_lit == 0) return false; return (v == a.id_lit) == (a.is_eq != 0); }
   else {
     const Val x = enc_tv(a.tt, v);
@@ -404,6 +416,91 @@ __global__ __launch_bounds__(kBlock) void filter_bits_kernel(const FilterStreamA
   __syncthreads();
   if (threadIdx.x == 0) a.tile_count[blockIdx.x] = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
 }
+// A BGP scan hands FILTER a slice that is sorted by the predicate's column (GPOS: the objects of one predicate): the ids
+// it can hold are [first, last] of that column, usually far fewer than its rows.  The typed comparison (any kinds: the
+// full promotion / decimal / string path of stream_pred<2>) runs ONCE per id; the streaming pass then tests one bit per
+// row — a 4-byte load that neighbouring lanes share instead of a 16-byte typed-value gather and 64 live VGPRs per lane.
+__global__ __launch_bounds__(256) void value_verdict_kernel(const FilterStreamArgs a, u32 first, u64 span, u32* words) {
+  const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool p = i < span && stream_pred<2>(a, first + (u32)i);
+  const u64 m = __ballot(p);
+  if ((threadIdx.x & 63) == 0) { words[(i >> 6) * 2] = (u32)m; words[(i >> 6) * 2 + 1] = (u32)(m >> 32); }
+}
+// When the ids of the sorted column are FEW next to the rows (a numeric property: thousands of distinct literals under
+// millions of triples), the rows of one id are one long run and FILTER is a copy of the qualifying runs — the predicate
+// column is never streamed: one wave per id answers the comparison and finds its run (two 65-ary searches), one
+// workgroup compacts the qualifying runs and scans their lengths, and the copy moves 4 bytes in + 4 bytes out per
+// SURVIVING row and column (8 sigma N instead of 8 N + 4 sigma N).  Output order = index order, as in the streaming form.
+__global__ __launch_bounds__(256) void value_runs_kernel(const FilterStreamArgs a, u32 first, u32 span, u64 n, u32* run_lo, u32* run_cnt) {
+  const u32 i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= span) return;                                   // wave-uniform
+  const u32 v = first + i;
+  u32 lo = 0, cnt = 0;
+  if (stream_pred<2>(a, v)) {                              // the same answer in every lane
+    const u64 l = wave_partition_point<false>(a.pcol, 0, n, v);
+    const u64 h = wave_partition_point<true>(a.pcol, l, n, v);
+    lo = (u32)l; cnt = (u32)(h - l);
+  }
+  if ((threadIdx.x & 63) == 0) { run_lo[i] = lo; run_cnt[i] = cnt; }
+}
+// one workgroup: qualifying runs compacted in id order, exclusive scan of their lengths (span <= kRunCopyMaxIds)
+__global__ __launch_bounds__(1024) void run_scan_kernel(const u32* run_lo, const u32* run_cnt, u32 span, u32 first,
+                                                         u32* c_lo, u32* c_off, u32* c_val, u32* n_runs, u64* n_out) {
+  __shared__ u32 w_rows[16], w_runs[16];
+  const u32 per = (span + 1023) / 1024;
+  const u32 i0 = threadIdx.x * per, i1 = i0 + per < span ? i0 + per : span;
+  u32 rows = 0, runs = 0;
+  for (u32 i = i0; i < i1; i++) { const u32 c = run_cnt[i]; rows += c; runs += c != 0; }
+  u32 inc_rows = rows, inc_runs = runs;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const u32 t = __shfl_up(inc_rows, d, 64), u = __shfl_up(inc_runs, d, 64);
+    if (lane >= d) { inc_rows += t; inc_runs += u; }
+  }
+  if (lane == 63) { w_rows[wave] = inc_rows; w_runs[wave] = inc_runs; }
+  __syncthreads();
+  u32 base_rows = 0, base_runs = 0;
+  for (int w = 0; w < wave; w++) { base_rows += w_rows[w]; base_runs += w_runs[w]; }
+  u32 off = base_rows + inc_rows - rows, k = base_runs + inc_runs - runs;
+  for (u32 i = i0; i < i1; i++) {
+    const u32 c = run_cnt[i];
+    if (c) { c_lo[k] = run_lo[i]; c_off[k] = off; c_val[k] = first + i; k++; off += c; }
+  }
+  if (threadIdx.x == 1023) { c_off[k] = off; *n_runs = k; *n_out = off; }
+}
+constexpr u32 kRunChunk = 4096;
+__global__ __launch_bounds__(256) void run_copy_kernel(const u32* c_lo, const u32* c_off, const u32* c_val, const u32* n_runs,
+                                                        const u32* pcol, const u32* proj0, const u32* proj1, u32* out0, u32* out1, u32 n_out_cols) {
+  const u32 R = *n_runs;
+  const u32 total = c_off[R];
+  const u64 P0 = (u64)blockIdx.x * kRunChunk;
+  if (P0 >= total) return;
+  const u32 P1 = (u32)(P0 + kRunChunk < total ? P0 + kRunChunk : total);
+  u32 k = (u32)wave_partition_point<true>(c_off, 0, R, (u32)P0) - 1;     // the run that holds output row P0 (runs are non-empty)
+  while (true) {
+    const u32 off = c_off[k], nxt = c_off[k + 1];
+    const u32 seg0 = off > (u32)P0 ? off : (u32)P0, seg1 = nxt < P1 ? nxt : P1;
+    const u32 src = c_lo[k] + (seg0 - off);
+    for (u32 c = 0; c < n_out_cols; c++) {
+      const u32* in = c == 0 ? proj0 : proj1;
+      u32* out = c == 0 ? out0 : out1;
+      if (in == pcol) {                                     // the sorted column itself: one id per run
+        const u32 v = c_val[k];
+        for (u32 p = seg0 + threadIdx.x; p < seg1; p += 256) out[p] = v;
+      } else {
+        u32 p = seg0 + threadIdx.x;
+        for (; p + 768 < seg1; p += 1024) {                 // four loads in flight per lane
+          const u32 v0 = in[src + (p - seg0)], v1 = in[src + (p - seg0) + 256], v2 = in[src + (p - seg0) + 512], v3 = in[src + (p - seg0) + 768];
+          out[p] = v0; out[p + 256] = v1; out[p + 512] = v2; out[p + 768] = v3;
+        }
+        for (; p < seg1; p += 256) out[p] = in[src + (p - seg0)];
+      }
+    }
+    if (nxt >= P1) break;
+    k++;
+  }
+}
 template <int NOUT>
 __global__ __launch_bounds__(kBlock) void filter_write_kernel(const FilterStreamArgs a) {
   __shared__ u32 rcnt[kStreamRounds][kBlock / 64];
@@ -498,14 +595,35 @@ static FilterStreamArgs stream_args(const FilterArgs& a0, int shape) {
   f.tt = a.tt; f.verdict = a.verdict; f.n_verdict = a.n_verdict;
   f.bits = a.stream_bits; f.tile_count = a.stream_counts; f.tile_off = a.stream_offs;
   if (shape == 1) { f.id_lit = a.prog.nodes[1].u; f.is_eq = a.prog.nodes[2].op == RDFGPU_EX_ID_EQ; }
-  if (shape == 2) { f.lit = a.prog.nodes[2]; f.op = a.prog.nodes[3].op; }
+  if (shape == 2 || shape == 4) { f.lit = a.prog.nodes[2]; f.op = a.prog.nodes[3].op; }
+  if (shape == 4) { f.verdict = reinterpret_cast<const unsigned char*>(a.value_bits); f.n_verdict = a.value_span; f.id_lit = a.value_min; }
   return f;
+}
+void launch_value_runs(const FilterArgs& a, const RunCopyBuffers& b, hipStream_t s) {
+  const FilterStreamArgs f = stream_args(a, 2);
+  const u32 span = (u32)a.value_span;
+  hipLaunchKernelGGL(value_runs_kernel, dim3((span + 3) / 4), dim3(256), 0, s, f, a.value_min, span, a.n_in_cap, b.run_lo, b.run_cnt);
+}
+void launch_run_scan(const FilterArgs& a, const RunCopyBuffers& b, hipStream_t s) {
+  hipLaunchKernelGGL(run_scan_kernel, dim3(1), dim3(1024), 0, s, b.run_lo, b.run_cnt, (u32)a.value_span, a.value_min, b.c_lo, b.c_off, b.c_val, b.n_runs, a.n_out_dev);
+}
+void launch_run_copy(const FilterArgs& a, const RunCopyBuffers& b, hipStream_t s) {
+  if (!a.n_out_cols) return;
+  const u32* pcol = a.in[a.prog.nodes[0].u];
+  hipLaunchKernelGGL(run_copy_kernel, dim3((unsigned)((a.n_in_cap + kRunChunk - 1) / kRunChunk)), dim3(256), 0, s, b.c_lo, b.c_off, b.c_val, b.n_runs,
+                     pcol, a.in[a.proj[0]], a.n_out_cols > 1 ? a.in[a.proj[1]] : nullptr, a.out[0], a.n_out_cols > 1 ? a.out[1] : nullptr, a.n_out_cols);
+}
+void launch_value_verdicts(const FilterArgs& a, hipStream_t s) {
+  if (!a.value_span) return;
+  const FilterStreamArgs f = stream_args(a, 2);
+  hipLaunchKernelGGL(value_verdict_kernel, dim3((unsigned)((a.value_span + 255) / 256)), dim3(256), 0, s, f, a.value_min, a.value_span, const_cast<u32*>(a.value_bits));
 }
 void launch_filter_bits(const FilterArgs& a, int shape, hipStream_t s) {     // pass 1 of the streaming form
   const FilterStreamArgs f = stream_args(a, shape);
   const dim3 sg((unsigned)filter_stream_tiles(a));
   if (shape == 1) hipLaunchKernelGGL((filter_bits_kernel<1>), sg, dim3(kBlock), 0, s, f);
   else if (shape == 2) hipLaunchKernelGGL((filter_bits_kernel<2>), sg, dim3(kBlock), 0, s, f);
+  else if (shape == 4) hipLaunchKernelGGL((filter_bits_kernel<4>), sg, dim3(kBlock), 0, s, f);
   else hipLaunchKernelGGL((filter_bits_kernel<3>), sg, dim3(kBlock), 0, s, f);
 }
 void launch_filter_write(const FilterArgs& a, int shape, hipStream_t s) {    // pass 2, after the scan of stream_counts into stream_offs

@@ -18,6 +18,8 @@ struct DevTable {
   u64 cap = 0;
   const u64* n_dev = nullptr;
   u64 stable_id = 0;   // non-zero: a pure slice of the store (same rows on every execution until the store changes)
+  int sorted_col = -1; // a zero-copy slice: the column that is sorted within it (the first level below the pinned prefix)
+  u32 key_min = 0, key_max = 0;   // .. and its first / last id
 };
 
 // ---- K1: range locate on a sorted permutation (prune_relevant_row_groups, quad_index_data.rs:155-284) ----
@@ -27,7 +29,10 @@ struct LocateJob {
   u32 n_levels;        // leading levels with a pruning predicate
   u32 from[4], to[4];  // inclusive id ranges per level (EqualTo => from == to)
 };
-void launch_locate(const LocateJob* jobs_dev, u32 n_jobs, u64* lo_hi_dev /* 2 per job */, hipStream_t s);
+// per job: lo, hi, then the level that is sorted within [lo, hi) (the first one not pinned to a single id; 4 = none) in the
+// upper half and its first id in the lower half, then its last id
+constexpr u32 kLocateWords = 4;
+void launch_locate(const LocateJob* jobs_dev, u32 n_jobs, u64* lo_hi_dev /* kLocateWords per job */, hipStream_t s);
 
 // ---- K2: ordered scan + residual predicates + compaction (scan.rs:264-340) ----
 struct ScanLevelPred {
@@ -59,6 +64,7 @@ struct FilterArgs {
   TypedTable tt;
   ExprProgram prog;
   const unsigned char* verdict; u64 n_verdict;   // shape 3: per-id verdicts of a string predicate (0 false / 1 true / 2 error)
+  const u32* value_bits; u32 value_min; u64 value_span;   // shape 4: one verdict BIT per id of [value_min, value_min + value_span) for a shape-2 predicate
   // streaming form (filter_streams): one verdict bit per row, tile counts (+ 1, the extra one zeroed), their scan, scan temp
   unsigned short* stream_bits; u32* stream_counts; u32* stream_offs; void* stream_temp; size_t stream_temp_bytes;
 };
@@ -70,6 +76,15 @@ void launch_filter_bits(const FilterArgs& a, int shape, hipStream_t s);    // pa
 void launch_filter_write(const FilterArgs& a, int shape, hipStream_t s);   // pass 2 (after the scan): ordered write
 u64 filter_stream_tiles(const FilterArgs& a);           // 4096-row tiles of the streaming form   // launch_filter will take the streaming kernel (filter_stream_kernel) for these arguments
 // Evaluates one string predicate for EVERY object id once (streaming through the string heap): out[id] = 0 / 1 / 2.
+// FILTER as a copy of qualifying runs (a typed comparison on the sorted column of a slice with few ids, kernels.hip):
+// runs per id, compaction + scan by one workgroup, copy.  a.value_min / value_span = the id range; at most 2 output columns.
+constexpr u64 kRunCopyMaxIds = 65536;
+struct RunCopyBuffers { u32* run_lo; u32* run_cnt; u32* c_lo; u32* c_off; u32* c_val; u32* n_runs; };
+void launch_value_runs(const FilterArgs& a, const RunCopyBuffers& b, hipStream_t s);
+void launch_run_scan(const FilterArgs& a, const RunCopyBuffers& b, hipStream_t s);
+void launch_run_copy(const FilterArgs& a, const RunCopyBuffers& b, hipStream_t s);
+// shape 2's predicate once per id of [a.value_min, + a.value_span): bit (id - value_min) of `a.value_bits` (64-id words)
+void launch_value_verdicts(const FilterArgs& a, hipStream_t s);
 void launch_regex_verdicts(const RegexProg* prog_dev, const TypedTable& tt, int64_t rhs_lang, unsigned char* out, u64 n_ids, hipStream_t s);
 
 // ---- K6: CrossJoinExec ----

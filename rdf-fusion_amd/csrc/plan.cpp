@@ -494,7 +494,8 @@ const char* kernel_class_name(int kc) {
       "rdfgpu::band_slow_kernel", "rocprim radix sort", "rdfgpu::band_bounds_kernel", "rdfgpu::band_blocks_kernel",
       "rdfgpu::band_decode_kernel", "void rdfgpu::band_mask_kernel", "rdfgpu::band_emit_kernel", "rdfgpu::band_entries_kernel",
       "rdfgpu::band_desc_kernel", "rdfgpu::band_pt_kernel", "rdfgpu::band_rows_kernel",
-      "void rdfgpu::filter_bits_kernel<1>", "void rdfgpu::filter_bits_kernel<2>", "void rdfgpu::filter_bits_kernel<3>",
+      "void rdfgpu::filter_bits_kernel<1>", "void rdfgpu::filter_bits_kernel<2>", "void rdfgpu::filter_bits_kernel<3>", "void rdfgpu::filter_bits_kernel<4>", "rdfgpu::value_verdict_kernel",
+      "rdfgpu::value_runs_kernel", "rdfgpu::run_scan_kernel", "rdfgpu::run_copy_kernel",
       "void rdfgpu::filter_write_kernel", "rdfgpu::part_keys_kernel", "void rdfgpu::part_join_kernel"};
   if (kc < KC_LDS_JOIN0) return fixed[kc];
   static std::string names[192];
@@ -638,9 +639,14 @@ void Plan::execute() {
     LocateJob* jobs_dev = static_cast<LocateJob*>(ctx->jobs_dev);
     RDFGPU_HIP(hipMemcpyAsync(jobs_dev, jobs, sources.size() * sizeof(LocateJob), hipMemcpyHostToDevice, stream));
     timed(KC_LOCATE, 0, sources.size(), nullptr, 0, nullptr, 0, 0, [&] { launch_locate(jobs_dev, (u32)sources.size(), ctx->lohi_dev, stream); });
-    RDFGPU_HIP(hipMemcpyAsync(ctx->lohi_host, ctx->lohi_dev, sources.size() * 2 * sizeof(u64), hipMemcpyDeviceToHost, stream));
+    RDFGPU_HIP(hipMemcpyAsync(ctx->lohi_host, ctx->lohi_dev, sources.size() * kLocateWords * sizeof(u64), hipMemcpyDeviceToHost, stream));
     RDFGPU_HIP(hipStreamSynchronize(stream)); metrics.host_syncs++;
-    for (size_t i = 0; i < sources.size(); i++) { sources[i].lo = ctx->lohi_host[2 * i]; sources[i].hi = ctx->lohi_host[2 * i + 1]; metrics.input_rows += sources[i].hi - sources[i].lo; }
+    for (size_t i = 0; i < sources.size(); i++) {
+      const u64* w = ctx->lohi_host + kLocateWords * i;
+      SourceInfo& s = sources[i];
+      s.lo = w[0]; s.hi = w[1]; s.sorted_level = (u32)(w[2] >> 32); s.key_min = (u32)w[2]; s.key_max = (u32)w[3];
+      metrics.input_rows += s.hi - s.lo;
+    }
   }
 
   result = exec_node(root);
@@ -755,6 +761,7 @@ DevTable Plan::exec_source(NodeInfo& nd) {
     for (u32 c = 0; c < s.n_out; c++) t.cols[c] = ix.col[s.out_level[c]] + s.lo;
     t.cap = n;
     t.stable_id = (u64)nd.source + 1;   // a pure slice of the store: identical on every execution until the store changes
+    for (u32 c = 0; c < s.n_out; c++) if (s.out_level[c] == s.sorted_level && t.sorted_col < 0) { t.sorted_col = (int)c; t.key_min = s.key_min; t.key_max = s.key_max; }
     return t;
   }
   ScanJob job{};
@@ -851,6 +858,22 @@ DevTable Plan::apply_filter(NodeInfo& nd, const DevTable& in) {
     }
     if (verdict) { a.verdict = verdict; a.n_verdict = n_ids; } else shape = 0;
   }
+  // a typed comparison on the sorted column of a big store slice with few distinct ids: the qualifying runs are copied, the
+  // predicate column is not streamed at all
+  if (shape == 2 && !opt.on(RDFGPU_OPT_NO_VALUE_VERDICTS) && !opt.on(RDFGPU_OPT_NO_RUN_COPY) && in.sorted_col >= 0 && (u32)in.sorted_col == nd.prog.nodes[0].u &&
+      in.key_max >= in.key_min && !in.n_dev && in.cap >= (1ull << 20) && in.cap < (1ull << 32) && nd.n_proj <= 2) {
+    const u64 span = (u64)in.key_max - in.key_min + 1;
+    if (span <= kRunCopyMaxIds && span * 1024 <= in.cap) {
+      a.value_min = in.key_min; a.value_span = span;
+      a.stream_bits = reinterpret_cast<unsigned short*>(scratch<u32>(1)); a.stream_counts = scratch<u32>(1); a.stream_offs = a.stream_counts;   // (the argument block wants them non-null)
+      RunCopyBuffers b{scratch<u32>(span), scratch<u32>(span), scratch<u32>(span + 1), scratch<u32>(span + 1), scratch<u32>(span + 1), scratch<u32>(1)};
+      timed(KC_VALUE_RUNS, 0, span, nullptr, 16, nullptr, 0, 0, [&] { launch_value_runs(a, b, stream); });
+      timed(KC_RUN_SCAN, 0, span, nullptr, 8, nullptr, 0, 0, [&] { launch_run_scan(a, b, stream); });
+      timed(KC_RUN_COPY, 0, 0, nullptr, 0, a.n_out_dev, 0, 8ull * nd.n_proj, [&] { launch_run_copy(a, b, stream); });
+      t.cap = in.cap; t.n_dev = a.n_out_dev;
+      return t;
+    }
+  }
   // FilterExec bytes: 4·c_r·N + t·N + 4·c_w·σN with t = 9 B per typed gather (tag + i64); shape 3: t = 1 B
   if (filter_streams(a, shape)) {   // two passes without atomics: verdict bits + tile counts, device scan, ordered write
     const u64 tiles = filter_stream_tiles(a);
@@ -861,7 +884,18 @@ DevTable Plan::apply_filter(NodeInfo& nd, const DevTable& in) {
     RDFGPU_HIP(hipMemsetAsync(a.stream_counts + tiles, 0, sizeof(u32), stream));
     // compulsory bytes: pass 1 streams the predicate column (its typed-value gathers hit a table that is cache-resident or
     // not: not counted) and writes one bit per row; pass 2 reads the bits and the output columns and writes the survivors
-    const int kc1 = shape == 1 ? KC_FILTER_BITS_ID : shape == 2 ? KC_FILTER_BITS_TV : KC_FILTER_BITS_VERDICT;
+    // a typed comparison over the sorted column of a store slice: answered once per id of the slice's id range when that
+    // range is small next to the rows (a GPOS slice of one predicate: its objects), then one bit per row
+    if (shape == 2 && !opt.on(RDFGPU_OPT_NO_VALUE_VERDICTS) && in.sorted_col >= 0 && (u32)in.sorted_col == nd.prog.nodes[0].u && in.key_max >= in.key_min) {
+      const u64 span = (u64)in.key_max - in.key_min + 1;
+      if (span * 4 <= in.cap) {
+        u32* words = scratch<u32>(((span + 63) / 64) * 2);
+        a.value_bits = words; a.value_min = in.key_min; a.value_span = span;
+        timed(KC_VALUE_VERDICTS, 0, span, nullptr, 16, nullptr, 0, 0, [&] { launch_value_verdicts(a, stream); });
+        shape = 4;
+      }
+    }
+    const int kc1 = shape == 1 ? KC_FILTER_BITS_ID : shape == 2 ? KC_FILTER_BITS_TV : shape == 4 ? KC_FILTER_BITS_VALUE : KC_FILTER_BITS_VERDICT;
     timed(kc1, tiles * 4, in.cap, in.n_dev, 4, nullptr, 0, 0, [&] { launch_filter_bits(a, shape, stream); });
     timed(KC_DEVICE_SCAN, 0, tiles + 1, nullptr, 8, nullptr, 0, 0, [&] { exclusive_scan_u32(a.stream_counts, a.stream_offs, tiles + 1, a.stream_temp, a.stream_temp_bytes, stream); });
     timed(KC_FILTER_WRITE, tiles * 8, in.cap, in.n_dev, 4ull * nd.n_proj, a.n_out_dev, 0, 4ull * nd.n_proj, [&] { launch_filter_write(a, shape, stream); });

@@ -64,7 +64,7 @@ void DevicePool::trim() {
 static const char* const kOptionNames[RDFGPU_OPT__COUNT] = {
     "FORCE_GENERIC_VM", "NO_JOIN_REORDER", "NO_SPECULATION", "NO_FIRST_RUN_SPECULATION", "NO_STRING_VERDICTS",
     "NO_TABLE_CACHE", "NO_INDEX_JOIN", "NO_CHAIN_FUSION", "NO_VALUE_TABLES", "NO_RANGE_INDEX", "NO_FILTER_FUSION",
-    "NO_LDS_JOIN", "NO_GLOBAL_TABLE_JOIN", "NO_DIRECT_TABLE", "NO_BAND_JOIN", "NO_PARTITIONED_JOIN",
+    "NO_LDS_JOIN", "NO_GLOBAL_TABLE_JOIN", "NO_DIRECT_TABLE", "NO_BAND_JOIN", "NO_PARTITIONED_JOIN", "NO_VALUE_VERDICTS", "NO_RUN_COPY",
     "LDS_MAX_BUILD", "CSR_ROW_LANES_LOG2", "JOIN_WAVE_Q", "PARTITION_MIN_BUILD"};
 const char* engine_option_name(u32 option) { return option < RDFGPU_OPT__COUNT ? kOptionNames[option] : nullptr; }
 const EngineOptions& default_engine_options() {
@@ -161,9 +161,9 @@ ExecContext* Store::acquire_context(u32 n_sources) {
     if (c->jobs_dev) { (void)hipFree(c->jobs_dev); (void)hipFree(c->lohi_dev); (void)hipHostFree(c->jobs_host); (void)hipHostFree(c->lohi_host); }
     const u32 cap = need < 16 ? 16 : need;
     RDFGPU_HIP(hipMalloc(&c->jobs_dev, cap * 128));          // sizeof(LocateJob) <= 128
-    RDFGPU_HIP(hipMalloc((void**)&c->lohi_dev, cap * 2 * sizeof(u64)));
+    RDFGPU_HIP(hipMalloc((void**)&c->lohi_dev, cap * kLocateWords * sizeof(u64)));
     RDFGPU_HIP(hipHostMalloc(&c->jobs_host, cap * 128, hipHostMallocDefault));
-    RDFGPU_HIP(hipHostMalloc((void**)&c->lohi_host, cap * 2 * sizeof(u64), hipHostMallocDefault));
+    RDFGPU_HIP(hipHostMalloc((void**)&c->lohi_host, cap * kLocateWords * sizeof(u64), hipHostMallocDefault));
     c->job_cap = cap;
   }
   return c;

@@ -15,16 +15,21 @@ def load_bench():
 
 def test_pmc_traffic_quotes_the_newest_summary_of_the_same_workload():
     b = load_bench()
-    kernel = "void rdfgpu::lds_join_kernel<2, 0, 4, 3, true>"
-    t, src = b.pmc_traffic(kernel, 262144, 285000)
+    wl = {"queries": 262144, "products": 285000}
     files = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_fetch_write_per_kernel.json"))
-    newest = max((f for f in files if json.load(open(os.path.join(ROOT, "profiles", f))).get("_workload", {}).get("queries") == 262144),
+    newest = max((f for f in files if all(json.load(open(os.path.join(ROOT, "profiles", f))).get("_workload", {}).get(k) == v for k, v in wl.items())),
                  key=lambda f: [int(x) for x in __import__("re").findall(r"\d+", f)])
-    assert src == os.path.join("profiles", newest) and t == json.load(open(os.path.join(ROOT, "profiles", newest)))[kernel]["hbm_bytes_per_launch"]
-    t14, src14 = b.pmc_traffic(kernel, 65536, 285000)                 # another batch size has its own counters
-    assert src14.endswith("r01_v14_pmc_fetch_write_per_kernel.json") and t14 != t
-    assert b.pmc_traffic(kernel, 12345, 285000) == (None, None)       # never quoted for a workload they were not collected on
-    assert b.pmc_traffic("no such kernel", 262144, 285000) == (None, None)
+    d = json.load(open(os.path.join(ROOT, "profiles", newest)))
+    kernels = [k for k in d if k != "_workload"][:2]
+    t, src = b.pmc_traffic(kernels[0], wl)
+    assert src == os.path.join("profiles", newest) and t == d[kernels[0]]["hbm_bytes_per_launch"]
+    t2, _ = b.pmc_traffic(kernels, wl)                                 # several kernels of one operator: summed
+    assert t2 == sum(d[k]["hbm_bytes_per_launch"] for k in kernels)
+    t14, src14 = b.pmc_traffic("void rdfgpu::lds_join_kernel<2, 0, 4, 3, true>", {"queries": 65536, "products": 285000})   # another batch size has its own counters
+    assert src14.endswith("r01_v14_pmc_fetch_write_per_kernel.json") and t14 > 0
+    assert b.pmc_traffic(kernels[0], {"queries": 12345, "products": 285000}) == (None, None)   # never quoted for a workload they were not collected on
+    assert b.pmc_traffic("no such kernel", wl) == (None, None)
+    assert b.pmc_traffic(kernels + ["no such kernel"], wl) == (None, None)
 
 
 def test_bench_flags_follow_the_contract():
