@@ -205,6 +205,10 @@ def main():
     kstats = {}
     lock = threading.Lock()
 
+    def mem(stage):
+        free_b, total_b = torch.cuda.mem_get_info(local_rank)
+        print(f"[bench] device memory after {stage}: {(total_b - free_b) / 2**30:.1f} GiB used of {total_b / 2**30:.0f}", file=sys.stderr, flush=True)
+
     def account(plan):
         with lock:
             for name, launches, ms, nbytes, rows in plan.kernel_stats():
@@ -363,6 +367,7 @@ def main():
         t1 = time.perf_counter(); step(batches[0], False); torch.cuda.synchronize(); second_ms = (time.perf_counter() - t1) * 1e3
         t1 = time.perf_counter(); step(batches[0], False); torch.cuda.synchronize(); third_ms = (time.perf_counter() - t1) * 1e3
         cold = {"cold_ms": round(cold_ms, 3), "second_execution_ms": round(second_ms, 3), "third_execution_ms": round(third_ms, 3)}
+        mem("cold start")
     overlap = world > 1 and not args.no_overlap
     if overlap:
         run_pipelined(batches[:args.warmup], False)
@@ -416,6 +421,7 @@ def main():
             shard_check = f"{len(probe_batch)} instances: {n_all} bindings over {world} shards, count and multiset checksum equal to the unsharded run on rank 0"
         barrier()
 
+    mem("timed steps")
     # ------------------------------------------------------------------ roofline of the dominant kernel
     # ONE formula: frac = compulsory bytes of the kernel / its time / 8 TB/s, compulsory = every input the
     # kernel has to read once + everything it has to write (recorded per launch next to the HIP-event time, plan.cpp
@@ -479,7 +485,9 @@ def main():
         rows_nc = sum(step_nc(b) for b in batches[-n_nc:])
         torch.cuda.synchronize()
         ms_nc = (time.perf_counter() - t1) * 1e3 / n_nc
+        mem("no-table-cache steps")
         plan_nc.close()
+        mem("closing the no-table-cache plan")
         steady = elapsed * 1e3 / args.steps
         cold["no_table_cache"] = {"ms_per_step": round(ms_nc, 3), "bindings_per_s": round(rows_nc / n_nc / (ms_nc * 1e-3), 2), "steps": n_nc,
                                   "what": "every join table (hash / CSR / direct) built inside the timed step: HashJoinExec-style per-query builds"}
@@ -627,6 +635,7 @@ def main():
             out["config"]["speedup_batched_vs_batched_columnar_cpu"] = round((n_q / elapsed) / cpu["tuned_columnar"]["queries_per_s"], 1)
         if world == 1 and not args.no_scan:
             # the BGP scan + FILTER kernel on a partition larger than the Infinity Cache (BASELINE config 2)
+            mem("the Q5 part")
             out["scan_roofline"] = scan_roofline(rf, local_rank, args.scan_log2_rows)
             # the same scan over a dictionary whose typed-value table (16 B per id) does not fit the 32 MiB of L2
             out["scan_roofline_large_dictionary"] = scan_roofline(rf, local_rank, args.scan_log2_rows, distinct=1 << 22)

@@ -516,11 +516,12 @@ enum {
   RDFGPU_OPT_NO_BAND_JOIN,              /* no key-partitioned band join for fused look-up chains over small groups    */
   RDFGPU_OPT_NO_PARTITIONED_JOIN,       /* no radix-partitioned LDS hash join for large non-cached build sides        */
   RDFGPU_OPT_NO_VALUE_VERDICTS,         /* typed comparison per row instead of per distinct term of a sorted slice     */
+  RDFGPU_OPT_NO_PRIMING,                /* no priming run over the first rows of big bound tables before a plan's first execution */
   RDFGPU_OPT_NO_RUN_COPY,               /* .. per distinct term, but rows streamed (verdict bits) instead of runs copied */
   RDFGPU_OPT_LDS_MAX_BUILD,             /* value: largest build side (rows) joined through a per-workgroup LDS table  */
   RDFGPU_OPT_CSR_ROW_LANES_LOG2,        /* value + 1: lanes sharing one probe row of a CSR join (0 = automatic)        */
   RDFGPU_OPT_JOIN_WAVE_Q,               /* value: entries of a wave's candidate queue (0 = automatic)                  */
-  RDFGPU_OPT_PARTITION_MIN_BUILD,       /* value: smallest non-cached build side (rows) that is radix-partitioned     */
+  RDFGPU_OPT_PARTITION_MIN_BUILD,       /* value: smallest non-cached build side (rows) that is radix-partitioned (default 2^21) */
   RDFGPU_OPT__COUNT
 };
 int rdfgpu_store_set_option(rdfgpu_store* store, uint32_t option, uint64_t value);

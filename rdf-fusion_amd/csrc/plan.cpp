@@ -577,11 +577,57 @@ u64 Plan::read_u64(const u64* dev) {
   return v;
 }
 
+// First execution of a plan over big caller-supplied tables (a batch of query instances): nothing is known yet, so every
+// join would be sized exactly and run un-fused — on the full batch that materialises every candidate pair (126 GiB of
+// intermediates for 262 144 BSBM Q5 instances).  Instead the plan first runs over the first kPrimeRows rows of each
+// bound table: that builds every join table of the store slices (cached per store version) and leaves cardinalities,
+// which are extrapolated by the row ratio; the full batch then takes the speculative, fused path at once.  A wrong
+// extrapolation is caught like any failed speculation (overflow flag -> exact re-run).
+constexpr u64 kPrimeRows = 2048;
+void Plan::prime() {
+  primed = true;
+  if (!allow_speculation || opt.on(RDFGPU_OPT_NO_SPECULATION) || opt.on(RDFGPU_OPT_NO_PRIMING) || opt.on(RDFGPU_OPT_NO_TABLE_CACHE) || opt.on(RDFGPU_OPT_NO_CHAIN_FUSION)) return;
+  u64 full = 0;
+  for (const BoundTable& b : tables) if (b.bound) full = std::max(full, b.n_rows);
+  if (full < 16 * kPrimeRows) return;
+  for (const NodeInfo& nd : nodes) if (nd.has_last) return;
+  std::vector<u64> saved(tables.size());
+  for (size_t i = 0; i < tables.size(); i++) { saved[i] = tables[i].n_rows; tables[i].n_rows = std::min<u64>(tables[i].n_rows, kPrimeRows); }
+  priming = true;
+  try { execute(); } catch (...) { priming = false; for (size_t i = 0; i < tables.size(); i++) tables[i].n_rows = saved[i]; throw; }
+  priming = false;
+  for (size_t i = 0; i < tables.size(); i++) tables[i].n_rows = saved[i];
+  // operators above a bound table scale with it; pure store subtrees keep their exact history
+  std::vector<int> dep(nodes.size(), -1);
+  std::function<bool(u32)> depends = [&](u32 i) -> bool {
+    if (dep[i] >= 0) return dep[i] != 0;
+    const NodeInfo& nd = nodes[i];
+    bool d = false;
+    if (nd.d.kind == RDFGPU_NODE_TABLE) d = true;
+    else if (nd.d.kind != RDFGPU_NODE_DATA_SOURCE) {
+      const bool binary = nd.d.kind == RDFGPU_NODE_HASH_JOIN || nd.d.kind == RDFGPU_NODE_CROSS_JOIN || nd.d.kind == RDFGPU_NODE_NESTED_LOOP_JOIN || nd.d.kind == RDFGPU_NODE_UNION;
+      if (nd.d.left >= 0) d = depends((u32)nd.d.left);
+      if (binary && nd.d.right >= 0) d = depends((u32)nd.d.right) || d;
+    }
+    dep[i] = d ? 1 : 0;
+    return d;
+  };
+  const u64 ratio = (full + kPrimeRows - 1) / kPrimeRows;
+  for (u32 i = 0; i < nodes.size(); i++) {
+    NodeInfo& nd = nodes[i];
+    if (nd.has_last && depends(i)) { nd.last_rows = nd.last_rows * ratio + 1024; nd.last_scaled = true; }
+  }
+}
+
 void Plan::execute() {
+  if (!primed && !priming) prime();
   store->activate();
   std::shared_lock<std::shared_mutex> lock(store->mu);   // a plan holds the snapshot while it runs (snapshot.rs:35-37)
   RDFGPU_HIP(hipStreamSynchronize(stream));
   release_intermediates();
+  // the pool keeps what an execution hands back for the next one — bounded by twice what the previous execution used
+  // (+ 1 GiB): the giant blocks of a one-off exact run go back to the device instead of staying cached for ever
+  store->pool.trim_to(2 * std::max(scratch_hist[0], scratch_hist[1]) + (1ull << 30));
   held = store->gen;         // ... and the generation it read until its next execute: the result may be zero-copy slices of it
   metrics = rdfgpu_metrics{};
   counters_used = 0;
@@ -663,7 +709,7 @@ void Plan::execute() {
   bool spec_failed = false;
   for (const SpecCheck& c : spec_checks) {
     if ((ctx->counters_host[c.counter + 1] & 0xFFFFFFFFull) != 0) spec_failed = true;
-    else { c.node->last_rows = ctx->counters_host[c.counter]; c.node->has_last = true; }
+    else { c.node->last_rows = ctx->counters_host[c.counter]; c.node->has_last = true; c.node->last_scaled = false; }
   }
   if (spec_failed) {   // rare: run again with exact sizes (one sync per join), then speculate again next time
     metrics.host_syncs++;
@@ -681,6 +727,7 @@ void Plan::execute() {
   metrics.output_rows = result_rows;
   resolve_timing();
   executed = true;
+  scratch_hist[1] = scratch_hist[0]; scratch_hist[0] = metrics.device_bytes;
 }
 
 DevTable Plan::exec_node(u32 idx) {
@@ -1617,7 +1664,7 @@ DevTable Plan::exec_lds_join(NodeInfo& nd, const DevTable& L, const DevTable& R,
       t.n_cols = a.n_out_cols;
     }
     const bool chained = a.n_chain != 0;
-    const u64 spec_cap = nd.has_last ? std::max<u64>(1024, size_node->last_rows + size_node->last_rows / 4 + 256)   // 25 % head room over the previous run
+    const u64 spec_cap = nd.has_last ? std::max<u64>(1024, size_node->last_rows + size_node->last_rows / (size_node->last_scaled ? 2 : 4) + 256)   // 25 % head room over the previous run (50 % over an extrapolation)
                                      : std::max<u64>(1024, first_guess);
     a.out_cap = spec_cap;
     for (u32 c = 0; c < a.n_out_cols; c++) { a.out[c] = scratch<u32>(spec_cap + tail); t.cols[c] = a.out[c]; }
@@ -1657,7 +1704,7 @@ DevTable Plan::exec_lds_join(NodeInfo& nd, const DevTable& L, const DevTable& R,
     out_cap = total;   // the count is exact even when the writes did not fit: run again with room for all
     RDFGPU_HIP(hipMemsetAsync(n_out, 0, 2 * sizeof(u64), stream));
   }
-  nd.last_rows = total; nd.has_last = true;   // history for the next (speculative) execution
+  nd.last_rows = total; nd.has_last = true; nd.last_scaled = false;   // history for the next (speculative) execution
   t.cap = total + tail;
   if (!left_join) { if (total == 0) t.cap = 0; return t; }
   // left join tail: unmatched build rows, nulls on the right

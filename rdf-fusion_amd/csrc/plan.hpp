@@ -37,6 +37,7 @@ struct NodeInfo {
   int source = -1;                // index into Plan::sources
   u32 refs = 0;                   // how many operators consume this node
   u64 last_rows = 0; bool has_last = false;   // output cardinality of the previous execution (speculative sizing)
+  bool last_scaled = false;                    // .. extrapolated from a priming run over a prefix of the bound tables
 };
 struct SpecCheck { NodeInfo* node; u32 counter; bool left_join; };   // counter = n_out slot, counter+1 = overflow flag
 
@@ -107,6 +108,9 @@ struct Plan {
   bool timing = false;
   u64 located_version = ~0ull;    // store version the cached scan ranges belong to
   bool allow_speculation = true, speculative = false;
+  u64 scratch_hist[2] = {0, 0};           // intermediates of the last two completed executions (bounds what the pool keeps cached)
+  bool priming = false, primed = false;   // the first execution over big bound tables is preceded by one over their first rows (Plan::prime)
+  void prime();
   std::vector<SpecCheck> spec_checks;
   std::vector<PendingLaunch> pending;
   std::vector<DevTable> memo; std::vector<char> memo_valid;   // node results of the current execution

@@ -19,17 +19,20 @@ namespace rdfgpu {
 // same HBM blocks instead of paying hipMalloc/hipFree per operator.
 class DevicePool {
  public:
+  DevicePool();
   ~DevicePool();
   void* alloc(size_t bytes);
   void free(void* p);
-  void trim();
+  void trim();                      // every cached block back to the device
+  void trim_to(u64 keep_bytes);     // largest cached blocks back to the device until at most keep_bytes stay cached
   u64 bytes_in_use() const { return in_use_; }
+  u64 bytes_cached() const { return cached_; }
 
  private:
   std::mutex mu_;
   std::multimap<size_t, void*> free_;
   std::map<void*, size_t> live_;
-  u64 in_use_ = 0;
+  u64 in_use_ = 0, cached_ = 0;
 };
 
 // Per-plan execution resources (a HIP stream, a grow-on-demand event pool, the device counters and

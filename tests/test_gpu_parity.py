@@ -529,8 +529,7 @@ def test_partitioned_join_matches_oracle(torch_cuda, nb, npr, n_ids, min_build):
     rng = np.random.default_rng(nb + npr)
     tv, dec = typed_zoo()
     gs, os_ = both_stores((np.zeros(0, np.uint32),) * 4, typed=tv, decimals=dec)
-    if min_build:
-        gs.set_option("PARTITION_MIN_BUILD", min_build)
+    gs.set_option("PARTITION_MIN_BUILD", min_build or 65536)      # (the default, 2^21 rows, leaves smaller builds to the L2-resident hash table)
     n_tv = len(tv)
     B = [rng.integers(1, n_ids + 1, nb).astype(np.uint32), rng.integers(1, max(2, n_ids // 50) + 1, nb).astype(np.uint32), rng.integers(1, n_tv, nb).astype(np.uint32)]
     Pr = [rng.integers(1, n_ids + 1, npr).astype(np.uint32), rng.integers(1, max(2, n_ids // 50) + 1, npr).astype(np.uint32), rng.integers(1, n_tv, npr).astype(np.uint32)]
@@ -656,6 +655,39 @@ def test_bsbm_q5_batched_equals_per_instance(bsbm_stores, torch_cuda, batch):
     plan_b.bind_table(0, ptrs_p, len(padded[0]))
     got_p = plan_b.execute().fetch()
     np.testing.assert_array_equal(ku.multiset(got_p), ku.multiset(got))
+
+
+def test_first_execution_over_a_big_batch_is_primed(torch_cuda):
+    """The very first execution of a plan over a big bound table is preceded by a priming run over the table's first
+    rows (join tables built, cardinalities extrapolated): the full batch then runs fused, with a small fraction of the
+    intermediates an exact un-fused first run materialises — and with the same bindings."""
+    ds = bsbm.generate(2000)
+    rng = np.random.default_rng(11)
+    batch = 60_000
+    prods = np.array([ds.product(i) for i in rng.integers(0, ds.n_products, batch)], dtype=np.uint32)
+    params = [np.arange(1, batch + 1, dtype=np.uint32), prods]
+    keep, ptrs = table_on_device(torch_cuda, params)
+
+    def first_run(option):
+        gs = rf.GpuQuadStore()
+        gs.extend(ds.g, ds.s, ds.p, ds.o); gs.set_typed_values(ds.typed_values, ds.decimals)
+        plan = gs.plan(bsbm.q5_batch_plan(ds))
+        if option:
+            plan.set_option(option)
+        plan.bind_table(0, ptrs, batch)
+        plan.execute()
+        first = ku.multiset(plan.fetch())
+        scratch = plan.metrics().device_bytes
+        second = ku.multiset(plan.execute().fetch())
+        np.testing.assert_array_equal(first, second)
+        return first, scratch
+
+    primed, scratch_primed = first_run(None)
+    exact, scratch_exact = first_run("NO_PRIMING")
+    np.testing.assert_array_equal(primed, exact)
+    assert len(primed) > batch
+    if not ENGINE_TOGGLED:
+        assert scratch_primed * 4 < scratch_exact, (scratch_primed, scratch_exact)
 
 
 @pytest.mark.parametrize("shape", ["unique_dense", "dup_sorted", "dup_scattered", "sparse"])
@@ -1070,7 +1102,7 @@ TOGGLES = ["RDFGPU_NO_CHAIN_FUSION", "RDFGPU_NO_INDEX_JOIN", "RDFGPU_NO_TABLE_CA
            "RDFGPU_NO_FIRST_RUN_SPECULATION", "RDFGPU_NO_DIRECT_TABLE", "RDFGPU_FORCE_GENERIC_VM", "RDFGPU_NO_LDS_JOIN",
            "RDFGPU_NO_GLOBAL_TABLE_JOIN", "RDFGPU_NO_FILTER_FUSION", "RDFGPU_NO_VALUE_TABLES", "RDFGPU_NO_RANGE_INDEX",
            "RDFGPU_NO_BAND_JOIN", "RDFGPU_NO_PARTITIONED_JOIN", "RDFGPU_NO_JOIN_REORDER", "RDFGPU_NO_STRING_VERDICTS",
-           "RDFGPU_NO_VALUE_VERDICTS", "RDFGPU_NO_RUN_COPY"]
+           "RDFGPU_NO_VALUE_VERDICTS", "RDFGPU_NO_RUN_COPY", "RDFGPU_NO_PRIMING"]
 
 
 @pytest.mark.parametrize("toggle", TOGGLES)
