@@ -125,6 +125,7 @@ __global__ __launch_bounds__(256) void band_decode_kernel(const BandArgs b) {
   u32 rv[kBandMaxRowCols] = {0u, 0u};
 #pragma unroll
   for (u32 u = 0; u < kBandMaxRowCols; u++) if (u < b.n_row_cols) rv[u] = b.row_col[u][j];
+  if (b.presorted) { b.rec_s[j] = rec; b.aux_s[j] = make_uint4(x, flags, rv[0], rv[1]); return; }   // row order IS the sorted order
   b.rec[2 * j] = rec;
   b.rec[2 * j + 1] = make_uint4(x, flags, rv[0], rv[1]);
 }

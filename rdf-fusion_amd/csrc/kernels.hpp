@@ -221,6 +221,26 @@ struct LdsJoinArgs {
 };
 void launch_lds_join(const LdsJoinArgs& a, hipStream_t s);
 
+// ---- ordered slice join (ordered_join.hip): a small table against a store slice, matches emitted in the slice's order ----
+struct OrderedJoinStage { const u32* key_col; const u32* direct; u32 kmin, kn; u32* row; };   // key_col: a column of the TABLE; row[r] = the stage's row of table row r
+struct OrderedJoinArgs {
+  const u32* build_key; u64 n_build;                                   // the slice's join-key column, rows in slice order
+  const u32* probe_key; const u64* n_probe_dev; u64 n_probe_cap;        // the table
+  u32 kmin, kn;                                                        // key range of the slice (its dense table's)
+  u32* head; u32* next;                                                // multimap of the table's rows by key: head[kn] (0xFF-filled), next[table rows]
+  u32 n_stages; u32 pad0; OrderedJoinStage stage[kMaxChain];
+  u32 n_out_cols; u32 n_rec; ColRef out_ref[kMaxCols]; u32* out[kMaxCols];   // src 0 = table row, 1 = slice row, 2 + t = stage t's row
+  // everything an output row takes from the table row or its stage rows, packed per table row (n_rec x 16 B, written by
+  // the probe pass): ONE gather per match instead of one per column.  out_slot[c] = word of the record, 0xFF = slice column
+  uint4* trec; u8 out_slot[kMaxCols];
+  u64 out_cap; u64* n_out_dev; u32* overflow;
+  u32* tile_count; u32* tile_off;                                      // per 1024-row tile of the slice (+ 1) and their exclusive scan
+};
+u64 ordered_join_tiles(u64 n_build);
+void launch_ordered_join_probe(const OrderedJoinArgs& a, hipStream_t s);
+void launch_ordered_join_count(const OrderedJoinArgs& a, hipStream_t s);
+void launch_ordered_join_write(const OrderedJoinArgs& a, hipStream_t s);
+
 // ---- radix-partitioned LDS hash join (part_join.hip): large build sides that are not cached store slices ----
 constexpr u32 kPartChunk = 2048;      // build rows per LDS table (a partition with more is joined chunk by chunk)
 constexpr u32 kPartSlots = 4096;      // slots of the LDS table: load <= 0.5, ~0.25 at the target partition size
@@ -275,7 +295,7 @@ struct BandArgs {
   uint4* bdesc;               // per block {first entry, entries (<= 64), first sorted row, rows (<= 64)}
   u64* masks;                 // 64 x u64 per block: bit e of lane r = (entry e, row r) joins
   u32* bcount; u32* bofs;     // per block (+ 1): output rows / their exclusive scan
-  u32 max_blocks, pad2;
+  u32 max_blocks, presorted;  // presorted: the probe rows arrive sorted by key — no sort, records written in place
   u32* slow_rows;             // number of probe rows that need the full typed-value semantics (usually 0)
   // output
   u32 n_out_cols, n_entry_cols, n_row_cols, pad1;

@@ -1,0 +1,179 @@
+// ordered_join.hip — HashJoinExec of a small table against a store slice, emitted IN THE SLICE'S ORDER.
+//
+// The index join (plan.cpp: build on the slice's cached CSR table, probe with the table's rows) emits its matches in
+// probe-row order.  When the slice is sorted by a column that is NOT the join key — a GPOS slice (?s <p> ?o) joined on
+// ?s is sorted by ?o — and the next operator partitions this join's output by that very column (the key-partitioned band
+// join above it: BSBM Q5's candidates by product feature), walking the join the other way round saves that partition
+// pass: the table's rows are hung into a multimap by key (head[key - kmin], next[row]), the slice is streamed once in its
+// own order and every slice row emits its chain.  Two streaming passes (counts per tile -> device scan -> ordered write),
+// no atomics on the output, no sort; the output is sorted like the slice.  Follow-up look-ups keyed by columns of the
+// table (the fused chain's stages: `<X> numeric1 ?v` by X) are done ONCE per table row, not per match.
+//
+// Same row multiset as lds_join_kernel<.., MODE 3> with the same arguments (inner join, NullEqualsNothing,
+// join/rewrite.rs:89,126-168); tests/test_gpu_parity.py::test_ordered_slice_join checks the two forms.
+#include <hip/hip_runtime.h>
+
+#include "join_device.hpp"
+
+namespace rdfgpu {
+
+constexpr int kOjBlock = 256;
+constexpr int kOjRounds = 4;                       // slice rows per lane and tile: tile = 1024 rows, round-major order
+constexpr u32 kOjTile = kOjBlock * kOjRounds;
+
+// table row -> its stage rows, and into the multimap when every stage has a row (inner joins: no stage row, no match)
+__global__ __launch_bounds__(256) void oj_probe_kernel(const OrderedJoinArgs a) {
+  const u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  const u64 n = live_rows(a.n_probe_dev, a.n_probe_cap);
+  if (r >= n) return;
+  const u32 key = a.probe_key[r];
+  const u32 d = key - a.kmin;
+  bool ok = key != 0 && d < a.kn;                  // null keys never join
+#pragma unroll
+  for (u32 t = 0; t < (u32)kMaxChain; t++) {
+    if (t >= a.n_stages) continue;
+    const u32 sk = a.stage[t].key_col[r];
+    const u32 sd = sk - a.stage[t].kmin;
+    const bool in = sk != 0 && sd < a.stage[t].kn;
+    const u32 row = in ? a.stage[t].direct[sd] : kNil;
+    a.stage[t].row[r] = row;
+    ok = ok && row != kNil;
+  }
+  if (!ok) return;
+  u32 w[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+  for (u32 c = 0; c < a.n_out_cols; c++) {
+    const u32 slot = a.out_slot[c];
+    if (slot == 0xFFu) continue;
+    const ColRef ref = a.out_ref[c];
+    const u64 src = ref.src == 0 ? r : (u64)a.stage[ref.src - 2].row[r];
+    const u32 val = ref.ptr[src];
+#pragma unroll
+    for (u32 k = 0; k < 8; k++) w[k] = k == slot ? val : w[k];
+  }
+  a.trec[r * a.n_rec] = make_uint4(w[0], w[1], w[2], w[3]);
+  if (a.n_rec > 1) a.trec[r * a.n_rec + 1] = make_uint4(w[4], w[5], w[6], w[7]);
+  a.next[r] = atomicExch(a.head + d, (u32)r);
+}
+
+__device__ __forceinline__ u32 oj_chain_length(const OrderedJoinArgs& a, u32 key) {
+  const u32 d = key - a.kmin;
+  if (key == 0 || d >= a.kn) return 0;
+  u32 c = 0;
+  for (u32 r = a.head[d]; r != kNil; r = a.next[r]) c++;
+  return c;
+}
+
+__global__ __launch_bounds__(kOjBlock) void oj_count_kernel(const OrderedJoinArgs a) {
+  __shared__ u32 wave_tot[kOjBlock / 64];
+  const u64 base = (u64)blockIdx.x * kOjTile;
+  u32 keys[kOjRounds];
+#pragma unroll
+  for (int it = 0; it < kOjRounds; it++) {
+    const u64 row = base + (u64)it * kOjBlock + threadIdx.x;
+    keys[it] = row < a.n_build ? a.build_key[row] : 0u;
+  }
+  u32 tot = 0;
+#pragma unroll
+  for (int it = 0; it < kOjRounds; it++) tot += oj_chain_length(a, keys[it]);
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) tot += __shfl_xor(tot, d, 64);
+  if ((threadIdx.x & 63) == 0) wave_tot[threadIdx.x >> 6] = tot;
+  __syncthreads();
+  if (threadIdx.x == 0) a.tile_count[blockIdx.x] = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+}
+
+// Pass 2.  A tile's matches are numbered 0 .. T-1 in slice order; match j is written by lane j mod 256 — every lane has
+// work whatever the chain lengths are, the stores of a wave are consecutive, and a match's gathers (table row, stage
+// rows, one value per output column) are all issued before the first store.  Which slice row a match belongs to: a
+// binary search over the tile's per-row start offsets in LDS (10 steps); which table row: that many hops down the
+// row's chain (chains are short: rows of the table that share one key).
+__global__ __launch_bounds__(kOjBlock) void oj_write_kernel(const OrderedJoinArgs a) {
+  __shared__ u32 starts[kOjTile];
+  __shared__ u32 heads[kOjTile];
+  __shared__ u32 rcnt[kOjRounds][kOjBlock / 64];
+  const u64 base = (u64)blockIdx.x * kOjTile;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    const u64 total = a.tile_off[gridDim.x];
+    *a.n_out_dev = total;
+    if (total > a.out_cap) *a.overflow = 1u;
+  }
+  const u32 tile_total = a.tile_count[blockIdx.x];
+  if (tile_total == 0) return;                     // uniform per workgroup
+  u32 cnt[kOjRounds], hd[kOjRounds];
+#pragma unroll
+  for (int it = 0; it < kOjRounds; it++) {
+    const u64 row = base + (u64)it * kOjBlock + threadIdx.x;
+    const u32 key = row < a.n_build ? a.build_key[row] : 0u;
+    const u32 d = key - a.kmin;
+    hd[it] = (key != 0 && d < a.kn) ? a.head[d] : kNil;
+  }
+#pragma unroll
+  for (int it = 0; it < kOjRounds; it++) {
+    u32 c = 0;
+    for (u32 r = hd[it]; r != kNil; r = a.next[r]) c++;
+    cnt[it] = c;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d, 64);
+    if (lane == 0) rcnt[it][wave] = c;
+  }
+  __syncthreads();
+  u32 off = 0;
+#pragma unroll
+  for (int it = 0; it < kOjRounds; it++) {
+    u32 woff = off;
+    for (int w = 0; w < wave; w++) woff += rcnt[it][w];
+    off += rcnt[it][0] + rcnt[it][1] + rcnt[it][2] + rcnt[it][3];
+    u32 incl = cnt[it];
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const u32 t = __shfl_up(incl, d, 64); if (lane >= d) incl += t; }
+    starts[it * kOjBlock + threadIdx.x] = woff + (incl - cnt[it]);
+    heads[it * kOjBlock + threadIdx.x] = hd[it];
+  }
+  __syncthreads();
+  const u64 tile_base = a.tile_off[blockIdx.x];
+  for (u32 j = threadIdx.x; j < tile_total; j += kOjBlock) {
+    u32 lo = 0, hi = kOjTile;                      // the last q with starts[q] <= j (rows without matches share their successor's start)
+#pragma unroll
+    for (int step = 0; step < 10; step++) { const u32 mid = (lo + hi) >> 1; if (starts[mid] <= j) lo = mid; else hi = mid; }
+    const u32 q = lo;
+    u32 r = heads[q];
+    for (u32 k = j - starts[q]; k; k--) r = a.next[r];
+    const u64 pos = tile_base + j;
+    if (pos >= a.out_cap) continue;                // the count stays exact: the plan re-runs with room for all
+    const u64 brow = base + q;
+    const uint4 r0 = a.trec[(u64)r * a.n_rec];
+    uint4 r1 = make_uint4(0u, 0u, 0u, 0u);
+    if (a.n_rec > 1) r1 = a.trec[(u64)r * a.n_rec + 1];
+    const u32 w[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+    u32 v[kMaxCols];
+#pragma unroll
+    for (u32 c = 0; c < (u32)kMaxCols; c++) {
+      if (c >= a.n_out_cols) continue;
+      const u32 slot = a.out_slot[c];
+      u32 val = 0;
+      if (slot == 0xFFu) val = a.out_ref[c].ptr[brow];
+      else {
+#pragma unroll
+        for (u32 k = 0; k < 8; k++) val = k == slot ? w[k] : val;
+      }
+      v[c] = val;
+    }
+#pragma unroll
+    for (u32 c = 0; c < (u32)kMaxCols; c++) if (c < a.n_out_cols) a.out[c][pos] = v[c];
+  }
+}
+
+void launch_ordered_join_probe(const OrderedJoinArgs& a, hipStream_t s) {
+  if (!a.n_probe_cap) return;
+  hipLaunchKernelGGL(oj_probe_kernel, dim3((unsigned)((a.n_probe_cap + 255) / 256)), dim3(256), 0, s, a);
+}
+u64 ordered_join_tiles(u64 n_build) { return (n_build + kOjTile - 1) / kOjTile; }
+void launch_ordered_join_count(const OrderedJoinArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(oj_count_kernel, dim3((unsigned)ordered_join_tiles(a.n_build)), dim3(kOjBlock), 0, s, a);
+}
+void launch_ordered_join_write(const OrderedJoinArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(oj_write_kernel, dim3((unsigned)ordered_join_tiles(a.n_build)), dim3(kOjBlock), 0, s, a);
+}
+
+}  // namespace rdfgpu

@@ -496,6 +496,7 @@ const char* kernel_class_name(int kc) {
       "rdfgpu::band_desc_kernel", "rdfgpu::band_pt_kernel", "rdfgpu::band_rows_kernel",
       "void rdfgpu::filter_bits_kernel<1>", "void rdfgpu::filter_bits_kernel<2>", "void rdfgpu::filter_bits_kernel<3>", "void rdfgpu::filter_bits_kernel<4>", "rdfgpu::value_verdict_kernel",
       "rdfgpu::value_runs_kernel", "rdfgpu::run_scan_kernel", "rdfgpu::run_copy_kernel",
+      "rdfgpu::oj_probe_kernel", "rdfgpu::oj_count_kernel", "rdfgpu::oj_write_kernel",
       "void rdfgpu::filter_write_kernel", "rdfgpu::part_keys_kernel", "void rdfgpu::part_join_kernel"};
   if (kc < KC_LDS_JOIN0) return fixed[kc];
   static std::string names[192];
@@ -1669,7 +1670,54 @@ DevTable Plan::exec_lds_join(NodeInfo& nd, const DevTable& L, const DevTable& R,
     a.out_cap = spec_cap;
     for (u32 c = 0; c < a.n_out_cols; c++) { a.out[c] = scratch<u32>(spec_cap + tail); t.cols[c] = a.out[c]; }
     if (left_join) RDFGPU_HIP(hipMemsetAsync(a.visited, 0, L.cap, stream));
-    if (use_band) exec_band_join(a, band, B, P, 4ull * (1 + build_payload), 4ull * probe_cols);
+    // A small table against a CSR slice that is sorted by another column, with an output about as large as the slice:
+    // the matches are emitted in the slice's order (ordered_join.hip) — what consumes them partitioned by that column
+    // (the band join above) then has nothing to sort; the chain's look-ups by table columns run once per table row.
+    bool use_ordered = false;
+    if (!use_band && !opt.on(RDFGPU_OPT_NO_ORDERED_JOIN) && a.csr_off && !a.range_rows && !left_join && a.has_filter == 0 && !a.has_probe_filter && !a.has_post &&
+        a.n_keys == 1 && B.sorted_col >= 0 && (u32)B.sorted_col != build_keys[0] && !B.n_dev && B.stable_id && B.cap < (1ull << 32) && P.cap <= (1ull << 24) &&
+        size_node->has_last && size_node->last_rows * 8 >= B.cap) {
+      use_ordered = true;
+      for (u32 s = 0; s < a.n_chain; s++) if (a.chain[s].key.src != 0 || a.chain[s].fs != 0) use_ordered = false;
+      u32 from_table = 0;   // output columns taken from the table row or a stage row travel in its packed record: at most 8
+      for (u32 c = 0; c < a.n_out_cols; c++) {
+        if (chained) from_table += a.chain_out[c].src != 1;
+        else { const u32 pc = a.proj[c]; from_table += ((pc < a.n_left_cols) == (a.build_is_left != 0)) ? 0u : 1u; }
+      }
+      if (from_table > 8) use_ordered = false;
+    }
+    if (use_ordered) {
+      OrderedJoinArgs o{};
+      o.build_key = a.build_key[0]; o.n_build = B.cap;
+      o.probe_key = a.probe_key[0]; o.n_probe_dev = P.n_dev; o.n_probe_cap = P.cap;
+      o.kmin = a.direct_min; o.kn = a.direct_n;
+      o.head = scratch<u32>(a.direct_n); o.next = scratch<u32>(P.cap);
+      RDFGPU_HIP(hipMemsetAsync(o.head, 0xFF, (size_t)a.direct_n * sizeof(u32), stream));
+      o.n_stages = a.n_chain;
+      for (u32 s = 0; s < a.n_chain; s++) o.stage[s] = OrderedJoinStage{a.chain[s].key.ptr, a.chain[s].direct, a.chain[s].kmin, a.chain[s].kn, scratch<u32>(P.cap)};
+      o.n_out_cols = a.n_out_cols;
+      u32 n_words = 0;
+      for (u32 c = 0; c < a.n_out_cols; c++) {
+        if (chained) o.out_ref[c] = a.chain_out[c];
+        else { const u32 pc = a.proj[c]; const bool from_left = pc < a.n_left_cols; o.out_ref[c] = ColRef{a.cols[pc], (from_left == (a.build_is_left != 0)) ? 1u : 0u, 0u}; }
+        o.out[c] = a.out[c];
+        o.out_slot[c] = o.out_ref[c].src == 1 ? (u8)0xFF : (u8)n_words++;
+        if (o.out_ref[c].src == 1 && o.out_ref[c].ptr == B.cols[B.sorted_col] && t.sorted_col < 0) { t.sorted_col = (int)c; t.key_min = B.key_min; t.key_max = B.key_max; }
+      }
+      o.n_rec = n_words > 4 ? 2u : 1u;
+      o.trec = scratch<uint4>(P.cap * o.n_rec);
+      o.out_cap = spec_cap; o.n_out_dev = n_out; o.overflow = overflow;
+      const u64 tiles = ordered_join_tiles(B.cap);
+      o.tile_count = scratch<u32>(tiles + 1); o.tile_off = scratch<u32>(tiles + 1);
+      const size_t tb = scan_temp_bytes(tiles + 1);
+      void* temp = scratch<unsigned char>(tb);
+      RDFGPU_HIP(hipMemsetAsync(o.tile_count + tiles, 0, sizeof(u32), stream));
+      timed(KC_OJ_PROBE, 0, P.cap, P.n_dev, 8 + 12ull * a.n_chain, nullptr, 0, 0, [&] { launch_ordered_join_probe(o, stream); });
+      timed(KC_OJ_COUNT, 0, B.cap, nullptr, 4, nullptr, 0, 0, [&] { launch_ordered_join_count(o, stream); });
+      timed(KC_DEVICE_SCAN, 0, tiles + 1, nullptr, 8, nullptr, 0, 0, [&] { exclusive_scan_u32(o.tile_count, o.tile_off, tiles + 1, temp, tb, stream); });
+      timed(KC_OJ_WRITE, 0, B.cap, nullptr, 4, n_out, 0, 8ull * a.n_out_cols, [&] { launch_ordered_join_write(o, stream); });
+    }
+    else if (use_band) exec_band_join(a, band, B, P, 4ull * (1 + build_payload), 4ull * probe_cols);
     else launch_join(lds_join_class(a.has_filter, a.has_probe_filter, lds_join_items(P.cap << a.row_lanes_log2, global_table), use_part ? kJoinTableLds : lds_join_mode(a), chained),
                      (global_table ? 0 : fixed) + stage_bytes, 4ull * a.n_out_cols);
     spec_checks.push_back({size_node, (u32)(n_out - counters), left_join});
@@ -1752,6 +1800,11 @@ void Plan::prepare_partitions(const LdsJoinArgs& a, const DevTable& B, const Dev
 void Plan::exec_band_join(LdsJoinArgs& a, BandArgs& b, const DevTable& B, const DevTable& P, u64 build_bytes_per_row, u64 probe_bytes_per_row) {
   const u32 kn = a.direct_n;
   const u64 np = P.cap, nb = B.cap;
+  // the probe side arrives sorted by the key (an ordered slice join below, ordered_join.hip): nothing to partition.  Keys
+  // below the table's range would map to "joins nothing" (= kn, the largest) out of order: the slice's id range rules that out.
+  bool presorted = false;
+  if (P.sorted_col >= 0 && P.cols[P.sorted_col] == a.probe_key[0] && P.key_min >= std::max<u32>(1u, a.direct_min) && !opt.on(RDFGPU_OPT_NO_ORDERED_JOIN)) presorted = true;
+  b.presorted = presorted ? 1u : 0u;
   b.csr_off = a.csr_off; b.csr_rows = a.csr_rows; b.kmin = a.direct_min; b.kn = kn;
   b.probe_key = a.probe_key[0]; b.n_probe_dev = P.n_dev; b.n_probe_cap = np;
   b.tt = a.tt;
@@ -1759,15 +1812,38 @@ void Plan::exec_band_join(LdsJoinArgs& a, BandArgs& b, const DevTable& B, const 
   for (u32 c = 0; c < a.n_out_cols; c++) b.out[c] = a.out[c];
   u32 bits = 1;
   while ((1ull << bits) <= kn) bits++;            // keys 0 .. kn (kn = joins nothing)
-  b.skey_in = scratch<u32>(np); b.sval_in = scratch<u32>(np);
   u32* skey = scratch<u32>(np); u32* perm = scratch<u32>(np);
+  if (presorted) { b.skey_in = skey; b.sval_in = perm; b.rec = nullptr; }
+  else { b.skey_in = scratch<u32>(np); b.sval_in = scratch<u32>(np); b.rec = scratch<uint4>(2 * np); }
   b.skey = skey; b.perm = perm;
-  b.rec = scratch<uint4>(2 * np); b.rec_s = scratch<uint4>(np); b.aux_s = scratch<uint4>(np);
+  b.rec_s = scratch<uint4>(np); b.aux_s = scratch<uint4>(np);
   b.slow_rows = reinterpret_cast<u32*>(new_counter());
   const size_t stb = sort_u32_temp_bytes(np, bits);
   void* stemp = scratch<unsigned char>(stb);
   u64 entry_bytes = build_bytes_per_row + (a.csr_rows ? 4 : 0) + (a.has_post ? 4 : 0);
   for (u32 t = 0; t < a.n_chain; t++) entry_bytes += 4 + (a.chain[t].val ? 8 : 0);
+  // The decoded entries depend on the store's slices and the chain's constants only: kept with the slice's CSR table
+  // (per store version, like every other join table), so a steady-state step does not decode 5.4 M build rows again.
+  std::string ekey;
+  {
+    auto put = [&](const void* p, size_t n) { ekey.append(reinterpret_cast<const char*>(p), n); };
+    put(&b.csr_off, sizeof b.csr_off); put(&b.csr_rows, sizeof b.csr_rows); put(&b.kmin, 4); put(&b.kn, 4); put(&b.n_stages, 4); put(&b.n_win, 4);
+    for (u32 t = 0; t < b.n_stages; t++) put(&b.stage[t], sizeof(BandStage));
+    for (u32 w = 0; w < b.n_win; w++) { put(&b.win[w].key_col, sizeof(void*)); put(&b.win[w].val, sizeof(void*)); put(&b.win[w].vkmin, 4); put(&b.win[w].vkn, 4); put(&b.win[w].vbase, 8); }
+    put(&b.has_post, 4); put(&b.post_lit, 4); put(&b.post_is_eq, 4); put(&b.post_col, sizeof(void*)); put(&b.has_neq, 4); put(&b.neq_build, sizeof(void*));
+    put(&b.n_entry_cols, 4);
+    for (u32 u = 0; u < b.n_entry_cols; u++) { put(&b.entry_col[u].ptr, sizeof(void*)); put(&b.entry_col[u].src, 4); }
+    put(&nb, 8);
+  }
+  bool have_entries = false;
+  const bool cache_entries = cur_build_table && B.stable_id != 0 && !opt.on(RDFGPU_OPT_NO_TABLE_CACHE);
+  std::unique_lock<std::mutex> entries_lock(store->slice_build_mu, std::defer_lock);
+  if (cache_entries) {
+    entries_lock.lock();
+    for (const auto& e : cur_build_table->band_entries) if (e.key == ekey) { b.et = e.et; for (u32 u = 0; u < b.n_entry_cols; u++) b.eo[u] = e.eo[u]; have_entries = true; }
+  }
+  b.n_entries = nb;
+  if (!have_entries) {
   // stages all keyed by one build column: their look-ups once per distinct key value instead of once per entry
   {
     const u32* kc = a.n_chain ? b.stage[0].key_col : nullptr;
@@ -1782,14 +1858,27 @@ void Plan::exec_band_join(LdsJoinArgs& a, BandArgs& b, const DevTable& B, const 
     }
   }
   // the build side, once: per row its columns + stage look-ups read, 16 B of operands + the output values written
-  b.n_entries = nb;
-  b.et = scratch<uint4>(nb + 64);                  // padded: the pair test reads whole groups of 8 entries
-  for (u32 u = 0; u < b.n_entry_cols; u++) b.eo[u] = scratch<u32>(nb);
+  const bool own_entries = cache_entries && cur_build_table->band_entries.size() < 8;
+  if (own_entries) {
+    RDFGPU_HIP(hipMalloc((void**)&b.et, (nb + 64) * sizeof(uint4)));
+    for (u32 u = 0; u < b.n_entry_cols; u++) RDFGPU_HIP(hipMalloc((void**)&b.eo[u], nb * sizeof(u32)));
+  } else {
+    b.et = scratch<uint4>(nb + 64);                  // padded: the pair test reads whole groups of 8 entries
+    for (u32 u = 0; u < b.n_entry_cols; u++) b.eo[u] = scratch<u32>(nb);
+  }
   timed(KC_BAND_ENTRIES, 0, nb, B.n_dev, entry_bytes + 4ull * b.n_entry_cols + 16 + 4ull * b.n_entry_cols, nullptr, 0, 0, [&] { launch_band_entries(b, stream); });
+    if (cache_entries && cur_build_table->band_entries.size() < 8) {   // publish only when complete
+      RDFGPU_HIP(hipStreamSynchronize(stream)); metrics.host_syncs++;
+      SliceTable::BandEntries e{ekey, b.et, {nullptr, nullptr, nullptr, nullptr}};
+      for (u32 u = 0; u < b.n_entry_cols; u++) e.eo[u] = b.eo[u];
+      cur_build_table->band_entries.push_back(e);
+    }
+  }
+  if (entries_lock.owns_lock()) entries_lock.unlock();
   // per probe row: key + the window operands + the id operand read, 24 B of record + 8 B of sort pair written
   timed(KC_BAND_DECODE, 0, np, P.n_dev, 4 + 4ull * (b.n_win + b.has_neq) + 9ull * b.n_win + 24 + 8, nullptr, 0, 0, [&] { launch_band_decode(b, stream); });
   // the partition pass: in the time, not in the algorithmic bytes
-  timed(KC_RADIX_SORT, 0, np, nullptr, 0, nullptr, 0, 0, [&] { sort_pairs_u32_u32(b.skey_in, skey, b.sval_in, perm, np, bits, stemp, stb, stream); });
+  if (!presorted) timed(KC_RADIX_SORT, 0, np, nullptr, 0, nullptr, 0, 0, [&] { sort_pairs_u32_u32(b.skey_in, skey, b.sval_in, perm, np, bits, stemp, stb, stream); });
   b.poff = scratch<u32>((u64)kn + 2);
   u32* nblk = scratch<u32>((u64)kn + 1);
   b.boff = scratch<u32>((u64)kn + 1);
@@ -1808,7 +1897,7 @@ void Plan::exec_band_join(LdsJoinArgs& a, BandArgs& b, const DevTable& B, const 
   timed(KC_BAND_BLOCKS, 12ull * kn, 0, nullptr, 0, nullptr, 0, 0, [&] { launch_band_blocks(a.csr_off, b.poff, kn, nblk, stream); });
   timed(KC_DEVICE_SCAN, 0, (u64)kn + 1, nullptr, 8, nullptr, 0, 0, [&] { exclusive_scan_u32(nblk, b.boff, (u64)kn + 1, temp, tb, stream); });
   timed(KC_BAND_DESC, 12ull * kn, 0, nullptr, 0, nullptr, 0, 0, [&] { launch_band_desc(b, stream); });
-  timed(KC_BAND_ROWS, 0, np, P.n_dev, 4 + 32 + 32, nullptr, 0, 0, [&] { launch_band_rows(b, stream); });
+  if (!presorted) timed(KC_BAND_ROWS, 0, np, P.n_dev, 4 + 32 + 32, nullptr, 0, 0, [&] { launch_band_rows(b, stream); });
   // per probe row 4 (sorted position) + 24 (record) read, per entry 16 B read, per pair one bit written; the pair count
   // is not known on the host
   timed(KC_BAND_MASK, 16ull * nb, np, P.n_dev, 4 + 24, nullptr, 0, 0, [&] { launch_band_mask(b, stream); });

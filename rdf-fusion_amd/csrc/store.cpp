@@ -32,9 +32,14 @@ DevicePool::~DevicePool() {
 void* DevicePool::alloc(size_t bytes) {
   const size_t b = bucket_of(bytes ? bytes : 1);
   std::lock_guard<std::mutex> g(mu_);
+  // the smallest cached block that fits, if it is not wastefully large (<= 1.5 x the bucket): speculative sizes drift by a few
+  // per cent from execution to execution, and a fresh hipMalloc of a 150 MB block costs about as much as the kernel that fills it
+  // (an exact fit first: taking a larger block away from the request it was cached for only moves the miss)
   auto it = free_.find(b);
+  if (it == free_.end()) { it = free_.upper_bound(b); if (it != free_.end() && it->first > b + b / 2) it = free_.end(); }
   void* p = nullptr;
-  if (it != free_.end()) { p = it->second; free_.erase(it); cached_ -= b; }
+  size_t got = b;
+  if (it != free_.end()) { p = it->second; got = it->first; free_.erase(it); cached_ -= got; }
   else {
     hipError_t e = hipMalloc(&p, b);
     if (e != hipSuccess) {
@@ -62,8 +67,8 @@ void* DevicePool::alloc(size_t bytes) {
       }
     }
   }
-  live_[p] = b;
-  in_use_ += b;
+  live_[p] = got;
+  in_use_ += got;
   return p;
 }
 void DevicePool::free(void* p) {
@@ -98,7 +103,7 @@ void DevicePool::trim() {
 static const char* const kOptionNames[RDFGPU_OPT__COUNT] = {
     "FORCE_GENERIC_VM", "NO_JOIN_REORDER", "NO_SPECULATION", "NO_FIRST_RUN_SPECULATION", "NO_STRING_VERDICTS",
     "NO_TABLE_CACHE", "NO_INDEX_JOIN", "NO_CHAIN_FUSION", "NO_VALUE_TABLES", "NO_RANGE_INDEX", "NO_FILTER_FUSION",
-    "NO_LDS_JOIN", "NO_GLOBAL_TABLE_JOIN", "NO_DIRECT_TABLE", "NO_BAND_JOIN", "NO_PARTITIONED_JOIN", "NO_VALUE_VERDICTS", "NO_PRIMING", "NO_RUN_COPY",
+    "NO_LDS_JOIN", "NO_GLOBAL_TABLE_JOIN", "NO_DIRECT_TABLE", "NO_BAND_JOIN", "NO_PARTITIONED_JOIN", "NO_VALUE_VERDICTS", "NO_PRIMING", "NO_ORDERED_JOIN", "NO_RUN_COPY",
     "LDS_MAX_BUILD", "CSR_ROW_LANES_LOG2", "JOIN_WAVE_Q", "PARTITION_MIN_BUILD"};
 const char* engine_option_name(u32 option) { return option < RDFGPU_OPT__COUNT ? kOptionNames[option] : nullptr; }
 const EngineOptions& default_engine_options() {
@@ -229,6 +234,7 @@ void Store::drop_slice_tables() {
     if (t.slots) (void)hipFree(t.slots);
     for (auto& v : t.values) if (v.val) (void)hipFree(v.val);
     for (auto& r : t.ranges) { if (r.rows) (void)hipFree(r.rows); if (r.vals) (void)hipFree(r.vals); if (r.link) (void)hipFree(r.link); }
+    for (auto& e : t.band_entries) { if (e.et) (void)hipFree(e.et); for (u32* p : e.eo) if (p) (void)hipFree(p); }
   }
   slice_tables.clear();
 }

@@ -95,6 +95,10 @@ struct SliceTable {
   // slice holding that slice's key): rows[p] / vals[p] for every CSR position p, ascending by value inside each group
   struct RangeIndex { const long long* val; const u32* link_col; u32* rows; u32* vals; long long vbase; u32* link; bool usable; };
   std::vector<RangeIndex> ranges;
+  // a CSR table's rows decoded for one band-join chain (band_join.hip: the pair test's operands and the entries' output
+  // values, in CSR order): a function of the store's slices and the chain's constants only — `key` spells them out
+  struct BandEntries { std::string key; uint4* et; u32* eo[4]; };
+  std::vector<BandEntries> band_entries;
 };
 struct SliceKey {
   const u32* key[RDFGPU_MAX_KEYS] = {}; u32 n_keys = 0; u64 rows = 0;

@@ -10,6 +10,6 @@ rocprofv3 --pmc SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VA
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/bp_fetch -- python3 $R/scratch/one_batch.py > $R/gpurun_out/bp_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/bp_write -- python3 $R/scratch/one_batch.py > $R/gpurun_out/bp_write.log 2>&1
 cd $R
-python3 profiles/summarize.py counters gpurun_out/bp_counters.json band_ gpurun_out/bp_sq1 gpurun_out/bp_sq2 gpurun_out/bp_fetch gpurun_out/bp_write
+python3 profiles/summarize.py counters gpurun_out/bp_counters.json ${KSUB:-band_} gpurun_out/bp_sq1 gpurun_out/bp_sq2 gpurun_out/bp_fetch gpurun_out/bp_write
 find gpurun_out/bp_trace -name "*kernel_stats.csv" -exec cp {} gpurun_out/bp_kernel_stats.csv \;
 rm -rf gpurun_out/bp_trace gpurun_out/bp_sq1 gpurun_out/bp_sq2 gpurun_out/bp_fetch gpurun_out/bp_write

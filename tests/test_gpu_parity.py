@@ -1102,7 +1102,7 @@ TOGGLES = ["RDFGPU_NO_CHAIN_FUSION", "RDFGPU_NO_INDEX_JOIN", "RDFGPU_NO_TABLE_CA
            "RDFGPU_NO_FIRST_RUN_SPECULATION", "RDFGPU_NO_DIRECT_TABLE", "RDFGPU_FORCE_GENERIC_VM", "RDFGPU_NO_LDS_JOIN",
            "RDFGPU_NO_GLOBAL_TABLE_JOIN", "RDFGPU_NO_FILTER_FUSION", "RDFGPU_NO_VALUE_TABLES", "RDFGPU_NO_RANGE_INDEX",
            "RDFGPU_NO_BAND_JOIN", "RDFGPU_NO_PARTITIONED_JOIN", "RDFGPU_NO_JOIN_REORDER", "RDFGPU_NO_STRING_VERDICTS",
-           "RDFGPU_NO_VALUE_VERDICTS", "RDFGPU_NO_RUN_COPY", "RDFGPU_NO_PRIMING"]
+           "RDFGPU_NO_VALUE_VERDICTS", "RDFGPU_NO_RUN_COPY", "RDFGPU_NO_PRIMING", "RDFGPU_NO_ORDERED_JOIN"]
 
 
 @pytest.mark.parametrize("toggle", TOGGLES)
@@ -1129,6 +1129,51 @@ def test_engine_toggles_do_not_change_results(bsbm_stores, torch_cuda, request, 
         got = plan.execute().fetch()
         exp, n_exp, _ = os_.execute(desc, [params])
         np.testing.assert_array_equal(ku.multiset(got), ku.multiset(exp, n_exp))
+
+
+@pytest.mark.parametrize("n_tab,dup", [(3_000, False), (40_000, True), (200_000, True)])
+def test_ordered_slice_join_matches_oracle(torch_cuda, n_tab, dup):
+    """A small table joined with a store slice on a column the slice is NOT sorted by, followed by look-up joins keyed by
+    table columns: on re-execution the matches are emitted in the slice's order (ordered_join.hip) — the same rows as the
+    probe-ordered index join and as the oracle, sorted by the slice's sort column; table rows with a null / unknown key or
+    without a look-up row join nothing; duplicate table keys multiply."""
+    rng = np.random.default_rng(n_tab)
+    n_subj, n_obj = 30_000, 900
+    P_LINK, P_A, P_B = 50_001, 50_002, 50_003
+    subj = rng.integers(1000, 1000 + n_subj, 150_000).astype(np.uint32)
+    obj = rng.integers(40_000, 40_000 + n_obj, 150_000).astype(np.uint32)
+    sa = rng.choice(np.arange(1000, 1000 + n_subj, dtype=np.uint32), int(n_subj * 0.9), replace=False)   # 10 % of the subjects have no <a>
+    sb = rng.choice(np.arange(1000, 1000 + n_subj, dtype=np.uint32), int(n_subj * 0.95), replace=False)
+    s_all = np.concatenate([subj, sa, sb])
+    p_all = np.concatenate([np.full(len(subj), P_LINK), np.full(len(sa), P_A), np.full(len(sb), P_B)]).astype(np.uint32)
+    o_all = np.concatenate([obj, rng.integers(1, 500, len(sa)).astype(np.uint32), rng.integers(1, 500, len(sb)).astype(np.uint32)])
+    gs, os_ = both_stores((np.zeros(len(s_all), np.uint32), s_all, p_all, o_all))
+    pb = PlanBuilder()
+    scan = lambda p_: pb.data_source(quad_pattern("s", p_, "v"))
+    c = pb.hash_join(pb.table(0, 2), scan(P_LINK), on=[(1, 0)], projection=[0, 1, 3])            # (tag, X, o)
+    c = pb.hash_join(c, scan(P_A), on=[(1, 0)], projection=[0, 1, 2, 4])                          # + a
+    c = pb.hash_join(c, scan(P_B), on=[(1, 0)], projection=[0, 1, 2, 3, 5])                       # + b
+    desc = pb.build(c)
+    plan = gs.plan(desc).enable_kernel_timing(True)
+    plan_off = gs.plan(desc).set_option("NO_ORDERED_JOIN")
+    used = 0
+    for it in range(4):
+        keys = rng.integers(1000, 1000 + n_subj, n_tab).astype(np.uint32) if dup else rng.choice(np.arange(1000, 1000 + n_subj, dtype=np.uint32), n_tab, replace=False)
+        keys[rng.random(n_tab) < 0.02] = 0                                   # unbound
+        keys[rng.random(n_tab) < 0.02] = 999_999                             # not a subject of the slice
+        tab = [np.arange(1, n_tab + 1, dtype=np.uint32), keys]
+        keep, ptrs = table_on_device(torch_cuda, tab)
+        exp, n_exp, _ = os_.execute(desc, [tab])
+        for pl in (plan, plan_off):
+            pl.bind_table(0, ptrs, n_tab)
+            got = pl.execute().fetch()
+            assert pl.result_info()[0] == n_exp
+            np.testing.assert_array_equal(ku.multiset(got), ku.multiset(exp, n_exp))
+        if any("oj_write_kernel" in k[0] for k in plan.kernel_stats()):
+            used += 1
+            got = plan.fetch()
+            assert np.all(np.diff(got[2].astype(np.int64)) >= 0)             # sorted by the slice's sort column (?o of the GPOS slice)
+    assert used >= 2 or ENGINE_TOGGLED or n_tab * 5 * 8 < 150_000
 
 
 def test_plan_outlives_its_store_handle(torch_cuda):
