@@ -17,9 +17,11 @@ results per instance are identical to the reference's per-query plan, tests/test
 `--threads` host threads instead.  value = solution bindings (rows leaving the top join, before
 DISTINCT / ORDER BY / LIMIT) per second over all ranks.
 
-N > 1 (strong scaling, the dataset is fixed): triples are sharded by hash(subject); each rank evaluates
-the batch's constant-subject patterns on its shard, the bindings are exchanged with ONE all-gather per
-table and step (counts + padded rows = all-gatherv) over RCCL, everything else is local.
+N > 1 (strong scaling, the dataset and the batch are fixed): triples are sharded by hash(subject); each rank
+evaluates the batch's constant-subject patterns on its shard (phase A), the resulting table C is re-sharded by
+prodFeature with ONE hash repartition per step (rdfgpu_exchange_repartition: counts first, then the rows, RCCL
+grouped send / recv), and the candidate join + FILTER pipeline (phase B) runs on the rank's object-sharded copy of
+the productFeature triples (sharding.shard_dataset_hybrid): both sides of the join shrink with N.
 """
 import argparse
 import json
@@ -54,9 +56,9 @@ def scan_roofline(rf, device, log2_rows=26, threshold=1000, reps=10, distinct=20
     if distinct == 2000:
         val = np.clip(np.rint(rng.normal(1000, 333, n)), 1, 2000).astype(np.uint32)
         values = np.arange(1, 2001)
-    else:                                    # uniform over a large dictionary; literal k carries the value k mod 2000 + 1
+    else:                                    # uniform over a large dictionary of integer literals
         val = rng.integers(1, distinct + 1, n).astype(np.uint32)
-        values = (np.arange(distinct) % 2000) + 1
+        values = rng.integers(1, 2001, distinct)                # a random value per literal: survivors are scattered, not clustered by id
     obj = (int_base + val - 1).astype(np.uint32)
     store = rf.GpuQuadStore(device=device)
     store.extend(np.zeros(n, np.uint32), subj, np.full(n, pred, np.uint32), obj)
@@ -184,7 +186,8 @@ def main():
     # ------------------------------------------------------------------ data, resident in HBM
     t0 = time.time()
     ds = bsbm.generate(args.products)
-    g, s, p, o = sharding.shard_dataset(ds, rank, world)
+    # N > 1: subject shard (default graph) + the candidate join's own layout in a named graph (sharding.shard_dataset_hybrid)
+    g, s, p, o = sharding.shard_dataset_hybrid(ds, rank, world) if world > 1 else sharding.shard_dataset(ds, rank, world)
     store = rf.GpuQuadStore(device=local_rank)
     store.extend(g, s, p, o)
     store.set_typed_values(ds.typed_values, ds.decimals)
@@ -233,7 +236,7 @@ def main():
         return resident[key]
 
     lat_ms = []
-    phase_ms = [0.0, 0.0, 0.0]    # sharded run, this rank: phase A (constant patterns), exchange (all-gather + table layout), phase B
+    phase_ms = [0.0, 0.0, 0.0]    # sharded run, this rank: phase A (constant patterns), exchange (hash repartition of C by feature), phase B
 
     # ------------------------------------------------------------------ the step
     if args.per_instance:
@@ -278,8 +281,8 @@ def main():
             return rows
     else:
         plan_a = store.plan(bsbm.q5_batch_const_plan(ds))
-        plan_b = store.plan(bsbm.q5_batch_plan(ds, tables=True))
-        # The exchange is part of the product: rdfgpu_exchange_allgatherv behind the C ABI (RCCL over xGMI, grouped send / recv,
+        plan_b = store.plan(bsbm.q5_batch_plan(ds, tables=True, graph=[sharding.candidate_graph(ds)]))
+        # The exchange is part of the product: rdfgpu_exchange_repartition behind the C ABI (RCCL over xGMI, grouped send / recv,
         # buffers sized from the exchanged row counts).  torch.distributed only carries the RCCL unique id, the barriers and the
         # final reductions.  Two communicators: the gathered table of batch i stays valid while batch i + 1 is exchanged.
         if rehearse:           # several ranks on ONE GPU (RCCL refuses that): the host-staged transport, gloo as the wire
@@ -321,10 +324,10 @@ def main():
         def step(batch, timing):
             """one batch, start to end (the sharded-result check; the timed loop pipelines the same three phases)"""
             ptrs, n = phase_a(batch, timing)
-            return phase_b(comms[0].allgatherv(ptrs, n), timing)
+            return phase_b(comms[0].repartition(ptrs, n, 2), timing)
 
         def run_pipelined(bs, timing):
-            """Software pipeline over independent batches: the all-gatherv of batch i + 1 (a host thread inside the library,
+            """Software pipeline over independent batches: the repartition of batch i + 1 (a host thread inside the library,
             its own HIP stream) is in flight while phase B of batch i runs on the plan's stream.  Same work per batch as step()."""
             total, pending = 0, None
             for i, b in enumerate(bs):
@@ -332,7 +335,7 @@ def main():
                 ptrs, n = phase_a(b, timing)
                 t_x = time.perf_counter()
                 box = {}
-                th = threading.Thread(target=lambda c=comms[i & 1], p=ptrs, r=n: box.update(tab=c.allgatherv(p, r)))
+                th = threading.Thread(target=lambda c=comms[i & 1], p=ptrs, r=n: box.update(tab=c.repartition(p, r, 2)))
                 th.start()
                 t_b = time.perf_counter()
                 if pending is not None:
@@ -610,7 +613,9 @@ def main():
                                       "; steady state: the join tables of the predicate slices are cached per store version (cold start and the "
                                       "no-cache step are under config.cold_start)"),
                        "mode": "per-instance" if args.per_instance else "batched",
-                       "triples_per_gpu": n_local, "sharding": "rdfgpu_shard_of(subject) over N ranks; rdfgpu_exchange_allgatherv (RCCL over xGMI, behind the C ABI) of the constant-pattern bindings" if world > 1 else "none",
+                       "triples_per_gpu": n_local, "sharding": ("rdfgpu_shard_of(subject) over N ranks (default graph) + the candidate join's layout in a named graph: productFeature sharded by OBJECT, "
+                                    "the three 1:1 star predicates replicated; rdfgpu_exchange_repartition (RCCL over xGMI, behind the C ABI) of the constant-pattern "
+                                    "bindings C by prodFeature") if world > 1 else "none",
                        "sharded_result_check": shard_check,
                        "exchange_overlapped_with_next_step": bool(world > 1 and not args.no_overlap),
                        "rank0_phase_ms_per_step": ({"constant_patterns": round(phase_ms[0] / args.steps, 3), "exchange": round(phase_ms[1] / args.steps, 3),

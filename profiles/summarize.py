@@ -18,7 +18,9 @@ import statistics
 import sys
 from collections import defaultdict
 
-STREAMING = ("filter_kernel", "filter_bits_kernel", "filter_write_kernel", "scan_count_kernel", "scan_write_kernel")   # 16-B-per-lane coalesced readers
+# coalesced streaming readers: 16 B per lane (the guide's case), and run_copy_kernel (4 B per lane, four loads in flight),
+# calibrated on its known byte count: 33.5 M survivors x 4 B = 134.1 MB read, FETCH_SIZE reports 67.6 MB
+STREAMING = ("filter_kernel", "filter_bits_kernel", "filter_write_kernel", "scan_count_kernel", "scan_write_kernel", "run_copy_kernel")
 
 
 def short(name):

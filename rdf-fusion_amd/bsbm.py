@@ -267,7 +267,7 @@ def q5_batch_const_plan(ds):
     return pb.build(_q5_batch_constants(pb, ds, pb.table(0, 2)))
 
 
-def q5_batch_plan(ds, w1=120, w2=170, tables=None, topk=False):
+def q5_batch_plan(ds, w1=120, w2=170, tables=None, topk=False, graph="default"):
     """BSBM Q5 for a BATCH of instances in one operator tree (shared scans: every triple-pattern partition
     is streamed once per batch instead of once per query).  Same operators as q5_plan; the per-instance
     constant becomes a column: the table C(inst, X, prodFeature, origProperty1, origProperty2) is either bound
@@ -276,18 +276,20 @@ def q5_batch_plan(ds, w1=120, w2=170, tables=None, topk=False):
     `product != X` is applied once, where the instance meets the product (all later joins are on product).
     Inner joins commute, so the batch is free to order them by cost: constants first, then the candidate
     join, then the two selective numeric windows, and the 1:1 label lookup last.
+    `graph`: the active graph of the product-side patterns (sharding.shard_dataset_hybrid keeps them in a named graph).
     Output: (inst, product, productLabel) — per instance exactly q5_plan's bindings (as a multiset)."""
     pr = ds.pred
     pb = PlanBuilder()
     c = _q5_batch_constants(pb, ds, pb.table(0, 2)) if tables is None else pb.table(0, 5)
-    pf = pb.data_source(quad_pattern("product", pr["bsbm:productFeature"], "prodFeature"))      # (product, prodFeature)
+    quad = lambda s_, p_, o_: quad_pattern(s_, p_, o_, graph=graph)
+    pf = pb.data_source(quad("product", pr["bsbm:productFeature"], "prodFeature"))      # (product, prodFeature)
     # candidates: JOIN (product, f) ON f, product != X   ->  (inst, product, orig1, orig2)
     node = pb.hash_join(c, pf, on=[(2, 1)], filter=ID_NEQ(col(5), col(1)), projection=[0, 5, 3, 4])
     # the two numeric windows cut the candidates down before anything else is looked up
     for k, w, orig in ((1, w1, 2), (2, w2, 3)):
-        sim = pb.data_source(quad_pattern("product", pr[f"bsbm:productPropertyNumeric{k}"], f"simProperty{k}"))
+        sim = pb.data_source(quad("product", pr[f"bsbm:productPropertyNumeric{k}"], f"simProperty{k}"))
         node = pb.hash_join(node, sim, on=[(1, 0)], filter=_window(5, orig, w), projection=[0, 1, 2, 3])
-    label = pb.data_source(quad_pattern("product", pr["rdfs:label"], "productLabel"))           # (product, label)
+    label = pb.data_source(quad("product", pr["rdfs:label"], "productLabel"))           # (product, label)
     out = pb.hash_join(node, label, on=[(1, 0)], projection=[0, 1, 5])                           # (inst, product, label)
     return pb.build(q5_topk(pb, out, True) if topk else out)
 

@@ -33,6 +33,30 @@ def shard_dataset(ds, rank, world_size):
     return ds.g[keep], ds.s[keep], ds.p[keep], ds.o[keep]
 
 
+def candidate_graph(ds):
+    """The named graph of shard_dataset_hybrid's second copy (an id beyond the dictionary: no term, no typed value)."""
+    return int(ds.n_ids) + 7
+
+
+def shard_dataset_hybrid(ds, rank, world_size):
+    """The layout of the sharded batched Q5 (bench.py --gpus N).  Default graph: this rank's SUBJECT shard of every triple
+    (star joins on ?product and the constant-subject patterns <X> p ?v are local).  Named graph candidate_graph(ds): what
+    the candidate join and its star look-ups read, laid out for THAT join — the productFeature triples whose OBJECT
+    (the feature, the join key) hashes to this rank, and all triples of the three 1:1 star predicates the candidate
+    filter reads (numeric1, numeric2, label: 0.9 % of BSBM's triples, replicated).  With it the C table is re-sharded by
+    feature (rdfgpu_exchange_repartition) and BOTH sides of the candidate join shrink with the number of ranks; with the
+    subject shard alone every rank has to look at every row of C."""
+    g, s, p, o = shard_dataset(ds, rank, world_size)
+    pr = ds.pred
+    pf = ds.p == pr["bsbm:productFeature"]
+    if world_size > 1:
+        pf = pf & (shard_of(ds.o, world_size) == rank)
+    star = (ds.p == pr["bsbm:productPropertyNumeric1"]) | (ds.p == pr["bsbm:productPropertyNumeric2"]) | (ds.p == pr["rdfs:label"])
+    keep = pf | star
+    g2 = np.full(int(keep.sum()), candidate_graph(ds), dtype=np.uint32)
+    return (np.concatenate([g, g2]), np.concatenate([s, ds.s[keep]]), np.concatenate([p, ds.p[keep]]), np.concatenate([o, ds.o[keep]]))
+
+
 def q5_const_plans(ds, product_id):
     """Three single-pattern plans for the constant-subject side of Q5."""
     X = int(product_id)
@@ -129,6 +153,17 @@ def run_q5_batch_sharded_tables(ds, params, execute, allgatherv):
     c_local = execute(bsbm.q5_batch_const_plan(ds), [params])
     c_all = allgatherv(c_local)
     return execute(bsbm.q5_batch_plan(ds, tables=True), [c_all])
+
+
+def run_q5_batch_hybrid(ds, params, execute, repartition):
+    """The same step over shard_dataset_hybrid's layout: phase A as above (default graph = subject shard); the exchange is a
+    hash REPARTITION of C by prodFeature (column 2) — a rank receives the rows of the features it holds the candidate
+    triples of; phase B reads the named graph.  The union of the ranks' bindings is the unsharded answer: a binding
+    belongs to exactly one (instance, shared feature, product) triple, and a feature lives on exactly one rank."""
+    from . import bsbm
+    c_local = execute(bsbm.q5_batch_const_plan(ds), [params])
+    c_mine = repartition(c_local, 2)
+    return execute(bsbm.q5_batch_plan(ds, tables=True, graph=[candidate_graph(ds)]), [c_mine])
 
 
 def run_stages(stages, execute, repartition):

@@ -242,6 +242,17 @@ decimal_to_float_cases = [
     dict(raw=str(I128_MAX), value=1.701412e20, tol=0.0),
     dict(raw=str(I128_MIN), value=-1.701412e20, tol=0.0),
 ]
+# Boolean::from(number) (lib/model/src/xsd/boolean.rs:139-170: from_integer, from_decimal, from_float, from_double) is the
+# xsd:boolean CAST; on every input but NaN it is also the effective boolean value the path computes
+# (builtin/native/effective_boolean_value.rs:108-113: `value != 0`).  The tests' NaN assertions (cast: false) are NOT
+# transcribed: EBV(NaN) is `NaN != 0` = true there, which tests/test_gpu_parity.py checks separately as a code-derived case.
+ebv_cases = []
+for kind, one in (("integer", 1), ("decimal", None), ("float", 1.0), ("double", 1.0)):
+    src = "M/boolean.rs from_" + kind
+    val = (lambda x: [kind, str(int(x) * E18)]) if kind == "decimal" else (lambda x: [kind, x])
+    ebv_cases += [dict(src=src, value=val(0), ebv=False), dict(src=src, value=val(1), ebv=True), dict(src=src, value=val(2), ebv=True)]
+    if kind in ("float", "double"):
+        ebv_cases += [dict(src=src, value=[kind, "INF"], ebv=True)]
 # TypedValueEncodingField type ids (lib/encoding/src/typed_value/encoding.rs fn test_type_ids + the enum's declaration
 # order :248-268): the dense-union type id of every field round-trips; the ids are the typed-value tags of the ABI.
 type_id_cases = [["NamedNode", 1], ["BlankNode", 2], ["String", 3], ["Boolean", 4], ["Float", 5], ["Double", 6], ["Decimal", 7],
@@ -298,7 +309,7 @@ out = dict(
     pushdown_display=pushdown_display_cases, rowgroups=rowgroup_cases, dedupe=dedupe_cases,
     prune=prune_cases, find_range=find_range_cases, numeric_arith=numeric_arith_cases,
     decimal_to_double=decimal_to_double_cases, compare=compare_cases, decimal_to_float=decimal_to_float_cases,
-    type_ids=type_id_cases, join_lowering=join_lowering_cases, plan_snapshots=plan_snapshot_cases)
+    ebv=ebv_cases, type_ids=type_id_cases, join_lowering=join_lowering_cases, plan_snapshots=plan_snapshot_cases)
 
 if __name__ == "__main__":
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "reference_kats.json")

@@ -111,6 +111,12 @@ def numeric_kat_plans(kats):
         pb = PlanBuilder()
         expr = EBV(EQ(kat_literal(["decimal", c["raw"]]), float32(c["value"])))
         out.append((f'decimal->float {c["raw"]}', pb.build(pb.filter(pb.table(0, 1), expr)), 1))
+    for kind in ("float", "double"):         # effective_boolean_value.rs:111-112: `value != 0` — NaN is not equal to 0: EBV(NaN) is true
+        pb = PlanBuilder()
+        out.append((f"EBV {kind} NaN (code-derived)", pb.build(pb.filter(pb.table(0, 1), EBV(kat_literal([kind, "NaN"])))), 1))
+    for c in kats.get("ebv", []):            # Boolean::from(number): the row survives FILTER(value) iff the EBV is true
+        pb = PlanBuilder()
+        out.append((f'{c["src"]} EBV {c["value"]}', pb.build(pb.filter(pb.table(0, 1), EBV(kat_literal(c["value"])))), 1 if c["ebv"] else 0))
     # PartialOrd of two values: which of `<`, `=`, `>` is true — none of them when the values are incomparable (error)
     for c in kats["compare"]:
         truth = {"Less": (1, 0, 0), "Equal": (0, 1, 0), "Greater": (0, 0, 1), "None": (0, 0, 0)}[c["ordering"]]

@@ -193,6 +193,61 @@ def test_sharded_q5_batch_exchange_equals_unsharded(world):
     assert total > 0 and all(r[4] == total for r in results)
 
 
+def _hybrid_worker(rank, world, port, q):
+    """bench.py's N > 1 step over shard_dataset_hybrid's layout: phase A on the subject shard (default graph), C re-sharded by
+    prodFeature (hash repartition), phase B on the object-sharded candidate triples + the replicated star predicates."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+    from rdf_fusion_amd import bsbm, sharding
+    from oracle import oracle as orc
+    import kat_util as ku
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ds = bsbm.generate(600)
+        g, s, p, o = sharding.shard_dataset_hybrid(ds, rank, world)
+        st = orc.OracleStore()
+        st.extend(g, s, p, o)
+        st.set_typed_values(ds.typed_values, ds.decimals)
+        batch = _batch_products(ds)
+        params = [np.arange(1, BATCH + 1, dtype=np.uint32), batch]
+        ex = sharding.NumpyExchange(dist, world, rank)
+        seen = {}
+
+        def repartition(cols, key_col):
+            out = ex.repartition(cols, key_col)
+            seen["sent"], seen["received"] = len(cols[0]), len(out[0])
+            assert np.all(sharding.shard_of(out[key_col], world) == rank)       # a rank only receives the features it holds
+            return out
+        cols = sharding.run_q5_batch_hybrid(ds, params, _oracle_executor(st, ku), repartition)
+        q.put((rank, len(cols[0]), ku.multiset(cols), seen["sent"], seen["received"]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_q5_batch_hybrid_layout_equals_unsharded(world):
+    """Both sides of the candidate join sharded (C re-partitioned by feature; the productFeature triples by object): the
+    union of the ranks' bindings is the unsharded answer, and no row of C is lost or duplicated by the repartition."""
+    from rdf_fusion_amd import bsbm
+    from oracle import oracle as orc
+    import kat_util as ku
+    results = _spawn(_hybrid_worker, world)
+    ds = bsbm.generate(600)
+    st = orc.OracleStore()
+    st.extend(ds.g, ds.s, ds.p, ds.o)
+    st.set_typed_values(ds.typed_values, ds.decimals)
+    batch = _batch_products(ds)
+    params = [np.arange(1, BATCH + 1, dtype=np.uint32), batch]
+    cols, n, _ = st.execute(bsbm.q5_batch_plan(ds), tables=[params])
+    got = ku.multiset(list(np.concatenate([r[2] for r in results]).T))
+    assert sum(r[1] for r in results) == n > 0
+    np.testing.assert_array_equal(got, ku.multiset(cols, n))
+    _, n_c, _ = st.execute(bsbm.q5_batch_const_plan(ds), tables=[params])
+    assert sum(r[3] for r in results) == sum(r[4] for r in results) == n_c
+
+
 # --------------------------------------------------------------------------- LUBM Q9: joins whose key is not the shard key
 def _q9_worker(rank, world, port, q):
     """lubm.q9_sharded_stages with the oracle as executor: three hash repartitions (by advisor, by course, by student)
