@@ -329,14 +329,17 @@ __global__ __launch_bounds__(256) void band_slow_kernel(const LdsJoinArgs* ap, c
   if (*b.slow_rows == 0) return;
   const LdsJoinArgs& a = *ap;
   const u32 lane = threadIdx.x & 63;
-  const u32 blk = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (threadIdx.x >> 6));
-  if (blk >= b.boff[b.kn] || blk >= b.max_blocks) return;
+  // (persistent waves: the usual case — no slow row at all — must not cost the launch of one wave per block)
+  const u32 n_all = b.boff[b.kn];
+  const u32 n_blocks = n_all < b.max_blocks ? n_all : b.max_blocks;
+  const u32 stride = gridDim.x * 4u;
+  for (u32 blk = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (threadIdx.x >> 6)); blk < n_blocks; blk += stride) {
   const uint4 d = b.bdesc[blk];
   const u32 eb = d.x, ne = d.y, rb = d.z, nr = d.w;
   u32 j = 0; uint4 aux = make_uint4(0u, 0u, 0u, 0u);
   if (lane < nr) { j = b.perm[rb + lane]; aux = b.aux_s[rb + lane]; }
   const bool slow = (aux.y & 1u) != 0;
-  if (!__any(slow)) return;
+  if (!__any(slow)) continue;
   const BandEntry en = band_entry(b, eb + lane, lane < ne);
   u32 m_lo = 0, m_hi = 0;
   for (u32 e = 0; e < ne; e++) {
@@ -358,6 +361,7 @@ __global__ __launch_bounds__(256) void band_slow_kernel(const LdsJoinArgs* ap, c
 #pragma unroll
   for (int dd = 32; dd >= 1; dd >>= 1) c += __shfl_xor(c, dd, 64);
   if (lane == 0 && c) b.bcount[blk] += c;
+  }
 }
 
 // ---- bits -> rows: one wave per block --------------------------------------------------------------------------------
@@ -464,7 +468,8 @@ void launch_band_mask(const BandArgs& b, hipStream_t s) {
   if (b.n_win == 2) launch_band_mask_w<2>(b, g, s); else launch_band_mask_w<1>(b, g, s);   // no window = one trivial window
 }
 void launch_band_slow(const LdsJoinArgs* a_dev, const BandArgs& b, hipStream_t s) {
-  hipLaunchKernelGGL(band_slow_kernel, dim3((b.max_blocks + 3) / 4), dim3(256), 0, s, a_dev, b);
+  const u32 g = (b.max_blocks + 3) / 4;
+  hipLaunchKernelGGL(band_slow_kernel, dim3(g < 2048u ? (g ? g : 1u) : 2048u), dim3(256), 0, s, a_dev, b);
 }
 void launch_band_emit(const BandArgs& b, hipStream_t s) {
   hipLaunchKernelGGL(band_emit_kernel, dim3((b.max_blocks + 3) / 4), dim3(256), 0, s, b);
