@@ -107,6 +107,7 @@ __global__ __launch_bounds__(256) void band_decode_kernel(const BandArgs b) {
   if (j < n) { const u32 v = b.probe_key[j]; const u32 d = v - b.kmin; if (v != 0 && d < b.kn) k = d; }   // null keys never join
   b.skey_in[j] = k; b.sval_in[j] = (u32)j;
   if (k == b.kn) return;
+  if (b.key_hist) atomicAdd(b.key_hist + k, 1u);
   uint4 rec = make_uint4(1u, 0u, 1u, 0u);              // no window: entries carry x_b = 1 (0 when the entry is dead)
   u32 flags = 0;
 #pragma unroll
@@ -136,6 +137,20 @@ __global__ __launch_bounds__(256) void band_rows_kernel(const BandArgs b) {
   const u32 j = b.perm[i];
   b.rec_s[i] = b.rec[2 * (u64)j];
   b.aux_s[i] = b.rec[2 * (u64)j + 1];
+}
+
+// Counting-sort form of the partition pass, for probe sides too small for rocPRIM's radix sort to leave its launch-latency
+// floor (135 us for 0.6 M rows — one rank's share of a sharded step): the decode pass counts the rows of every key, a scan
+// gives poff, and every row takes the next free position of its key (order inside a key is irrelevant to the join).
+__global__ __launch_bounds__(256) void band_scatter_kernel(const BandArgs b) {
+  const u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= b.n_probe_cap) return;
+  const u32 k = b.skey_in[j];
+  if (k >= b.kn) return;                               // joins nothing: no position
+  const u32 pos = atomicAdd(b.key_cursor + k, 1u);
+  const_cast<u32*>(b.perm)[pos] = (u32)j;
+  b.rec_s[pos] = b.rec[2 * j];
+  b.aux_s[pos] = b.rec[2 * j + 1];
 }
 
 // ---- per group entry: the chain's look-ups, once ------------------------------------------------------------------
@@ -262,6 +277,7 @@ __global__ __launch_bounds__(256) void band_entries_kernel(const BandArgs b) {
 // Block descriptors: key k owns the blocks boff[k] .. boff[k + 1), entry chunk major.
 __global__ __launch_bounds__(256) void band_desc_kernel(const BandArgs b) {
   const u32 k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k == 0 && b.n_blocks_out) *b.n_blocks_out = b.boff[b.kn];
   if (k >= b.kn) return;
   const u32 e0 = b.csr_off[k], e1 = b.csr_off[k + 1], p0 = b.poff[k], p1 = b.poff[k + 1];
   if (e0 >= e1 || p0 >= p1) return;
@@ -274,21 +290,29 @@ __global__ __launch_bounds__(256) void band_desc_kernel(const BandArgs b) {
 // ---- the pair tests: one wave per 64 x 64 block --------------------------------------------------------------------
 // lane = probe row (its decoded record in registers); the block's entries are wave-uniform: they stream through the
 // scalar cache (s_load_dwordx8 = two entries) and feed the vector compares as scalar operands — per pair two unsigned
-// range checks and one id compare, no vector memory and no LDS inside the loop.
+// range checks and one id compare (6 VALU instructions per pair), no vector memory and no LDS inside the loop.  Measured: the
+// kernel is NOT bound by those instructions (7 -> 6 per pair changed nothing; 200 k short waves with exposed scalar-load
+// latency are what it waits for; persistent waves made it slower, 240 -> 325 us).
 // NWIN = window stages (1..2; no window = one trivial window); NEQ = base filter: 0 none / 1 `!=` / 2 `=`.
 struct BandEntry8 { uint4 a[8]; };
 template <int NWIN, int NEQ>
 __global__ __launch_bounds__(256) void band_mask_kernel(const BandArgs b) {
   const u32 lane = threadIdx.x & 63;
-  const u32 blk = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (threadIdx.x >> 6));
-  if (blk >= b.boff[b.kn] || blk >= b.max_blocks) return;
+  // one wave per block; the grid is sized from the previous execution's block count, so a wave strides on in the rare case
+  // that there are more blocks than waves (sizing the grid by the upper bound launches twice as many waves as there are blocks)
+  const u32 n_all = b.boff[b.kn];
+  const u32 n_blocks = n_all < b.max_blocks ? n_all : b.max_blocks;
+  for (u32 blk = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (threadIdx.x >> 6)); blk < n_blocks; blk += gridDim.x * 4u) {
   const uint4 d = b.bdesc[blk];
   const u32 eb = __builtin_amdgcn_readfirstlane(d.x), ne = __builtin_amdgcn_readfirstlane(d.y);
   const u32 rb = __builtin_amdgcn_readfirstlane(d.z), nr = __builtin_amdgcn_readfirstlane(d.w);
   uint4 rec = make_uint4(kBandInvalidLo, 0u, 1u, 0u);
   u32 x = 0;
   if (lane < nr) { rec = b.rec_s[rb + lane]; if (NEQ) x = b.aux_s[rb + lane].x; }
-  const BandEntry8* __restrict__ p = reinterpret_cast<const BandEntry8*>(b.et + eb);   // the table is padded: reading past the group is harmless
+  // (constant address space: the entries are read-only for the whole kernel, so wave-uniform loads from them stay scalar loads
+  //  although the loop also stores masks and counts)
+  typedef const u32 __attribute__((address_space(4))) * ConstWords;
+  const ConstWords p = (ConstWords)(uintptr_t)(b.et + eb);   // the table is padded: reading past the group is harmless
   u32 m[2] = {0u, 0u};
 #pragma unroll
   for (u32 h = 0; h < 2; h++) {
@@ -296,21 +320,22 @@ __global__ __launch_bounds__(256) void band_mask_kernel(const BandArgs b) {
     u32 acc = 0;
 #pragma unroll 1
     for (u32 g = 0; g < 4; g++) {
-      const BandEntry8 cur = p[h * 4 + g];
-      u32 part = 0;
+      const u32 w0 = (h * 4 + g) * 32;                // 8 entries x 4 words: one s_load_dwordx8 per two entries
 #pragma unroll
       for (u32 e = 0; e < 8; e++) {
-        const uint4 q = cur.a[e];
+        const uint4 q = make_uint4(p[w0 + e * 4], p[w0 + e * 4 + 1], p[w0 + e * 4 + 2], 0u);
         // branch-free on purpose (bitwise &, not &&): a short-circuit here becomes an exec-mask branch per pair
-        u32 pass = (u32)((q.x - rec.x) <= rec.y);
-        if (NWIN > 1) pass &= (u32)((q.y - rec.z) <= rec.w);
-        if (NEQ == 1) pass &= (u32)(q.z != x);
-        if (NEQ == 2) pass &= (u32)(q.z == x);
-        part |= pass << e;
+        // the verdict of the 64 lanes IS the compares' lane mask (SGPR pairs, AND-ed on the scalar unit): shifting it into
+        // every lane's word is ONE add-with-carry (acc + acc + carry) instead of a select and an or per pair
+        u64 lanes = __builtin_amdgcn_ballot_w64((q.x - rec.x) <= rec.y);
+        if (NWIN > 1) lanes &= __builtin_amdgcn_ballot_w64((q.y - rec.z) <= rec.w);
+        if (NEQ == 1) lanes &= __builtin_amdgcn_ballot_w64(q.z != x);
+        if (NEQ == 2) lanes &= __builtin_amdgcn_ballot_w64(q.z == x);
+        u64 carry_out;
+        asm("v_addc_co_u32_e64 %0, %1, %2, %2, %3" : "=v"(acc), "=s"(carry_out) : "v"(acc), "s"(lanes));
       }
-      acc |= part << (8 * g);
     }
-    m[h] = acc;
+    m[h] = __builtin_bitreverse32(acc);             // entry 0 was shifted in first: it sits at bit 31
   }
   // entries past the group's end belong to the next key: their bits do not count
   const u64 live = ne >= 64 ? ~0ull : ((1ull << ne) - 1ull);
@@ -320,6 +345,7 @@ __global__ __launch_bounds__(256) void band_mask_kernel(const BandArgs b) {
 #pragma unroll
   for (int dd = 32; dd >= 1; dd >>= 1) c += __shfl_xor(c, dd, 64);
   if (lane == 0) b.bcount[blk] = c;
+  }
 }
 
 // Rare: probe rows whose window operands are not all xsd:integer (or overflow i64) take the full typed-value semantics,
@@ -372,16 +398,16 @@ constexpr u32 kBandList = 1024;   // survivors listed at a time: a block with mo
 __global__ __launch_bounds__(256) void band_emit_kernel(const BandArgs b) {
   __shared__ unsigned short list[4][kBandList];
   const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const u32 blk = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + wave);
-  const u32 n_blocks = b.boff[b.kn] < b.max_blocks ? b.boff[b.kn] : b.max_blocks;
-  if (blk == 0 && lane == 0) {   // the exact total, whether or not it fitted (like the fused join kernel's count)
+  const u32 n_all = b.boff[b.kn];
+  const u32 n_blocks = n_all < b.max_blocks ? n_all : b.max_blocks;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {   // the exact total, whether or not it fitted (like the fused join kernel's count)
     const u64 total = b.bofs[b.max_blocks];
     *b.n_out_dev = total;
     if (total > b.out_cap) *b.overflow = 1u;
   }
-  if (blk >= n_blocks) return;
+  for (u32 blk = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + wave); blk < n_blocks; blk += gridDim.x * 4u) {   // (grid ~ blocks, see band_mask_kernel)
   const u32 tot = __builtin_amdgcn_readfirstlane(b.bcount[blk]);
-  if (tot == 0) return;
+  if (tot == 0) continue;
   const uint4 d = b.bdesc[blk];
   const u32 eb = __builtin_amdgcn_readfirstlane(d.x), ne = __builtin_amdgcn_readfirstlane(d.y);
   const u32 rb = __builtin_amdgcn_readfirstlane(d.z), nr = __builtin_amdgcn_readfirstlane(d.w);
@@ -432,6 +458,7 @@ __global__ __launch_bounds__(256) void band_emit_kernel(const BandArgs b) {
     run += n_round;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");              // the list is free again
   }
+  }
 }
 
 // ---- host side -------------------------------------------------------------------------------------------------------
@@ -447,6 +474,9 @@ void launch_band_blocks(const u32* csr_off, const u32* poff, u32 kn, u32* nblk, 
 }
 void launch_band_pt(const BandArgs& b, hipStream_t s) {
   if (b.pt && b.pt_n) hipLaunchKernelGGL(band_pt_kernel, grid256(b.pt_n), dim3(256), 0, s, b);
+}
+void launch_band_scatter(const BandArgs& b, hipStream_t s) {
+  if (b.n_probe_cap) hipLaunchKernelGGL(band_scatter_kernel, grid256(b.n_probe_cap), dim3(256), 0, s, b);
 }
 void launch_band_rows(const BandArgs& b, hipStream_t s) {
   if (b.n_probe_cap) hipLaunchKernelGGL(band_rows_kernel, grid256(b.n_probe_cap), dim3(256), 0, s, b);
@@ -464,7 +494,7 @@ template <int NWIN> static void launch_band_mask_w(const BandArgs& b, dim3 g, hi
   else hipLaunchKernelGGL((band_mask_kernel<NWIN, 2>), g, dim3(256), 0, s, b);
 }
 void launch_band_mask(const BandArgs& b, hipStream_t s) {
-  const dim3 g((b.max_blocks + 3) / 4);           // the number of blocks lives on the device: surplus waves leave at once
+  const dim3 g((b.launch_blocks + 3) / 4 ? (b.launch_blocks + 3) / 4 : 1);   // the number of blocks lives on the device: surplus waves leave at once, missing ones are made up by striding
   if (b.n_win == 2) launch_band_mask_w<2>(b, g, s); else launch_band_mask_w<1>(b, g, s);   // no window = one trivial window
 }
 void launch_band_slow(const LdsJoinArgs* a_dev, const BandArgs& b, hipStream_t s) {
@@ -472,7 +502,7 @@ void launch_band_slow(const LdsJoinArgs* a_dev, const BandArgs& b, hipStream_t s
   hipLaunchKernelGGL(band_slow_kernel, dim3(g < 2048u ? (g ? g : 1u) : 2048u), dim3(256), 0, s, a_dev, b);
 }
 void launch_band_emit(const BandArgs& b, hipStream_t s) {
-  hipLaunchKernelGGL(band_emit_kernel, dim3((b.max_blocks + 3) / 4), dim3(256), 0, s, b);
+  hipLaunchKernelGGL(band_emit_kernel, dim3((b.launch_blocks + 3) / 4 ? (b.launch_blocks + 3) / 4 : 1), dim3(256), 0, s, b);
 }
 
 // rocPRIM radix sort of (u32 key, u32 value) pairs on the low `bits` bits: the partition pass of the probe side

@@ -295,6 +295,8 @@ struct BandArgs {
   uint4* bdesc;               // per block {first entry, entries (<= 64), first sorted row, rows (<= 64)}
   u64* masks;                 // 64 x u64 per block: bit e of lane r = (entry e, row r) joins
   u32* bcount; u32* bofs;     // per block (+ 1): output rows / their exclusive scan
+  u32* key_hist; u32* key_cursor;   // counting-sort form of the partition pass (small probe sides): rows per key, counted by the decode pass; the scatter's cursors
+  u32 launch_blocks; u32 pad3; u64* n_blocks_out;   // waves launched by the block kernels (>= the previous execution's blocks; they stride on if there are more); the count, for next time
   u32 max_blocks, presorted;  // presorted: the probe rows arrive sorted by key — no sort, records written in place
   u32* slow_rows;             // number of probe rows that need the full typed-value semantics (usually 0)
   // output
@@ -306,6 +308,7 @@ struct BandArgs {
 void launch_band_pt(const BandArgs& b, hipStream_t s);
 void launch_band_entries(const BandArgs& b, hipStream_t s);
 void launch_band_rows(const BandArgs& b, hipStream_t s);      // records into sorted order
+void launch_band_scatter(const BandArgs& b, hipStream_t s);   // counting-sort form: records to their key's range (poff = scan of key_hist)
 void launch_band_desc(const BandArgs& b, hipStream_t s);
 void launch_band_decode(const BandArgs& b, hipStream_t s);   // + sort keys
 void launch_band_bounds(const u32* skey_sorted, u64 n, u32 kn, u32* poff, hipStream_t s);

@@ -642,6 +642,7 @@ void Plan::execute() {
   RDFGPU_HIP(hipMemsetAsync(counters, 0, 256 * sizeof(u64), stream));
 
   spec_checks.clear();
+  band_block_counters.clear();
   memo.assign(nodes.size(), DevTable{}); memo_valid.assign(nodes.size(), 0);
   speculative = allow_speculation && !opt.on(RDFGPU_OPT_NO_SPECULATION);
 
@@ -706,6 +707,7 @@ void Plan::execute() {
     if (rt & 1u) fail(RDFGPU_ERR_UNSUPPORTED, "REGEX with \\d \\w \\s or \\b over a string with non-ASCII characters needs the regex crate's Unicode tables (not restated)");
     fail(RDFGPU_ERR_UNSUPPORTED, "REGEX with a per-row pattern: a row's pattern literal was not announced in the plan's pattern table");
   }
+  for (const BandBlockCounter& c : band_block_counters) if (c.node) c.node->band_blocks = ctx->counters_host[c.counter];
   // speculative joins: did every output fit the size taken from the previous run?
   bool spec_failed = false;
   for (const SpecCheck& c : spec_checks) {
@@ -1717,7 +1719,7 @@ DevTable Plan::exec_lds_join(NodeInfo& nd, const DevTable& L, const DevTable& R,
       timed(KC_DEVICE_SCAN, 0, tiles + 1, nullptr, 8, nullptr, 0, 0, [&] { exclusive_scan_u32(o.tile_count, o.tile_off, tiles + 1, temp, tb, stream); });
       timed(KC_OJ_WRITE, 0, B.cap, nullptr, 4, n_out, 0, 8ull * a.n_out_cols, [&] { launch_ordered_join_write(o, stream); });
     }
-    else if (use_band) exec_band_join(a, band, B, P, 4ull * (1 + build_payload), 4ull * probe_cols);
+    else if (use_band) { cur_band_node = &nd; exec_band_join(a, band, B, P, 4ull * (1 + build_payload), 4ull * probe_cols); cur_band_node = nullptr; }
     else launch_join(lds_join_class(a.has_filter, a.has_probe_filter, lds_join_items(P.cap << a.row_lanes_log2, global_table), use_part ? kJoinTableLds : lds_join_mode(a), chained),
                      (global_table ? 0 : fixed) + stage_bytes, 4ull * a.n_out_cols);
     spec_checks.push_back({size_node, (u32)(n_out - counters), left_join});
@@ -1805,6 +1807,12 @@ void Plan::exec_band_join(LdsJoinArgs& a, BandArgs& b, const DevTable& B, const 
   bool presorted = false;
   if (P.sorted_col >= 0 && P.cols[P.sorted_col] == a.probe_key[0] && P.key_min >= std::max<u32>(1u, a.direct_min) && !opt.on(RDFGPU_OPT_NO_ORDERED_JOIN)) presorted = true;
   b.presorted = presorted ? 1u : 0u;
+  // small probe side, not sorted: counting sort on the key (band_scatter_kernel) instead of rocPRIM's radix sort
+  const bool counting = !presorted && np <= (1ull << 21) && !opt.on(RDFGPU_OPT_NO_ORDERED_JOIN);
+  if (counting) {
+    b.key_hist = scratch<u32>((u64)kn + 2); b.key_cursor = scratch<u32>((u64)kn + 2);
+    RDFGPU_HIP(hipMemsetAsync(b.key_hist, 0, ((size_t)kn + 2) * sizeof(u32), stream));
+  }
   b.csr_off = a.csr_off; b.csr_rows = a.csr_rows; b.kmin = a.direct_min; b.kn = kn;
   b.probe_key = a.probe_key[0]; b.n_probe_dev = P.n_dev; b.n_probe_cap = np;
   b.tt = a.tt;
@@ -1878,7 +1886,7 @@ void Plan::exec_band_join(LdsJoinArgs& a, BandArgs& b, const DevTable& B, const 
   // per probe row: key + the window operands + the id operand read, 24 B of record + 8 B of sort pair written
   timed(KC_BAND_DECODE, 0, np, P.n_dev, 4 + 4ull * (b.n_win + b.has_neq) + 9ull * b.n_win + 24 + 8, nullptr, 0, 0, [&] { launch_band_decode(b, stream); });
   // the partition pass: in the time, not in the algorithmic bytes
-  if (!presorted) timed(KC_RADIX_SORT, 0, np, nullptr, 0, nullptr, 0, 0, [&] { sort_pairs_u32_u32(b.skey_in, skey, b.sval_in, perm, np, bits, stemp, stb, stream); });
+  if (!presorted && !counting) timed(KC_RADIX_SORT, 0, np, nullptr, 0, nullptr, 0, 0, [&] { sort_pairs_u32_u32(b.skey_in, skey, b.sval_in, perm, np, bits, stemp, stb, stream); });
   b.poff = scratch<u32>((u64)kn + 2);
   u32* nblk = scratch<u32>((u64)kn + 1);
   b.boff = scratch<u32>((u64)kn + 1);
@@ -1887,17 +1895,26 @@ void Plan::exec_band_join(LdsJoinArgs& a, BandArgs& b, const DevTable& B, const 
   const u64 max_blocks = cmax * (np / 64 + 1) + nb / 64 + kn + 1;
   if (max_blocks >= (1ull << 31)) fail(RDFGPU_ERR_UNSUPPORTED, "band join of %llu blocks", (unsigned long long)max_blocks);
   b.max_blocks = (u32)max_blocks;
+  // the block kernels launch one wave per block: sized from the previous execution's count (+ 25 %), not from the upper bound
+  b.n_blocks_out = new_counter();
+  band_block_counters.push_back({cur_band_node, (u32)(b.n_blocks_out - counters)});
+  const u64 hist = cur_band_node ? cur_band_node->band_blocks : 0;
+  b.launch_blocks = (u32)std::min<u64>(max_blocks, hist ? hist + hist / 4 + 1024 : max_blocks);
   b.bdesc = scratch<uint4>(max_blocks);
   b.masks = scratch<u64>(max_blocks * 64);
   b.bcount = scratch<u32>(max_blocks + 1); b.bofs = scratch<u32>(max_blocks + 1);
   const size_t tb = scan_temp_bytes(std::max<u64>((u64)kn + 1, max_blocks + 1));
   void* temp = scratch<unsigned char>(tb);
   RDFGPU_HIP(hipMemsetAsync(b.bcount, 0, (max_blocks + 1) * sizeof(u32), stream));
-  timed(KC_BAND_BOUNDS, 0, np, nullptr, 4, nullptr, 0, 0, [&] { launch_band_bounds(skey, np, kn, b.poff, stream); });
+  if (counting) {   // poff = exclusive scan of the rows per key (entry kn = the rows that join something); then the scatter
+    timed(KC_DEVICE_SCAN, 0, (u64)kn + 1, nullptr, 8, nullptr, 0, 0, [&] { exclusive_scan_u32(b.key_hist, b.poff, (u64)kn + 1, temp, tb, stream); });
+    RDFGPU_HIP(hipMemcpyAsync(b.key_cursor, b.poff, ((size_t)kn + 1) * sizeof(u32), hipMemcpyDeviceToDevice, stream));
+    timed(KC_BAND_ROWS, 0, np, P.n_dev, 8 + 32 + 32, nullptr, 0, 0, [&] { launch_band_scatter(b, stream); });
+  } else timed(KC_BAND_BOUNDS, 0, np, nullptr, 4, nullptr, 0, 0, [&] { launch_band_bounds(skey, np, kn, b.poff, stream); });
   timed(KC_BAND_BLOCKS, 12ull * kn, 0, nullptr, 0, nullptr, 0, 0, [&] { launch_band_blocks(a.csr_off, b.poff, kn, nblk, stream); });
   timed(KC_DEVICE_SCAN, 0, (u64)kn + 1, nullptr, 8, nullptr, 0, 0, [&] { exclusive_scan_u32(nblk, b.boff, (u64)kn + 1, temp, tb, stream); });
   timed(KC_BAND_DESC, 12ull * kn, 0, nullptr, 0, nullptr, 0, 0, [&] { launch_band_desc(b, stream); });
-  if (!presorted) timed(KC_BAND_ROWS, 0, np, P.n_dev, 4 + 32 + 32, nullptr, 0, 0, [&] { launch_band_rows(b, stream); });
+  if (!presorted && !counting) timed(KC_BAND_ROWS, 0, np, P.n_dev, 4 + 32 + 32, nullptr, 0, 0, [&] { launch_band_rows(b, stream); });
   // per probe row 4 (sorted position) + 24 (record) read, per entry 16 B read, per pair one bit written; the pair count
   // is not known on the host
   timed(KC_BAND_MASK, 16ull * nb, np, P.n_dev, 4 + 24, nullptr, 0, 0, [&] { launch_band_mask(b, stream); });

@@ -37,7 +37,8 @@ struct NodeInfo {
   int source = -1;                // index into Plan::sources
   u32 refs = 0;                   // how many operators consume this node
   u64 last_rows = 0; bool has_last = false;   // output cardinality of the previous execution (speculative sizing)
-  bool last_scaled = false;                    // .. extrapolated from a priming run over a prefix of the bound tables
+  bool last_scaled = false;
+  u64 band_blocks = 0;                         // blocks of the band join based on this node in its previous execution (launch sizing)                    // .. extrapolated from a priming run over a prefix of the bound tables
 };
 struct SpecCheck { NodeInfo* node; u32 counter; bool left_join; };   // counter = n_out slot, counter+1 = overflow flag
 
@@ -112,6 +113,9 @@ struct Plan {
   bool priming = false, primed = false;   // the first execution over big bound tables is preceded by one over their first rows (Plan::prime)
   void prime();
   std::vector<SpecCheck> spec_checks;
+  struct BandBlockCounter { NodeInfo* node; u32 counter; };
+  std::vector<BandBlockCounter> band_block_counters;   // device-side block counts of this execution's band joins -> NodeInfo::band_blocks
+  NodeInfo* cur_band_node = nullptr;                   // the base join whose band join is being set up
   std::vector<PendingLaunch> pending;
   std::vector<DevTable> memo; std::vector<char> memo_valid;   // node results of the current execution
   ChainRequest* pending_chain = nullptr;                        // set while the base join of a fusable chain executes
