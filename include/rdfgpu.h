@@ -423,6 +423,21 @@ int rdfgpu_plan_metrics(rdfgpu_plan* plan, rdfgpu_metrics* out);
 int rdfgpu_plan_selected_index(const rdfgpu_plan* plan, uint32_t node, uint32_t* components);
 /* Opaque hipStream_t of the plan, so the host can order its own work after it. */
 int rdfgpu_plan_stream(rdfgpu_plan* plan, void** hip_stream);
+/*
+ * ENC_PT of a result column (MemObjectIdMapping::decode_array, lib/storage/src/memory/object_id_mapping.rs:331-374): object
+ * ids -> plain terms, decoded on the device from the store's string heap (rdfgpu_store_set_strings must hold the lexical
+ * form of EVERY id that can appear) and typed-value table.  Rows [first_row, first_row + n_rows) of column `col`, as an
+ * Arrow struct array
+ *     struct<term_type: uint8, value: utf8, tag: uint8, aux: uint32>
+ * term_type = PlainTermType (plain_term/encoding.rs:90-127: 0 named node, 1 blank node, 2 literal); value = the lexical
+ * form; a null struct where the id is 0 / unknown (builder.append_null()).  data_type and language_tag of the reference's
+ * struct are functions of (tag, aux) through the host's small tables — tag = the datatype of a typed literal (the ABI's
+ * RDFGPU_TV_*; RDFGPU_TV_OTHER: aux = the host's datatype id), aux = the language id of a string (0 = none) — and are
+ * attached there as dictionary arrays: the per-row string work, the gather of n_rows lexical forms out of the heap,
+ * happens here.  The lexical forms of one call may not exceed 2^31 - 1 bytes (utf8 offsets are int32): decode fewer rows.
+ */
+int rdfgpu_plan_decode_terms(rdfgpu_plan* plan, uint32_t col, uint64_t first_row, uint64_t n_rows,
+                             struct ArrowArray* out, struct ArrowSchema* schema);
 
 /*
  * Filter push-down into a DataSourceExec leaf.  When a subtree is NOT fused into one rdfgpu plan, DataFusion's physical

@@ -108,6 +108,24 @@ def regex_is_match(pattern, flags, subject):
     return None if r < 0 else bool(r)
 
 
+def decode_terms(ids, typed_values, offsets, heap):
+    """ENC_PT restated (MemObjectIdMapping::decode_array, object_id_mapping.rs:331-374; PlainTermType, plain_term/
+    encoding.rs:90-127): per id None (null), or (term_type, lexical form, tag, aux) with term_type 0 named node / 1 blank
+    node / 2 literal."""
+    from rdf_fusion_amd import abi
+    out = []
+    n_ids = len(typed_values)
+    for i in np.asarray(ids, dtype=np.uint32).tolist():
+        if i == 0 or i >= n_ids or typed_values["tag"][i] == abi.TV_NULL:
+            out.append(None)
+            continue
+        tag = int(typed_values["tag"][i])
+        tt = 0 if tag == abi.TV_NAMED_NODE else 1 if tag == abi.TV_BLANK_NODE else 2
+        form = bytes(heap[int(offsets[i]):int(offsets[i + 1])]).decode("utf-8") if i + 1 < len(offsets) else ""
+        out.append((tt, form, tag, int(typed_values["aux"][i])))
+    return out
+
+
 def find_range_between(values, lo, hi):
     """MemColumnChunk::find_range_between; None values = nulls (stored as 0)."""
     v = np.array([0 if x is None else x for x in values], dtype=np.uint32)

@@ -181,11 +181,11 @@ int rdfgpu_plan_fetch(rdfgpu_plan* plan, uint32_t* const* host_cols, uint32_t n_
 
 // Arrow C Data Interface export -----------------------------------------------------------------
 namespace {
-struct ChildPriv { void* buffers[2]; };
+struct ChildPriv { void* buffers[3] = {nullptr, nullptr, nullptr}; };
 void release_child_array(struct ArrowArray* a) {
   if (!a || !a->release) return;
   ChildPriv* pr = static_cast<ChildPriv*>(a->private_data);
-  std::free(pr->buffers[0]); std::free(pr->buffers[1]);
+  std::free(pr->buffers[0]); std::free(pr->buffers[1]); std::free(pr->buffers[2]);
   delete pr;
   a->release = nullptr;
 }
@@ -260,6 +260,102 @@ int rdfgpu_plan_next(rdfgpu_plan* plan, struct ArrowArray* out, struct ArrowSche
       schema->release = release_schema; schema->private_data = pr;
     }
     p->cursor += len;
+    return RDFGPU_OK;
+  } catch (const Error& e) { set_last_error(e.what()); return e.status; }
+  catch (const std::exception& e) { set_last_error(e.what()); return RDFGPU_ERR_INVALID; }
+}
+int rdfgpu_plan_decode_terms(rdfgpu_plan* plan, uint32_t col, uint64_t first_row, uint64_t n_rows, struct ArrowArray* out, struct ArrowSchema* schema) {
+  try {
+    Plan* p = P(plan);
+    if (!out) fail(RDFGPU_ERR_INVALID, "null out array");
+    if (!p->executed) fail(RDFGPU_ERR_INVALID, "plan has not been executed");
+    if (col >= p->result.n_cols) fail(RDFGPU_ERR_INVALID, "column %u of a %u-column result", col, p->result.n_cols);
+    if (first_row > p->result_rows || n_rows > p->result_rows - first_row) fail(RDFGPU_ERR_INVALID, "rows %llu .. + %llu of a %llu-row result", (unsigned long long)first_row, (unsigned long long)n_rows, (unsigned long long)p->result_rows);
+    Store* st = p->store;
+    st->activate();
+    std::shared_lock<std::shared_mutex> lock(st->mu);          // the dictionary tables must not be replaced underneath
+    if (!st->str_off) fail(RDFGPU_ERR_INVALID, "ENC_PT needs the lexical forms (rdfgpu_store_set_strings)");
+    const u64 n = n_rows;
+    hipStream_t s = p->stream;
+    DevicePool& pool = st->pool;
+    std::vector<void*> dev;
+    auto dalloc = [&](size_t bytes) { void* q = pool.alloc(bytes ? bytes : 4); dev.push_back(q); return q; };
+    struct Guard { DevicePool& pool; std::vector<void*>& v; ~Guard() { for (void* q : v) pool.free(q); } } guard{pool, dev};
+    DecodeArgs a{};
+    a.ids = p->result.cols[col] + first_row; a.n = n; a.tt = st->typed_table();
+    u32* len = static_cast<u32*>(dalloc((n + 1) * 4)); u32* off = static_cast<u32*>(dalloc((n + 1) * 4));
+    a.len = len; a.off = off;
+    a.term_type = static_cast<unsigned char*>(dalloc(n)); a.tag = static_cast<unsigned char*>(dalloc(n)); a.aux = static_cast<u32*>(dalloc(n * 4));
+    RDFGPU_HIP(hipMemsetAsync(len + n, 0, 4, s));
+    launch_decode_lengths(a, s);
+    // the total first (64-bit on the host side: utf8 offsets are int32)
+    std::vector<u32> h_len(n + 1);
+    RDFGPU_HIP(hipMemcpyAsync(h_len.data(), len, (n + 1) * 4, hipMemcpyDeviceToHost, s));
+    RDFGPU_HIP(hipStreamSynchronize(s));
+    u64 total = 0;
+    for (u64 i = 0; i < n; i++) total += h_len[i];
+    if (total > 0x7FFFFFFFull) fail(RDFGPU_ERR_UNSUPPORTED, "ENC_PT: %llu bytes of lexical forms in one call (utf8 offsets are int32): decode fewer rows", (unsigned long long)total);
+    const size_t tb = scan_temp_bytes(n + 1);
+    void* temp = dalloc(tb);
+    exclusive_scan_u32(len, off, n + 1, temp, tb, s);
+    a.bytes = static_cast<unsigned char*>(dalloc(total));
+    launch_decode_bytes(a, s);
+    // host side of the Arrow arrays
+    auto halloc = [](size_t bytes) { void* q = std::malloc(bytes ? bytes : 1); if (!q) fail(RDFGPU_ERR_OOM, "host allocation of %zu bytes failed", bytes); return q; };
+    unsigned char* h_tt = static_cast<unsigned char*>(halloc(n)); unsigned char* h_tag = static_cast<unsigned char*>(halloc(n));
+    u32* h_aux = static_cast<u32*>(halloc(n * 4)); int32_t* h_off = static_cast<int32_t*>(halloc((n + 1) * 4));
+    char* h_bytes = static_cast<char*>(halloc(total));
+    if (n) {
+      RDFGPU_HIP(hipMemcpyAsync(h_tt, a.term_type, n, hipMemcpyDeviceToHost, s));
+      RDFGPU_HIP(hipMemcpyAsync(h_tag, a.tag, n, hipMemcpyDeviceToHost, s));
+      RDFGPU_HIP(hipMemcpyAsync(h_aux, a.aux, n * 4, hipMemcpyDeviceToHost, s));
+    }
+    RDFGPU_HIP(hipMemcpyAsync(h_off, off, (n + 1) * 4, hipMemcpyDeviceToHost, s));
+    if (total) RDFGPU_HIP(hipMemcpyAsync(h_bytes, a.bytes, total, hipMemcpyDeviceToHost, s));
+    RDFGPU_HIP(hipStreamSynchronize(s));
+    int64_t nulls = 0;
+    uint8_t* valid = static_cast<uint8_t*>(std::calloc((n + 7) / 8 + 1, 1));
+    for (u64 i = 0; i < n; i++) { if (h_tt[i] == 0xFF) { nulls++; h_tt[i] = 0; } else valid[i >> 3] |= (uint8_t)(1u << (i & 7)); }
+    StructPriv* sp = new StructPriv();
+    sp->n = 4; sp->children = new ArrowArray*[4];
+    auto child = [&](void* b1, void* b2, int n_buffers) {
+      ArrowArray* ch = new ArrowArray();
+      std::memset(ch, 0, sizeof *ch);
+      ChildPriv* cp = new ChildPriv();
+      cp->buffers[0] = nullptr; cp->buffers[1] = b1; cp->buffers[2] = b2;
+      ch->length = (int64_t)n; ch->null_count = 0; ch->n_buffers = n_buffers;
+      ch->buffers = const_cast<const void**>(reinterpret_cast<void**>(cp->buffers));
+      ch->release = release_child_array; ch->private_data = cp;
+      return ch;
+    };
+    sp->children[0] = child(h_tt, nullptr, 2);
+    sp->children[1] = child(h_off, h_bytes, 3);
+    sp->children[2] = child(h_tag, nullptr, 2);
+    sp->children[3] = child(h_aux, nullptr, 2);
+    // the struct's validity bitmap is owned through the first child's spare slot
+    static_cast<ChildPriv*>(sp->children[0]->private_data)->buffers[2] = valid;
+    sp->buffers[0] = nulls ? valid : nullptr;
+    std::memset(out, 0, sizeof *out);
+    out->length = (int64_t)n; out->null_count = nulls; out->n_buffers = 1; out->buffers = sp->buffers;
+    out->n_children = 4; out->children = sp->children;
+    out->release = release_struct_array; out->private_data = sp;
+    if (schema) {
+      std::memset(schema, 0, sizeof *schema);
+      SchemaPriv* pr = new SchemaPriv();
+      pr->n = 4; pr->children = new ArrowSchema*[4]; pr->names = new std::string[4];
+      const char* names[4] = {"term_type", "value", "tag", "aux"};
+      const char* formats[4] = {"C", "u", "C", "I"};
+      for (u32 c = 0; c < 4; c++) {
+        ArrowSchema* cs = new ArrowSchema();
+        std::memset(cs, 0, sizeof *cs);
+        pr->names[c] = names[c];
+        cs->format = formats[c]; cs->name = pr->names[c].c_str(); cs->flags = 0;
+        cs->release = release_schema; cs->private_data = nullptr;
+        pr->children[c] = cs;
+      }
+      schema->format = "+s"; schema->name = ""; schema->flags = 2 /* ARROW_FLAG_NULLABLE */; schema->n_children = 4; schema->children = pr->children;
+      schema->release = release_schema; schema->private_data = pr;
+    }
     return RDFGPU_OK;
   } catch (const Error& e) { set_last_error(e.what()); return e.status; }
   catch (const std::exception& e) { set_last_error(e.what()); return RDFGPU_ERR_INVALID; }

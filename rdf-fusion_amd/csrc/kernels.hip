@@ -272,6 +272,43 @@ __global__ __launch_bounds__(256) void regex_verdict_kernel(const RegexProg* pro
   const Val r = tv_regex(*prog, tt, v, rhs_lang);
   out[id] = r.tag == RDFGPU_TV_BOOLEAN ? (unsigned char)(r.lo != 0) : r.aux == kRegexNeedsUnicode ? (unsigned char)3 : (unsigned char)2;   // 3: needs the Unicode tables
 }
+// ENC_PT (object_id_mapping.rs:331-374).  Pass 1: per row the term type, the typed value's tag / aux and the length of the
+// lexical form; pass 2 (after a scan of the lengths): a wave copies the forms of 16 consecutive rows, 64 bytes per step.
+__global__ __launch_bounds__(256) void decode_lengths_kernel(const DecodeArgs a) {
+  const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.n) return;
+  const u32 id = a.ids[i];
+  const bool known = id != 0 && id < a.tt.n_ids;
+  unsigned char tt = 0xFF, tag = 0; u32 aux = 0, len = 0;
+  if (known) {
+    const rdfgpu_typed_value v = a.tt.tv[id];
+    tag = v.tag; aux = v.aux;
+    tt = v.tag == RDFGPU_TV_NAMED_NODE ? 0 : v.tag == RDFGPU_TV_BLANK_NODE ? 1 : 2;   // PlainTermType
+    if (v.tag == RDFGPU_TV_NULL) tt = 0xFF;
+    if (tt != 0xFF && a.tt.str_off && id < a.tt.n_str_ids) len = (u32)(a.tt.str_off[id + 1] - a.tt.str_off[id]);
+  }
+  a.term_type[i] = tt; a.tag[i] = tag; a.aux[i] = aux; a.len[i] = len;
+}
+__global__ __launch_bounds__(256) void decode_bytes_kernel(const DecodeArgs a) {
+  const u64 wave = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const u32 lane = threadIdx.x & 63;
+  for (u32 r = 0; r < 16; r++) {
+    const u64 i = wave * 16 + r;
+    if (i >= a.n) return;                                  // wave-uniform
+    const u32 n = a.len[i];
+    if (n == 0) continue;
+    const unsigned char* src = a.tt.heap + a.tt.str_off[a.ids[i]];
+    unsigned char* dst = a.bytes + a.off[i];
+    for (u32 b = lane; b < n; b += 64) dst[b] = src[b];
+  }
+}
+void launch_decode_lengths(const DecodeArgs& a, hipStream_t s) {
+  if (a.n) hipLaunchKernelGGL(decode_lengths_kernel, dim3((unsigned)((a.n + 255) / 256)), dim3(256), 0, s, a);
+}
+void launch_decode_bytes(const DecodeArgs& a, hipStream_t s) {
+  const u64 waves = (a.n + 15) / 16;
+  if (a.n) hipLaunchKernelGGL(decode_bytes_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, a);
+}
 void launch_regex_verdicts(const RegexProg* prog_dev, const TypedTable& tt, int64_t rhs_lang, unsigned char* out, u64 n_ids, hipStream_t s) {
   if (!n_ids) return;
   hipLaunchKernelGGL(regex_verdict_kernel, dim3((unsigned)((n_ids + 255) / 256)), dim3(256), 0, s, prog_dev, tt, rhs_lang, out, n_ids);

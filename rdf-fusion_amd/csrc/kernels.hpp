@@ -85,6 +85,14 @@ void launch_run_scan(const FilterArgs& a, const RunCopyBuffers& b, hipStream_t s
 void launch_run_copy(const FilterArgs& a, const RunCopyBuffers& b, hipStream_t s);
 // shape 2's predicate once per id of [a.value_min, + a.value_span): bit (id - value_min) of `a.value_bits` (64-id words)
 void launch_value_verdicts(const FilterArgs& a, hipStream_t s);
+// ---- ENC_PT: ids -> (term type, tag, aux, length of the lexical form), then the bytes (object_id_mapping.rs:331-374) ----
+struct DecodeArgs {
+  const u32* ids; u64 n; TypedTable tt;
+  u32* len; unsigned char* term_type; unsigned char* tag; u32* aux;   // per row (term_type 0xFF = null)
+  const u32* off; unsigned char* bytes;                               // exclusive scan of len; the packed lexical forms
+};
+void launch_decode_lengths(const DecodeArgs& a, hipStream_t s);
+void launch_decode_bytes(const DecodeArgs& a, hipStream_t s);
 void launch_regex_verdicts(const RegexProg* prog_dev, const TypedTable& tt, int64_t rhs_lang, unsigned char* out, u64 n_ids, hipStream_t s);
 
 // ---- K6: CrossJoinExec ----

@@ -69,6 +69,7 @@ def load_library():
     lib.rdfgpu_plan_fetch.argtypes = [vp, C.POINTER(vp), C.c_uint32]
     lib.rdfgpu_plan_next.argtypes = [vp, C.POINTER(abi.ArrowArray), C.POINTER(abi.ArrowSchema)]
     lib.rdfgpu_plan_rewind.argtypes = [vp]
+    lib.rdfgpu_plan_decode_terms.argtypes = [vp, C.c_uint32, C.c_uint64, C.c_uint64, C.POINTER(abi.ArrowArray), C.POINTER(abi.ArrowSchema)]
     lib.rdfgpu_plan_metrics.argtypes = [vp, C.POINTER(abi.Metrics)]
     lib.rdfgpu_plan_selected_index.argtypes = [vp, C.c_uint32, u32p]
     lib.rdfgpu_plan_stream.argtypes = [vp, C.POINTER(vp)]
@@ -433,6 +434,16 @@ class GpuPlan:
             if st == abi.END:
                 return
             yield pa.Array._import_from_c(C.addressof(arr), C.addressof(sch))
+
+    def decode_terms(self, col, first_row=0, n_rows=None):
+        """ENC_PT of rows [first_row, first_row + n_rows) of result column `col` (object_id_mapping.rs:331-374), decoded on the
+        device: a pyarrow StructArray<term_type: uint8, value: utf8, tag: uint8, aux: uint32>, null where the id is null."""
+        import pyarrow as pa
+        if n_rows is None:
+            n_rows = self.result_info()[0] - first_row
+        arr, sch = abi.ArrowArray(), abi.ArrowSchema()
+        _check(self._lib.rdfgpu_plan_decode_terms(self._h, col, first_row, n_rows, C.byref(arr), C.byref(sch)))
+        return pa.Array._import_from_c(C.addressof(arr), C.addressof(sch))
 
     def metrics(self):
         m = abi.Metrics()

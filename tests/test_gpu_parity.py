@@ -964,6 +964,51 @@ def test_regex_variable_patterns_match_oracle(torch_cuda):
         plan.execute()
 
 
+def test_enc_pt_decode_on_device(torch_cuda):
+    """ENC_PT (object_id_mapping.rs:331-374) of result columns, decoded on the device: term type, lexical form, tag and aux
+    of every row against the CPU restatement; null / unknown ids are null structs; windows of rows; multi-byte UTF-8, empty
+    and long forms; an empty result; a store without lexical forms refuses."""
+    rng = np.random.default_rng(21)
+    forms = ["http://example.org/" + "x" * int(rng.integers(0, 40)) + str(i) for i in range(300)]
+    forms += ["_:b%d" % i for i in range(50)] + ["", "caf\u00e9", "\u20acuro \U0001F600", "y" * 5000] + [ku.random_subject(rng) for _ in range(600)]
+    tv, offsets, heap = string_dictionary(forms, n_other=6)
+    tv["tag"][1:301] = abi.TV_NAMED_NODE; tv["tag"][301:351] = abi.TV_BLANK_NODE
+    # the non-string ids get lexical forms too (ENC_PT needs every term's): rebuild offsets / heap for ALL ids
+    n_ids = len(tv)
+    all_forms = [""] + forms + [str(int(tv["lo"][i])) for i in range(1 + len(forms), n_ids)]
+    blob = [f.encode("utf-8") for f in all_forms]
+    offsets = np.zeros(n_ids + 1, dtype=np.uint64); offsets[1:] = np.cumsum([len(b) for b in blob])
+    heap = b"".join(blob)
+    gs, os_ = both_stores((np.zeros(0, np.uint32),) * 4, typed=tv)
+    ids = rng.integers(0, n_ids + 3, 50_000).astype(np.uint32)           # 0 = null, >= n_ids = unknown
+    other = np.arange(1, len(ids) + 1, dtype=np.uint32)
+    keep, ptrs = table_on_device(torch_cuda, [ids, other])
+    pb = PlanBuilder()
+    plan = gs.plan(pb.build(pb.filter(pb.table(0, 2), lit_bool(True))))
+    plan.bind_table(0, ptrs, len(ids)); plan.execute()
+    with pytest.raises(rf.RdfGpuError):                                  # no lexical forms installed yet
+        plan.decode_terms(0)
+    gs.set_strings(offsets, heap)
+    got_ids = plan.fetch()[0]
+    exp = orc.decode_terms(got_ids, tv, offsets, heap)
+    for first, n in ((0, None), (0, 0), (17, 1), (4999, 20_001), (len(ids), 0)):
+        arr = plan.decode_terms(0, first, n)
+        rows = arr.to_pylist()
+        want = exp[first:] if n is None else exp[first:first + n]
+        assert len(rows) == len(want)
+        for r, w in zip(rows, want):
+            assert (r is None) == (w is None)
+            if w is not None:
+                assert (r["term_type"], r["value"], r["tag"], r["aux"]) == w
+    assert arr.type.field(1).type == __import__("pyarrow").utf8()
+    pb = PlanBuilder()
+    empty = gs.plan(pb.build(pb.filter(pb.table(0, 2), lit_bool(False))))
+    empty.bind_table(0, ptrs, len(ids)); empty.execute()
+    assert len(empty.decode_terms(1)) == 0
+    with pytest.raises(rf.RdfGpuError):
+        plan.decode_terms(5)
+
+
 def test_regex_unsupported_is_refused_loudly(torch_cuda):
     tv, offsets, heap = string_dictionary(["abc"])
     gs, _ = both_stores((np.zeros(0, np.uint32),) * 4, typed=tv)
