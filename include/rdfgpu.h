@@ -624,6 +624,30 @@ int rdfgpu_exchange_repartition(rdfgpu_comm* comm, const uint32_t* const* cols, 
 /* The shard of an object id among `world` ranks (host logic, no device access): the function triples are sharded by. */
 uint32_t rdfgpu_shard_of(uint32_t id, uint32_t world);
 
+/* ------------------------------------------------------------------------------------ */
+/* 7. Bulk load, first half: N-Triples text -> object ids on the device                   */
+/* ------------------------------------------------------------------------------------ */
+/*
+ * The reference parses on the host and interns the three terms of every quad through a DashMap (Store::load_from_reader /
+ * bulk_loader, lib/rdf-fusion/src/store.rs:477-493 -> MemObjectIdMapping::encode_quad, lib/storage/src/memory/
+ * object_id_mapping.rs:106-116).  rdfgpu_ntriples_parse does the per-triple half on the device: line and term splitting,
+ * one id per DISTINCT term (first_id .. first_id + n_terms - 1; a bijection, not the reference's insertion order — no query
+ * can observe the difference), and the s / p / o id columns in HBM, ready for rdfgpu_store_extend_device (graph column =
+ * zeros = the default graph).  The distinct terms come back exactly as written in the file (`<iri>`, `_:b1`, `"lex"`,
+ * `"lex"@en`, `"lex"^^<dt>`; escapes are kept, not rewritten): the host builds its dictionary and the typed values of the
+ * new literals from them — per distinct term, not per triple.  Text: UTF-8, one triple per line, blank lines and `#`
+ * comment lines allowed.  A malformed line is RDFGPU_ERR_INVALID with its number; two different terms with one 64-bit
+ * hash (probability ~ n_terms^2 / 2^65) is RDFGPU_ERR_UNSUPPORTED — loud, never a wrong id.
+ */
+typedef struct rdfgpu_ntriples rdfgpu_ntriples;
+int rdfgpu_ntriples_parse(int32_t device, const char* text, uint64_t text_bytes, uint32_t first_id, rdfgpu_ntriples** out);
+int rdfgpu_ntriples_info(const rdfgpu_ntriples* nt, uint64_t* n_triples, uint32_t* n_terms, uint64_t* term_bytes);
+/* offsets[n_terms + 1] and the terms' bytes (term t has id first_id + t); either pointer may be null */
+int rdfgpu_ntriples_terms(const rdfgpu_ntriples* nt, uint64_t* offsets, uint8_t* bytes);
+/* device pointers of the id columns (n_triples each, file order); valid until rdfgpu_ntriples_destroy */
+int rdfgpu_ntriples_columns(const rdfgpu_ntriples* nt, const uint32_t** s, const uint32_t** p, const uint32_t** o);
+void rdfgpu_ntriples_destroy(rdfgpu_ntriples* nt);
+
 #ifdef __cplusplus
 }
 #endif

@@ -108,6 +108,65 @@ def regex_is_match(pattern, flags, subject):
     return None if r < 0 else bool(r)
 
 
+def ntriples_encode(text):
+    """The per-triple half of the reference's bulk load, restated (Store::load_from_reader, lib/rdf-fusion/src/store.rs:477-493
+    -> MemObjectIdMapping::encode_quad, object_id_mapping.rs:106-116): every term of every triple line is interned, ids in
+    insertion order from 1.  Returns (terms: list of bytes, id t + 1 = terms[t]; s, p, o id lists).  Terms are kept as
+    written (`<iri>`, `_:b`, `"lex"`, `"lex"@en`, `"lex"^^<dt>`).  Raises ValueError(line number) on a malformed line."""
+    data = text.encode("utf-8") if isinstance(text, str) else bytes(text)
+    ids, terms, cols = {}, [], ([], [], [])
+    n_line = 0
+    for raw in data.split(b"\n"):
+        line = raw.strip(b" \t\r")
+        if not line or line.startswith(b"#"):
+            continue
+        n_line += 1
+        p, got = 0, []
+        for k in range(3):
+            while p < len(line) and line[p:p + 1] in b" \t\r":
+                p += 1
+            b = p
+            c = line[p:p + 1]
+            if c == b"<":
+                e = line.find(b">", p)
+                if e < 0:
+                    raise ValueError(n_line)
+                p = e + 1
+            elif line[p:p + 2] == b"_:":
+                while p < len(line) and line[p:p + 1] not in b" \t\r":
+                    p += 1
+                if k == 2 and p > b + 2 and line[p - 1:p] == b".":
+                    p -= 1
+            elif c == b'"' and k == 2:
+                p += 1
+                while p < len(line) and line[p:p + 1] != b'"':
+                    p += 2 if line[p:p + 1] == b"\\" else 1
+                if p >= len(line):
+                    raise ValueError(n_line)
+                p += 1
+                if line[p:p + 1] == b"@":
+                    p += 1
+                    while p < len(line) and (line[p:p + 1].isalnum() or line[p:p + 1] == b"-"):
+                        p += 1
+                elif line[p:p + 3] == b"^^<":
+                    e = line.find(b">", p)
+                    if e < 0:
+                        raise ValueError(n_line)
+                    p = e + 1
+            else:
+                raise ValueError(n_line)
+            got.append(line[b:p])
+        rest = line[p:].strip(b" \t\r")
+        if not rest.startswith(b".") or (rest[1:].strip(b" \t\r") and not rest[1:].strip(b" \t\r").startswith(b"#")):
+            raise ValueError(n_line)
+        for k, t in enumerate(got):
+            if t not in ids:
+                ids[t] = len(terms) + 1
+                terms.append(t)
+            cols[k].append(ids[t])
+    return terms, cols[0], cols[1], cols[2]
+
+
 def decode_terms(ids, typed_values, offsets, heap):
     """ENC_PT restated (MemObjectIdMapping::decode_array, object_id_mapping.rs:331-374; PlainTermType, plain_term/
     encoding.rs:90-127): per id None (null), or (term_type, lexical form, tag, aux) with term_type 0 named node / 1 blank

@@ -145,7 +145,7 @@ EXPORTED_SYMBOLS = [
     "rdfgpu_store_read_index",
     "rdfgpu_plan_compile", "rdfgpu_plan_destroy", "rdfgpu_plan_bind_table", "rdfgpu_plan_execute",
     "rdfgpu_plan_result_info", "rdfgpu_plan_result_device", "rdfgpu_plan_fetch", "rdfgpu_plan_next",
-    "rdfgpu_plan_rewind", "rdfgpu_plan_decode_terms", "rdfgpu_plan_metrics", "rdfgpu_plan_selected_index", "rdfgpu_plan_stream",
+    "rdfgpu_plan_rewind", "rdfgpu_plan_decode_terms", "rdfgpu_ntriples_parse", "rdfgpu_ntriples_info", "rdfgpu_ntriples_terms", "rdfgpu_ntriples_columns", "rdfgpu_ntriples_destroy", "rdfgpu_plan_metrics", "rdfgpu_plan_selected_index", "rdfgpu_plan_stream",
     "rdfgpu_plan_enable_kernel_timing", "rdfgpu_plan_kernel_stats",
     "rdfgpu_plan_pushdown_filters", "rdfgpu_plan_set_dynamic_filters", "rdfgpu_plan_source_predicate",
     "rdfgpu_store_set_option", "rdfgpu_store_get_option", "rdfgpu_plan_set_option", "rdfgpu_option_name",

@@ -7,6 +7,7 @@
 
 #include "exchange.hpp"
 #include "host_logic.hpp"
+#include "ntriples.hpp"
 #include "plan.hpp"
 #include "regex_compile.hpp"
 #include "store.hpp"
@@ -520,5 +521,42 @@ int rdfgpu_regex_check(const char* pattern, uint32_t pattern_len, const char* fl
     return RDFGPU_OK;
   } catch (const Error& e) { set_last_error(e.what()); return e.status; }
 }
+
+int rdfgpu_ntriples_parse(int32_t device, const char* text, uint64_t text_bytes, uint32_t first_id, rdfgpu_ntriples** out) {
+  try {
+    if (!out) fail(RDFGPU_ERR_INVALID, "null out pointer");
+    if (!text && text_bytes) fail(RDFGPU_ERR_INVALID, "null text");
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count == 0) { (void)hipGetLastError(); fail(RDFGPU_ERR_NO_DEVICE, "no usable HIP device; this library has no CPU fallback"); }
+    *out = reinterpret_cast<rdfgpu_ntriples*>(ntriples_parse(device, text, text_bytes, first_id));
+    return RDFGPU_OK;
+  } catch (const Error& e) { set_last_error(e.what()); return e.status; }
+  catch (const std::exception& e) { set_last_error(e.what()); return RDFGPU_ERR_INVALID; }
+}
+int rdfgpu_ntriples_info(const rdfgpu_ntriples* nt, uint64_t* n_triples, uint32_t* n_terms, uint64_t* term_bytes) {
+  ABI_BEGIN
+  if (!nt) fail(RDFGPU_ERR_INVALID, "null handle");
+  const NTriples* t = reinterpret_cast<const NTriples*>(nt);
+  if (n_triples) *n_triples = t->n_triples;
+  if (n_terms) *n_terms = t->n_terms;
+  if (term_bytes) *term_bytes = t->term_total;
+  ABI_END
+}
+int rdfgpu_ntriples_terms(const rdfgpu_ntriples* nt, uint64_t* offsets, uint8_t* bytes) {
+  ABI_BEGIN
+  if (!nt) fail(RDFGPU_ERR_INVALID, "null handle");
+  ntriples_terms(reinterpret_cast<const NTriples*>(nt), offsets, bytes);
+  ABI_END
+}
+int rdfgpu_ntriples_columns(const rdfgpu_ntriples* nt, const uint32_t** s, const uint32_t** p, const uint32_t** o) {
+  ABI_BEGIN
+  if (!nt) fail(RDFGPU_ERR_INVALID, "null handle");
+  const NTriples* t = reinterpret_cast<const NTriples*>(nt);
+  if (s) *s = t->s;
+  if (p) *p = t->p;
+  if (o) *o = t->o;
+  ABI_END
+}
+void rdfgpu_ntriples_destroy(rdfgpu_ntriples* nt) { delete reinterpret_cast<NTriples*>(nt); }
 
 }  // extern "C"

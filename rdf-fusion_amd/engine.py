@@ -69,6 +69,12 @@ def load_library():
     lib.rdfgpu_plan_fetch.argtypes = [vp, C.POINTER(vp), C.c_uint32]
     lib.rdfgpu_plan_next.argtypes = [vp, C.POINTER(abi.ArrowArray), C.POINTER(abi.ArrowSchema)]
     lib.rdfgpu_plan_rewind.argtypes = [vp]
+    lib.rdfgpu_ntriples_parse.argtypes = [C.c_int32, C.c_char_p, C.c_uint64, C.c_uint32, C.POINTER(vp)]
+    lib.rdfgpu_ntriples_info.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]
+    lib.rdfgpu_ntriples_terms.argtypes = [vp, C.c_void_p, C.c_void_p]
+    lib.rdfgpu_ntriples_columns.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
+    lib.rdfgpu_ntriples_destroy.argtypes = [vp]
+    lib.rdfgpu_ntriples_destroy.restype = None
     lib.rdfgpu_plan_decode_terms.argtypes = [vp, C.c_uint32, C.c_uint64, C.c_uint64, C.POINTER(abi.ArrowArray), C.POINTER(abi.ArrowSchema)]
     lib.rdfgpu_plan_metrics.argtypes = [vp, C.POINTER(abi.Metrics)]
     lib.rdfgpu_plan_selected_index.argtypes = [vp, C.c_uint32, u32p]
@@ -365,6 +371,46 @@ class Comm:
     def repartition(self, device_ptrs, n_rows, key_col):
         """Row i goes to rank shard_of(cols[key_col][i]): the table re-sharded by the key of the next join."""
         return self._call(self._lib.rdfgpu_exchange_repartition, device_ptrs, n_rows, C.c_uint32(key_col))
+
+
+class NTriples:
+    """rdfgpu_ntriples_*: N-Triples text -> object ids on the device (the per-triple half of the reference's bulk load,
+    store.rs:477-493 + object_id_mapping.rs:106-116).  `terms()` = the distinct terms as written, term t has id first_id + t;
+    `columns()` = device pointers of the s / p / o id columns (file order)."""
+
+    def __init__(self, text, first_id=1, device=-1):
+        self._lib = load_library()
+        data = text.encode("utf-8") if isinstance(text, str) else bytes(text)
+        h = C.c_void_p()
+        _check(self._lib.rdfgpu_ntriples_parse(device, data, len(data), first_id, C.byref(h)))
+        self._h = h
+        self.first_id = first_id
+        nt, nm, nb = C.c_uint64(), C.c_uint32(), C.c_uint64()
+        _check(self._lib.rdfgpu_ntriples_info(self._h, C.byref(nt), C.byref(nm), C.byref(nb)))
+        self.n_triples, self.n_terms, self.term_bytes = nt.value, nm.value, nb.value
+
+    def terms(self):
+        off = np.zeros(self.n_terms + 1, dtype=np.uint64)
+        buf = np.zeros(max(1, self.term_bytes), dtype=np.uint8)
+        _check(self._lib.rdfgpu_ntriples_terms(self._h, off.ctypes.data_as(C.c_void_p), buf.ctypes.data_as(C.c_void_p)))
+        raw = buf.tobytes()
+        return [raw[int(off[t]):int(off[t + 1])] for t in range(self.n_terms)]
+
+    def columns(self):
+        s, p, o = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        _check(self._lib.rdfgpu_ntriples_columns(self._h, C.byref(s), C.byref(p), C.byref(o)))
+        return s.value or 0, p.value or 0, o.value or 0
+
+    def close(self):
+        if self._h:
+            self._lib.rdfgpu_ntriples_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def shard_of(object_id, world):

@@ -1009,6 +1009,64 @@ def test_enc_pt_decode_on_device(torch_cuda):
         plan.decode_terms(5)
 
 
+def _nt_text(rng, n, n_subj=500, messy=True):
+    """random N-Triples: IRIs, blank nodes, plain / language-tagged / typed literals with escapes, `>` `.` `#` and multi-byte
+    UTF-8 inside strings; blank lines, comment lines, tabs, CRLF and trailing comments when `messy`"""
+    subj = ["<http://example.org/s%d>" % i for i in range(n_subj)] + ["_:b%d" % i for i in range(n_subj // 10)]
+    pred = ["<http://example.org/p%d>" % i for i in range(20)]
+    lits = ['"plain %d"' % i for i in range(300)] + ['"caf\u00e9 \u20ac"@fr', '"quote \\" inside > . # x"', '"tab\\tnew\\nline"@en-GB', '""',
+            '"12"^^<http://www.w3.org/2001/XMLSchema#integer>', '"1.5E3"^^<http://www.w3.org/2001/XMLSchema#double>', '"\U0001F600"']
+    lines = []
+    for i in range(n):
+        s_ = subj[int(rng.integers(0, len(subj)))]
+        p_ = pred[int(rng.integers(0, len(pred)))]
+        o_ = (subj if rng.random() < 0.5 else lits)[int(rng.integers(0, len(subj) if rng.random() < 0 else min(len(subj), len(lits))))]
+        sep = "\t" if messy and i % 7 == 0 else " "
+        end = " ." if not (messy and i % 11 == 0) else "."
+        if o_.startswith("_:") and end == ".":
+            end = " ."                                   # `_:b1.` would make the dot part of nothing: keep it unambiguous half the time
+        line = s_ + sep + p_ + sep + o_ + end
+        if messy and i % 13 == 0:
+            line += "  # trailing comment"
+        if messy and i % 17 == 0:
+            line += "\r"
+        lines.append(line)
+        if messy and i % 29 == 0:
+            lines.append("")
+        if messy and i % 31 == 0:
+            lines.append("# a comment line <x> <y> <z> .")
+    return "\n".join(lines) + ("\n" if n % 2 else "")
+
+
+@pytest.mark.parametrize("n", [0, 1, 1000, 200_000])
+def test_ntriples_to_ids_on_device(torch_cuda, n):
+    """N-Triples text -> object ids on the device (rdfgpu_ntriples_parse): the same triples as the CPU restatement of the
+    reference's interning loop, through a different id assignment (a bijection onto the distinct terms); the id columns feed
+    rdfgpu_store_extend_device directly; malformed lines fail with their number."""
+    rng = np.random.default_rng(n + 3)
+    text = _nt_text(rng, n)
+    terms_ref, s_ref, p_ref, o_ref = orc.ntriples_encode(text)
+    nt = rf.NTriples(text, first_id=5)
+    assert nt.n_triples == len(s_ref) and nt.n_terms == len(terms_ref)
+    terms = nt.terms()
+    assert sorted(terms) == sorted(terms_ref) and len(set(terms)) == len(terms)
+    if n:
+        sp, pp, op = nt.columns()
+        gs = rf.GpuQuadStore()
+        zeros = torch_cuda.zeros(nt.n_triples, dtype=torch_cuda.int32, device="cuda")
+        gs.extend_device(zeros.data_ptr(), sp, pp, op, nt.n_triples)
+        g, s_, p_, o_ = gs.read_index(abi.GSPO)
+        got = sorted({(terms[a - 5], terms[b - 5], terms[c - 5]) for a, b, c in zip(s_.tolist(), p_.tolist(), o_.tolist())})
+        exp = sorted({(terms_ref[a - 1], terms_ref[b - 1], terms_ref[c - 1]) for a, b, c in zip(s_ref, p_ref, o_ref)})
+        assert got == exp and len(got) > 0
+    nt.close()
+    for bad, line in (("<a> <b> <c> .\n<a> <b> .\n", 2), ('<a> <b> "open\n', 1), ("<a> <b> <c> <d> .\n", 1), ('"lit" <b> <c> .\n', 1), ("<a> <b> <c>\n", 1)):
+        with pytest.raises(rf.RdfGpuError, match="triple line %d" % line):
+            rf.NTriples(bad)
+        with pytest.raises(ValueError):
+            orc.ntriples_encode(bad)
+
+
 def test_regex_unsupported_is_refused_loudly(torch_cuda):
     tv, offsets, heap = string_dictionary(["abc"])
     gs, _ = both_stores((np.zeros(0, np.uint32),) * 4, typed=tv)
