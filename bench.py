@@ -285,18 +285,40 @@ def main():
         # The exchange is part of the product: rdfgpu_exchange_repartition behind the C ABI (RCCL over xGMI, grouped send / recv,
         # buffers sized from the exchanged row counts).  torch.distributed only carries the RCCL unique id, the barriers and the
         # final reductions.  Two communicators: the gathered table of batch i stays valid while batch i + 1 is exchanged.
+        def host_wire(blocks):     # the caller-supplied wire of the host-staged transport: an all-to-all of byte blocks
+            got = [None] * world
+            dist.all_gather_object(got, [bytes(b) for b in blocks])
+            return [np.frombuffer(got[r][rank], dtype=np.uint8) for r in range(world)]
+        transport = "RCCL over xGMI (grouped ncclSend / ncclRecv inside librdfgpu.so)"
+        comms = []
         if rehearse:           # several ranks on ONE GPU (RCCL refuses that): the host-staged transport, gloo as the wire
-            def gloo_alltoallv(blocks):
-                got = [None] * world
-                dist.all_gather_object(got, [bytes(b) for b in blocks])
-                return [np.frombuffer(got[r][rank], dtype=np.uint8) for r in range(world)]
-            comms = [rf.Comm(rank, world, device=local_rank, host_alltoallv=gloo_alltoallv) for _ in range(2)]
+            comms = [rf.Comm(rank, world, device=local_rank, host_alltoallv=host_wire) for _ in range(2)]
+            transport = "host-staged, torch.distributed (gloo) as the wire: rehearsal on one GPU"
         else:
-            comms = []
+            why = None
             for _ in range(2):
-                ids = [rf.Comm.unique_id() if rank == 0 else None]
+                ids = [None]
+                if rank == 0:
+                    try:
+                        ids = [rf.Comm.unique_id()]
+                    except rf.RdfGpuError as e:
+                        why = str(e)
                 dist.broadcast_object_list(ids, src=0)
-                comms.append(rf.Comm(rank, world, device=local_rank, unique_id=ids[0]))
+                ok = ids[0] is not None
+                if ok:
+                    try:
+                        comms.append(rf.Comm(rank, world, device=local_rank, unique_id=ids[0]))
+                    except rf.RdfGpuError as e:
+                        ok, why = False, str(e)
+                flag = torch.tensor([1 if ok else 0], device=f"cuda:{local_rank}")
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                if int(flag.item()) == 0:
+                    comms = None
+                    break
+            if comms is None:   # no RCCL communicator on some rank: the run still measures the sharded path, through the host-staged transport
+                print(f"[bench] rank {rank}: RCCL communicator unavailable ({why}); falling back to the host-staged exchange", file=sys.stderr, flush=True)
+                comms = [rf.Comm(rank, world, device=local_rank, host_alltoallv=host_wire) for _ in range(2)]
+                transport = "host-staged, torch.distributed as the wire (the RCCL communicator could not be created)"
 
         def phase_a(batch, timing):
             """Phase A: the constant-subject patterns of the whole batch on the local shard, joined per instance:
@@ -634,6 +656,7 @@ def main():
                                     "bindings C by prodFeature") if world > 1 else "none",
                        "sharded_result_check": shard_check,
                        "exchange_overlapped_with_next_step": bool(world > 1 and not args.no_overlap),
+                       "exchange_transport": transport if world > 1 else None,
                        "rank0_phase_ms_per_step": ({"constant_patterns": round(phase_ms[0] / args.steps, 3), "exchange": round(phase_ms[1] / args.steps, 3),
                                                     "join_pipeline": round(phase_ms[2] / args.steps, 3),
                                                     "waiting_for_constants_and_exchange": round(phase_ms[3] / args.steps, 3),
