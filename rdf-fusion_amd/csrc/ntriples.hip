@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256) void nt_terms_kernel(const unsigned char* text
       while (p < n && text[p] != '"' && text[p] != '\n') p += text[p] == '\\' ? 2 : 1;
       if (p >= n || text[p] != '"') { nt_fail(err, l, 3); return; }
       p++;
-      if (p < n && text[p] == '@') { p++; while (p < n && ((text[p] | 32) >= 'a' && (text[p] | 32) <= 'z' || (text[p] >= '0' && text[p] <= '9') || text[p] == '-')) p++; }
+      if (p < n && text[p] == '@') { p++; while (p < n && (((text[p] | 32) >= 'a' && (text[p] | 32) <= 'z') || (text[p] >= '0' && text[p] <= '9') || text[p] == '-')) p++; }
       else if (p + 2 < n && text[p] == '^' && text[p + 1] == '^' && text[p + 2] == '<') {
         while (p < n && text[p] != '>' && text[p] != '\n') p++;
         if (p >= n || text[p] != '>') { nt_fail(err, l, 2); return; }
