@@ -192,3 +192,47 @@ def test_sharded_q5_batch_on_device_equals_oracle(torch_cuda):
     got = [np.concatenate([r[k] for r in res]) for k in range(3)]
     assert len(got[0]) == n_exp > 0
     np.testing.assert_array_equal(ku.multiset(got), ku.multiset(exp, n_exp))
+
+
+def test_sharded_q5_batch_hybrid_layout_on_device_equals_oracle(torch_cuda):
+    """bench.py --gpus N's step as it runs now, on 3 shards of one GPU: phase A on the subject shard, C re-sharded by
+    prodFeature (rdfgpu_exchange_repartition), phase B on the object-sharded candidate triples in their named graph."""
+    world = 3
+    ds = bsbm.generate(2500)
+    full = orc.OracleStore()
+    full.extend(ds.g, ds.s, ds.p, ds.o)
+    full.set_typed_values(ds.typed_values, ds.decimals)
+    rng = np.random.default_rng(9)
+    batch = 500
+    prods = np.array([ds.product(int(i)) for i in rng.integers(0, ds.n_products, batch)], dtype=np.uint32)   # with repeats
+    params = [np.arange(1, batch + 1, dtype=np.uint32), prods]
+    exp, n_exp, _ = full.execute(bsbm.q5_batch_plan(ds), [params])
+
+    def body(rank, comm):
+        g, s, p, o = sharding.shard_dataset_hybrid(ds, rank, world)
+        st = rf.GpuQuadStore(device=0)
+        st.extend(g, s, p, o)
+        st.set_typed_values(ds.typed_values, ds.decimals)
+        keep, pp = on_device(torch_cuda, params)
+        plans, calls = {}, [0]
+
+        def execute(desc, tabs):
+            stage = calls[0] % 2                                  # phase A, phase B, phase A, ...
+            calls[0] += 1
+            plan = plans.get(stage)
+            if plan is None:
+                plan = plans[stage] = st.plan(desc)               # compiled once per stage: re-executions speculate and fuse
+            for slot, (ptrs, rows) in enumerate(tabs):
+                plan.bind_table(slot, ptrs, rows)
+            plan.execute()
+            return plan.result_device()
+        out = None
+        for rep in range(3):
+            ptrs, rows = sharding.run_q5_batch_hybrid(ds, (pp, batch), execute, lambda t, key_col: comm.repartition(t[0], t[1], key_col))
+            out = from_device(torch_cuda, ptrs, rows)
+        del keep
+        return out
+    res = run_ranks(world, body)
+    got = [np.concatenate([r[k] for r in res]) for k in range(3)]
+    assert len(got[0]) == n_exp > 0
+    np.testing.assert_array_equal(ku.multiset(got), ku.multiset(exp, n_exp))
