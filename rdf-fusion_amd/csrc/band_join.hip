@@ -288,8 +288,8 @@ __global__ __launch_bounds__(256) void band_desc_kernel(const BandArgs b) {
 }
 
 // ---- the pair tests: one wave per 64 x 64 block --------------------------------------------------------------------
-// lane = probe row (its decoded record in registers); the block's entries are wave-uniform: they stream through the
-// scalar cache (s_load_dwordx8 = two entries) and feed the vector compares as scalar operands — per pair two unsigned
+// lane = probe row (its decoded record in registers); the block's entries are wave-uniform: staged in LDS once per block and
+// broadcast to all lanes — per pair two unsigned
 // range checks and one id compare (6 VALU instructions per pair), no vector memory and no LDS inside the loop.  Measured: the
 // kernel is NOT bound by those instructions (7 -> 6 per pair changed nothing; 200 k short waves with exposed scalar-load
 // latency are what it waits for; persistent waves made it slower, 240 -> 325 us).
@@ -297,7 +297,8 @@ __global__ __launch_bounds__(256) void band_desc_kernel(const BandArgs b) {
 struct BandEntry8 { uint4 a[8]; };
 template <int NWIN, int NEQ>
 __global__ __launch_bounds__(256) void band_mask_kernel(const BandArgs b) {
-  const u32 lane = threadIdx.x & 63;
+  __shared__ uint4 ent[4][64];
+  const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   // one wave per block; the grid is sized from the previous execution's block count, so a wave strides on in the rare case
   // that there are more blocks than waves (sizing the grid by the upper bound launches twice as many waves as there are blocks)
   const u32 n_all = b.boff[b.kn];
@@ -309,10 +310,12 @@ __global__ __launch_bounds__(256) void band_mask_kernel(const BandArgs b) {
   uint4 rec = make_uint4(kBandInvalidLo, 0u, 1u, 0u);
   u32 x = 0;
   if (lane < nr) { rec = b.rec_s[rb + lane]; if (NEQ) x = b.aux_s[rb + lane].x; }
-  // (constant address space: the entries are read-only for the whole kernel, so wave-uniform loads from them stay scalar loads
-  //  although the loop also stores masks and counts)
-  typedef const u32 __attribute__((address_space(4))) * ConstWords;
-  const ConstWords p = (ConstWords)(uintptr_t)(b.et + eb);   // the table is padded: reading past the group is harmless
+  // The block's 64 entries go through LDS: lane e fetches entry e (one coalesced 1 KB load per block), every test then reads
+  // ITS entry with a broadcast ds_read_b128 (all lanes one address).  Scalar loads (s_load_dwordx8 from the entry table) looked
+  // cheaper — no LDS, operands in SGPRs — but 200 k blocks x 1 KB through the scalar caches is what the kernel then waits
+  // for (measured: VALU work 7 -> 6 instructions per pair changed nothing, more resident waves made it slower).
+  ent[wave][lane] = b.et[eb + lane];                   // the table is padded: reading past the group is harmless
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   u32 m[2] = {0u, 0u};
 #pragma unroll
   for (u32 h = 0; h < 2; h++) {
@@ -320,11 +323,12 @@ __global__ __launch_bounds__(256) void band_mask_kernel(const BandArgs b) {
     u32 acc = 0;
 #pragma unroll 1
     for (u32 g = 0; g < 4; g++) {
-      const u32 w0 = (h * 4 + g) * 32;                // 8 entries x 4 words: one s_load_dwordx8 per two entries
+      uint4 q8[8];
+#pragma unroll
+      for (u32 e = 0; e < 8; e++) q8[e] = ent[wave][h * 32 + g * 8 + e];
 #pragma unroll
       for (u32 e = 0; e < 8; e++) {
-        const uint4 q = make_uint4(p[w0 + e * 4], p[w0 + e * 4 + 1], p[w0 + e * 4 + 2], 0u);
-        // branch-free on purpose (bitwise &, not &&): a short-circuit here becomes an exec-mask branch per pair
+        const uint4 q = q8[e];
         // the verdict of the 64 lanes IS the compares' lane mask (SGPR pairs, AND-ed on the scalar unit): shifting it into
         // every lane's word is ONE add-with-carry (acc + acc + carry) instead of a select and an or per pair
         u64 lanes = __builtin_amdgcn_ballot_w64((q.x - rec.x) <= rec.y);
@@ -337,6 +341,7 @@ __global__ __launch_bounds__(256) void band_mask_kernel(const BandArgs b) {
     }
     m[h] = __builtin_bitreverse32(acc);             // entry 0 was shifted in first: it sits at bit 31
   }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // the staging area is free for the wave's next block
   // entries past the group's end belong to the next key: their bits do not count
   const u64 live = ne >= 64 ? ~0ull : ((1ull << ne) - 1ull);
   const u64 mask = ((((u64)m[1]) << 32) | m[0]) & live;
