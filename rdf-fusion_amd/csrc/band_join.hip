@@ -405,6 +405,11 @@ __global__ __launch_bounds__(256) void band_emit_kernel(const BandArgs b) {
   const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const u32 n_all = b.boff[b.kn];
   const u32 n_blocks = n_all < b.max_blocks ? n_all : b.max_blocks;
+  // the column schedule, out of the argument block once per wave (constant indices: SGPRs)
+  u32* outp[kBandMaxRowCols + kBandMaxSideCols]; u32 out_sel[kBandMaxRowCols + kBandMaxSideCols];
+#pragma unroll
+  for (u32 oc = 0; oc < kBandMaxRowCols + kBandMaxSideCols; oc++) { outp[oc] = b.out[oc]; out_sel[oc] = b.out_sel[oc]; }
+  const u32 n_out_cols = b.n_out_cols; const u64 out_cap = b.out_cap;
   if (blockIdx.x == 0 && threadIdx.x == 0) {   // the exact total, whether or not it fitted (like the fused join kernel's count)
     const u64 total = b.bofs[b.max_blocks];
     *b.n_out_dev = total;
@@ -446,18 +451,19 @@ __global__ __launch_bounds__(256) void band_emit_kernel(const BandArgs b) {
       const u32 pr = valid ? (u32)list[wave][idx] : 0u;
       const u32 r = pr >> 6, e = pr & 63u;
       const u64 pos = run + idx;
-      u32 ue = 0, ur = 0;
-      for (u32 oc = 0; oc < b.n_out_cols; oc++) {                       // wave-uniform schedule of the output columns
-        u32 v;
-        if (b.out_from_row[oc]) { v = __shfl(ur == 0 ? rv[0] : rv[1], r, 64); ur++; }
-        else {
-          u32 src = ev[0];
+      // the column schedule with CONSTANT indices into the argument block: the pointers and selectors are loaded into SGPRs
+      // once per wave — indexed by a run-time `oc` they were two dependent scalar loads per column and round, and the wave
+      // spent 94 of its 270 us waiting for them
 #pragma unroll
-          for (u32 u = 1; u < kBandMaxSideCols; u++) src = ue == u ? ev[u] : src;
-          v = __shfl(src, e, 64);
-          ue++;
-        }
-        if (valid && pos < b.out_cap) b.out[oc][pos] = v;
+      for (u32 oc = 0; oc < kBandMaxRowCols + kBandMaxSideCols; oc++) {   // (a band join has at most 2 + 4 output columns)
+        if (oc >= n_out_cols) continue;                                 // wave-uniform
+        const u32 sel = out_sel[oc];
+        u32 src = rv[0];
+        src = sel == 1 ? rv[1] : src;
+#pragma unroll
+        for (u32 u = 0; u < kBandMaxSideCols; u++) src = sel == 2 + u ? ev[u] : src;
+        const u32 v = __shfl(src, sel < 2 ? r : e, 64);
+        if (valid && pos < out_cap) outp[oc][pos] = v;
       }
     }
     run += n_round;

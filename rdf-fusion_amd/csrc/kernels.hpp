@@ -312,6 +312,7 @@ struct BandArgs {
   u32* out[kMaxCols]; u64 out_cap; u64* n_out_dev; u32* overflow;
   ColRef entry_col[kBandMaxSideCols]; const u32* row_col[kBandMaxSideCols];
   u8 out_from_row[kMaxCols];  // per output column: 1 = next row column, 0 = next entry column
+  u8 out_sel[kMaxCols];       // .. resolved: 0 / 1 = row column 0 / 1, 2 + u = entry column u
 };
 void launch_band_pt(const BandArgs& b, hipStream_t s);
 void launch_band_entries(const BandArgs& b, hipStream_t s);

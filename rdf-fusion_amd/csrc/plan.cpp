@@ -1213,8 +1213,8 @@ bool Plan::apply_chain(const ChainRequest& req, NodeInfo& base, const DevTable& 
       w.y0 = st.f[1].ptr; w.y1 = st.f[3].ptr; w.l0 = st.l0; w.l1 = st.l1; w.stage = (u32)t;
     }
     for (size_t k = 0; ok && k < cur.size(); k++) {
-      if (cur[k].src == 0) { ok = b.n_row_cols < kBandMaxRowCols; if (ok) { b.out_from_row[k] = 1; b.row_col[b.n_row_cols++] = cur[k].ptr; } }
-      else { ok = b.n_entry_cols < kBandMaxSideCols; if (ok) { b.out_from_row[k] = 0; b.entry_col[b.n_entry_cols++] = cur[k]; } }
+      if (cur[k].src == 0) { ok = b.n_row_cols < kBandMaxRowCols; if (ok) { b.out_from_row[k] = 1; b.out_sel[k] = (u8)b.n_row_cols; b.row_col[b.n_row_cols++] = cur[k].ptr; } }
+      else { ok = b.n_entry_cols < kBandMaxSideCols; if (ok) { b.out_from_row[k] = 0; b.out_sel[k] = (u8)(2 + b.n_entry_cols); b.entry_col[b.n_entry_cols++] = cur[k]; } }
     }
     if (ok) {   // group sizes: the largest decides (one wave joins a whole group), measured once per table
       SliceTable* tab = cur_build_table;
