@@ -230,6 +230,7 @@ struct LdsJoinArgs {
 void launch_lds_join(const LdsJoinArgs& a, hipStream_t s);
 
 // ---- ordered slice join (ordered_join.hip): a small table against a store slice, matches emitted in the slice's order ----
+constexpr u32 kOjMaxOutCols = 8;   // output columns of an ordered slice join (its write kernel keeps the column schedule in SGPRs)
 struct OrderedJoinStage { const u32* key_col; const u32* direct; u32 kmin, kn; u32* row; };   // key_col: a column of the TABLE; row[r] = the stage's row of table row r
 struct OrderedJoinArgs {
   const u32* build_key; u64 n_build;                                   // the slice's join-key column, rows in slice order

@@ -132,6 +132,13 @@ __global__ __launch_bounds__(kOjBlock) void oj_write_kernel(const OrderedJoinArg
   }
   __syncthreads();
   const u64 tile_base = a.tile_off[blockIdx.x];
+  // the column schedule out of the argument block ONCE (constant indices -> SGPRs): indexed inside the loop it is two
+  // dependent scalar loads per column and match (the same trap as in band_emit_kernel)
+  u32* outp[kOjMaxOutCols]; const u32* refp[kOjMaxOutCols]; u32 slot[kOjMaxOutCols];
+#pragma unroll
+  for (u32 c = 0; c < kOjMaxOutCols; c++) { outp[c] = a.out[c]; refp[c] = a.out_ref[c].ptr; slot[c] = a.out_slot[c]; }
+  const u32 n_out_cols = a.n_out_cols, n_rec = a.n_rec;
+  const u64 out_cap = a.out_cap;
   for (u32 j = threadIdx.x; j < tile_total; j += kOjBlock) {
     u32 lo = 0, hi = kOjTile;                      // the last q with starts[q] <= j (rows without matches share their successor's start)
 #pragma unroll
@@ -140,27 +147,26 @@ __global__ __launch_bounds__(kOjBlock) void oj_write_kernel(const OrderedJoinArg
     u32 r = heads[q];
     for (u32 k = j - starts[q]; k; k--) r = a.next[r];
     const u64 pos = tile_base + j;
-    if (pos >= a.out_cap) continue;                // the count stays exact: the plan re-runs with room for all
+    if (pos >= out_cap) continue;                  // the count stays exact: the plan re-runs with room for all
     const u64 brow = base + q;
-    const uint4 r0 = a.trec[(u64)r * a.n_rec];
+    const uint4 r0 = a.trec[(u64)r * n_rec];
     uint4 r1 = make_uint4(0u, 0u, 0u, 0u);
-    if (a.n_rec > 1) r1 = a.trec[(u64)r * a.n_rec + 1];
+    if (n_rec > 1) r1 = a.trec[(u64)r * n_rec + 1];
     const u32 w[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
-    u32 v[kMaxCols];
+    u32 v[kOjMaxOutCols];
 #pragma unroll
-    for (u32 c = 0; c < (u32)kMaxCols; c++) {
-      if (c >= a.n_out_cols) continue;
-      const u32 slot = a.out_slot[c];
+    for (u32 c = 0; c < kOjMaxOutCols; c++) {
+      if (c >= n_out_cols) continue;
       u32 val = 0;
-      if (slot == 0xFFu) val = a.out_ref[c].ptr[brow];
+      if (slot[c] == 0xFFu) val = refp[c][brow];
       else {
 #pragma unroll
-        for (u32 k = 0; k < 8; k++) val = k == slot ? w[k] : val;
+        for (u32 k = 0; k < 8; k++) val = k == slot[c] ? w[k] : val;
       }
       v[c] = val;
     }
 #pragma unroll
-    for (u32 c = 0; c < (u32)kMaxCols; c++) if (c < a.n_out_cols) a.out[c][pos] = v[c];
+    for (u32 c = 0; c < kOjMaxOutCols; c++) if (c < n_out_cols) outp[c][pos] = v[c];
   }
 }
 

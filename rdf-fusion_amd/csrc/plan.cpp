@@ -1686,7 +1686,7 @@ DevTable Plan::exec_lds_join(NodeInfo& nd, const DevTable& L, const DevTable& R,
         if (chained) from_table += a.chain_out[c].src != 1;
         else { const u32 pc = a.proj[c]; from_table += ((pc < a.n_left_cols) == (a.build_is_left != 0)) ? 0u : 1u; }
       }
-      if (from_table > 8) use_ordered = false;
+      if (from_table > 8 || a.n_out_cols > kOjMaxOutCols) use_ordered = false;
     }
     if (use_ordered) {
       OrderedJoinArgs o{};
