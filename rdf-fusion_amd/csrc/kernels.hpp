@@ -244,6 +244,7 @@ struct OrderedJoinArgs {
   uint4* trec; u8 out_slot[kMaxCols];
   u64 out_cap; u64* n_out_dev; u32* overflow;
   u32* tile_count; u32* tile_off;                                      // per 1024-row tile of the slice (+ 1) and their exclusive scan
+  u32* row_head; unsigned char* row_cnt;                               // per slice row, from the count pass: first table row of its chain, chain length (capped at 255: longer chains are re-walked)
 };
 u64 ordered_join_tiles(u64 n_build);
 void launch_ordered_join_probe(const OrderedJoinArgs& a, hipStream_t s);

@@ -74,7 +74,15 @@ __global__ __launch_bounds__(kOjBlock) void oj_count_kernel(const OrderedJoinArg
   }
   u32 tot = 0;
 #pragma unroll
-  for (int it = 0; it < kOjRounds; it++) tot += oj_chain_length(a, keys[it]);
+  for (int it = 0; it < kOjRounds; it++) {
+    const u64 row = base + (u64)it * kOjBlock + threadIdx.x;
+    const u32 d = keys[it] - a.kmin;
+    const u32 hd = (keys[it] != 0 && d < a.kn) ? a.head[d] : kNil;
+    u32 c = 0;
+    for (u32 r = hd; r != kNil; r = a.next[r]) c++;
+    if (row < a.n_build) { a.row_head[row] = hd; a.row_cnt[row] = (unsigned char)(c < 255u ? c : 255u); }
+    tot += c;
+  }
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) tot += __shfl_xor(tot, d, 64);
   if ((threadIdx.x & 63) == 0) wave_tot[threadIdx.x >> 6] = tot;
@@ -102,16 +110,15 @@ __global__ __launch_bounds__(kOjBlock) void oj_write_kernel(const OrderedJoinArg
   if (tile_total == 0) return;                     // uniform per workgroup
   u32 cnt[kOjRounds], hd[kOjRounds];
 #pragma unroll
-  for (int it = 0; it < kOjRounds; it++) {
+  for (int it = 0; it < kOjRounds; it++) {   // what the count pass found: streamed, not gathered again
     const u64 row = base + (u64)it * kOjBlock + threadIdx.x;
-    const u32 key = row < a.n_build ? a.build_key[row] : 0u;
-    const u32 d = key - a.kmin;
-    hd[it] = (key != 0 && d < a.kn) ? a.head[d] : kNil;
+    hd[it] = row < a.n_build ? a.row_head[row] : kNil;
+    cnt[it] = row < a.n_build ? (u32)a.row_cnt[row] : 0u;
   }
 #pragma unroll
   for (int it = 0; it < kOjRounds; it++) {
-    u32 c = 0;
-    for (u32 r = hd[it]; r != kNil; r = a.next[r]) c++;
+    u32 c = cnt[it];
+    if (c == 255u) { c = 0; for (u32 r = hd[it]; r != kNil; r = a.next[r]) c++; }   // (a chain of 255 or more table rows: its exact length)
     cnt[it] = c;
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d, 64);

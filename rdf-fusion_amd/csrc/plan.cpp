@@ -1711,6 +1711,7 @@ DevTable Plan::exec_lds_join(NodeInfo& nd, const DevTable& L, const DevTable& R,
       o.out_cap = spec_cap; o.n_out_dev = n_out; o.overflow = overflow;
       const u64 tiles = ordered_join_tiles(B.cap);
       o.tile_count = scratch<u32>(tiles + 1); o.tile_off = scratch<u32>(tiles + 1);
+      o.row_head = scratch<u32>(B.cap); o.row_cnt = scratch<unsigned char>(B.cap);
       const size_t tb = scan_temp_bytes(tiles + 1);
       void* temp = scratch<unsigned char>(tb);
       RDFGPU_HIP(hipMemsetAsync(o.tile_count + tiles, 0, sizeof(u32), stream));
