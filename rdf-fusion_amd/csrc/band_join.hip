@@ -68,7 +68,8 @@ __device__ __forceinline__ bool band_window_of(const TypedTable& tt, const BandW
   if (tt.n_ids == 0 || iy0 == 0 || iy1 == 0 || iy0 >= tt.n_ids || iy1 >= tt.n_ids) return false;
   if (w.l0.tag != RDFGPU_TV_INTEGER || w.l1.tag != RDFGPU_TV_INTEGER) return false;
   const int4* tv = reinterpret_cast<const int4*>(tt.tv);
-  const int4 r0 = tv[iy0], r1 = tv[iy1];
+  const int4 r0 = tv[iy0];
+  const int4 r1 = iy1 == iy0 ? r0 : tv[iy1];            // both halves of a window usually read ONE value (x < y + c AND x > y - c)
   if (((u32)r0.w & 0xff) != RDFGPU_TV_INTEGER || ((u32)r1.w & 0xff) != RDFGPU_TV_INTEGER) return false;
   auto i64 = [](const int4& r) { return (long long)(((u64)(u32)r.y << 32) | (u32)r.x); };
   bool ok = true;
