@@ -102,10 +102,15 @@ __device__ __forceinline__ uint2 band_interval(long long lo, long long hi, long 
 // joins nothing) and, for the rows that can join, the decoded windows + the id operand of the base join's filter.
 __global__ __launch_bounds__(256) void band_decode_kernel(const BandArgs b) {
   const u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= b.n_probe_cap) return;
+  if (j > b.n_probe_cap) return;
   const u64 n = live_rows(b.n_probe_dev, b.n_probe_cap);
-  u32 k = b.kn;
-  if (j < n) { const u32 v = b.probe_key[j]; const u32 d = v - b.kmin; if (v != 0 && d < b.kn) k = d; }   // null keys never join
+  auto key_of = [&](u64 r) { u32 kk = b.kn; if (r < n) { const u32 v = b.probe_key[r]; const u32 d = v - b.kmin; if (v != 0 && d < b.kn) kk = d; } return kk; };   // null keys never join
+  const u32 k = j < b.n_probe_cap ? key_of(j) : b.kn;
+  if (b.presorted) {   // rows arrive sorted by key: the key boundaries (band_bounds_kernel's job) fall out here — poff[q] = first row with key >= q
+    const u32 first = j > 0 ? key_of(j - 1) + 1u : 0u;
+    for (u32 q = first; q <= k && q <= b.kn; q++) b.poff[q] = (u32)j;
+  }
+  if (j >= b.n_probe_cap) return;
   b.skey_in[j] = k; b.sval_in[j] = (u32)j;
   if (k == b.kn) return;
   if (b.key_hist) atomicAdd(b.key_hist + k, 1u);
@@ -476,7 +481,7 @@ __global__ __launch_bounds__(256) void band_emit_kernel(const BandArgs b) {
 // ---- host side -------------------------------------------------------------------------------------------------------
 static inline dim3 grid256(u64 n) { const u64 g = (n + 255) / 256; return dim3((unsigned)(g ? g : 1)); }
 void launch_band_decode(const BandArgs& b, hipStream_t s) {
-  if (b.n_probe_cap) hipLaunchKernelGGL(band_decode_kernel, grid256(b.n_probe_cap), dim3(256), 0, s, b);
+  if (b.n_probe_cap) hipLaunchKernelGGL(band_decode_kernel, grid256(b.n_probe_cap + 1), dim3(256), 0, s, b);   // (+ 1: the row after the last closes the key boundaries)
 }
 void launch_band_bounds(const u32* skey_sorted, u64 n, u32 kn, u32* poff, hipStream_t s) {
   hipLaunchKernelGGL(band_bounds_kernel, grid256(n + 1), dim3(256), 0, s, skey_sorted, n, kn, poff);

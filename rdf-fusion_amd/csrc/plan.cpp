@@ -1885,10 +1885,10 @@ void Plan::exec_band_join(LdsJoinArgs& a, BandArgs& b, const DevTable& B, const 
   }
   if (entries_lock.owns_lock()) entries_lock.unlock();
   // per probe row: key + the window operands + the id operand read, 24 B of record + 8 B of sort pair written
+  b.poff = scratch<u32>((u64)kn + 2);
   timed(KC_BAND_DECODE, 0, np, P.n_dev, 4 + 4ull * (b.n_win + b.has_neq) + 9ull * b.n_win + 24 + 8, nullptr, 0, 0, [&] { launch_band_decode(b, stream); });
   // the partition pass: in the time, not in the algorithmic bytes
   if (!presorted && !counting) timed(KC_RADIX_SORT, 0, np, nullptr, 0, nullptr, 0, 0, [&] { sort_pairs_u32_u32(b.skey_in, skey, b.sval_in, perm, np, bits, stemp, stb, stream); });
-  b.poff = scratch<u32>((u64)kn + 2);
   u32* nblk = scratch<u32>((u64)kn + 1);
   b.boff = scratch<u32>((u64)kn + 1);
   // blocks: sum over keys of ceil(E/64) * ceil(R/64) <= cmax * (rows / 64) + sum of ceil(E/64) over the keys
@@ -1911,7 +1911,7 @@ void Plan::exec_band_join(LdsJoinArgs& a, BandArgs& b, const DevTable& B, const 
     timed(KC_DEVICE_SCAN, 0, (u64)kn + 1, nullptr, 8, nullptr, 0, 0, [&] { exclusive_scan_u32(b.key_hist, b.poff, (u64)kn + 1, temp, tb, stream); });
     RDFGPU_HIP(hipMemcpyAsync(b.key_cursor, b.poff, ((size_t)kn + 1) * sizeof(u32), hipMemcpyDeviceToDevice, stream));
     timed(KC_BAND_ROWS, 0, np, P.n_dev, 8 + 32 + 32, nullptr, 0, 0, [&] { launch_band_scatter(b, stream); });
-  } else timed(KC_BAND_BOUNDS, 0, np, nullptr, 4, nullptr, 0, 0, [&] { launch_band_bounds(skey, np, kn, b.poff, stream); });
+  } else if (!presorted) timed(KC_BAND_BOUNDS, 0, np, nullptr, 4, nullptr, 0, 0, [&] { launch_band_bounds(skey, np, kn, b.poff, stream); });   // (presorted: the decode pass wrote poff)
   timed(KC_BAND_BLOCKS, 12ull * kn, 0, nullptr, 0, nullptr, 0, 0, [&] { launch_band_blocks(a.csr_off, b.poff, kn, nblk, stream); });
   timed(KC_DEVICE_SCAN, 0, (u64)kn + 1, nullptr, 8, nullptr, 0, 0, [&] { exclusive_scan_u32(nblk, b.boff, (u64)kn + 1, temp, tb, stream); });
   timed(KC_BAND_DESC, 12ull * kn, 0, nullptr, 0, nullptr, 0, 0, [&] { launch_band_desc(b, stream); });
