@@ -523,9 +523,9 @@ def main():
             print(f"[bench] no-table-cache step: {step_ms[-1]:.1f} ms wall, {m_nc.elapsed_compute_ms:.1f} ms device, {m_nc.host_syncs} syncs, "
                   f"{m_nc.kernels_launched} launches, {m_nc.device_bytes / 2**30:.1f} GiB of intermediates", file=sys.stderr, flush=True)
         torch.cuda.synchronize()
-        # a side measurement over 5 long steps.  The un-fused candidate join writes 0.54 G rows through one output counter
-        # (2.1 M same-address reservations, the floor of its 27 ms); the same step is observed at 45 ms or at 250-370 ms
-        # (45 / 45 / 367 / 45 / 367 ms for identical work): the median is reported, with the mean and the fastest beside it
+        # a side measurement over 5 long steps: the median, with the mean and the fastest beside it.  (Its 0.54 G-row candidate
+        # join used to reserve output per full queue — 2.1 M same-address atomics — and ran at 27 ms or at 250-350 ms from step
+        # to step; it now counts a partition's matches first and reserves once per partition: 30 ms per step, every step.)
         ms_nc = float(np.median(step_ms))
         mem("no-table-cache steps")
         plan_nc.close()

@@ -538,6 +538,7 @@ enum {
   RDFGPU_OPT_CSR_ROW_LANES_LOG2,        /* value + 1: lanes sharing one probe row of a CSR join (0 = automatic)        */
   RDFGPU_OPT_JOIN_WAVE_Q,               /* value: entries of a wave's candidate queue (0 = automatic)                  */
   RDFGPU_OPT_PARTITION_MIN_BUILD,       /* value: smallest non-cached build side (rows) that is radix-partitioned (default 2^21) */
+  RDFGPU_OPT_PARTITION_TWO_PASS_ROWS,   /* value: expected output rows from which a partitioned join counts before it writes (default 50 M) */
   RDFGPU_OPT__COUNT
 };
 int rdfgpu_store_set_option(rdfgpu_store* store, uint32_t option, uint64_t value);

@@ -258,7 +258,8 @@ constexpr u32 kPartTargetRows = 1024; // build rows per partition aimed for
 struct PartArgs {
   const uint4* bpart; const uint4* ppart;   // {row, key0, key1, -} records of the build / probe side, grouped by partition
   const u32* bstart; const u32* pstart;     // [n_parts + 1] first record of every partition
-  u32 n_parts, chunk, tbl_mask, pad;
+  u32 n_parts, chunk, tbl_mask;
+  u32 two_pass;   // 1: count a partition's matches first and reserve its output range once (large outputs); 0: one reservation per full queue
 };
 void launch_part_keys(const u32* k0, const u32* k1, u32 n_keys, const u64* n_dev, u64 cap, u32 bits, u32 n_parts, u32* skey, uint4* sval, hipStream_t s);
 size_t part_sort_temp_bytes(u64 n, u32 bits);

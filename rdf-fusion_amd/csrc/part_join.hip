@@ -49,7 +49,7 @@ __global__ __launch_bounds__(kLdsBlock) __attribute__((amdgpu_waves_per_eu(4))) 
   u32* k1s = reinterpret_cast<u32*>(slots + (pa.tbl_mask + 1u));
   u32* rows = k1s + pa.chunk;
   uint2* queues = reinterpret_cast<uint2*>(rows + pa.chunk);
-  __shared__ u32 wave_tot[kLdsBlock / 64];
+  __shared__ u32 wg_count, wg_cursor;
   __shared__ u64 wg_base;
   const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const u32 qcap = a.wave_q;
@@ -98,86 +98,103 @@ __global__ __launch_bounds__(kLdsBlock) __attribute__((amdgpu_waves_per_eu(4))) 
     qn = kept;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   };
-  auto flush = [&]() {     // one reservation for the wave's queue
+  // A partition is joined TWICE: a counting pass (matches that survive the filter), ONE reservation of the partition's whole
+  // output range in the global counter, then the writing pass, whose waves take their places from a cursor in LDS.  One
+  // reservation per queue-full was 2.1 M same-address atomics for a 0.54 G-row output — 24 ms at the chip's 88 per
+  // microsecond, and an order of magnitude more when that rate collapsed (observed: the same join at 27 ms or at 250-350 ms).
+  // A join with a small output (LUBM Q9's closing join: 2 M rows out of 98 M x 229 M) keeps the single pass: its few
+  // reservations cost nothing, a second walk over the partition would.
+  auto flush = [&](bool counting) {
     resolve();
-    unsigned long long b = 0;
-    if (lane == 0 && qn) {
-      b = atomicAdd((unsigned long long*)a.n_out_dev, (unsigned long long)qn);
-      if (b + qn > a.out_cap) *a.overflow = 1u;
+    if (counting) { if (lane == 0 && qn) atomicAdd(&wg_count, qn); }
+    else if (!pa.two_pass) {
+      unsigned long long b = 0;
+      if (lane == 0 && qn) {
+        b = atomicAdd((unsigned long long*)a.n_out_dev, (unsigned long long)qn);
+        if (b + qn > a.out_cap) *a.overflow = 1u;
+      }
+      b = __shfl(b, 0, 64);
+      write_out(b);
+    } else {
+      u32 off = 0;
+      if (lane == 0 && qn) off = atomicAdd(&wg_cursor, qn);
+      off = __shfl(off, 0, 64);
+      write_out(wg_base + off);
     }
-    b = __shfl(b, 0, 64);
-    write_out(b);
     qn = 0;
   };
 
   for (u32 p = blockIdx.x; p < pa.n_parts; p += gridDim.x) {
     const u32 bs = pa.bstart[p], be = pa.bstart[p + 1], ps = pa.pstart[p], pe = pa.pstart[p + 1];
     if (bs >= be || ps >= pe) continue;              // uniform per workgroup
-    for (u32 cb = bs; cb < be; cb += pa.chunk) {
-      const u32 nb = be - cb < pa.chunk ? be - cb : pa.chunk;
-      __syncthreads();                               // every wave is done with the previous table
-      for (u32 s = tid; s <= pa.tbl_mask; s += kLdsBlock) slots[s] = make_uint2(0u, kNil);
-      __syncthreads();
-      for (u32 i = tid; i < nb; i += kLdsBlock) {
-        const uint4 r = pa.bpart[cb + i];            // {row, key0, key1, -}
-        k1s[i] = r.z; rows[i] = r.x;
-        if (r.x == kNil) continue;                   // a row that joins nothing
-        Keys key; key.k[0] = r.y; key.k[1] = r.z; key.k[2] = 0; key.k[3] = 0;
-        u32 h = hash_keys4(key, a.n_keys) & pa.tbl_mask;
-        for (;;) {
-          if (atomicCAS(&slots[h].y, kNil, i) == kNil) { slots[h].x = r.y; break; }
-          h = (h + 1) & pa.tbl_mask;
-        }
-      }
-      __syncthreads();
-      const u32 n_probe = pe - ps;
-      for (u32 t0 = 0; t0 < n_probe; t0 += kLdsBlock) {   // uniform trip count per workgroup
-        const u32 t = t0 + tid;
-        const bool live = t < n_probe;
-        uint4 r = make_uint4(0u, 0u, 0u, 0u);
-        if (live) r = pa.ppart[ps + t];
-        Keys key; key.k[0] = r.y; key.k[1] = r.z; key.k[2] = 0; key.k[3] = 0;
-        u32 h = hash_keys4(key, a.n_keys) & pa.tbl_mask;
-        bool walking = live && r.x != kNil;
-        for (;;) {
-          u32 hit = kNil;
-          while (walking) {
-            const uint2 c = slots[h];
-            if (c.y == kNil) { walking = false; break; }
+    __syncthreads();
+    if (tid == 0) { wg_count = 0; wg_cursor = 0; }
+    for (int pass = pa.two_pass ? 0 : 1; pass < 2; pass++) {
+      const bool counting = pass == 0;
+      for (u32 cb = bs; cb < be; cb += pa.chunk) {
+        const u32 nb = be - cb < pa.chunk ? be - cb : pa.chunk;
+        __syncthreads();                             // every wave is done with the previous table
+        for (u32 s = tid; s <= pa.tbl_mask; s += kLdsBlock) slots[s] = make_uint2(0u, kNil);
+        __syncthreads();
+        for (u32 i = tid; i < nb; i += kLdsBlock) {
+          const uint4 r = pa.bpart[cb + i];          // {row, key0, key1, -}
+          k1s[i] = r.z; rows[i] = r.x;
+          if (r.x == kNil) continue;                 // a row that joins nothing
+          Keys key; key.k[0] = r.y; key.k[1] = r.z; key.k[2] = 0; key.k[3] = 0;
+          u32 h = hash_keys4(key, a.n_keys) & pa.tbl_mask;
+          for (;;) {
+            if (atomicCAS(&slots[h].y, kNil, i) == kNil) { slots[h].x = r.y; break; }
             h = (h + 1) & pa.tbl_mask;
-            if (c.x != r.y) continue;
-            if (a.n_keys > 1 && k1s[c.y] != r.z) continue;
-            hit = rows[c.y];
-            break;
           }
-          const unsigned long long found = __ballot(hit != kNil);
-          if (found == 0) break;
-          const u32 n_found = (u32)__popcll(found);
-          if (qn + n_found > qcap) flush();          // wave-uniform: the queue is empty afterwards and 64 <= qcap
-          if (hit != kNil) wq[qn + lane_prefix(found)] = make_uint2(hit, r.x);
-          qn += n_found;
         }
+        __syncthreads();
+        const u32 n_probe = pe - ps;
+        for (u32 t0 = 0; t0 < n_probe; t0 += kLdsBlock) {   // uniform trip count per workgroup
+          const u32 t = t0 + tid;
+          const bool live = t < n_probe;
+          uint4 r = make_uint4(0u, 0u, 0u, 0u);
+          if (live) r = pa.ppart[ps + t];
+          Keys key; key.k[0] = r.y; key.k[1] = r.z; key.k[2] = 0; key.k[3] = 0;
+          u32 h = hash_keys4(key, a.n_keys) & pa.tbl_mask;
+          bool walking = live && r.x != kNil;
+          for (;;) {
+            u32 hit = kNil;
+            while (walking) {
+              const uint2 c = slots[h];
+              if (c.y == kNil) { walking = false; break; }
+              h = (h + 1) & pa.tbl_mask;
+              if (c.x != r.y) continue;
+              if (a.n_keys > 1 && k1s[c.y] != r.z) continue;
+              hit = rows[c.y];
+              break;
+            }
+            const unsigned long long found = __ballot(hit != kNil);
+            if (found == 0) break;
+            const u32 n_found = (u32)__popcll(found);
+            if (qn + n_found > qcap) flush(counting);   // wave-uniform: the queue is empty afterwards and 64 <= qcap
+            if (hit != kNil) wq[qn + lane_prefix(found)] = make_uint2(hit, r.x);
+            qn += n_found;
+          }
+        }
+      }
+      if (pa.two_pass) flush(counting);              // what is still queued belongs to this partition's range (single pass: the queue carries over)
+      __syncthreads();
+      if (counting) {
+        if (tid == 0) {
+          const u32 t = wg_count;
+          u64 b = 0;
+          if (t) {
+            b = atomicAdd((unsigned long long*)a.n_out_dev, (unsigned long long)t);
+            if (b + t > a.out_cap) *a.overflow = 1u;
+          }
+          wg_base = b;
+        }
+        __syncthreads();
+        if (wg_count == 0) break;                    // uniform: nothing to write for this partition
       }
     }
   }
-  // what is still queued leaves with one reservation for the whole workgroup
-  resolve();
-  if (lane == 0) wave_tot[wave] = qn;
-  __syncthreads();
-  if (tid == 0) {
-    u32 t = 0;
-    for (int w = 0; w < kLdsBlock / 64; w++) t += wave_tot[w];
-    u64 b = 0;
-    if (t) {
-      b = atomicAdd((unsigned long long*)a.n_out_dev, (unsigned long long)t);
-      if (b + t > a.out_cap) *a.overflow = 1u;
-    }
-    wg_base = b;
-  }
-  __syncthreads();
-  u64 out_base = wg_base;
-  for (u32 w = 0; w < wave; w++) out_base += wave_tot[w];
-  write_out(out_base);
+  if (!pa.two_pass) flush(false);                    // single pass: what is still queued leaves with one last reservation per wave
 }
 
 // ---- host side -------------------------------------------------------------------------------------------------------

@@ -1630,7 +1630,13 @@ DevTable Plan::exec_lds_join(NodeInfo& nd, const DevTable& L, const DevTable& R,
   // SURVEY §8d hash join: 4(k+p_b)N_b + 8N_b + 4(k+p_p)N_p + 8N_p + 4 c_o N_o  (the 8-byte slot lives in LDS here)
   const u64 fixed = (4ull * (a.n_keys + build_payload) + 8) * B.cap;
 
-  if (use_part) prepare_partitions(a, B, P, part);   // the build half of this HashJoinExec: inside the operator, every execution
+  if (use_part) {
+    prepare_partitions(a, B, P, part);   // the build half of this HashJoinExec: inside the operator, every execution
+    // output of the previous execution (none: single pass): above ~50 M rows the reservations of a single pass (one
+    // same-address atomic per 256 rows, ~88 per microsecond) cost more than walking every partition twice
+    const u64 expect_out = nd.has_last ? nd.last_rows : 0;
+    part.two_pass = expect_out >= opt.v[RDFGPU_OPT_PARTITION_TWO_PASS_ROWS] ? 1u : 0u;
+  }
   // SURVEY 8d hash-join bytes of a partitioned join: both sides' key + payload columns and one 8-byte slot per row, the output;
   // the partition passes are in the time of the operator, not in its bytes
   const u64 part_fixed = (4ull * (a.n_keys + build_payload) + 8) * B.cap;

@@ -104,7 +104,7 @@ static const char* const kOptionNames[RDFGPU_OPT__COUNT] = {
     "FORCE_GENERIC_VM", "NO_JOIN_REORDER", "NO_SPECULATION", "NO_FIRST_RUN_SPECULATION", "NO_STRING_VERDICTS",
     "NO_TABLE_CACHE", "NO_INDEX_JOIN", "NO_CHAIN_FUSION", "NO_VALUE_TABLES", "NO_RANGE_INDEX", "NO_FILTER_FUSION",
     "NO_LDS_JOIN", "NO_GLOBAL_TABLE_JOIN", "NO_DIRECT_TABLE", "NO_BAND_JOIN", "NO_PARTITIONED_JOIN", "NO_VALUE_VERDICTS", "NO_PRIMING", "NO_ORDERED_JOIN", "NO_RUN_COPY",
-    "LDS_MAX_BUILD", "CSR_ROW_LANES_LOG2", "JOIN_WAVE_Q", "PARTITION_MIN_BUILD"};
+    "LDS_MAX_BUILD", "CSR_ROW_LANES_LOG2", "JOIN_WAVE_Q", "PARTITION_MIN_BUILD", "PARTITION_TWO_PASS_ROWS"};
 const char* engine_option_name(u32 option) { return option < RDFGPU_OPT__COUNT ? kOptionNames[option] : nullptr; }
 const EngineOptions& default_engine_options() {
   static const EngineOptions defaults = [] {
@@ -113,6 +113,7 @@ const EngineOptions& default_engine_options() {
     // a hash table of up to ~2 M rows (32 MB of slots) stays in the 32 MiB of L2 / the Infinity Cache: probing it is cheaper than
     // sorting both sides into partitions (BSBM Q5 un-fused: 0.54 G probe rows against a 285 k-row build: 59 ms vs 330 ms)
     o.v[RDFGPU_OPT_PARTITION_MIN_BUILD] = 1ull << 21;
+    o.v[RDFGPU_OPT_PARTITION_TWO_PASS_ROWS] = 50ull << 20;
     for (u32 i = 0; i < RDFGPU_OPT__COUNT; i++) {
       const std::string name = std::string("RDFGPU_") + kOptionNames[i];
       if (const char* e = std::getenv(name.c_str())) {

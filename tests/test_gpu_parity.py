@@ -557,7 +557,9 @@ def test_partitioned_join_matches_oracle(torch_cuda, nb, npr, n_ids, min_build):
         want = ku.multiset(exp, n_exp)
         plan = gs.plan(desc)
         plan.bind_table(0, pbp, nb); plan.bind_table(1, ppp, npr)
-        for rep in range(2):                  # exact sizing, then speculative sizing from the first run
+        for rep in range(3):                  # exact sizing, speculative sizing from the first run, then the two-pass form
+            if rep == 2:                          # (count a partition's matches, reserve its output range once, write)
+                plan.set_option("PARTITION_TWO_PASS_ROWS", 1)
             plan.enable_kernel_timing(True)
             got = plan.execute().fetch()
             assert plan.result_info()[0] == n_exp, (on, jt, rep)
