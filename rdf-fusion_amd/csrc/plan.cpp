@@ -707,9 +707,16 @@ void Plan::execute() {
     if (rt & 1u) fail(RDFGPU_ERR_UNSUPPORTED, "REGEX with \\d \\w \\s or \\b over a string with non-ASCII characters needs the regex crate's Unicode tables (not restated)");
     fail(RDFGPU_ERR_UNSUPPORTED, "REGEX with a per-row pattern: a row's pattern literal was not announced in the plan's pattern table");
   }
-  for (const BandBlockCounter& c : band_block_counters) if (c.node) c.node->band_blocks = ctx->counters_host[c.counter];
+  bool slow_missed = false;
+  for (const BandBlockCounter& c : band_block_counters) {
+    if (!c.node) continue;
+    c.node->band_blocks = ctx->counters_host[c.counter];
+    c.node->band_slow_rows = ctx->counters_host[c.slow_counter] & 0xFFFFFFFFull;
+    c.node->band_ran = true;
+    if (c.slow_skipped && c.node->band_slow_rows) slow_missed = true;   // rows with non-integer operands, and their pass was not launched
+  }
   // speculative joins: did every output fit the size taken from the previous run?
-  bool spec_failed = false;
+  bool spec_failed = slow_missed;
   for (const SpecCheck& c : spec_checks) {
     if ((ctx->counters_host[c.counter + 1] & 0xFFFFFFFFull) != 0) spec_failed = true;
     else { c.node->last_rows = ctx->counters_host[c.counter]; c.node->has_last = true; c.node->last_scaled = false; }
@@ -1904,7 +1911,10 @@ void Plan::exec_band_join(LdsJoinArgs& a, BandArgs& b, const DevTable& B, const 
   b.max_blocks = (u32)max_blocks;
   // the block kernels launch one wave per block: sized from the previous execution's count (+ 25 %), not from the upper bound
   b.n_blocks_out = new_counter();
-  band_block_counters.push_back({cur_band_node, (u32)(b.n_blocks_out - counters)});
+  // the full-semantics pass is launched when the previous execution met a row that needed it (or there was none); a row that
+  // needs it after all is caught at the end of the plan like any failed speculation
+  const bool skip_slow = speculative && cur_band_node && cur_band_node->band_ran && cur_band_node->band_slow_rows == 0;
+  band_block_counters.push_back({cur_band_node, (u32)(b.n_blocks_out - counters), (u32)(reinterpret_cast<u64*>(b.slow_rows) - counters), skip_slow});
   const u64 hist = cur_band_node ? cur_band_node->band_blocks : 0;
   b.launch_blocks = (u32)std::min<u64>(max_blocks, hist ? hist + hist / 4 + 1024 : max_blocks);
   b.bdesc = scratch<uint4>(max_blocks);
@@ -1925,7 +1935,7 @@ void Plan::exec_band_join(LdsJoinArgs& a, BandArgs& b, const DevTable& B, const 
   // per probe row 4 (sorted position) + 24 (record) read, per entry 16 B read, per pair one bit written; the pair count
   // is not known on the host
   timed(KC_BAND_MASK, 16ull * nb, np, P.n_dev, 4 + 24, nullptr, 0, 0, [&] { launch_band_mask(b, stream); });
-  {
+  if (!skip_slow) {
     // the full-semantics pass needs the chain's literals and columns: the fused join kernel's argument block, by pointer
     static_assert(sizeof(LdsJoinArgs) <= ExecContext::kArgBytes, "argument staging slot too small");
     const u32 slot = arg_slots_used++;

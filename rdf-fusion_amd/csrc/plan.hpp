@@ -38,7 +38,8 @@ struct NodeInfo {
   u32 refs = 0;                   // how many operators consume this node
   u64 last_rows = 0; bool has_last = false;   // output cardinality of the previous execution (speculative sizing)
   bool last_scaled = false;
-  u64 band_blocks = 0;                         // blocks of the band join based on this node in its previous execution (launch sizing)                    // .. extrapolated from a priming run over a prefix of the bound tables
+  u64 band_blocks = 0;                         // blocks of the band join based on this node in its previous execution (launch sizing)
+  bool band_ran = false; u64 band_slow_rows = 0;   // .. and how many of its probe rows needed the full typed-value semantics                    // .. extrapolated from a priming run over a prefix of the bound tables
 };
 struct SpecCheck { NodeInfo* node; u32 counter; bool left_join; };   // counter = n_out slot, counter+1 = overflow flag
 
@@ -113,7 +114,7 @@ struct Plan {
   bool priming = false, primed = false;   // the first execution over big bound tables is preceded by one over their first rows (Plan::prime)
   void prime();
   std::vector<SpecCheck> spec_checks;
-  struct BandBlockCounter { NodeInfo* node; u32 counter; };
+  struct BandBlockCounter { NodeInfo* node; u32 counter; u32 slow_counter; bool slow_skipped; };
   std::vector<BandBlockCounter> band_block_counters;   // device-side block counts of this execution's band joins -> NodeInfo::band_blocks
   NodeInfo* cur_band_node = nullptr;                   // the base join whose band join is being set up
   std::vector<PendingLaunch> pending;
