@@ -87,7 +87,10 @@ __global__ __launch_bounds__(kOjBlock) void oj_count_kernel(const OrderedJoinArg
   for (int d = 32; d >= 1; d >>= 1) tot += __shfl_xor(tot, d, 64);
   if ((threadIdx.x & 63) == 0) wave_tot[threadIdx.x >> 6] = tot;
   __syncthreads();
-  if (threadIdx.x == 0) a.tile_count[blockIdx.x] = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+  if (threadIdx.x == 0) {
+    a.tile_count[blockIdx.x] = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+    if (blockIdx.x == 0) a.tile_count[gridDim.x] = 0;   // the scan's extra element (total = its exclusive prefix): no memset launch for 4 bytes
+  }
 }
 
 // Pass 2.  A tile's matches are numbered 0 .. T-1 in slice order; match j is written by lane j mod 256 — every lane has

@@ -1727,7 +1727,6 @@ DevTable Plan::exec_lds_join(NodeInfo& nd, const DevTable& L, const DevTable& R,
       o.row_head = scratch<u32>(B.cap); o.row_cnt = scratch<unsigned char>(B.cap);
       const size_t tb = scan_temp_bytes(tiles + 1);
       void* temp = scratch<unsigned char>(tb);
-      RDFGPU_HIP(hipMemsetAsync(o.tile_count + tiles, 0, sizeof(u32), stream));
       timed(KC_OJ_PROBE, 0, P.cap, P.n_dev, 8 + 12ull * a.n_chain, nullptr, 0, 0, [&] { launch_ordered_join_probe(o, stream); });
       timed(KC_OJ_COUNT, 0, B.cap, nullptr, 4, nullptr, 0, 0, [&] { launch_ordered_join_count(o, stream); });
       timed(KC_DEVICE_SCAN, 0, tiles + 1, nullptr, 8, nullptr, 0, 0, [&] { exclusive_scan_u32(o.tile_count, o.tile_off, tiles + 1, temp, tb, stream); });
