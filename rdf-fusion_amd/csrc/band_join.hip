@@ -301,7 +301,14 @@ __global__ __launch_bounds__(256) void band_desc_kernel(const BandArgs b) {
 // latency are what it waits for; persistent waves made it slower, 240 -> 325 us).
 // NWIN = window stages (1..2; no window = one trivial window); NEQ = base filter: 0 none / 1 `!=` / 2 `=`.
 struct BandEntry8 { uint4 a[8]; };
-template <int NWIN, int NEQ>
+typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+// [lo, lo + w] over 32-bit biased values -> the same interval over 16 bits (values are <= 65533 when this form is chosen)
+__device__ __forceinline__ void band_pack_interval(u32 lo, u32 w, u32& lo16, u32& w16) {
+  if (lo > 65534u) { lo16 = 0xFFFFu; w16 = 0u; return; }           // empty (or the "nothing passes" marker): (x - 0xFFFF) mod 2^16 >= 1 > 0
+  const u64 hi = (u64)lo + w;
+  lo16 = lo; w16 = (u32)(hi < 65534ull ? hi : 65534ull) - lo;      // a dead entry (x = 0) gives 65536 - lo > w16: never passes
+}
+template <int NWIN, int NEQ, bool PACK>
 __global__ __launch_bounds__(256) void band_mask_kernel(const BandArgs b) {
   __shared__ uint4 ent[4][64];
   const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -320,7 +327,18 @@ __global__ __launch_bounds__(256) void band_mask_kernel(const BandArgs b) {
   // ITS entry with a broadcast ds_read_b128 (all lanes one address).  Scalar loads (s_load_dwordx8 from the entry table) looked
   // cheaper — no LDS, operands in SGPRs — but 200 k blocks x 1 KB through the scalar caches is what the kernel then waits
   // for (measured: VALU work 7 -> 6 instructions per pair changed nothing, more resident waves made it slower).
-  ent[wave][lane] = b.et[eb + lane];                   // the table is padded: reading past the group is harmless
+  u32 plo = 0, pw = 0;                                 // PACK: both windows' intervals as 2 x 16 bits
+  {
+    uint4 q = b.et[eb + lane];                          // the table is padded: reading past the group is harmless
+    if (PACK) {
+      q.x = (q.x & 0xFFFFu) | (q.y << 16);              // both windows' operands in one word
+      u32 l0, w0, l1, w1;
+      band_pack_interval(rec.x, rec.y, l0, w0);
+      band_pack_interval(rec.z, rec.w, l1, w1);
+      plo = l0 | (l1 << 16); pw = w0 | (w1 << 16);
+    }
+    ent[wave][lane] = q;
+  }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   u32 m[2] = {0u, 0u};
 #pragma unroll
@@ -337,8 +355,15 @@ __global__ __launch_bounds__(256) void band_mask_kernel(const BandArgs b) {
         const uint4 q = q8[e];
         // the verdict of the 64 lanes IS the compares' lane mask (SGPR pairs, AND-ed on the scalar unit): shifting it into
         // every lane's word is ONE add-with-carry (acc + acc + carry) instead of a select and an or per pair
-        u64 lanes = __builtin_amdgcn_ballot_w64((q.x - rec.x) <= rec.y);
-        if (NWIN > 1) lanes &= __builtin_amdgcn_ballot_w64((q.y - rec.z) <= rec.w);
+        u64 lanes;
+        if (PACK) {   // (x - lo) <= w in both 16-bit halves  <=>  min(x - lo, w) == x - lo as a 32-bit word: 3 instructions for two windows
+          const us2 d = __builtin_bit_cast(us2, q.x) - __builtin_bit_cast(us2, plo);
+          const us2 mn = __builtin_elementwise_min(d, __builtin_bit_cast(us2, pw));
+          lanes = __builtin_amdgcn_ballot_w64(__builtin_bit_cast(u32, mn) == __builtin_bit_cast(u32, d));
+        } else {
+          lanes = __builtin_amdgcn_ballot_w64((q.x - rec.x) <= rec.y);
+          if (NWIN > 1) lanes &= __builtin_amdgcn_ballot_w64((q.y - rec.z) <= rec.w);
+        }
         if (NEQ == 1) lanes &= __builtin_amdgcn_ballot_w64(q.z != x);
         if (NEQ == 2) lanes &= __builtin_amdgcn_ballot_w64(q.z == x);
         u64 carry_out;
@@ -504,16 +529,17 @@ void launch_band_entries(const BandArgs& b, hipStream_t s) {
 void launch_band_desc(const BandArgs& b, hipStream_t s) {
   hipLaunchKernelGGL(band_desc_kernel, grid256(b.kn), dim3(256), 0, s, b);
 }
-template <int NWIN> static void launch_band_mask_w(const BandArgs& b, dim3 g, hipStream_t s) {
+template <int NWIN, bool PACK> static void launch_band_mask_w(const BandArgs& b, dim3 g, hipStream_t s) {
   const int neq = b.has_neq ? (b.neq_is_eq ? 2 : 1) : 0;
-  if (neq == 0) hipLaunchKernelGGL((band_mask_kernel<NWIN, 0>), g, dim3(256), 0, s, b);
-  else if (neq == 1) hipLaunchKernelGGL((band_mask_kernel<NWIN, 1>), g, dim3(256), 0, s, b);
-  else hipLaunchKernelGGL((band_mask_kernel<NWIN, 2>), g, dim3(256), 0, s, b);
+  if (neq == 0) hipLaunchKernelGGL((band_mask_kernel<NWIN, 0, PACK>), g, dim3(256), 0, s, b);
+  else if (neq == 1) hipLaunchKernelGGL((band_mask_kernel<NWIN, 1, PACK>), g, dim3(256), 0, s, b);
+  else hipLaunchKernelGGL((band_mask_kernel<NWIN, 2, PACK>), g, dim3(256), 0, s, b);
 }
 void launch_band_mask(const BandArgs& b, hipStream_t s) {
   const dim3 g((b.launch_blocks + 3) / 4 ? (b.launch_blocks + 3) / 4 : 1);   // the number of blocks lives on the device: surplus waves leave at once, missing ones are made up by striding
   // (one wave per block beats persistent waves here: 2048 / 4096 / 8192 workgroups striding over the blocks took 223 / 211 / 202 us against 187)
-  if (b.n_win == 2) launch_band_mask_w<2>(b, g, s); else launch_band_mask_w<1>(b, g, s);   // no window = one trivial window
+  if (b.pack16) { if (b.n_win == 2) launch_band_mask_w<2, true>(b, g, s); else launch_band_mask_w<1, true>(b, g, s); }
+  else if (b.n_win == 2) launch_band_mask_w<2, false>(b, g, s); else launch_band_mask_w<1, false>(b, g, s);   // no window = one trivial window
 }
 void launch_band_slow(const LdsJoinArgs* a_dev, const BandArgs& b, hipStream_t s) {
   const u32 g = (b.max_blocks + 3) / 4;

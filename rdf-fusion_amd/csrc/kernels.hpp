@@ -306,6 +306,7 @@ struct BandArgs {
   uint4* bdesc;               // per block {first entry, entries (<= 64), first sorted row, rows (<= 64)}
   u64* masks;                 // 64 x u64 per block: bit e of lane r = (entry e, row r) joins
   u32* bcount; u32* bofs;     // per block (+ 1): output rows / their exclusive scan
+  u32 pack16, pad4;             // every window's biased values fit 16 bits: the pair test checks both windows with packed 16-bit arithmetic
   u32* key_hist; u32* key_cursor;   // counting-sort form of the partition pass (small probe sides): rows per key, counted by the decode pass; the scatter's cursors
   u32 launch_blocks; u32 pad3; u64* n_blocks_out;   // waves launched by the block kernels (>= the previous execution's blocks; they stride on if there are more); the count, for next time
   u32 max_blocks, presorted;  // presorted: the probe rows arrive sorted by key — no sort, records written in place

@@ -1205,6 +1205,7 @@ bool Plan::apply_chain(const ChainRequest& req, NodeInfo& base, const DevTable& 
       b.has_post = 1; b.post_col = a.cols[a.post.col]; b.post_lit = a.post.lit; b.post_is_eq = a.post.is_eq;
     }
     b.n_stages = (u32)req.links.size();
+    bool pack16 = !opt.on(RDFGPU_OPT_NO_BAND_PACK16);
     for (size_t t = 0; ok && t < req.links.size(); t++) {
       const ChainStage& st = stages[t];
       ok = st.key.src == 1 && (st.fs == 0 || st.fs == 3);
@@ -1216,9 +1217,11 @@ bool Plan::apply_chain(const ChainRequest& req, NodeInfo& base, const DevTable& 
            vc->vmin <= vc->vmax && (unsigned long long)(vc->vmax - vc->vmin) < 0xFFFFFFE0ull;
       if (!ok) break;
       BandWin& w = b.win[b.n_win++];
+      if ((unsigned long long)(vc->vmax - vc->vmin) > 65530ull) pack16 = false;   // biased values 1 .. range + 1 have to fit 16 bits
       w.key_col = st.key.ptr; w.val = st.val; w.vkmin = st.kmin; w.vkn = st.kn; w.vbase = vc->vmin;
       w.y0 = st.f[1].ptr; w.y1 = st.f[3].ptr; w.l0 = st.l0; w.l1 = st.l1; w.stage = (u32)t;
     }
+    b.pack16 = pack16 ? 1u : 0u;
     for (size_t k = 0; ok && k < cur.size(); k++) {
       if (cur[k].src == 0) { ok = b.n_row_cols < kBandMaxRowCols; if (ok) { b.out_from_row[k] = 1; b.out_sel[k] = (u8)b.n_row_cols; b.row_col[b.n_row_cols++] = cur[k].ptr; } }
       else { ok = b.n_entry_cols < kBandMaxSideCols; if (ok) { b.out_from_row[k] = 0; b.out_sel[k] = (u8)(2 + b.n_entry_cols); b.entry_col[b.n_entry_cols++] = cur[k]; } }

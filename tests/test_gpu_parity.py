@@ -1207,7 +1207,7 @@ TOGGLES = ["RDFGPU_NO_CHAIN_FUSION", "RDFGPU_NO_INDEX_JOIN", "RDFGPU_NO_TABLE_CA
            "RDFGPU_NO_FIRST_RUN_SPECULATION", "RDFGPU_NO_DIRECT_TABLE", "RDFGPU_FORCE_GENERIC_VM", "RDFGPU_NO_LDS_JOIN",
            "RDFGPU_NO_GLOBAL_TABLE_JOIN", "RDFGPU_NO_FILTER_FUSION", "RDFGPU_NO_VALUE_TABLES", "RDFGPU_NO_RANGE_INDEX",
            "RDFGPU_NO_BAND_JOIN", "RDFGPU_NO_PARTITIONED_JOIN", "RDFGPU_NO_JOIN_REORDER", "RDFGPU_NO_STRING_VERDICTS",
-           "RDFGPU_NO_VALUE_VERDICTS", "RDFGPU_NO_RUN_COPY", "RDFGPU_NO_PRIMING", "RDFGPU_NO_ORDERED_JOIN"]
+           "RDFGPU_NO_VALUE_VERDICTS", "RDFGPU_NO_RUN_COPY", "RDFGPU_NO_PRIMING", "RDFGPU_NO_ORDERED_JOIN", "RDFGPU_NO_BAND_PACK16"]
 
 
 @pytest.mark.parametrize("toggle", TOGGLES)
@@ -1550,6 +1550,10 @@ def test_band_join_matches_oracle(torch_cuda, shape):
         seen |= {k[0] for k in plan.kernel_stats()}
     if shape != "leq_geq_eq" and not ENGINE_TOGGLED:
         assert any("band_mask_kernel" in k for k in seen) and any("band_emit_kernel" in k for k in seen), seen
+    plan.set_option("NO_BAND_PACK16", 1)                            # both windows with 32-bit arithmetic instead of packed 16-bit
+    got = plan.execute().fetch()
+    np.testing.assert_array_equal(ku.multiset(got, n_exp), want)
+    plan.set_option("NO_BAND_PACK16", 0)
     plan.set_option("NO_BAND_JOIN", 1)
     got = plan.execute().fetch()
     assert not any("band_" in k[0] for k in plan.kernel_stats())
