@@ -17,7 +17,10 @@ results per instance are identical to the reference's per-query plan, tests/test
 `--threads` host threads instead.  value = solution bindings (rows leaving the top join, before
 DISTINCT / ORDER BY / LIMIT) per second over all ranks.
 
-N > 1 (strong scaling, the dataset and the batch are fixed): triples are sharded by hash(subject); each rank
+N > 1: the dataset is fixed (BSBM-100M, graph-sharded over the N GPUs) and, by default, the batch grows with N
+(`--scaling weak`: N x `--queries` instances per step — the per-GPU join work stays what one GPU does at N = 1, every
+row of C still crosses the exchange; `--scaling strong` keeps the batch fixed, and a short run of the OTHER mode is
+reported under config.other_scaling either way).  Triples are sharded by hash(subject); each rank
 evaluates the batch's constant-subject patterns on its shard (phase A), the resulting table C is re-sharded by
 prodFeature with ONE hash repartition per step (rdfgpu_exchange_repartition: counts first, then the rows, RCCL
 grouped send / recv), and the candidate join + FILTER pipeline (phase B) runs on the rank's object-sharded copy of
@@ -142,6 +145,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--products", type=int, default=285_000, help="BSBM scale (285000 products = ~100 M triples)")
     ap.add_argument("--queries", type=int, default=262144, help="Q5 instances per step (the batch)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="N > 1: weak = N x --queries instances per step over the same sharded graph; strong = --queries instances per step")
     ap.add_argument("--per-instance", action="store_true", help="one reference plan per instance instead of one batched tree")
     ap.add_argument("--threads", type=int, default=4, help="--per-instance: host threads submitting queries")
     ap.add_argument("--cpu-sample", type=int, default=14, help="Q5 instances timed on the CPU oracle (rank 0, N=1)")
@@ -202,7 +207,16 @@ def main():
         raise SystemExit(f"--queries {Q} exceeds the {ds.n_products} products of this scale (instances of one batch are distinct products)")
     # every step gets its own query mix: Q distinct products, drawn independently per batch (same seed on every rank)
     all_products = np.array([ds.product(i) for i in range(ds.n_products)], dtype=np.uint32)
-    batches = [np.ascontiguousarray(all_products[rng.choice(ds.n_products, size=Q, replace=False)]) for _ in range(n_batches)]
+    def draw(n_inst):
+        """one batch: draws of Q distinct products each (a batch of more than Q instances repeats products, as a BSBM driver's
+        uniform draws would; instance tags stay distinct)"""
+        parts = [all_products[rng.choice(ds.n_products, size=min(Q, n_inst - k), replace=False)] for k in range(0, n_inst, Q)]
+        return np.ascontiguousarray(np.concatenate(parts))
+    Q_step = Q * world if args.scaling == "weak" else Q      # instances per step over all ranks
+    batches = [draw(Q_step) for _ in range(n_batches)]
+    # N > 1: a short run of the other scaling mode after the timed region (3 warm-up + 5 timed steps), reported beside the headline
+    Q_other = Q if args.scaling == "weak" else Q * world
+    other_batches = [draw(Q_other) for _ in range(8)] if world > 1 and not args.per_instance else []
     products = np.concatenate(batches)                   # the instances the latency / CPU-baseline samples are taken from
 
     kstats = {}
@@ -230,9 +244,16 @@ def main():
     resident = {}
 
     def params_on_device(batch):
+        """PARAMS(inst, X) of one batch in HBM.  N > 1: the rows this rank's shard can answer — the instances whose %Product%
+        it owns (the router's job, like sharding the graph itself; the instance tags stay the batch-wide ones)."""
         key = batch.ctypes.data
         if key not in resident:
-            resident[key] = dev_table([np.arange(1, len(batch) + 1, dtype=np.uint32), batch])
+            inst = np.arange(1, len(batch) + 1, dtype=np.uint32)
+            if world > 1:
+                mine = sharding.shard_of(batch, world) == rank
+                resident[key] = dev_table([inst[mine], batch[mine]])
+            else:
+                resident[key] = dev_table([inst, batch])
         return resident[key]
 
     lat_ms = []
@@ -386,7 +407,7 @@ def main():
             return total
 
     if not args.per_instance:
-        for b in batches:
+        for b in batches + other_batches:
             params_on_device(b)
         torch.cuda.synchronize()
     # Cold start: the FIRST execution of the batch on a fresh store version builds every join table of the predicate slices
@@ -426,6 +447,26 @@ def main():
         tsum = t.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
         elapsed = float(tmax[0].item()); total_rows = int(tsum[1].item())
 
+    # ------------------------------------------------------------------ the other scaling mode, briefly (same code path, other batch size)
+    other = None
+    if other_batches:
+        saved = list(phase_ms)
+        run = (lambda bs: run_pipelined(bs, False)) if overlap else (lambda bs: sum(step(b, False) for b in bs))
+        run(other_batches[:3])
+        barrier()
+        t1 = time.perf_counter()
+        rows_o = run(other_batches[3:])
+        barrier()
+        el_o = time.perf_counter() - t1
+        t = torch.tensor([el_o, float(rows_o)], dtype=torch.float64, device=xdev)
+        tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = t.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        n_o = len(other_batches) - 3
+        other = {"scaling": "strong" if args.scaling == "weak" else "weak", "instances_per_step": Q_other, "steps": n_o,
+                 "ms_per_step": round(float(tmax[0].item()) * 1e3 / n_o, 3),
+                 "bindings_per_s": round(float(tsum[1].item()) / float(tmax[0].item()), 2)}
+        phase_ms[:] = saved
+
     # ------------------------------------------------------------------ sharded run: are the shards' bindings the unsharded answer?
     shard_check = None
     if dist is not None and not args.no_shard_check:
@@ -434,7 +475,7 @@ def main():
             with np.errstate(over="ignore"):
                 mix = a * np.uint64(0x9E3779B97F4A7C15) ^ b * np.uint64(0xC2B2AE3D27D4EB4F) ^ c * np.uint64(0x165667B19E3779F9)
                 return len(a), int(mix.sum(dtype=np.uint64))
-        probe_batch = batches[args.warmup][:min(Q, 8192)].copy()
+        probe_batch = batches[args.warmup][:min(Q, 8192)].copy()      # (distinct products: the first draw of the batch)
         step(probe_batch, False)
         n_loc, sum_loc = checksum(plan_b.fetch())
         t = torch.tensor([n_loc, sum_loc - (1 << 64) if sum_loc >= (1 << 63) else sum_loc], dtype=torch.int64, device=xdev)
@@ -633,7 +674,7 @@ def main():
                                      "sample": f"3 batches of {ab_batch} instances, {t_ab:.1f} s; the last batch compared multiset-equal with the GPU"}
 
     if rank == 0:
-        n_q = args.steps * Q
+        n_q = args.steps * Q_step
         out = {
             "metric": "solution bindings/sec + achieved HBM GB/s, BSBM Q5 at 1/2/4/8 GPUs",
             "value": round(total_rows / elapsed, 2),
@@ -641,12 +682,13 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed * 1e3 / args.steps, 3),
             "higher_is_better": True,
-            "scaling": "strong",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "u32 ids / i64 typed values",
             "data": "synthetic",
             "config": {"workload": f"BSBM-shaped store, {args.products} products ({ds.n_triples} triples), Explore Q5 "
-                                   f"(7 triple patterns -> scans, hash joins, FILTERs), {Q} instances per step, "
+                                   f"(7 triple patterns -> scans, hash joins, FILTERs), {Q_step} instances per step"
+                                   + (f" ({Q} x {world} ranks: the batch grows with N, the graph does not)" if world > 1 and args.scaling == "weak" else "") + ", "
                                    + ("one reference plan per instance" if args.per_instance else "batched into one operator tree (shared scans)")
                                    + ("; every join table built inside the timed step (--no-table-cache)" if args.no_table_cache else
                                       "; steady state: the join tables of the predicate slices are cached per store version (cold start and the "
@@ -655,7 +697,7 @@ def main():
                        "triples_per_gpu": n_local, "sharding": ("rdfgpu_shard_of(subject) over N ranks (default graph) + the candidate join's layout in a named graph: productFeature sharded by OBJECT, "
                                     "the three 1:1 star predicates replicated; rdfgpu_exchange_repartition (RCCL over xGMI, behind the C ABI) of the constant-pattern "
                                     "bindings C by prodFeature") if world > 1 else "none",
-                       "sharded_result_check": shard_check,
+                       "sharded_result_check": shard_check, "instances_per_step": Q_step, "other_scaling": other,
                        "exchange_overlapped_with_next_step": bool(world > 1 and not args.no_overlap),
                        "exchange_transport": transport if world > 1 else None,
                        "rank0_phase_ms_per_step": ({"constant_patterns": round(phase_ms[0] / args.steps, 3), "exchange": round(phase_ms[1] / args.steps, 3),

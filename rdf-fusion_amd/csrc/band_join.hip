@@ -98,14 +98,40 @@ __device__ __forceinline__ uint2 band_interval(long long lo, long long hi, long 
   const u32 hi_b = dh >= 0xFFFFFFF0ull ? 0xFFFFFFF0u : (u32)dh + 1u;
   return make_uint2(lo_b, hi_b - lo_b);
 }
+// One atomic per RUN of equal keys among neighbouring lanes of a wave instead of one per lane: the re-sharded probe side of
+// a sharded step arrives as N sorted runs, so neighbouring rows share their key (any input is handled: a lane whose
+// neighbours differ is a run of one).  Every lane of the wave calls it; returns the lane's own position (counter value
+// before the run + the lane's rank in the run) for `valid` lanes.
+__device__ __forceinline__ u32 band_run_atomic_add(u32* counters, u32 k, bool valid) {
+  const int lane = threadIdx.x & 63;
+  const u32 prev = __shfl_up(k, 1, 64);
+  const unsigned long long vm = __ballot(valid);
+  const bool pvalid = lane > 0 && ((vm >> (lane - 1)) & 1ull);
+  const bool head = valid && (!pvalid || prev != k);
+  const unsigned long long hm = __ballot(head);
+  const unsigned long long upto = lane == 63 ? ~0ull : ((2ull << lane) - 1ull);
+  const int leader = 63 - __builtin_clzll((hm & upto) | 1ull);                 // (| 1: defined for invalid lanes; their result is unused)
+  const unsigned long long above = (hm | ~vm) & (leader == 63 ? 0ull : ~((2ull << leader) - 1ull));
+  const int end = above ? __builtin_ctzll(above) : 64;
+  u32 r = 0;
+  if (valid && lane == leader) r = atomicAdd(counters + k, (u32)(end - leader));
+  r = __shfl(r, leader, 64);
+  return r + (u32)(lane - leader);
+}
 // One pass over the probe side in ROW order (coalesced column reads): the sort key of every row (key - kmin; kn =
 // joins nothing) and, for the rows that can join, the decoded windows + the id operand of the base join's filter.
 __global__ __launch_bounds__(256) void band_decode_kernel(const BandArgs b) {
   const u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-  if (j > b.n_probe_cap) return;
   const u64 n = live_rows(b.n_probe_dev, b.n_probe_cap);
   auto key_of = [&](u64 r) { u32 kk = b.kn; if (r < n) { const u32 v = b.probe_key[r]; const u32 d = v - b.kmin; if (v != 0 && d < b.kn) kk = d; } return kk; };   // null keys never join
   const u32 k = j < b.n_probe_cap ? key_of(j) : b.kn;
+  if (b.key_hist) band_run_atomic_add(b.key_hist, k, k != b.kn);   // (whole waves: before any lane leaves)
+  if (!b.presorted && (blockIdx.x & 63u) == 0) {      // a sample of the waves: rows that can join, and runs of equal neighbouring keys among them
+    const u32 prev = __shfl_up(k, 1, 64);
+    const unsigned long long vm = __ballot(k != b.kn), hm = __ballot(k != b.kn && ((threadIdx.x & 63) == 0 || prev != k));
+    if ((threadIdx.x & 63) == 0 && vm) atomicAdd(b.run_stats, ((unsigned long long)__popcll(vm) << 32) | (unsigned long long)__popcll(hm));
+  }
+  if (j > b.n_probe_cap) return;
   if (b.presorted) {   // rows arrive sorted by key: the key boundaries (band_bounds_kernel's job) fall out here — poff[q] = first row with key >= q
     const u32 first = j > 0 ? key_of(j - 1) + 1u : 0u;
     for (u32 q = first; q <= k && q <= b.kn; q++) b.poff[q] = (u32)j;
@@ -113,7 +139,6 @@ __global__ __launch_bounds__(256) void band_decode_kernel(const BandArgs b) {
   if (j >= b.n_probe_cap) return;
   b.skey_in[j] = k; b.sval_in[j] = (u32)j;
   if (k == b.kn) return;
-  if (b.key_hist) atomicAdd(b.key_hist + k, 1u);
   uint4 rec = make_uint4(1u, 0u, 1u, 0u);              // no window: entries carry x_b = 1 (0 when the entry is dead)
   u32 flags = 0;
 #pragma unroll
@@ -150,10 +175,9 @@ __global__ __launch_bounds__(256) void band_rows_kernel(const BandArgs b) {
 // gives poff, and every row takes the next free position of its key (order inside a key is irrelevant to the join).
 __global__ __launch_bounds__(256) void band_scatter_kernel(const BandArgs b) {
   const u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= b.n_probe_cap) return;
-  const u32 k = b.skey_in[j];
+  const u32 k = j < b.n_probe_cap ? b.skey_in[j] : b.kn;
+  const u32 pos = band_run_atomic_add(b.key_cursor, k, k < b.kn);   // a run of equal keys lands in consecutive positions
   if (k >= b.kn) return;                               // joins nothing: no position
-  const u32 pos = atomicAdd(b.key_cursor + k, 1u);
   const_cast<u32*>(b.perm)[pos] = (u32)j;
   b.rec_s[pos] = b.rec[2 * j];
   b.aux_s[pos] = b.rec[2 * j + 1];

@@ -311,6 +311,7 @@ struct BandArgs {
   u32 launch_blocks; u32 pad3; u64* n_blocks_out;   // waves launched by the block kernels (>= the previous execution's blocks; they stride on if there are more); the count, for next time
   u32 max_blocks, presorted;  // presorted: the probe rows arrive sorted by key — no sort, records written in place
   u32* slow_rows;             // number of probe rows that need the full typed-value semantics (usually 0)
+  unsigned long long* run_stats;   // sampled (rows << 32 | runs of equal neighbouring keys): is the probe side piecewise sorted? (next execution's partition pass)
   // output
   u32 n_out_cols, n_entry_cols, n_row_cols, pad1;
   u32* out[kMaxCols]; u64 out_cap; u64* n_out_dev; u32* overflow;

@@ -712,6 +712,7 @@ void Plan::execute() {
     if (!c.node) continue;
     c.node->band_blocks = ctx->counters_host[c.counter];
     c.node->band_slow_rows = ctx->counters_host[c.slow_counter] & 0xFFFFFFFFull;
+    c.node->band_run_stats = ctx->counters_host[c.runs_counter];
     c.node->band_ran = true;
     if (c.slow_skipped && c.node->band_slow_rows) slow_missed = true;   // rows with non-integer operands, and their pass was not launched
   }
@@ -1823,8 +1824,11 @@ void Plan::exec_band_join(LdsJoinArgs& a, BandArgs& b, const DevTable& B, const 
   bool presorted = false;
   if (P.sorted_col >= 0 && P.cols[P.sorted_col] == a.probe_key[0] && P.key_min >= std::max<u32>(1u, a.direct_min) && !opt.on(RDFGPU_OPT_NO_ORDERED_JOIN)) presorted = true;
   b.presorted = presorted ? 1u : 0u;
-  // small probe side, not sorted: counting sort on the key (band_scatter_kernel) instead of rocPRIM's radix sort
-  const bool counting = !presorted && np <= (1ull << 21) && !opt.on(RDFGPU_OPT_NO_ORDERED_JOIN);
+  // small probe side, not sorted: counting sort on the key (band_scatter_kernel) instead of rocPRIM's radix sort; a larger one
+  // when the previous execution found it piecewise sorted (>= 4 rows per run of equal neighbouring keys: the N sorted runs
+  // a repartition delivers) — one atomic per run, rows of a run scattered together
+  const u64 runs_seen = cur_band_node ? (cur_band_node->band_run_stats & 0xFFFFFFFFull) : 0, run_rows = cur_band_node ? (cur_band_node->band_run_stats >> 32) : 0;
+  const bool counting = !presorted && !opt.on(RDFGPU_OPT_NO_ORDERED_JOIN) && (np <= (1ull << 21) || (runs_seen && run_rows >= 4 * runs_seen));
   if (counting) {
     b.key_hist = scratch<u32>((u64)kn + 2); b.key_cursor = scratch<u32>((u64)kn + 2);
     RDFGPU_HIP(hipMemsetAsync(b.key_hist, 0, ((size_t)kn + 2) * sizeof(u32), stream));
@@ -1842,6 +1846,7 @@ void Plan::exec_band_join(LdsJoinArgs& a, BandArgs& b, const DevTable& B, const 
   b.skey = skey; b.perm = perm;
   b.rec_s = scratch<uint4>(np); b.aux_s = scratch<uint4>(np);
   b.slow_rows = reinterpret_cast<u32*>(new_counter());
+  b.run_stats = reinterpret_cast<unsigned long long*>(new_counter());
   const size_t stb = sort_u32_temp_bytes(np, bits);
   void* stemp = scratch<unsigned char>(stb);
   u64 entry_bytes = build_bytes_per_row + (a.csr_rows ? 4 : 0) + (a.has_post ? 4 : 0);
@@ -1916,7 +1921,7 @@ void Plan::exec_band_join(LdsJoinArgs& a, BandArgs& b, const DevTable& B, const 
   // the full-semantics pass is launched when the previous execution met a row that needed it (or there was none); a row that
   // needs it after all is caught at the end of the plan like any failed speculation
   const bool skip_slow = speculative && cur_band_node && cur_band_node->band_ran && cur_band_node->band_slow_rows == 0;
-  band_block_counters.push_back({cur_band_node, (u32)(b.n_blocks_out - counters), (u32)(reinterpret_cast<u64*>(b.slow_rows) - counters), skip_slow});
+  band_block_counters.push_back({cur_band_node, (u32)(b.n_blocks_out - counters), (u32)(reinterpret_cast<u64*>(b.slow_rows) - counters), (u32)(reinterpret_cast<u64*>(b.run_stats) - counters), skip_slow});
   const u64 hist = cur_band_node ? cur_band_node->band_blocks : 0;
   b.launch_blocks = (u32)std::min<u64>(max_blocks, hist ? hist + hist / 4 + 1024 : max_blocks);
   b.bdesc = scratch<uint4>(max_blocks);

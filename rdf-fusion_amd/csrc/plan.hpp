@@ -39,6 +39,7 @@ struct NodeInfo {
   u64 last_rows = 0; bool has_last = false;   // output cardinality of the previous execution (speculative sizing)
   bool last_scaled = false;
   u64 band_blocks = 0;                         // blocks of the band join based on this node in its previous execution (launch sizing)
+  u64 band_run_stats = 0;                      // sampled rows << 32 | runs of equal neighbouring probe keys (a piecewise sorted probe side takes the counting partition)
   bool band_ran = false; u64 band_slow_rows = 0;   // .. and how many of its probe rows needed the full typed-value semantics                    // .. extrapolated from a priming run over a prefix of the bound tables
 };
 struct SpecCheck { NodeInfo* node; u32 counter; bool left_join; };   // counter = n_out slot, counter+1 = overflow flag
@@ -114,7 +115,7 @@ struct Plan {
   bool priming = false, primed = false;   // the first execution over big bound tables is preceded by one over their first rows (Plan::prime)
   void prime();
   std::vector<SpecCheck> spec_checks;
-  struct BandBlockCounter { NodeInfo* node; u32 counter; u32 slow_counter; bool slow_skipped; };
+  struct BandBlockCounter { NodeInfo* node; u32 counter; u32 slow_counter; u32 runs_counter; bool slow_skipped; };
   std::vector<BandBlockCounter> band_block_counters;   // device-side block counts of this execution's band joins -> NodeInfo::band_blocks
   NodeInfo* cur_band_node = nullptr;                   // the base join whose band join is being set up
   std::vector<PendingLaunch> pending;

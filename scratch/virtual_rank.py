@@ -16,7 +16,7 @@ g, s, p, o = sharding.shard_dataset_hybrid(ds, 0, N)
 shard = rf.GpuQuadStore(); shard.extend(g, s, p, o); shard.set_typed_values(ds.typed_values, ds.decimals)
 rng = np.random.default_rng(3)
 plan_a = shard.plan(bsbm.q5_batch_const_plan(ds))
-plan_c = full.plan(bsbm.q5_batch_const_plan(ds)).set_option("NO_ORDERED_JOIN")   # the gathered table is N sorted segments, not one sorted table: phase B has to partition it
+plan_c = full.plan(bsbm.q5_batch_const_plan(ds))     # sorted by feature (ordered slice join); cut below into the N sorted runs the repartition delivers
 plan_b = shard.plan(bsbm.q5_batch_plan(ds, tables=True, graph=[sharding.candidate_graph(ds)]))
 
 def dev(cols):
@@ -28,18 +28,22 @@ for it in range(6):
     prods = np.array([ds.product(i) for i in rng.choice(ds.n_products, Q, replace=True)], dtype=np.uint32)
     params = [np.arange(1, Q + 1, dtype=np.uint32), prods]
     keep, ptrs = dev(params)
+    own = sharding.shard_of(prods, N) == 0                               # the router hands a rank the instances whose product it owns
+    keep_a, ptrs_a = dev([c[own] for c in params]); n_own = int(own.sum())
     torch.cuda.synchronize(); t0 = time.perf_counter()
-    plan_a.bind_table(0, ptrs, Q); plan_a.execute(); a_rows = plan_a.result_info()[0]
+    plan_a.bind_table(0, ptrs_a, n_own); plan_a.execute(); a_rows = plan_a.result_info()[0]
     torch.cuda.synchronize(); t_a = (time.perf_counter() - t0) * 1e3
     plan_c.bind_table(0, ptrs, Q); plan_c.execute()                      # the gathered table (not timed: stands in for the all-gather)
     call = plan_c.fetch()                                                # what the repartition delivers to rank 0: the rows of its features
     mine = sharding.shard_of(call[2], N) == 0
-    keep_c, c_ptrs = dev([c[mine] for c in call]); n_c = int(mine.sum())
+    src = sharding.shard_of(call[1], N)[mine]                            # the rank that owns the instance's product: one sorted run per source rank
+    order = np.argsort(src, kind="stable")
+    keep_c, c_ptrs = dev([c[mine][order] for c in call]); n_c = int(mine.sum())
     torch.cuda.synchronize(); t0 = time.perf_counter()
     plan_b.bind_table(0, c_ptrs, n_c); plan_b.execute(); b_rows = plan_b.result_info()[0]
     torch.cuda.synchronize(); t_b = (time.perf_counter() - t0) * 1e3
     rows.append((t_a, plan_a.metrics().elapsed_compute_ms, t_b, plan_b.metrics().elapsed_compute_ms, a_rows, n_c, b_rows))
-    print(f"it {it}: phase A {t_a:.3f} ms wall ({rows[-1][1]:.3f} device, {a_rows} rows of C), phase B {t_b:.3f} ms wall ({rows[-1][3]:.3f} device), C {n_c} rows, {b_rows} bindings", flush=True)
+    print(f"it {it}: phase A {t_a:.3f} ms wall ({rows[-1][1]:.3f} device, {a_rows} rows of C), phase B {t_b:.3f} ms wall ({rows[-1][3]:.3f} device), C {n_c} rows, {b_rows} bindings; A: {plan_a.metrics().kernels_launched} launches {plan_a.metrics().host_syncs} syncs, B: {plan_b.metrics().kernels_launched} launches {plan_b.metrics().host_syncs} syncs", flush=True)
 best = min(rows[2:], key=lambda r: r[0] + r[2])
 print({"ranks": N, "instances": Q, "phase_a_ms": round(best[0], 3), "phase_b_ms": round(best[2], 3), "c_rows": int(best[5]), "c_rows_of_this_rank": int(best[4]),
        "exchange_bytes_per_rank": int(best[4]) * 20, "bindings_of_this_rank": int(best[6])})

@@ -1589,6 +1589,57 @@ def test_band_join_matches_oracle(torch_cuda, shape):
     del keep, keep2, keep3
 
 
+def test_band_join_piecewise_sorted_probe(torch_cuda):
+    """A probe side of more than 2^21 rows that arrives as a few runs sorted by the join key (what a hash repartition of
+    sorted shards delivers): after one execution has seen the runs, the partition pass is the counting sort with one
+    atomic per run of equal neighbouring keys instead of the radix sort.  Same multiset either way and as the oracle's;
+    then the same plan over the rows in random order (no runs: back to the radix sort)."""
+    rng = np.random.default_rng(77)
+    quads, tv, ids = _band_store(rng, n_prod=6000, n_feat=3000, fan=(1, 4))
+    gs, os_ = both_stores(quads, typed=tv)
+    n = (1 << 21) + 300_001
+    runs = []
+    for r in range(4):                                                # four sorted runs of unequal length, null keys and strangers inside
+        m = n // 4 + (r - 1) * 1000 if r < 3 else n - sum(len(x) for x in runs)
+        f = (ids["feat0"] + rng.integers(-2, ids["n_feat"] + 2, m)).astype(np.uint32)
+        f[rng.random(m) < 0.01] = 0
+        runs.append(np.sort(f))
+    f = np.concatenate(runs)
+    inst = np.arange(1, n + 1, dtype=np.uint32)
+    X = (ids["prod0"] + rng.integers(0, ids["n_prod"], n)).astype(np.uint32)
+    y = lambda: (ids["int0"] + rng.integers(0, ids["n_int"], n)).astype(np.uint32)
+    T = [inst, X, f, y(), y()]
+    pb = PlanBuilder()
+    t = pb.table(0, 5)
+    scan = lambda p, v: pb.data_source(quad_pattern("product", ids[p], v))
+    win = lambda x, yy, w: AND(EBV(LT(ENC_TV(col(x)), ADD(ENC_TV(col(yy)), integer(w)))), EBV(GT(ENC_TV(col(x)), SUB(ENC_TV(col(yy)), integer(w)))))
+    node = pb.hash_join(t, scan("pF", "f"), on=[(2, 1)], filter=ID_NEQ(col(5), col(1)), projection=[0, 5, 3, 4])
+    node = pb.hash_join(node, scan("pV1", "v1"), on=[(1, 0)], filter=win(5, 2, 400), projection=[0, 1, 2, 3])
+    node = pb.hash_join(node, scan("pV2", "v2"), on=[(1, 0)], filter=win(5, 3, 900), projection=[0, 1, 2, 3])
+    node = pb.hash_join(node, scan("pL", "label"), on=[(1, 0)], projection=[0, 1, 5])
+    desc = pb.build(node)
+    plan = gs.plan(desc)
+    for order in ("runs", "random"):
+        if order == "random":
+            perm = rng.permutation(n)
+            T = [c[perm] for c in T]
+        keep, ptrs = table_on_device(torch_cuda, T)
+        exp, n_exp, _ = os_.execute(desc, [T])
+        assert n_exp > 10_000
+        want = ku.multiset(exp, n_exp)
+        plan.bind_table(0, ptrs, n)
+        for rep in range(3):
+            plan.enable_kernel_timing(True)
+            got = plan.execute().fetch()
+            assert plan.result_info()[0] == n_exp
+            np.testing.assert_array_equal(ku.multiset(got, n_exp), want, err_msg=f"{order} rep {rep}")
+        names = {k[0] for k in plan.kernel_stats()}
+        if not ENGINE_TOGGLED:
+            assert any("band_mask_kernel" in k for k in names), names
+            assert ("rocprim radix sort" in names) == (order == "random"), (order, names)
+        del keep
+
+
 @pytest.mark.parametrize("cross", [False, True])
 @pytest.mark.parametrize("n,n_nodes,n_graphs", [(0, 5, 1), (1, 1, 1), (3, 3, 1), (300, 40, 2), (2000, 900, 4), (60_000, 120_000, 3), (5000, 5000, 700)])
 def test_closure_matches_oracle(torch_cuda, cross, n, n_nodes, n_graphs):
