@@ -80,33 +80,70 @@ __device__ __forceinline__ u32 shard_of(u32 id, u32 world) {
   return (u32)(h % world);
 }
 constexpr int kMaxWorld = 64;
-// pass 1: rows per destination (workgroup-private histogram in LDS, one global atomic per workgroup and destination)
-__global__ __launch_bounds__(256) void repart_count_kernel(const u32* key, u64 n, u32 world, unsigned long long* counts) {
-  __shared__ u32 h[kMaxWorld];
-  if (threadIdx.x < kMaxWorld) h[threadIdx.x] = 0;
-  __syncthreads();
-  for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) atomicAdd(&h[shard_of(key[i], world)], 1u);
-  __syncthreads();
-  if (threadIdx.x < world && h[threadIdx.x]) atomicAdd(&counts[threadIdx.x], (unsigned long long)h[threadIdx.x]);
+// The repartition is STABLE: rows of one destination keep their order (a table sorted by the key column leaves as sorted
+// blocks, so the receiver gets `world` sorted runs — what the band join's partition pass counts on, and the same bytes on
+// every run).  Every wave owns a contiguous piece of the table: pass 1 counts its rows per destination, a scan over the
+// (wave, destination) matrix gives every wave its start inside each destination's block, pass 2 ranks the rows of a
+// 64-row round with one ballot per destination.  No atomics, nothing depends on scheduling.
+constexpr int kRepartWaves = 4;                    // waves per workgroup
+__device__ __forceinline__ void repart_piece(u64 n, u64& lo, u64& hi) {   // rows of this wave
+  const u64 waves = (u64)gridDim.x * kRepartWaves;
+  const u64 per = ((n + waves - 1) / waves + 63) / 64 * 64;
+  const u64 w = (u64)blockIdx.x * kRepartWaves + (threadIdx.x >> 6);
+  lo = w * per < n ? w * per : n;
+  hi = lo + per < n ? lo + per : n;
 }
-// pass 2: every workgroup reserves its share of each destination's range (cursor = exclusive scan of the counts), then its
-// lanes take consecutive slots of it; out column c of destination d starts at out[c] + offset[d]
-struct RepartArgs { const u32* in[kMaxCols]; u32* out[kMaxCols]; u32 n_cols, world, key_col, pad; u64 n; unsigned long long* cursor; };
+__global__ __launch_bounds__(256) void repart_count_kernel(const u32* key, u64 n, u32 world, u32* wave_counts) {
+  __shared__ u32 h[kRepartWaves][kMaxWorld];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane < kMaxWorld) h[wave][lane] = 0;
+  __syncthreads();
+  u64 lo, hi;
+  repart_piece(n, lo, hi);
+  for (u64 i = lo + lane; i < hi; i += 64) atomicAdd(&h[wave][shard_of(key[i], world)], 1u);
+  __syncthreads();
+  if ((u32)lane < world) wave_counts[((u64)blockIdx.x * kRepartWaves + wave) * world + lane] = h[wave][lane];
+}
+// one workgroup per destination: exclusive scan of its column of the matrix (in place), the total into counts[d]
+__global__ __launch_bounds__(256) void repart_scan_kernel(u32* wave_counts, u64 n_waves, u32 world, unsigned long long* counts) {
+  __shared__ u32 part[256];
+  const u32 d = blockIdx.x;
+  const u64 chunk = (n_waves + 255) / 256, lo = threadIdx.x * chunk, hi = lo + chunk < n_waves ? lo + chunk : n_waves;
+  u32 sum = 0;
+  for (u64 w = lo; w < hi; w++) sum += wave_counts[w * world + d];
+  part[threadIdx.x] = sum;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    u32 run = 0;
+    for (int t = 0; t < 256; t++) { const u32 v = part[t]; part[t] = run; run += v; }
+    counts[d] = run;
+  }
+  __syncthreads();
+  u32 run = part[threadIdx.x];
+  for (u64 w = lo; w < hi; w++) { const u32 v = wave_counts[w * world + d]; wave_counts[w * world + d] = run; run += v; }
+}
+// pass 2: out column c of destination d starts at out[c] + offset[d]
+struct RepartArgs { const u32* in[kMaxCols]; u32* out[kMaxCols]; u32 n_cols, world, key_col, pad; u64 n; const u32* wave_base; const unsigned long long* offset; };
 __global__ __launch_bounds__(256) void repart_scatter_kernel(const RepartArgs a) {
-  __shared__ u32 h[kMaxWorld];
-  __shared__ unsigned long long base[kMaxWorld];
-  const u64 per = ((a.n + gridDim.x - 1) / gridDim.x + 255) / 256 * 256;   // rows of this workgroup: a contiguous slab
-  const u64 lo = (u64)blockIdx.x * per, hi = lo + per < a.n ? lo + per : a.n;
-  if (threadIdx.x < kMaxWorld) h[threadIdx.x] = 0;
-  __syncthreads();
-  for (u64 i = lo + threadIdx.x; i < hi; i += 256) atomicAdd(&h[shard_of(a.in[a.key_col][i], a.world)], 1u);
-  __syncthreads();
-  if (threadIdx.x < a.world) { base[threadIdx.x] = h[threadIdx.x] ? atomicAdd(&a.cursor[threadIdx.x], (unsigned long long)h[threadIdx.x]) : 0ull; h[threadIdx.x] = 0; }
-  __syncthreads();
-  for (u64 i = lo + threadIdx.x; i < hi; i += 256) {
-    const u32 d = shard_of(a.in[a.key_col][i], a.world);
-    const u64 pos = base[d] + atomicAdd(&h[d], 1u);
-    for (u32 c = 0; c < a.n_cols; c++) a.out[c][pos] = a.in[c][i];
+  __shared__ unsigned long long next[kRepartWaves][kMaxWorld];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if ((u32)lane < a.world) next[wave][lane] = a.offset[lane] + a.wave_base[((u64)blockIdx.x * kRepartWaves + wave) * a.world + lane];
+  __syncthreads();                                  // (only so that the compiler keeps the LDS writes before the reads: a wave reads its own row)
+  u64 lo, hi;
+  repart_piece(a.n, lo, hi);
+  for (u64 r = lo; r < hi; r += 64) {
+    const u64 i = r + lane;
+    const bool live = i < hi;
+    const u32 d = live ? shard_of(a.in[a.key_col][i], a.world) : 0xFFFFFFFFu;
+    u64 pos = 0;
+    for (u32 t = 0; t < a.world; t++) {             // uniform loop: one ballot per destination
+      const unsigned long long m = __ballot(d == t);
+      if (m == 0) continue;
+      const unsigned long long base = next[wave][t];
+      if (d == t) pos = base + (u64)__popcll(m & ((1ull << lane) - 1ull));
+      if (lane == 0) next[wave][t] = base + (u64)__popcll(m);
+    }
+    if (live) for (u32 c = 0; c < a.n_cols; c++) a.out[c][pos] = a.in[c][i];
   }
 }
 
@@ -247,21 +284,27 @@ u64 exchange_repartition(Comm* c, const u32* const* cols, u32 n_cols, u64 n_rows
   if (n_cols == 0 || n_cols > (u32)kMaxCols || key_col >= n_cols) fail(RDFGPU_ERR_INVALID, "repartition of %u columns by column %u", n_cols, key_col);
   RDFGPU_HIP(hipSetDevice(c->device));
   const u32 W = c->world;
-  unsigned long long* counts = c->counts_dev + (size_t)W * W + W;   // [W] rows per destination, then reused as cursors
-  RDFGPU_HIP(hipMemsetAsync(counts, 0, W * sizeof(unsigned long long), c->stream));
+  unsigned long long* counts = c->counts_dev + (size_t)W * W + W;   // [W] rows per destination, then their offsets in the send buffer
   const u64 g = n_rows ? std::min<u64>((n_rows + 256 * 16 - 1) / (256 * 16), 4096) : 1;
-  if (n_rows) hipLaunchKernelGGL(repart_count_kernel, dim3((unsigned)g), dim3(256), 0, c->stream, cols[key_col], n_rows, W, counts);
+  const u64 n_waves = g * kRepartWaves;
+  u32* wave_counts = static_cast<u32*>(c->buf(2 * kMaxCols, n_waves * W * sizeof(u32)));
   std::vector<u64> rows(W, 0), off(W + 1, 0);
-  RDFGPU_HIP(hipMemcpyAsync(rows.data(), counts, W * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
-  RDFGPU_HIP(hipStreamSynchronize(c->stream));
+  if (n_rows) {
+    hipLaunchKernelGGL(repart_count_kernel, dim3((unsigned)g), dim3(256), 0, c->stream, cols[key_col], n_rows, W, wave_counts);
+    hipLaunchKernelGGL(repart_scan_kernel, dim3(W), dim3(256), 0, c->stream, wave_counts, n_waves, W, counts);
+    RDFGPU_HIP(hipMemcpyAsync(rows.data(), counts, W * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+    RDFGPU_HIP(hipStreamSynchronize(c->stream));
+  }
   for (u32 d = 0; d < W; d++) off[d + 1] = off[d] + rows[d];
   // rows grouped by destination (send side, comm-owned slots behind the output slots)
   RepartArgs a{};
-  a.n_cols = n_cols; a.world = W; a.key_col = key_col; a.n = n_rows; a.cursor = counts;
+  a.n_cols = n_cols; a.world = W; a.key_col = key_col; a.n = n_rows; a.wave_base = wave_counts; a.offset = counts;
   std::vector<const u32*> send(n_cols);
   for (u32 col = 0; col < n_cols; col++) { a.in[col] = cols[col]; a.out[col] = static_cast<u32*>(c->buf(kMaxCols + col, (n_rows ? n_rows : 1) * sizeof(u32))); send[col] = a.out[col]; }
-  RDFGPU_HIP(hipMemcpyAsync(counts, off.data(), W * sizeof(u64), hipMemcpyHostToDevice, c->stream));   // cursors start at the destinations' offsets
-  if (n_rows) hipLaunchKernelGGL(repart_scatter_kernel, dim3((unsigned)g), dim3(256), 0, c->stream, a);
+  if (n_rows) {
+    RDFGPU_HIP(hipMemcpyAsync(counts, off.data(), W * sizeof(u64), hipMemcpyHostToDevice, c->stream));   // where each destination's block starts
+    hipLaunchKernelGGL(repart_scatter_kernel, dim3((unsigned)g), dim3(256), 0, c->stream, a);
+  }
   RDFGPU_HIP(hipStreamSynchronize(c->stream));
   return alltoallv_tables(c, send.data(), n_cols, rows.data(), off.data(), out_cols, 0);
 }

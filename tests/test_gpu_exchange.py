@@ -113,6 +113,34 @@ def test_exchange_steps_between_ranks_on_one_gpu(torch_cuda, world):
         assert (sharding.shard_of(mine[2], world) == rank).all()                # every row where its key lives
     moved = [np.concatenate([r[1][k] for r in res]) for k in range(3)]
     np.testing.assert_array_equal(ku.multiset(moved), ku.multiset(everything))  # moved, not lost, not invented
+    # the repartition is stable: a rank receives, source rank after source rank, that rank's rows for it in their order
+    for rank, (_, mine) in enumerate(res):
+        want = [np.concatenate([t[k][sharding.shard_of(t[2], world) == rank] for t in tables]) for k in range(3)]
+        for a, b in zip(mine, want):
+            np.testing.assert_array_equal(a, b)
+
+
+def test_repartition_is_stable_at_scale(torch_cuda):
+    """3 M rows sorted by the key column, sent by one of four ranks: rows of every destination keep their order, so a sorted
+    table leaves (and arrives) as sorted blocks — what the band join's partition pass counts on after a repartition."""
+    rng = np.random.default_rng(4)
+    n = 3_000_017
+    key = np.sort(rng.integers(1, 60_000, n).astype(np.uint32))
+    cols = [np.arange(n, dtype=np.uint32), rng.integers(0, 1 << 31, n).astype(np.uint32), key]
+
+    def body(rank, comm):
+        keep, ptrs = on_device(torch_cuda, cols if rank == 0 else [c[:0] for c in cols])
+        out, rows = comm.repartition(ptrs, n if rank == 0 else 0, 2)
+        got = from_device(torch_cuda, out, rows)
+        del keep
+        return got
+    world = 4
+    res = run_ranks(world, body)
+    for rank, got in enumerate(res):
+        sel = sharding.shard_of(key, world) == rank
+        for a, b in zip(got, cols):
+            np.testing.assert_array_equal(a, b[sel])
+        assert (np.diff(got[2].astype(np.int64)) >= 0).all()
 
 
 @pytest.mark.parametrize("world", [2, 3])
