@@ -535,6 +535,7 @@ enum {
   RDFGPU_OPT_NO_ORDERED_JOIN,           /* no slice-ordered emission of a table x slice join / no sort-free band join on it */
   RDFGPU_OPT_NO_BAND_PACK16,            /* band join: both windows always tested with 32-bit arithmetic                    */
   RDFGPU_OPT_NO_RUN_COPY,               /* .. per distinct term, but rows streamed (verdict bits) instead of runs copied */
+  RDFGPU_OPT_NO_RANGE_PARTITION,        /* partitioned join: hash-partition BOTH sides even when the probe side is a slice sorted by a join key */
   RDFGPU_OPT_LDS_MAX_BUILD,             /* value: largest build side (rows) joined through a per-workgroup LDS table  */
   RDFGPU_OPT_CSR_ROW_LANES_LOG2,        /* value + 1: lanes sharing one probe row of a CSR join (0 = automatic)        */
   RDFGPU_OPT_JOIN_WAVE_Q,               /* value: entries of a wave's candidate queue (0 = automatic)                  */

@@ -260,8 +260,20 @@ struct PartArgs {
   const u32* bstart; const u32* pstart;     // [n_parts + 1] first record of every partition
   u32 n_parts, chunk, tbl_mask;
   u32 two_pass;   // 1: count a partition's matches first and reserve its output range once (large outputs); 0: one reservation per full queue
+  // range mode (ppart == nullptr): the probe side is a store slice sorted by one of the join keys and is read in place —
+  // partition p = the slice rows pstart[p] .. pstart[p + 1] (key ranges of 2^shift ids), only the build side was partitioned
+  const u32* pcol0; const u32* pcol1;
 };
-void launch_part_keys(const u32* k0, const u32* k1, u32 n_keys, const u64* n_dev, u64 cap, u32 bits, u32 n_parts, u32* skey, uint4* sval, hipStream_t s);
+// range < 0: partition = top `bits` bits of the key hash.  Else the probe side is a slice sorted by key[range]: partitions are
+// key ranges of that column, equalised over the slice's rows through a coarse directory — coarse bucket c = (key - range_min)
+// >> cshift owns dir[c].y consecutive partitions from dir[c].x on (in proportion to the slice rows that fall into it), and
+// inside a bucket the ids are split evenly: partition = dir[c].x + (((key - bucket start) * dir[c].y) >> cshift).  Keys outside
+// [range_min, range_max] join nothing.
+struct PartKeyRange { int range; u32 range_min, range_max, cshift, n_coarse; const uint2* dir; };
+void launch_part_keys(const u32* k0, const u32* k1, u32 n_keys, const u64* n_dev, u64 cap, u32 bits, u32 n_parts, PartKeyRange kr, u32* skey, uint4* sval, hipStream_t s);
+void launch_part_equalise(const u32* sorted_col, u64 n, PartKeyRange kr, u32 n_parts, uint2* dir, hipStream_t s);
+void launch_part_range_bounds(const u32* sorted_col, u64 n, PartKeyRange kr, u32 n_parts, u32* pstart, hipStream_t s);
+void launch_sorted_bounds(const u32* sorted_keys, u64 n, u32 n_keys, u32* start, hipStream_t s);   // start[k] = first position with key >= k, k = 0 .. n_keys
 size_t part_sort_temp_bytes(u64 n, u32 bits);
 void part_sort(const u32* kin, u32* kout, const uint4* vin, uint4* vout, u64 n, u32 bits, void* temp, size_t temp_bytes, hipStream_t s);
 void launch_part_join(const LdsJoinArgs& a, const PartArgs& pa, hipStream_t s);

@@ -26,7 +26,7 @@ namespace rdfgpu {
 // sort key of a row = its partition (top `bits` bits of the key hash).  A row that joins nothing (null key / beyond the live
 // rows) rides in the last partition with row = kNil — the sort then needs exactly `bits` bits (16 bits = two radix passes)
 __global__ __launch_bounds__(256) void part_keys_kernel(const u32* k0, const u32* k1, u32 n_keys, const u64* n_dev, u64 cap, u32 bits, u32 n_parts,
-                                                         u32* skey, uint4* sval) {
+                                                         PartKeyRange kr, u32* skey, uint4* sval) {
   const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= cap) return;
   const u64 n = live_rows(n_dev, cap);
@@ -35,10 +35,73 @@ __global__ __launch_bounds__(256) void part_keys_kernel(const u32* k0, const u32
   if (i < n) {
     key.k[0] = k0[i]; key.k[1] = n_keys > 1 ? k1[i] : 0u;
     const bool null_key = key.k[0] == 0 || (n_keys > 1 && key.k[1] == 0);   // NullEqualsNothing
-    if (!null_key) { pid = bits ? hash_keys4(key, n_keys) >> (32 - bits) : 0u; row = (u32)i; }
+    if (!null_key && kr.range >= 0) {                // range partitions of the probe slice's sort key; outside its id range: joins nothing
+      const u32 k = key.k[kr.range];
+      if (k >= kr.range_min && k <= kr.range_max) {
+        const u32 rel = k - kr.range_min, c = rel >> kr.cshift;
+        const uint2 d = kr.dir[c];
+        pid = d.x + (u32)(((unsigned long long)(rel - (c << kr.cshift)) * d.y) >> kr.cshift);
+        row = (u32)i;
+      }
+    } else if (!null_key) { pid = bits ? hash_keys4(key, n_keys) >> (32 - bits) : 0u; row = (u32)i; }
   }
   skey[i] = pid;
   sval[i] = make_uint4(row, key.k[0], key.k[1], 0u);
+}
+
+__device__ __forceinline__ u64 lower_bound_u32(const u32* col, u64 n, u64 target) {   // first row with col[row] >= target
+  u64 lo = 0, hi = n;
+  while (lo < hi) { const u64 mid = (lo + hi) >> 1; if ((u64)col[mid] < target) lo = mid + 1; else hi = mid; }
+  return lo;
+}
+// start[k] = first position of a sorted key array with key >= k (the partition boundaries after the sort: 65 537 searches
+// instead of a pass over every row)
+__global__ __launch_bounds__(256) void sorted_bounds_kernel(const u32* keys, u64 n, u32 n_keys, u32* start) {
+  const u32 k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k <= n_keys) start[k] = (u32)lower_bound_u32(keys, n, k);
+}
+// range mode, step 1 (one workgroup): slice rows per coarse id bucket -> partitions per bucket (one each + the rest of the
+// n_parts in proportion to the rows) -> dir[c] = {first partition, partitions}; dir[n_coarse].x = partitions in use
+constexpr u32 kPartMaxCoarse = 4096;
+__global__ __launch_bounds__(1024) void part_equalise_kernel(const u32* col, u64 n, PartKeyRange kr, u32 n_parts, uint2* dir) {
+  __shared__ u32 cs[kPartMaxCoarse + 1];
+  __shared__ u32 sums[1024];
+  const u32 tid = threadIdx.x;
+  for (u32 c = tid; c <= kr.n_coarse; c += 1024) cs[c] = c == kr.n_coarse ? (u32)n : (u32)lower_bound_u32(col, n, (u64)kr.range_min + ((u64)c << kr.cshift));
+  __syncthreads();
+  const u32 per = (kr.n_coarse + 1023) / 1024;       // <= 4
+  const u64 budget = n_parts - kr.n_coarse;
+  u32 local[4] = {0u, 0u, 0u, 0u}, tot = 0;
+  for (u32 u = 0; u < per; u++) {
+    const u32 c = tid * per + u;
+    if (c < kr.n_coarse) { local[u] = 1u + (u32)(((u64)(cs[c + 1] - cs[c]) * budget) / n); tot += local[u]; }
+  }
+  sums[tid] = tot;
+  __syncthreads();
+  for (u32 d = 1; d < 1024; d <<= 1) {
+    const u32 v = tid >= d ? sums[tid - d] : 0u;
+    __syncthreads();
+    sums[tid] += v;
+    __syncthreads();
+  }
+  u32 run = sums[tid] - tot;
+  for (u32 u = 0; u < per; u++) {
+    const u32 c = tid * per + u;
+    if (c < kr.n_coarse) { dir[c] = make_uint2(run, local[u]); run += local[u]; }
+  }
+  if (tid == 1023) dir[kr.n_coarse] = make_uint2(sums[1023], 0u);
+}
+// range mode, step 2: where the slice rows of partition p start = the first row whose key is >= the partition's first id
+__global__ __launch_bounds__(256) void part_range_bounds_kernel(const u32* col, u64 n, PartKeyRange kr, u32 n_parts, u32* pstart) {
+  const u32 p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p > n_parts) return;
+  if (p >= kr.dir[kr.n_coarse].x) { pstart[p] = (u32)n; return; }
+  u32 lo = 0, hi = kr.n_coarse;                      // the bucket of partition p: the last c with dir[c].x <= p (every bucket owns >= 1)
+  while (hi - lo > 1) { const u32 mid = (lo + hi) >> 1; if (kr.dir[mid].x <= p) lo = mid; else hi = mid; }
+  const uint2 d = kr.dir[lo];
+  const u64 sub = p - d.x;
+  const u64 first = (u64)kr.range_min + ((u64)lo << kr.cshift) + (((sub << kr.cshift) + d.y - 1) / d.y);   // smallest id of the bucket that maps to `sub`
+  pstart[p] = (u32)lower_bound_u32(col, n, first);
 }
 
 template <int FS>
@@ -153,7 +216,13 @@ __global__ __launch_bounds__(kLdsBlock) __attribute__((amdgpu_waves_per_eu(4))) 
           const u32 t = t0 + tid;
           const bool live = t < n_probe;
           uint4 r = make_uint4(0u, 0u, 0u, 0u);
-          if (live) r = pa.ppart[ps + t];
+          if (live) {
+            if (pa.ppart) r = pa.ppart[ps + t];
+            else {                                   // range mode: the slice itself, in place
+              r.x = ps + t; r.y = pa.pcol0[ps + t]; r.z = a.n_keys > 1 ? pa.pcol1[ps + t] : 0u;
+              if (r.y == 0 || (a.n_keys > 1 && r.z == 0)) r.x = kNil;   // NullEqualsNothing
+            }
+          }
           Keys key; key.k[0] = r.y; key.k[1] = r.z; key.k[2] = 0; key.k[3] = 0;
           u32 h = hash_keys4(key, a.n_keys) & pa.tbl_mask;
           bool walking = live && r.x != kNil;
@@ -198,8 +267,18 @@ __global__ __launch_bounds__(kLdsBlock) __attribute__((amdgpu_waves_per_eu(4))) 
 }
 
 // ---- host side -------------------------------------------------------------------------------------------------------
-void launch_part_keys(const u32* k0, const u32* k1, u32 n_keys, const u64* n_dev, u64 cap, u32 bits, u32 n_parts, u32* skey, uint4* sval, hipStream_t s) {
-  if (cap) hipLaunchKernelGGL(part_keys_kernel, dim3((unsigned)((cap + 255) / 256)), dim3(256), 0, s, k0, k1, n_keys, n_dev, cap, bits, n_parts, skey, sval);
+void launch_part_keys(const u32* k0, const u32* k1, u32 n_keys, const u64* n_dev, u64 cap, u32 bits, u32 n_parts, PartKeyRange kr, u32* skey, uint4* sval, hipStream_t s) {
+  if (cap) hipLaunchKernelGGL(part_keys_kernel, dim3((unsigned)((cap + 255) / 256)), dim3(256), 0, s, k0, k1, n_keys, n_dev, cap, bits, n_parts, kr, skey, sval);
+}
+void launch_part_equalise(const u32* sorted_col, u64 n, PartKeyRange kr, u32 n_parts, uint2* dir, hipStream_t s) {
+  if (kr.n_coarse == 0 || kr.n_coarse > kPartMaxCoarse || kr.n_coarse > n_parts || n == 0) fail(RDFGPU_ERR_INVALID, "range partitions: %u coarse buckets for %u partitions", kr.n_coarse, n_parts);
+  hipLaunchKernelGGL(part_equalise_kernel, dim3(1), dim3(1024), 0, s, sorted_col, n, kr, n_parts, dir);
+}
+void launch_part_range_bounds(const u32* sorted_col, u64 n, PartKeyRange kr, u32 n_parts, u32* pstart, hipStream_t s) {
+  hipLaunchKernelGGL(part_range_bounds_kernel, dim3((n_parts + 1 + 255) / 256), dim3(256), 0, s, sorted_col, n, kr, n_parts, pstart);
+}
+void launch_sorted_bounds(const u32* sorted_keys, u64 n, u32 n_keys, u32* start, hipStream_t s) {
+  hipLaunchKernelGGL(sorted_bounds_kernel, dim3((n_keys + 1 + 255) / 256), dim3(256), 0, s, sorted_keys, n, n_keys, start);
 }
 size_t part_sort_temp_bytes(u64 n, u32 bits) {
   size_t bytes = 0;

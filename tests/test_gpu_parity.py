@@ -575,6 +575,59 @@ def test_partitioned_join_matches_oracle(torch_cuda, nb, npr, n_ids, min_build):
     del kb, kp
 
 
+@pytest.mark.parametrize("n_quads,nb", [(300_000, 200_000), (2_500_000, 1_200_000)])
+def test_partitioned_join_over_sorted_slice(torch_cuda, n_quads, nb):
+    """Partitioned join whose probe side is a store slice sorted by one of the join keys: the slice is read in place, its
+    partitions are key ranges found by binary search, only the build side (a bound table) is partition-sorted.  One and
+    two key columns (the slice's sort key first or second), keys below / above the slice's id range, null keys, inner and
+    left joins with a filter; the oracle's multiset, the hash-partitioned form (RDFGPU_OPT_NO_RANGE_PARTITION) and the
+    un-partitioned join give the same rows."""
+    rng = np.random.default_rng(n_quads)
+    n_subj, n_obj = n_quads // 3, n_quads // 40
+    s = (1000 + rng.integers(0, n_subj, n_quads)).astype(np.uint32)
+    o = (1000 + n_subj + rng.integers(0, n_obj, n_quads)).astype(np.uint32)
+    s[rng.random(n_quads) < 0.3] += np.uint32(n_subj + n_obj + 5000)          # a second island of subject ids: empty key ranges in between
+    quads = (np.zeros(n_quads, np.uint32), s, np.full(n_quads, 7, np.uint32), o)
+    tv, dec = typed_zoo()
+    tvx = np.zeros(int(s.max()) + 2, dtype=TV_DTYPE); tvx["tag"][1:] = abi.TV_NAMED_NODE; tvx["lo"][1:] = np.arange(1, len(tvx))
+    gs, os_ = both_stores(quads, typed=tvx)
+    gs.set_option("PARTITION_MIN_BUILD", 65536)
+    gs.set_option("NO_TABLE_CACHE", 1)                    # the slice's own cached table would answer this join without any partitioning
+    pick = rng.integers(0, n_quads, nb)
+    B = [s[pick].copy(), o[pick].copy(), rng.integers(1, 1000, nb).astype(np.uint32)]
+    miss = rng.random(nb) < 0.3
+    B[1][miss] = (1000 + n_subj + rng.integers(0, n_obj, int(miss.sum()))).astype(np.uint32)   # pairs that are (mostly) no triple
+    B[0][rng.random(nb) < 0.01] = 0                                                            # null keys
+    B[0][rng.random(nb) < 0.01] = 5                                                            # below the slice's id range
+    B[0][rng.random(nb) < 0.01] = np.uint32(int(s.max()) + 1)                                  # above it
+    kb, pbp = table_on_device(torch_cuda, B)
+    for on, flt, proj, jt in [([(0, 0), (1, 1)], None, None, abi.JOIN_INNER),
+                              ([(1, 1)], ID_EQ(col(0), col(3)), [0, 2, 4], abi.JOIN_INNER),
+                              ([(0, 0)], ID_NEQ(col(1), col(4)), [0, 1, 4], abi.JOIN_LEFT)]:
+        pb = PlanBuilder()
+        desc = pb.build(pb.hash_join(pb.table(0, 3), pb.data_source(quad_pattern("s", 7, "o")), on=on, join_type=jt, filter=flt, projection=proj))
+        exp, n_exp, _ = os_.execute(desc, [B])
+        want = ku.multiset(exp, n_exp)
+        assert n_exp > 1000
+        plan = gs.plan(desc)
+        plan.bind_table(0, pbp, nb)
+        sorts = {}
+        for mode in ("range", "range again", "hash", "off"):
+            plan.set_option("NO_RANGE_PARTITION", 1 if mode == "hash" else 0)
+            plan.set_option("NO_PARTITIONED_JOIN", 1 if mode == "off" else 0)
+            plan.enable_kernel_timing(True)
+            got = plan.execute().fetch()
+            assert plan.result_info()[0] == n_exp, (on, jt, mode)
+            np.testing.assert_array_equal(ku.multiset(got, n_exp), want, err_msg=f"{on} {jt} {mode}")
+            stats = {k[0]: k[1] for k in plan.kernel_stats()}
+            sorts[mode] = (stats.get("rocprim radix sort", 0), any("part_join_kernel" in k for k in stats))
+        if not ENGINE_TOGGLED:
+            in_place = 1 if any(r == 1 for _, r in on) else 2     # the slice of (?s <7> ?o) is sorted by ?o: a join on ?s alone partitions both sides
+            assert sorts["range"] == (in_place, True) and sorts["range again"] == (in_place, True) and sorts["hash"] == (2, True) and not sorts["off"][1], (on, sorts)
+        plan.close()
+    del kb
+
+
 def test_cross_and_nested_loop_join(torch_cuda):
     rng = np.random.default_rng(3)
     tv, dec = typed_zoo()
@@ -1207,7 +1260,7 @@ TOGGLES = ["RDFGPU_NO_CHAIN_FUSION", "RDFGPU_NO_INDEX_JOIN", "RDFGPU_NO_TABLE_CA
            "RDFGPU_NO_FIRST_RUN_SPECULATION", "RDFGPU_NO_DIRECT_TABLE", "RDFGPU_FORCE_GENERIC_VM", "RDFGPU_NO_LDS_JOIN",
            "RDFGPU_NO_GLOBAL_TABLE_JOIN", "RDFGPU_NO_FILTER_FUSION", "RDFGPU_NO_VALUE_TABLES", "RDFGPU_NO_RANGE_INDEX",
            "RDFGPU_NO_BAND_JOIN", "RDFGPU_NO_PARTITIONED_JOIN", "RDFGPU_NO_JOIN_REORDER", "RDFGPU_NO_STRING_VERDICTS",
-           "RDFGPU_NO_VALUE_VERDICTS", "RDFGPU_NO_RUN_COPY", "RDFGPU_NO_PRIMING", "RDFGPU_NO_ORDERED_JOIN", "RDFGPU_NO_BAND_PACK16"]
+           "RDFGPU_NO_VALUE_VERDICTS", "RDFGPU_NO_RUN_COPY", "RDFGPU_NO_PRIMING", "RDFGPU_NO_ORDERED_JOIN", "RDFGPU_NO_BAND_PACK16", "RDFGPU_NO_RANGE_PARTITION"]
 
 
 @pytest.mark.parametrize("toggle", TOGGLES)
