@@ -307,9 +307,17 @@ def main():
         # buffers sized from the exchanged row counts).  torch.distributed only carries the RCCL unique id, the barriers and the
         # final reductions.  Two communicators: the gathered table of batch i stays valid while batch i + 1 is exchanged.
         def host_wire(blocks):     # the caller-supplied wire of the host-staged transport: an all-to-all of byte blocks
-            got = [None] * world
-            dist.all_gather_object(got, [bytes(b) for b in blocks])
-            return [np.frombuffer(got[r][rank], dtype=np.uint8) for r in range(world)]
+            sizes = torch.tensor([len(b) for b in blocks], dtype=torch.int64, device=xdev)
+            rsizes = torch.empty_like(sizes)
+            dist.all_to_all_single(rsizes, sizes)
+            send = torch.from_numpy(np.concatenate([np.frombuffer(b, dtype=np.uint8) for b in blocks] + [np.zeros(0, np.uint8)]).copy()).to(xdev)
+            recv = torch.empty(int(rsizes.sum().item()), dtype=torch.uint8, device=xdev)
+            dist.all_to_all_single(recv, send, output_split_sizes=rsizes.tolist(), input_split_sizes=sizes.tolist())
+            out, at = [], 0
+            host = recv.cpu().numpy()
+            for n_b in rsizes.tolist():
+                out.append(host[at:at + n_b]); at += n_b
+            return out
         transport = "RCCL over xGMI (grouped ncclSend / ncclRecv inside librdfgpu.so)"
         comms = []
         if rehearse:           # several ranks on ONE GPU (RCCL refuses that): the host-staged transport, gloo as the wire

@@ -1592,7 +1592,9 @@ DevTable Plan::exec_lds_join(NodeInfo& nd, const DevTable& L, const DevTable& R,
     while (q < want && q < 1024) q <<= 1;
     if (!global_table && (size_t)slots * sizeof(uint2) > 64 * 1024) q = 256;
     a.wave_q = q_env ? q_env : q;
-    if (use_part) a.wave_q = 256;
+    // partitioned join: a sparse output (the previous execution found less than one match per 8 probe rows) needs no deep queues —
+    // 52 KB of LDS per workgroup instead of 64: three workgroups per CU instead of two
+    if (use_part) a.wave_q = nd.has_last && !nd.last_scaled && nd.last_rows * 8 < P.cap ? 64 : 256;
   }
   a.probe_col_base = build_left ? L.n_cols : 0;
   a.has_filter = (u32)nd.shape;   // 0 none / 1 generic VM / 3 window
