@@ -255,8 +255,9 @@ void launch_ordered_join_write(const OrderedJoinArgs& a, hipStream_t s);
 constexpr u32 kPartChunk = 2048;      // build rows per LDS table (a partition with more is joined chunk by chunk)
 constexpr u32 kPartSlots = 4096;      // slots of the LDS table: load <= 0.5, ~0.25 at the target partition size
 constexpr u32 kPartTargetRows = 1024; // build rows per partition aimed for
+struct PartRec { u32 row, k0, k1; };   // 12 bytes: what travels through the partition sort (a padded 16-byte record cost a quarter more sort traffic)
 struct PartArgs {
-  const uint4* bpart; const uint4* ppart;   // {row, key0, key1, -} records of the build / probe side, grouped by partition
+  const PartRec* bpart; const PartRec* ppart;   // {row, key0, key1} records of the build / probe side, grouped by partition
   const u32* bstart; const u32* pstart;     // [n_parts + 1] first record of every partition
   u32 n_parts, chunk, tbl_mask;
   u32 two_pass;   // 1: count a partition's matches first and reserve its output range once (large outputs); 0: one reservation per full queue
@@ -270,12 +271,12 @@ struct PartArgs {
 // inside a bucket the ids are split evenly: partition = dir[c].x + (((key - bucket start) * dir[c].y) >> cshift).  Keys outside
 // [range_min, range_max] join nothing.
 struct PartKeyRange { int range; u32 range_min, range_max, cshift, n_coarse; const uint2* dir; };
-void launch_part_keys(const u32* k0, const u32* k1, u32 n_keys, const u64* n_dev, u64 cap, u32 bits, u32 n_parts, PartKeyRange kr, u32* skey, uint4* sval, hipStream_t s);
+void launch_part_keys(const u32* k0, const u32* k1, u32 n_keys, const u64* n_dev, u64 cap, u32 bits, u32 n_parts, PartKeyRange kr, u32* skey, PartRec* sval, hipStream_t s);
 void launch_part_equalise(const u32* sorted_col, u64 n, PartKeyRange kr, u32 n_parts, uint2* dir, hipStream_t s);
 void launch_part_range_bounds(const u32* sorted_col, u64 n, PartKeyRange kr, u32 n_parts, u32* pstart, hipStream_t s);
 void launch_sorted_bounds(const u32* sorted_keys, u64 n, u32 n_keys, u32* start, hipStream_t s);   // start[k] = first position with key >= k, k = 0 .. n_keys
 size_t part_sort_temp_bytes(u64 n, u32 bits);
-void part_sort(const u32* kin, u32* kout, const uint4* vin, uint4* vout, u64 n, u32 bits, void* temp, size_t temp_bytes, hipStream_t s);
+void part_sort(const u32* kin, u32* kout, const PartRec* vin, PartRec* vout, u64 n, u32 bits, void* temp, size_t temp_bytes, hipStream_t s);
 void launch_part_join(const LdsJoinArgs& a, const PartArgs& pa, hipStream_t s);
 
 // ---- key-partitioned band join (band_join.hip): the fused chain over a CSR join with small groups, group by group ----

@@ -7,10 +7,10 @@
 // per query, inside the operator.
 //
 // Both sides are partitioned by the TOP bits of the key hash (rocPRIM radix sort of (partition, {row, key0, key1})
-// records: the records travel with the sort, so neither side is gathered afterwards) into partitions of ~1 K build rows;
+// 12-byte records: the records travel with the sort, so neither side is gathered afterwards) into partitions of ~1 K build rows;
 // one workgroup owns one partition at a time: it builds the partition's {key0, index} open-addressing table in LDS (the
 // LOW hash bits pick the slot; second key and row id in LDS next to it), streams the partition's probe records
-// (16-byte coalesced loads), and compacts the key-equal (build row, probe row) candidates with ballot + mbcnt into
+// (12-byte records, coalesced), and compacts the key-equal (build row, probe row) candidates with ballot + mbcnt into
 // wave-private LDS queues; a full queue runs the join filter on its candidates, reserves its output range with ONE
 // atomicAdd and writes consecutive rows (the resolve phase of the fused join kernel, join_device.hpp).
 // A partition with more build rows than a table holds (duplicate-heavy keys) is joined chunk by chunk: every chunk's
@@ -26,7 +26,7 @@ namespace rdfgpu {
 // sort key of a row = its partition (top `bits` bits of the key hash).  A row that joins nothing (null key / beyond the live
 // rows) rides in the last partition with row = kNil — the sort then needs exactly `bits` bits (16 bits = two radix passes)
 __global__ __launch_bounds__(256) void part_keys_kernel(const u32* k0, const u32* k1, u32 n_keys, const u64* n_dev, u64 cap, u32 bits, u32 n_parts,
-                                                         PartKeyRange kr, u32* skey, uint4* sval) {
+                                                         PartKeyRange kr, u32* skey, PartRec* sval) {
   const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= cap) return;
   const u64 n = live_rows(n_dev, cap);
@@ -46,7 +46,7 @@ __global__ __launch_bounds__(256) void part_keys_kernel(const u32* k0, const u32
     } else if (!null_key) { pid = bits ? hash_keys4(key, n_keys) >> (32 - bits) : 0u; row = (u32)i; }
   }
   skey[i] = pid;
-  sval[i] = make_uint4(row, key.k[0], key.k[1], 0u);
+  sval[i] = PartRec{row, key.k[0], key.k[1]};
 }
 
 __device__ __forceinline__ u64 lower_bound_u32(const u32* col, u64 n, u64 target) {   // first row with col[row] >= target
@@ -200,7 +200,8 @@ __global__ __launch_bounds__(kLdsBlock) __attribute__((amdgpu_waves_per_eu(4))) 
         for (u32 s = tid; s <= pa.tbl_mask; s += kLdsBlock) slots[s] = make_uint2(0u, kNil);
         __syncthreads();
         for (u32 i = tid; i < nb; i += kLdsBlock) {
-          const uint4 r = pa.bpart[cb + i];          // {row, key0, key1, -}
+          const PartRec q = pa.bpart[cb + i];
+          const uint4 r = make_uint4(q.row, q.k0, q.k1, 0u);   // {row, key0, key1, -}
           k1s[i] = r.z; rows[i] = r.x;
           if (r.x == kNil) continue;                 // a row that joins nothing
           Keys key; key.k[0] = r.y; key.k[1] = r.z; key.k[2] = 0; key.k[3] = 0;
@@ -217,7 +218,7 @@ __global__ __launch_bounds__(kLdsBlock) __attribute__((amdgpu_waves_per_eu(4))) 
           const bool live = t < n_probe;
           uint4 r = make_uint4(0u, 0u, 0u, 0u);
           if (live) {
-            if (pa.ppart) r = pa.ppart[ps + t];
+            if (pa.ppart) { const PartRec q = pa.ppart[ps + t]; r = make_uint4(q.row, q.k0, q.k1, 0u); }
             else {                                   // range mode: the slice itself, in place
               r.x = ps + t; r.y = pa.pcol0[ps + t]; r.z = a.n_keys > 1 ? pa.pcol1[ps + t] : 0u;
               if (r.y == 0 || (a.n_keys > 1 && r.z == 0)) r.x = kNil;   // NullEqualsNothing
@@ -267,7 +268,7 @@ __global__ __launch_bounds__(kLdsBlock) __attribute__((amdgpu_waves_per_eu(4))) 
 }
 
 // ---- host side -------------------------------------------------------------------------------------------------------
-void launch_part_keys(const u32* k0, const u32* k1, u32 n_keys, const u64* n_dev, u64 cap, u32 bits, u32 n_parts, PartKeyRange kr, u32* skey, uint4* sval, hipStream_t s) {
+void launch_part_keys(const u32* k0, const u32* k1, u32 n_keys, const u64* n_dev, u64 cap, u32 bits, u32 n_parts, PartKeyRange kr, u32* skey, PartRec* sval, hipStream_t s) {
   if (cap) hipLaunchKernelGGL(part_keys_kernel, dim3((unsigned)((cap + 255) / 256)), dim3(256), 0, s, k0, k1, n_keys, n_dev, cap, bits, n_parts, kr, skey, sval);
 }
 void launch_part_equalise(const u32* sorted_col, u64 n, PartKeyRange kr, u32 n_parts, uint2* dir, hipStream_t s) {
@@ -282,10 +283,10 @@ void launch_sorted_bounds(const u32* sorted_keys, u64 n, u32 n_keys, u32* start,
 }
 size_t part_sort_temp_bytes(u64 n, u32 bits) {
   size_t bytes = 0;
-  (void)rocprim::radix_sort_pairs(nullptr, bytes, (const u32*)nullptr, (u32*)nullptr, (const uint4*)nullptr, (uint4*)nullptr, (size_t)(n ? n : 1), 0, bits);
+  (void)rocprim::radix_sort_pairs(nullptr, bytes, (const u32*)nullptr, (u32*)nullptr, (const PartRec*)nullptr, (PartRec*)nullptr, (size_t)(n ? n : 1), 0, bits);
   return bytes + 256;
 }
-void part_sort(const u32* kin, u32* kout, const uint4* vin, uint4* vout, u64 n, u32 bits, void* temp, size_t temp_bytes, hipStream_t s) {
+void part_sort(const u32* kin, u32* kout, const PartRec* vin, PartRec* vout, u64 n, u32 bits, void* temp, size_t temp_bytes, hipStream_t s) {
   if (!n) return;
   RDFGPU_HIP(rocprim::radix_sort_pairs(temp, temp_bytes, kin, kout, vin, vout, (size_t)n, 0, bits, s));
 }

@@ -1789,7 +1789,7 @@ DevTable Plan::exec_lds_join(NodeInfo& nd, const DevTable& L, const DevTable& R,
 }
 
 // Radix partitioning of both sides of a HashJoinExec by the top bits of the key hash (part_join.hip): per side one pass
-// that computes (partition, {row, key0, key1}) per row, one rocPRIM radix sort moving the 16-byte records, one pass that
+// that computes (partition, {row, key0, key1}) per row, one rocPRIM radix sort moving the 12-byte records, one pass that
 // finds the partition boundaries.  Rows with a null key (NullEqualsNothing) or beyond the live row count ride in the last
 // partition, marked (row = kNil) so that the join skips them.
 void Plan::prepare_partitions(const LdsJoinArgs& a, const DevTable& B, const DevTable& P, PartArgs& pa) {
@@ -1814,10 +1814,10 @@ void Plan::prepare_partitions(const LdsJoinArgs& a, const DevTable& B, const Dev
         kr = PartKeyRange{(int)k, P.key_min, P.key_max, cshift, n_coarse, dir};
         timed(KC_BAND_BOUNDS, 0, n_coarse, nullptr, 0, nullptr, 0, 0, [&] { launch_part_equalise(a.probe_key[k], P.cap, kr, n_parts, dir, stream); });
       }
-  auto side = [&](const DevTable& T, const u32* const* keys, const uint4*& recs, const u32*& start, PartKeyRange r) {
+  auto side = [&](const DevTable& T, const u32* const* keys, const PartRec*& recs, const u32*& start, PartKeyRange r) {
     const u64 n = T.cap;
     u32* skey_in = scratch<u32>(n); u32* skey = scratch<u32>(n);
-    uint4* sval_in = scratch<uint4>(n); uint4* sval = scratch<uint4>(n);
+    PartRec* sval_in = scratch<PartRec>(n); PartRec* sval = scratch<PartRec>(n);
     u32* st = scratch<u32>((u64)n_parts + 2);
     const size_t tb = part_sort_temp_bytes(n, bits ? bits : 1);
     void* temp = scratch<unsigned char>(tb);
