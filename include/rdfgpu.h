@@ -602,7 +602,9 @@ int rdfgpu_regex_check(const char* pattern, uint32_t pattern_len, const char* fl
  * that live in HBM (e.g. rdfgpu_plan_result_device of one plan -> rdfgpu_plan_bind_table of the next):
  *   rdfgpu_exchange_allgatherv   every rank contributes its rows, every rank receives all ranks' rows (rank order)
  *   rdfgpu_exchange_repartition  row i goes to rank rdfgpu_shard_of(cols[key_col][i]): re-shards a table by the key of the
- *                                next join
+ *                                next join.  STABLE: a rank receives, source rank after source rank, that rank's rows for it
+ *                                in their original order (a table sorted by key_col arrives as `world` sorted runs; the
+ *                                received bytes do not depend on scheduling)
  * Row counts travel first, receive buffers are sized from them (nothing is padded or clipped).  Both calls are collective
  * (every rank of the communicator calls them in the same order) and return when the received columns are complete; the
  * columns belong to the communicator and stay valid until its next exchange.
