@@ -455,29 +455,38 @@ __global__ __launch_bounds__(256) void band_slow_kernel(const LdsJoinArgs* ap, c
 // output rows 64 at a time — consecutive rows, every column one coalesced 256-byte store — fetching each value from the
 // owning lane's registers (ds_bpermute).
 constexpr u32 kBandList = 1024;   // survivors listed at a time: a block with more is emitted 16 rows at a time (16 x 64 <= 1024)
+// NCOLS = output columns (1 .. 6): a template parameter so that only the live columns' pointers and selectors sit in SGPRs (the
+// six-column form kept 18 of them pinned and spilled scalars into vector lanes inside the loops)
+template <int NCOLS>
 __global__ __launch_bounds__(256) void band_emit_kernel(const BandArgs b) {
   __shared__ unsigned short list[4][kBandList];
   const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const u32 n_all = b.boff[b.kn];
   const u32 n_blocks = n_all < b.max_blocks ? n_all : b.max_blocks;
   // the column schedule, out of the argument block once per wave (constant indices: SGPRs)
-  u32* outp[kBandMaxRowCols + kBandMaxSideCols]; u32 out_sel[kBandMaxRowCols + kBandMaxSideCols];
+  u32* outp[NCOLS]; u32 out_sel[NCOLS];
 #pragma unroll
-  for (u32 oc = 0; oc < kBandMaxRowCols + kBandMaxSideCols; oc++) { outp[oc] = b.out[oc]; out_sel[oc] = b.out_sel[oc]; }
-  const u32 n_out_cols = b.n_out_cols; const u64 out_cap = b.out_cap;
+  for (u32 oc = 0; oc < (u32)NCOLS; oc++) { outp[oc] = b.out[oc]; out_sel[oc] = b.out_sel[oc]; }
+  const u64 out_cap = b.out_cap;
   if (blockIdx.x == 0 && threadIdx.x == 0) {   // the exact total, whether or not it fitted (like the fused join kernel's count)
     const u64 total = b.bofs[b.max_blocks];
     *b.n_out_dev = total;
     if (total > b.out_cap) *b.overflow = 1u;
   }
   for (u32 blk = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + wave); blk < n_blocks; blk += gridDim.x * 4u) {   // (grid ~ blocks, see band_mask_kernel)
-  const u32 tot = __builtin_amdgcn_readfirstlane(b.bcount[blk]);
-  if (tot == 0) continue;
+  // everything that is indexed by the block number in ONE round trip (count, descriptor, output offset, the rows' bits), before
+  // the count decides whether the block has anything to emit: a wave lives for its memory round trips (one block each, 8 waves
+  // per SIMD hide nothing of a chain), and count -> descriptor -> rows / entries were three of them
+  const u32 tot_v = b.bcount[blk];
   const uint4 d = b.bdesc[blk];
+  u64 run = b.bofs[blk];
+  const u64 mask_raw = b.masks[(u64)blk * 64 + lane];
+  asm volatile("" :: "v"(tot_v), "v"(d.x), "v"(d.y), "v"(d.z), "v"(d.w), "v"(run), "v"(mask_raw));   // (all four loads issued before the first wait: the compiler would sink them below the branch)
+  const u32 tot = __builtin_amdgcn_readfirstlane(tot_v);
+  if (tot == 0) continue;
   const u32 eb = __builtin_amdgcn_readfirstlane(d.x), ne = __builtin_amdgcn_readfirstlane(d.y);
   const u32 rb = __builtin_amdgcn_readfirstlane(d.z), nr = __builtin_amdgcn_readfirstlane(d.w);
-  u64 run = b.bofs[blk];
-  const u64 mask_all = lane < nr ? b.masks[(u64)blk * 64 + lane] : 0ull;
+  const u64 mask_all = lane < nr ? mask_raw : 0ull;
   u32 ev[kBandMaxSideCols], rv[kBandMaxRowCols];   // output values of the entry (lane = entry) / of the probe row (lane = row)
   {
     uint4 aux = make_uint4(0u, 0u, 0u, 0u);
@@ -486,12 +495,27 @@ __global__ __launch_bounds__(256) void band_emit_kernel(const BandArgs b) {
   }
 #pragma unroll
   for (u32 u = 0; u < kBandMaxSideCols; u++) { ev[u] = 0; if (u < b.n_entry_cols && lane < ne) ev[u] = b.eo[u][eb + lane]; }
+  // per output column, once per block: the register the column comes from (row value of lane r / entry value of lane e) — the
+  // selection is the same for every survivor, and the kernel is VALU-bound (320 vector instructions per block: 67 % of the
+  // SIMDs' issue slots in the SQ counters), so nothing that is uniform per block is computed per survivor
+  u32 srcv[NCOLS];
+#pragma unroll
+  for (u32 oc = 0; oc < (u32)NCOLS; oc++) {
+    const u32 sel = out_sel[oc];
+    u32 src = rv[0];
+    src = sel == 1 ? rv[1] : src;
+#pragma unroll
+    for (u32 u = 0; u < kBandMaxSideCols; u++) src = sel == 2 + u ? ev[u] : src;
+    srcv[oc] = src;
+  }
+  // the block's output range starts at a wave-uniform offset: scalar base + 32-bit lane offset per store
+  u64 run_s = ((u64)__builtin_amdgcn_readfirstlane((u32)(run >> 32)) << 32) | __builtin_amdgcn_readfirstlane((u32)run);
   const u32 step = tot <= kBandList ? 64u : 16u;   // rows listed per round (wave-uniform)
   for (u32 r0 = 0; r0 < nr; r0 += step) {
     u64 mask = (lane >= r0 && lane < r0 + step) ? mask_all : 0ull;
     const u32 cnt = (u32)__popcll(mask);
     const u32 incl = wave_incl_scan(cnt);
-    const u32 n_round = __shfl(incl, 63, 64);
+    const u32 n_round = __builtin_amdgcn_readfirstlane(__shfl(incl, 63, 64));
     if (n_round == 0) continue;                                         // wave-uniform
     u32 at = incl - cnt;
     while (mask) {                                                      // this lane's survivors, in entry order
@@ -500,28 +524,20 @@ __global__ __launch_bounds__(256) void band_emit_kernel(const BandArgs b) {
       list[wave][at++] = (unsigned short)((lane << 6) | e);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    const u64 room = out_cap > run_s ? out_cap - run_s : 0ull;          // rows that still fit (the count stays exact either way)
+    const u32 lim = room < (u64)n_round ? (u32)room : n_round;
     for (u32 t0 = 0; t0 < n_round; t0 += 64) {
       const u32 idx = t0 + lane;
-      const bool valid = idx < n_round;
-      const u32 pr = valid ? (u32)list[wave][idx] : 0u;
+      const u32 pr = idx < n_round ? (u32)list[wave][idx] : 0u;
       const u32 r = pr >> 6, e = pr & 63u;
-      const u64 pos = run + idx;
-      // the column schedule with CONSTANT indices into the argument block: the pointers and selectors are loaded into SGPRs
-      // once per wave — indexed by a run-time `oc` they were two dependent scalar loads per column and round, and the wave
-      // spent 94 of its 270 us waiting for them
 #pragma unroll
-      for (u32 oc = 0; oc < kBandMaxRowCols + kBandMaxSideCols; oc++) {   // (a band join has at most 2 + 4 output columns)
-        if (oc >= n_out_cols) continue;                                 // wave-uniform
-        const u32 sel = out_sel[oc];
-        u32 src = rv[0];
-        src = sel == 1 ? rv[1] : src;
-#pragma unroll
-        for (u32 u = 0; u < kBandMaxSideCols; u++) src = sel == 2 + u ? ev[u] : src;
-        const u32 v = __shfl(src, sel < 2 ? r : e, 64);
-        if (valid && pos < out_cap) outp[oc][pos] = v;
+      for (u32 oc = 0; oc < (u32)NCOLS; oc++) {
+        const u32 v = __shfl(srcv[oc], out_sel[oc] < 2 ? r : e, 64);
+        u32* base = outp[oc] + run_s;                                   // scalar
+        if (idx < lim) base[idx] = v;
       }
     }
-    run += n_round;
+    run_s += n_round;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");              // the list is free again
   }
   }
@@ -570,7 +586,17 @@ void launch_band_slow(const LdsJoinArgs* a_dev, const BandArgs& b, hipStream_t s
   hipLaunchKernelGGL(band_slow_kernel, dim3(g < 2048u ? (g ? g : 1u) : 2048u), dim3(256), 0, s, a_dev, b);
 }
 void launch_band_emit(const BandArgs& b, hipStream_t s) {
-  hipLaunchKernelGGL(band_emit_kernel, dim3((b.launch_blocks + 3) / 4 ? (b.launch_blocks + 3) / 4 : 1), dim3(256), 0, s, b);
+  const dim3 g((b.launch_blocks + 3) / 4 ? (b.launch_blocks + 3) / 4 : 1);
+  static_assert(kBandMaxRowCols + kBandMaxSideCols == 6, "one instantiation per column count");
+  switch (b.n_out_cols) {
+    case 1: hipLaunchKernelGGL(band_emit_kernel<1>, g, dim3(256), 0, s, b); return;
+    case 2: hipLaunchKernelGGL(band_emit_kernel<2>, g, dim3(256), 0, s, b); return;
+    case 3: hipLaunchKernelGGL(band_emit_kernel<3>, g, dim3(256), 0, s, b); return;
+    case 4: hipLaunchKernelGGL(band_emit_kernel<4>, g, dim3(256), 0, s, b); return;
+    case 5: hipLaunchKernelGGL(band_emit_kernel<5>, g, dim3(256), 0, s, b); return;
+    case 6: hipLaunchKernelGGL(band_emit_kernel<6>, g, dim3(256), 0, s, b); return;
+  }
+  fail(RDFGPU_ERR_INVALID, "band join with %u output columns", b.n_out_cols);
 }
 
 // rocPRIM radix sort of (u32 key, u32 value) pairs on the low `bits` bits: the partition pass of the probe side

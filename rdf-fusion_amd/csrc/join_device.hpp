@@ -37,9 +37,16 @@ static inline dim3 grid_for(u64 rows) { u64 g = (rows + kTile - 1) / kTile; retu
 // --------------------------------------------------------------------------------------------------
 constexpr int kLdsBlock = 512;
 
+// Inclusive scan over the 64 lanes with DPP moves (no LDS round trips: six ds_bpermute + waits were ~600 cycles of latency and
+// 18 address instructions per scan): four row_shr steps scan every 16-lane row, row_bcast15 / row_bcast31 carry the row totals
+// on (GFX9 wave64).  Every lane of the wave must be active.
 __device__ __forceinline__ u32 wave_incl_scan(u32 v) {
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) { const u32 t = __shfl_up(v, d, 64); if ((int)(threadIdx.x & 63) >= d) v += t; }
+  v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);   // row_shr:1 (lanes without a source add 0)
+  v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);   // row_shr:2
+  v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);   // row_shr:4
+  v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);   // row_shr:8
+  v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);   // row_bcast15 into rows 1 and 3
+  v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast31 into rows 2 and 3
   return v;
 }
 // A build-side column at candidate `i`.  Normally i is the build row.  In range-index mode (LdsJoinArgs::range_link) a
