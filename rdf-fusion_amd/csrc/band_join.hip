@@ -401,10 +401,8 @@ __global__ __launch_bounds__(256) void band_mask_kernel(const BandArgs b) {
   const u64 live = ne >= 64 ? ~0ull : ((1ull << ne) - 1ull);
   const u64 mask = ((((u64)m[1]) << 32) | m[0]) & live;
   b.masks[(u64)blk * 64 + lane] = mask;
-  u32 c = (u32)__popcll(mask);
-#pragma unroll
-  for (int dd = 32; dd >= 1; dd >>= 1) c += __shfl_xor(c, dd, 64);
-  if (lane == 0) b.bcount[blk] = c;
+  const u32 c = wave_incl_scan((u32)__popcll(mask));      // (DPP: lane 63 holds the block's count)
+  if (lane == 63) b.bcount[blk] = c;
   }
 }
 

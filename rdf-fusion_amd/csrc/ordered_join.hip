@@ -83,9 +83,8 @@ __global__ __launch_bounds__(kOjBlock) void oj_count_kernel(const OrderedJoinArg
     if (row < a.n_build) { a.row_head[row] = hd; a.row_cnt[row] = (unsigned char)(c < 255u ? c : 255u); }
     tot += c;
   }
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) tot += __shfl_xor(tot, d, 64);
-  if ((threadIdx.x & 63) == 0) wave_tot[threadIdx.x >> 6] = tot;
+  tot = wave_incl_scan(tot);                               // (DPP: lane 63 holds the wave's total)
+  if ((threadIdx.x & 63) == 63) wave_tot[threadIdx.x >> 6] = tot;
   __syncthreads();
   if (threadIdx.x == 0) {
     a.tile_count[blockIdx.x] = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
@@ -98,6 +97,10 @@ __global__ __launch_bounds__(kOjBlock) void oj_count_kernel(const OrderedJoinArg
 // rows, one value per output column) are all issued before the first store.  Which slice row a match belongs to: a
 // binary search over the tile's per-row start offsets in LDS (10 steps); which table row: that many hops down the
 // row's chain (chains are short: rows of the table that share one key).
+// NCOLS = output columns: a template parameter, so that only the live columns' pointers sit in SGPRs (with room for
+// kOjMaxOutCols the kernel spilled scalars into vector lanes inside the loop: 244 v_readlane / v_writelane).  The scans are
+// DPP scans (wave_incl_scan), one per round giving the round's total as well — the shuffle forms were 48 ds_bpermute.
+template <int NCOLS>
 __global__ __launch_bounds__(kOjBlock) void oj_write_kernel(const OrderedJoinArgs a) {
   __shared__ u32 starts[kOjTile];
   __shared__ u32 heads[kOjTile];
@@ -111,7 +114,7 @@ __global__ __launch_bounds__(kOjBlock) void oj_write_kernel(const OrderedJoinArg
   }
   const u32 tile_total = a.tile_count[blockIdx.x];
   if (tile_total == 0) return;                     // uniform per workgroup
-  u32 cnt[kOjRounds], hd[kOjRounds];
+  u32 cnt[kOjRounds], hd[kOjRounds], incl[kOjRounds];
 #pragma unroll
   for (int it = 0; it < kOjRounds; it++) {   // what the count pass found: streamed, not gathered again
     const u64 row = base + (u64)it * kOjBlock + threadIdx.x;
@@ -123,9 +126,8 @@ __global__ __launch_bounds__(kOjBlock) void oj_write_kernel(const OrderedJoinArg
     u32 c = cnt[it];
     if (c == 255u) { c = 0; for (u32 r = hd[it]; r != kNil; r = a.next[r]) c++; }   // (a chain of 255 or more table rows: its exact length)
     cnt[it] = c;
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d, 64);
-    if (lane == 0) rcnt[it][wave] = c;
+    incl[it] = wave_incl_scan(c);
+    if (lane == 63) rcnt[it][wave] = incl[it];
   }
   __syncthreads();
   u32 off = 0;
@@ -134,20 +136,25 @@ __global__ __launch_bounds__(kOjBlock) void oj_write_kernel(const OrderedJoinArg
     u32 woff = off;
     for (int w = 0; w < wave; w++) woff += rcnt[it][w];
     off += rcnt[it][0] + rcnt[it][1] + rcnt[it][2] + rcnt[it][3];
-    u32 incl = cnt[it];
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { const u32 t = __shfl_up(incl, d, 64); if (lane >= d) incl += t; }
-    starts[it * kOjBlock + threadIdx.x] = woff + (incl - cnt[it]);
+    starts[it * kOjBlock + threadIdx.x] = woff + (incl[it] - cnt[it]);
     heads[it * kOjBlock + threadIdx.x] = hd[it];
   }
   __syncthreads();
   const u64 tile_base = a.tile_off[blockIdx.x];
-  // the column schedule out of the argument block ONCE (constant indices -> SGPRs): indexed inside the loop it is two
-  // dependent scalar loads per column and match (the same trap as in band_emit_kernel)
-  u32* outp[kOjMaxOutCols]; const u32* refp[kOjMaxOutCols]; u32 slot[kOjMaxOutCols];
+  // the column schedule out of the argument block ONCE (constant indices -> SGPRs), turned round: per WORD of the packed table
+  // record the column it feeds (no per-match selection among the record's words), per slice-sourced column its source
+  u32* word_out[8]; u32* ref_out[NCOLS]; const u32* ref_in[NCOLS];
 #pragma unroll
-  for (u32 c = 0; c < kOjMaxOutCols; c++) { outp[c] = a.out[c]; refp[c] = a.out_ref[c].ptr; slot[c] = a.out_slot[c]; }
-  const u32 n_out_cols = a.n_out_cols, n_rec = a.n_rec;
+  for (u32 k = 0; k < 8; k++) word_out[k] = nullptr;
+#pragma unroll
+  for (u32 c = 0; c < (u32)NCOLS; c++) {
+    const u32 sl = a.out_slot[c];
+    ref_out[c] = sl == 0xFFu ? a.out[c] : nullptr;
+    ref_in[c] = a.out_ref[c].ptr;
+#pragma unroll
+    for (u32 k = 0; k < 8; k++) word_out[k] = sl == k ? a.out[c] : word_out[k];
+  }
+  const u32 n_rec = a.n_rec;
   const u64 out_cap = a.out_cap;
   for (u32 j = threadIdx.x; j < tile_total; j += kOjBlock) {
     u32 lo = 0, hi = kOjTile;                      // the last q with starts[q] <= j (rows without matches share their successor's start)
@@ -162,21 +169,14 @@ __global__ __launch_bounds__(kOjBlock) void oj_write_kernel(const OrderedJoinArg
     const uint4 r0 = a.trec[(u64)r * n_rec];
     uint4 r1 = make_uint4(0u, 0u, 0u, 0u);
     if (n_rec > 1) r1 = a.trec[(u64)r * n_rec + 1];
+    u32 v[NCOLS];
+#pragma unroll
+    for (u32 c = 0; c < (u32)NCOLS; c++) v[c] = ref_out[c] ? ref_in[c][brow] : 0u;   // (wave-uniform conditions)
     const u32 w[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
-    u32 v[kOjMaxOutCols];
 #pragma unroll
-    for (u32 c = 0; c < kOjMaxOutCols; c++) {
-      if (c >= n_out_cols) continue;
-      u32 val = 0;
-      if (slot[c] == 0xFFu) val = refp[c][brow];
-      else {
+    for (u32 k = 0; k < 8; k++) if (word_out[k]) word_out[k][pos] = w[k];
 #pragma unroll
-        for (u32 k = 0; k < 8; k++) val = k == slot[c] ? w[k] : val;
-      }
-      v[c] = val;
-    }
-#pragma unroll
-    for (u32 c = 0; c < kOjMaxOutCols; c++) if (c < n_out_cols) outp[c][pos] = v[c];
+    for (u32 c = 0; c < (u32)NCOLS; c++) if (ref_out[c]) ref_out[c][pos] = v[c];
   }
 }
 
@@ -189,7 +189,19 @@ void launch_ordered_join_count(const OrderedJoinArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(oj_count_kernel, dim3((unsigned)ordered_join_tiles(a.n_build)), dim3(kOjBlock), 0, s, a);
 }
 void launch_ordered_join_write(const OrderedJoinArgs& a, hipStream_t s) {
-  hipLaunchKernelGGL(oj_write_kernel, dim3((unsigned)ordered_join_tiles(a.n_build)), dim3(kOjBlock), 0, s, a);
+  const dim3 g((unsigned)ordered_join_tiles(a.n_build));
+  static_assert(kOjMaxOutCols == 8, "one instantiation per column count");
+  switch (a.n_out_cols) {
+    case 1: hipLaunchKernelGGL(oj_write_kernel<1>, g, dim3(kOjBlock), 0, s, a); return;
+    case 2: hipLaunchKernelGGL(oj_write_kernel<2>, g, dim3(kOjBlock), 0, s, a); return;
+    case 3: hipLaunchKernelGGL(oj_write_kernel<3>, g, dim3(kOjBlock), 0, s, a); return;
+    case 4: hipLaunchKernelGGL(oj_write_kernel<4>, g, dim3(kOjBlock), 0, s, a); return;
+    case 5: hipLaunchKernelGGL(oj_write_kernel<5>, g, dim3(kOjBlock), 0, s, a); return;
+    case 6: hipLaunchKernelGGL(oj_write_kernel<6>, g, dim3(kOjBlock), 0, s, a); return;
+    case 7: hipLaunchKernelGGL(oj_write_kernel<7>, g, dim3(kOjBlock), 0, s, a); return;
+    case 8: hipLaunchKernelGGL(oj_write_kernel<8>, g, dim3(kOjBlock), 0, s, a); return;
+  }
+  fail(RDFGPU_ERR_INVALID, "ordered join with %u output columns", a.n_out_cols);
 }
 
 }  // namespace rdfgpu
