@@ -24,7 +24,7 @@
 //   band_decode_kernel  per probe row, in row order: sort key (key - kmin; kn = "joins nothing"), window bounds (checked
 //                       i64 -> biased u32 interval), id operand                                    -> rocPRIM radix sort
 //   band_bounds_kernel  poff[k] = first sorted position with key >= k (one pass, gaps filled)
-//   band_blocks_kernel  blocks (64 entries x 64 rows) per key -> exclusive scan = first block of a key -> band_desc_kernel
+//   band_blocks_scan    blocks (64 entries x 64 rows) per key, computed inside the scan's input iterator: boff = first block of a key -> band_desc_kernel
 //   band_mask_kernel    per block: the pair tests, 1 bit per pair, count per block
 //   band_slow_kernel    rows whose operands are not all xsd:integer: full semantics (exits at once if there are none)
 //   band_emit_kernel    per block: bits -> output rows at the block's scanned offset, coalesced
@@ -47,16 +47,6 @@ __global__ __launch_bounds__(256) void band_bounds_kernel(const u32* skey_sorted
   const u32 prev = i > 0 ? skey_sorted[i - 1] + 1u : 0u;          // first key not yet answered
   const u32 cur = i < n ? skey_sorted[i] : kn;                     // keys <= cur start at or before i
   for (u32 k = prev; k <= cur && k <= kn; k++) poff[k] = (u32)i;
-}
-__global__ __launch_bounds__(256) void band_blocks_kernel(const u32* csr_off, const u32* poff, u32 kn, u32* nblk) {
-  const u32 k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k > kn) return;
-  u32 b = 0;
-  if (k < kn) {
-    const u32 e = csr_off[k + 1] - csr_off[k], r = poff[k + 1] - poff[k];
-    b = (e && r) ? ((e + 63) >> 6) * ((r + 63) >> 6) : 0u;
-  }
-  nblk[k] = b;
 }
 
 // ---- per probe row: the window of every stage as a biased 32-bit interval -----------------------------------------
@@ -549,9 +539,6 @@ void launch_band_decode(const BandArgs& b, hipStream_t s) {
 void launch_band_bounds(const u32* skey_sorted, u64 n, u32 kn, u32* poff, hipStream_t s) {
   hipLaunchKernelGGL(band_bounds_kernel, grid256(n + 1), dim3(256), 0, s, skey_sorted, n, kn, poff);
 }
-void launch_band_blocks(const u32* csr_off, const u32* poff, u32 kn, u32* nblk, hipStream_t s) {
-  hipLaunchKernelGGL(band_blocks_kernel, grid256((u64)kn + 1), dim3(256), 0, s, csr_off, poff, kn, nblk);
-}
 void launch_band_pt(const BandArgs& b, hipStream_t s) {
   if (b.pt && b.pt_n) hipLaunchKernelGGL(band_pt_kernel, grid256(b.pt_n), dim3(256), 0, s, b);
 }
@@ -595,6 +582,27 @@ void launch_band_emit(const BandArgs& b, hipStream_t s) {
     case 6: hipLaunchKernelGGL(band_emit_kernel<6>, g, dim3(256), 0, s, b); return;
   }
   fail(RDFGPU_ERR_INVALID, "band join with %u output columns", b.n_out_cols);
+}
+
+// blocks (64 entries x 64 rows) per key, scanned in one go: boff[k] = first block of key k, boff[kn] = all blocks.  The per-key
+// counts are the scan's INPUT ITERATOR (computed on the fly from the two offset arrays): no band_blocks launch, no count array.
+struct BandBlocksOfKey {
+  const u32* csr_off; const u32* poff; u32 kn;
+  __host__ __device__ u32 operator()(u32 k) const {
+    if (k >= kn) return 0u;
+    const u32 e = csr_off[k + 1] - csr_off[k], r = poff[k + 1] - poff[k];
+    return (e && r) ? ((e + 63) >> 6) * ((r + 63) >> 6) : 0u;
+  }
+};
+size_t band_blocks_scan_temp_bytes(u32 kn) {
+  size_t bytes = 0;
+  auto in = rocprim::make_transform_iterator(rocprim::make_counting_iterator<u32>(0u), BandBlocksOfKey{nullptr, nullptr, kn});
+  (void)rocprim::exclusive_scan(nullptr, bytes, in, (u32*)nullptr, 0u, (size_t)kn + 1, rocprim::plus<u32>());
+  return bytes + 256;
+}
+void band_blocks_scan(const u32* csr_off, const u32* poff, u32 kn, u32* boff, void* temp, size_t temp_bytes, hipStream_t s) {
+  auto in = rocprim::make_transform_iterator(rocprim::make_counting_iterator<u32>(0u), BandBlocksOfKey{csr_off, poff, kn});
+  RDFGPU_HIP(rocprim::exclusive_scan(temp, temp_bytes, in, boff, 0u, (size_t)kn + 1, rocprim::plus<u32>(), s));
 }
 
 // rocPRIM radix sort of (u32 key, u32 value) pairs on the low `bits` bits: the partition pass of the probe side

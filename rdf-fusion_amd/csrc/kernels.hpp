@@ -339,7 +339,8 @@ void launch_band_scatter(const BandArgs& b, hipStream_t s);   // counting-sort f
 void launch_band_desc(const BandArgs& b, hipStream_t s);
 void launch_band_decode(const BandArgs& b, hipStream_t s);   // + sort keys
 void launch_band_bounds(const u32* skey_sorted, u64 n, u32 kn, u32* poff, hipStream_t s);
-void launch_band_blocks(const u32* csr_off, const u32* poff, u32 kn, u32* nblk, hipStream_t s);
+size_t band_blocks_scan_temp_bytes(u32 kn);
+void band_blocks_scan(const u32* csr_off, const u32* poff, u32 kn, u32* boff, void* temp, size_t temp_bytes, hipStream_t s);   // blocks per key computed inside the scan's input iterator
 void launch_band_mask(const BandArgs& b, hipStream_t s);
 void launch_band_slow(const LdsJoinArgs* a_dev, const BandArgs& b, hipStream_t s);   // patches masks / counts of the rare slow rows
 void launch_band_emit(const BandArgs& b, hipStream_t s);

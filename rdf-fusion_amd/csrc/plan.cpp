@@ -1932,7 +1932,6 @@ void Plan::exec_band_join(LdsJoinArgs& a, BandArgs& b, const DevTable& B, const 
   timed(KC_BAND_DECODE, 0, np, P.n_dev, 4 + 4ull * (b.n_win + b.has_neq) + 9ull * b.n_win + 24 + 8, nullptr, 0, 0, [&] { launch_band_decode(b, stream); });
   // the partition pass: in the time, not in the algorithmic bytes
   if (!presorted && !counting) timed(KC_RADIX_SORT, 0, np, nullptr, 0, nullptr, 0, 0, [&] { sort_pairs_u32_u32(b.skey_in, skey, b.sval_in, perm, np, bits, stemp, stb, stream); });
-  u32* nblk = scratch<u32>((u64)kn + 1);
   b.boff = scratch<u32>((u64)kn + 1);
   // blocks: sum over keys of ceil(E/64) * ceil(R/64) <= cmax * (rows / 64) + sum of ceil(E/64) over the keys
   const u64 cmax = (cur_build_table->csr_max_group + 63) / 64;
@@ -1950,7 +1949,7 @@ void Plan::exec_band_join(LdsJoinArgs& a, BandArgs& b, const DevTable& B, const 
   b.bdesc = scratch<uint4>(max_blocks);
   b.masks = scratch<u64>(max_blocks * 64);
   b.bcount = scratch<u32>(max_blocks + 1); b.bofs = scratch<u32>(max_blocks + 1);
-  const size_t tb = scan_temp_bytes(std::max<u64>((u64)kn + 1, max_blocks + 1));
+  const size_t tb = std::max(scan_temp_bytes(std::max<u64>((u64)kn + 1, max_blocks + 1)), band_blocks_scan_temp_bytes(kn));
   void* temp = scratch<unsigned char>(tb);
   RDFGPU_HIP(hipMemsetAsync(b.bcount, 0, (max_blocks + 1) * sizeof(u32), stream));
   if (counting) {   // poff = exclusive scan of the rows per key (entry kn = the rows that join something); then the scatter
@@ -1958,8 +1957,7 @@ void Plan::exec_band_join(LdsJoinArgs& a, BandArgs& b, const DevTable& B, const 
     RDFGPU_HIP(hipMemcpyAsync(b.key_cursor, b.poff, ((size_t)kn + 1) * sizeof(u32), hipMemcpyDeviceToDevice, stream));
     timed(KC_BAND_ROWS, 0, np, P.n_dev, 8 + 32 + 32, nullptr, 0, 0, [&] { launch_band_scatter(b, stream); });
   } else if (!presorted) timed(KC_BAND_BOUNDS, 0, np, nullptr, 4, nullptr, 0, 0, [&] { launch_band_bounds(skey, np, kn, b.poff, stream); });   // (presorted: the decode pass wrote poff)
-  timed(KC_BAND_BLOCKS, 12ull * kn, 0, nullptr, 0, nullptr, 0, 0, [&] { launch_band_blocks(a.csr_off, b.poff, kn, nblk, stream); });
-  timed(KC_DEVICE_SCAN, 0, (u64)kn + 1, nullptr, 8, nullptr, 0, 0, [&] { exclusive_scan_u32(nblk, b.boff, (u64)kn + 1, temp, tb, stream); });
+  timed(KC_DEVICE_SCAN, 12ull * kn, (u64)kn + 1, nullptr, 4, nullptr, 0, 0, [&] { band_blocks_scan(a.csr_off, b.poff, kn, b.boff, temp, tb, stream); });   // (blocks per key: the scan's input iterator)
   timed(KC_BAND_DESC, 12ull * kn, 0, nullptr, 0, nullptr, 0, 0, [&] { launch_band_desc(b, stream); });
   if (!presorted && !counting) timed(KC_BAND_ROWS, 0, np, P.n_dev, 4 + 32 + 32, nullptr, 0, 0, [&] { launch_band_rows(b, stream); });
   // per probe row 4 (sorted position) + 24 (record) read, per entry 16 B read, per pair one bit written; the pair count
