@@ -359,8 +359,10 @@ __global__ __launch_bounds__(256) void band_mask_kernel(const BandArgs b) {
   for (u32 h = 0; h < 2; h++) {
     if (h * 32 >= ne) continue;                       // wave-uniform
     u32 acc = 0;
+    const u32 left = ne - h * 32;                      // entries of this half (wave-uniform): tested 8 at a time, not 32
+    const u32 g_end = left >= 32 ? 4u : (left + 7) >> 3;
 #pragma unroll 1
-    for (u32 g = 0; g < 4; g++) {
+    for (u32 g = 0; g < g_end; g++) {
       uint4 q8[8];
 #pragma unroll
       for (u32 e = 0; e < 8; e++) q8[e] = ent[wave][h * 32 + g * 8 + e];
@@ -384,7 +386,7 @@ __global__ __launch_bounds__(256) void band_mask_kernel(const BandArgs b) {
         asm("v_addc_co_u32_e64 %0, %1, %2, %2, %3" : "=v"(acc), "=s"(carry_out) : "v"(acc), "s"(lanes));
       }
     }
-    m[h] = __builtin_bitreverse32(acc);             // entry 0 was shifted in first: it sits at bit 31
+    m[h] = __builtin_bitreverse32(g_end == 4 ? acc : acc << (32 - 8 * g_end));   // entry 0 was shifted in first: it belongs at bit 31
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // the staging area is free for the wave's next block
   // entries past the group's end belong to the next key: their bits do not count
