@@ -469,16 +469,13 @@ __global__ __launch_bounds__(256) void value_verdict_kernel(const FilterStreamAr
 // workgroup compacts the qualifying runs and scans their lengths, and the copy moves 4 bytes in + 4 bytes out per
 // SURVIVING row and column (8 sigma N instead of 8 N + 4 sigma N).  Output order = index order, as in the streaming form.
 __global__ __launch_bounds__(256) void value_runs_kernel(const FilterStreamArgs a, u32 first, u32 span, u64 n, u32* run_lo, u32* run_cnt) {
+  // ONE search per id (where its run starts; it ends where the next id's starts; entry `span` = where the last one ends): the
+  // searches are chains of dependent HBM loads, and two per qualifying id were most of this kernel's time
   const u32 i = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (i >= span) return;                                   // wave-uniform
-  const u32 v = first + i;
-  u32 lo = 0, cnt = 0;
-  if (stream_pred<2>(a, v)) {                              // the same answer in every lane
-    const u64 l = wave_partition_point<false>(a.pcol, 0, n, v);
-    const u64 h = wave_partition_point<true>(a.pcol, l, n, v);
-    lo = (u32)l; cnt = (u32)(h - l);
-  }
-  if ((threadIdx.x & 63) == 0) { run_lo[i] = lo; run_cnt[i] = cnt; }
+  if (i > span) return;                                    // wave-uniform
+  const u64 l = i < span ? wave_partition_point<false>(a.pcol, 0, n, first + i) : wave_partition_point<true>(a.pcol, 0, n, first + span - 1u);
+  const bool ok = i < span && stream_pred<2>(a, first + i);   // the same answer in every lane
+  if ((threadIdx.x & 63) == 0) { run_lo[i] = (u32)l; if (i < span) run_cnt[i] = ok ? 1u : 0u; }
 }
 // one workgroup: qualifying runs compacted in id order, exclusive scan of their lengths (span <= kRunCopyMaxIds)
 __global__ __launch_bounds__(1024) void run_scan_kernel(const u32* run_lo, const u32* run_cnt, u32 span, u32 first,
@@ -487,7 +484,7 @@ __global__ __launch_bounds__(1024) void run_scan_kernel(const u32* run_lo, const
   const u32 per = (span + 1023) / 1024;
   const u32 i0 = threadIdx.x * per, i1 = i0 + per < span ? i0 + per : span;
   u32 rows = 0, runs = 0;
-  for (u32 i = i0; i < i1; i++) { const u32 c = run_cnt[i]; rows += c; runs += c != 0; }
+  for (u32 i = i0; i < i1; i++) { const u32 c = run_cnt[i] ? run_lo[i + 1] - run_lo[i] : 0u; rows += c; runs += c != 0; }   // (run_cnt: the id qualifies)
   u32 inc_rows = rows, inc_runs = runs;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
@@ -501,7 +498,7 @@ __global__ __launch_bounds__(1024) void run_scan_kernel(const u32* run_lo, const
   for (int w = 0; w < wave; w++) { base_rows += w_rows[w]; base_runs += w_runs[w]; }
   u32 off = base_rows + inc_rows - rows, k = base_runs + inc_runs - runs;
   for (u32 i = i0; i < i1; i++) {
-    const u32 c = run_cnt[i];
+    const u32 c = run_cnt[i] ? run_lo[i + 1] - run_lo[i] : 0u;
     if (c) { c_lo[k] = run_lo[i]; c_off[k] = off; c_val[k] = first + i; k++; off += c; }
   }
   if (threadIdx.x == 1023) { c_off[k] = off; *n_runs = k; *n_out = off; }
@@ -526,12 +523,20 @@ __global__ __launch_bounds__(256) void run_copy_kernel(const u32* c_lo, const u3
         const u32 v = c_val[k];
         for (u32 p = seg0 + threadIdx.x; p < seg1; p += 256) out[p] = v;
       } else {
-        u32 p = seg0 + threadIdx.x;
-        for (; p + 768 < seg1; p += 1024) {                 // four loads in flight per lane
-          const u32 v0 = in[src + (p - seg0)], v1 = in[src + (p - seg0) + 256], v2 = in[src + (p - seg0) + 512], v3 = in[src + (p - seg0) + 768];
-          out[p] = v0; out[p + 256] = v1; out[p + 512] = v2; out[p + 768] = v3;
+        // 16 bytes per lane and access: the stores aligned (the output position is what the lanes are laid out by), the loads at
+        // whatever 4-byte alignment the run starts with
+        typedef u32 u32x4a __attribute__((ext_vector_type(4), aligned(16)));
+        typedef u32 u32x4u __attribute__((ext_vector_type(4), aligned(4)));
+        const u32 h = (seg0 + 3u) & ~3u;                    // first output row that is a multiple of 4
+        const u32 body0 = h < seg1 ? h : seg1, body1 = body0 + ((seg1 - body0) & ~3u);
+        if (threadIdx.x < body0 - seg0) out[seg0 + threadIdx.x] = in[src + threadIdx.x];
+        u32 p = body0 + threadIdx.x * 4u;
+        for (; p + 1024 < body1; p += 2048) {               // two 16-byte loads in flight per lane
+          const u32x4u v0 = *reinterpret_cast<const u32x4u*>(in + src + (p - seg0)), v1 = *reinterpret_cast<const u32x4u*>(in + src + (p - seg0) + 1024);
+          *reinterpret_cast<u32x4a*>(out + p) = v0; *reinterpret_cast<u32x4a*>(out + p + 1024) = v1;
         }
-        for (; p < seg1; p += 256) out[p] = in[src + (p - seg0)];
+        for (; p < body1; p += 1024) *reinterpret_cast<u32x4a*>(out + p) = *reinterpret_cast<const u32x4u*>(in + src + (p - seg0));
+        if (threadIdx.x < seg1 - body1) out[body1 + threadIdx.x] = in[src + (body1 - seg0) + threadIdx.x];
       }
     }
     if (nxt >= P1) break;
@@ -639,7 +644,7 @@ static FilterStreamArgs stream_args(const FilterArgs& a0, int shape) {
 void launch_value_runs(const FilterArgs& a, const RunCopyBuffers& b, hipStream_t s) {
   const FilterStreamArgs f = stream_args(a, 2);
   const u32 span = (u32)a.value_span;
-  hipLaunchKernelGGL(value_runs_kernel, dim3((span + 3) / 4), dim3(256), 0, s, f, a.value_min, span, a.n_in_cap, b.run_lo, b.run_cnt);
+  hipLaunchKernelGGL(value_runs_kernel, dim3((span + 1 + 3) / 4), dim3(256), 0, s, f, a.value_min, span, a.n_in_cap, b.run_lo, b.run_cnt);
 }
 void launch_run_scan(const FilterArgs& a, const RunCopyBuffers& b, hipStream_t s) {
   hipLaunchKernelGGL(run_scan_kernel, dim3(1), dim3(1024), 0, s, b.run_lo, b.run_cnt, (u32)a.value_span, a.value_min, b.c_lo, b.c_off, b.c_val, b.n_runs, a.n_out_dev);

@@ -924,7 +924,7 @@ DevTable Plan::apply_filter(NodeInfo& nd, const DevTable& in) {
     if (span <= kRunCopyMaxIds && span * 1024 <= in.cap) {
       a.value_min = in.key_min; a.value_span = span;
       a.stream_bits = reinterpret_cast<unsigned short*>(scratch<u32>(1)); a.stream_counts = scratch<u32>(1); a.stream_offs = a.stream_counts;   // (the argument block wants them non-null)
-      RunCopyBuffers b{scratch<u32>(span), scratch<u32>(span), scratch<u32>(span + 1), scratch<u32>(span + 1), scratch<u32>(span + 1), scratch<u32>(1)};
+      RunCopyBuffers b{scratch<u32>(span + 1), scratch<u32>(span), scratch<u32>(span + 1), scratch<u32>(span + 1), scratch<u32>(span + 1), scratch<u32>(1)};   // (run_lo: one entry past the last id)
       timed(KC_VALUE_RUNS, 0, span, nullptr, 16, nullptr, 0, 0, [&] { launch_value_runs(a, b, stream); });
       timed(KC_RUN_SCAN, 0, span, nullptr, 8, nullptr, 0, 0, [&] { launch_run_scan(a, b, stream); });
       timed(KC_RUN_COPY, 0, 0, nullptr, 0, a.n_out_dev, 0, 8ull * nd.n_proj, [&] { launch_run_copy(a, b, stream); });
