@@ -112,6 +112,7 @@ __device__ __forceinline__ u32 band_run_atomic_add(u32* counters, u32 k, bool va
 // joins nothing) and, for the rows that can join, the decoded windows + the id operand of the base join's filter.
 __global__ __launch_bounds__(256) void band_decode_kernel(const BandArgs b) {
   const u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  for (u64 z = j; z <= b.max_blocks; z += (u64)gridDim.x * blockDim.x) b.bcount[z] = 0u;   // the blocks' counts start at 0 (no memset launches)
   const u64 n = live_rows(b.n_probe_dev, b.n_probe_cap);
   auto key_of = [&](u64 r) { u32 kk = b.kn; if (r < n) { const u32 v = b.probe_key[r]; const u32 d = v - b.kmin; if (v != 0 && d < b.kn) kk = d; } return kk; };   // null keys never join
   const u32 k = j < b.n_probe_cap ? key_of(j) : b.kn;

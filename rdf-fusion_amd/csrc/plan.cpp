@@ -1929,15 +1929,16 @@ void Plan::exec_band_join(LdsJoinArgs& a, BandArgs& b, const DevTable& B, const 
   if (entries_lock.owns_lock()) entries_lock.unlock();
   // per probe row: key + the window operands + the id operand read, 24 B of record + 8 B of sort pair written
   b.poff = scratch<u32>((u64)kn + 2);
-  timed(KC_BAND_DECODE, 0, np, P.n_dev, 4 + 4ull * (b.n_win + b.has_neq) + 9ull * b.n_win + 24 + 8, nullptr, 0, 0, [&] { launch_band_decode(b, stream); });
-  // the partition pass: in the time, not in the algorithmic bytes (SURVEY 8d)
-  if (!presorted && !counting) timed(KC_RADIX_SORT, 0, np, nullptr, 0, nullptr, 0, 0, [&] { sort_pairs_u32_u32(b.skey_in, skey, b.sval_in, perm, np, bits, stemp, stb, stream); });
-  b.boff = scratch<u32>((u64)kn + 1);
   // blocks: sum over keys of ceil(E/64) * ceil(R/64) <= cmax * (rows / 64) + sum of ceil(E/64) over the keys
   const u64 cmax = (cur_build_table->csr_max_group + 63) / 64;
   const u64 max_blocks = cmax * (np / 64 + 1) + nb / 64 + kn + 1;
   if (max_blocks >= (1ull << 31)) fail(RDFGPU_ERR_UNSUPPORTED, "band join of %llu blocks", (unsigned long long)max_blocks);
   b.max_blocks = (u32)max_blocks;
+  b.bcount = scratch<u32>(max_blocks + 1); b.bofs = scratch<u32>(max_blocks + 1);   // (bcount is zeroed by the decode pass: a memset is two more launches, ~10 us of launch gap each on this part)
+  timed(KC_BAND_DECODE, 0, np, P.n_dev, 4 + 4ull * (b.n_win + b.has_neq) + 9ull * b.n_win + 24 + 8, nullptr, 0, 0, [&] { launch_band_decode(b, stream); });
+  // the partition pass: in the time, not in the algorithmic bytes (SURVEY 8d)
+  if (!presorted && !counting) timed(KC_RADIX_SORT, 0, np, nullptr, 0, nullptr, 0, 0, [&] { sort_pairs_u32_u32(b.skey_in, skey, b.sval_in, perm, np, bits, stemp, stb, stream); });
+  b.boff = scratch<u32>((u64)kn + 1);
   // the block kernels launch one wave per block: sized from the previous execution's count (+ 25 %), not from the upper bound
   b.n_blocks_out = new_counter();
   // the full-semantics pass is launched when the previous execution met a row that needed it (or there was none); a row that
@@ -1948,10 +1949,8 @@ void Plan::exec_band_join(LdsJoinArgs& a, BandArgs& b, const DevTable& B, const 
   b.launch_blocks = (u32)std::min<u64>(max_blocks, hist ? hist + hist / 4 + 1024 : max_blocks);
   b.bdesc = scratch<uint4>(max_blocks);
   b.masks = scratch<u64>(max_blocks * 64);
-  b.bcount = scratch<u32>(max_blocks + 1); b.bofs = scratch<u32>(max_blocks + 1);
   const size_t tb = std::max(scan_temp_bytes(std::max<u64>((u64)kn + 1, max_blocks + 1)), band_blocks_scan_temp_bytes(kn));
   void* temp = scratch<unsigned char>(tb);
-  RDFGPU_HIP(hipMemsetAsync(b.bcount, 0, (max_blocks + 1) * sizeof(u32), stream));
   if (counting) {   // poff = exclusive scan of the rows per key (entry kn = the rows that join something); then the scatter
     timed(KC_DEVICE_SCAN, 0, (u64)kn + 1, nullptr, 8, nullptr, 0, 0, [&] { exclusive_scan_u32(b.key_hist, b.poff, (u64)kn + 1, temp, tb, stream); });
     RDFGPU_HIP(hipMemcpyAsync(b.key_cursor, b.poff, ((size_t)kn + 1) * sizeof(u32), hipMemcpyDeviceToDevice, stream));
