@@ -495,6 +495,9 @@ typedef struct rdfgpu_kernel_stat {
   uint64_t algorithmic_bytes;/* sum over those launches                                     */
   uint64_t rows_in;          /* rows streamed by those launches                             */
 } rdfgpu_kernel_stat;
+/* on = 1: every launch of the plan's later executions is bracketed with HIP events (two events per launch: ~5 us of stream time
+ * each, a tenth of a short step); on = 2: only the launches of the kernel that took longest in the last execution timed with
+ * on = 1 — the one a roofline is quoted for — so that a timed region is not slowed down by its own instrumentation; 0: off. */
 int rdfgpu_plan_enable_kernel_timing(rdfgpu_plan* plan, int on);
 int rdfgpu_plan_kernel_stats(rdfgpu_plan* plan, rdfgpu_kernel_stat* out, uint32_t cap, uint32_t* n);
 

@@ -409,7 +409,13 @@ int rdfgpu_plan_stream(rdfgpu_plan* plan, void** hip_stream) {
   ABI_END
 }
 
-int rdfgpu_plan_enable_kernel_timing(rdfgpu_plan* plan, int on) { ABI_BEGIN P(plan)->timing = on != 0; ABI_END }
+int rdfgpu_plan_enable_kernel_timing(rdfgpu_plan* plan, int on) {
+  ABI_BEGIN
+  Plan* p = P(plan);
+  p->timing = on != 0;
+  p->timing_focus = on >= 2 ? p->last_top_kc : -1;   // 2: only the class that took longest when every launch was timed (all of them if that never happened)
+  ABI_END
+}
 int rdfgpu_plan_kernel_stats(rdfgpu_plan* plan, rdfgpu_kernel_stat* out, uint32_t cap, uint32_t* n) {
   ABI_BEGIN
   Plan* p = P(plan);

@@ -514,7 +514,7 @@ template <class F>
 void Plan::timed(int kc, u64 fixed_bytes, u64 rows_cap, const u64* rows_dev, u64 bytes_per_row,
                  const u64* out_dev, u64 out_rows, u64 bytes_per_out, F&& launch) {
   metrics.kernels_launched++;
-  if (!timing) { launch(); return; }
+  if (!timing || (timing_focus >= 0 && kc != timing_focus)) { launch(); return; }
   PendingLaunch p{kc, ctx->event(events_used), ctx->event(events_used + 1), fixed_bytes, rows_cap, rows_dev, bytes_per_row, out_dev, out_rows, bytes_per_out};
   events_used += 2;
   RDFGPU_HIP(hipEventRecord(p.start, stream));
@@ -543,6 +543,10 @@ void Plan::resolve_timing() {
     k.bytes += p.fixed_bytes + rows * p.bytes_per_row + out * p.bytes_per_out;
   }
   pending.clear();
+  if (timing_focus < 0) {   // every launch was timed: remember the class that took longest (rdfgpu_plan_enable_kernel_timing(plan, 2))
+    double top = 0;
+    for (int kc = 0; kc < (int)(sizeof kstats / sizeof kstats[0]); kc++) if (kstats[kc].ms > top) { top = kstats[kc].ms; last_top_kc = kc; }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------

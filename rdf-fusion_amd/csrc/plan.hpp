@@ -109,6 +109,8 @@ struct Plan {
   std::shared_ptr<IndexGeneration> held;   // the store generation the last execute ran against: zero-copy result slices point into it
   rdfgpu_metrics metrics{};
   bool timing = false;
+  int timing_focus = -1;    // >= 0: only launches of this kernel class are bracketed with events (the longest class of the last fully timed execution)
+  int last_top_kc = -1;
   u64 located_version = ~0ull;    // store version the cached scan ranges belong to
   bool allow_speculation = true, speculative = false;
   u64 scratch_hist[2] = {0, 0};           // intermediates of the last two completed executions (bounds what the pool keeps cached)

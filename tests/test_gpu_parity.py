@@ -1603,6 +1603,14 @@ def test_band_join_matches_oracle(torch_cuda, shape):
         seen |= {k[0] for k in plan.kernel_stats()}
     if shape != "leq_geq_eq" and not ENGINE_TOGGLED:
         assert any("band_mask_kernel" in k for k in seen) and any("band_emit_kernel" in k for k in seen), seen
+    # timing mode 2: only the launches of the kernel that took longest in the last fully timed execution are bracketed
+    full = {k[0]: k[2] for k in plan.kernel_stats()}
+    plan.enable_kernel_timing(2)
+    got = plan.execute().fetch()
+    np.testing.assert_array_equal(ku.multiset(got, n_exp), want)
+    focus = [k[0] for k in plan.kernel_stats()]
+    assert focus == [max(full, key=full.get)], (focus, full)
+    plan.enable_kernel_timing(True)
     plan.set_option("NO_BAND_PACK16", 1)                            # both windows with 32-bit arithmetic instead of packed 16-bit
     got = plan.execute().fetch()
     np.testing.assert_array_equal(ku.multiset(got, n_exp), want)
