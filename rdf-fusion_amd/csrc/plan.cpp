@@ -492,11 +492,11 @@ const char* kernel_class_name(int kc) {
       "rdfgpu::topk_max_kernel", "rdfgpu::topk_hist_kernel", "rdfgpu::topk_scatter_kernel", "rdfgpu::topk_select_kernel",
       "rdfgpu::topk_write_kernel", "void rdfgpu::filter_kernel<3>", "rdfgpu::regex_verdict_kernel", "rdfgpu::union_kernel",
       "rdfgpu::band_slow_kernel", "rocprim radix sort", "rdfgpu::band_bounds_kernel", "rdfgpu::band_blocks_kernel",
-      "rdfgpu::band_decode_kernel", "void rdfgpu::band_mask_kernel", "rdfgpu::band_emit_kernel", "rdfgpu::band_entries_kernel",
+      "rdfgpu::band_decode_kernel", "void rdfgpu::band_mask_kernel", "void rdfgpu::band_emit_kernel", "rdfgpu::band_entries_kernel",
       "rdfgpu::band_desc_kernel", "rdfgpu::band_pt_kernel", "rdfgpu::band_rows_kernel",
       "void rdfgpu::filter_bits_kernel<1>", "void rdfgpu::filter_bits_kernel<2>", "void rdfgpu::filter_bits_kernel<3>", "void rdfgpu::filter_bits_kernel<4>", "rdfgpu::value_verdict_kernel",
       "rdfgpu::value_runs_kernel", "rdfgpu::run_scan_kernel", "rdfgpu::run_copy_kernel",
-      "rdfgpu::oj_probe_kernel", "rdfgpu::oj_count_kernel", "rdfgpu::oj_write_kernel",
+      "rdfgpu::oj_probe_kernel", "rdfgpu::oj_count_kernel", "void rdfgpu::oj_write_kernel",
       "void rdfgpu::filter_write_kernel", "rdfgpu::part_keys_kernel", "void rdfgpu::part_join_kernel"};
   if (kc < KC_LDS_JOIN0) return fixed[kc];
   static std::string names[192];
