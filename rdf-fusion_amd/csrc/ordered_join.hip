@@ -52,16 +52,9 @@ __global__ __launch_bounds__(256) void oj_probe_kernel(const OrderedJoinArgs a) 
   }
   a.trec[r * a.n_rec] = make_uint4(w[0], w[1], w[2], w[3]);
   if (a.n_rec > 1) a.trec[r * a.n_rec + 1] = make_uint4(w[4], w[5], w[6], w[7]);
-  a.next[r] = atomicExch(a.head + d, (u32)r);
-}
-
-__device__ __forceinline__ u32 oj_chain_length(const OrderedJoinArgs& a, u32 key) {
-  const u32 d = key - a.kmin;
-  if (key == 0 || d >= a.kn) return 0;
-  u32 c = 0;
-  for (u32 r = a.head[d]; r != kNil; r = a.next[r]) c++;
-  return c;
-}
+  a.next[r] = atomicExch(&a.head[d].x, (u32)r);
+  atomicAdd(&a.head[d].y, 1u);                    // (0xFFFFFFFF + 1 = 0: the stored value is the chain's length - 1) — the count pass reads
+}                                                  // head and length with ONE 8-byte gather: its gathers are what it is bound by
 
 __global__ __launch_bounds__(kOjBlock) void oj_count_kernel(const OrderedJoinArgs a) {
   __shared__ u32 wave_tot[kOjBlock / 64];
@@ -77,9 +70,8 @@ __global__ __launch_bounds__(kOjBlock) void oj_count_kernel(const OrderedJoinArg
   for (int it = 0; it < kOjRounds; it++) {
     const u64 row = base + (u64)it * kOjBlock + threadIdx.x;
     const u32 d = keys[it] - a.kmin;
-    const u32 hd = (keys[it] != 0 && d < a.kn) ? a.head[d] : kNil;
-    u32 c = 0;
-    for (u32 r = hd; r != kNil; r = a.next[r]) c++;
+    const uint2 hc = (keys[it] != 0 && d < a.kn) ? a.head[d] : make_uint2(kNil, 0xFFFFFFFFu);
+    const u32 hd = hc.x, c = hc.y + 1u;
     if (row < a.n_build) { a.row_head[row] = hd; a.row_cnt[row] = (unsigned char)(c < 255u ? c : 255u); }
     tot += c;
   }

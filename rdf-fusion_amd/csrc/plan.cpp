@@ -1716,8 +1716,8 @@ DevTable Plan::exec_lds_join(NodeInfo& nd, const DevTable& L, const DevTable& R,
       o.build_key = a.build_key[0]; o.n_build = B.cap;
       o.probe_key = a.probe_key[0]; o.n_probe_dev = P.n_dev; o.n_probe_cap = P.cap;
       o.kmin = a.direct_min; o.kn = a.direct_n;
-      o.head = scratch<u32>(a.direct_n); o.next = scratch<u32>(P.cap);
-      RDFGPU_HIP(hipMemsetAsync(o.head, 0xFF, (size_t)a.direct_n * sizeof(u32), stream));
+      o.head = scratch<uint2>(a.direct_n); o.next = scratch<u32>(P.cap);
+      RDFGPU_HIP(hipMemsetAsync(o.head, 0xFF, (size_t)a.direct_n * sizeof(uint2), stream));
       o.n_stages = a.n_chain;
       for (u32 s = 0; s < a.n_chain; s++) o.stage[s] = OrderedJoinStage{a.chain[s].key.ptr, a.chain[s].direct, a.chain[s].kmin, a.chain[s].kn, scratch<u32>(P.cap)};
       o.n_out_cols = a.n_out_cols;
