@@ -236,7 +236,7 @@ struct OrderedJoinArgs {
   const u32* build_key; u64 n_build;                                   // the slice's join-key column, rows in slice order
   const u32* probe_key; const u64* n_probe_dev; u64 n_probe_cap;        // the table
   u32 kmin, kn;                                                        // key range of the slice (its dense table's)
-  uint2* head; u32* next;                                              // multimap of the table's rows by key: head[kn] = {first row of the chain, chain length - 1} (0xFF-filled: empty), next[table rows]
+  uint2* head; u32* next;                                              // multimap of the table's rows by key: head[kn] = {first row of the chain, chain length - 2} (0xFF-filled: empty; a one-row chain leaves the second word alone), next[table rows]
   u32 n_stages; u32 pad0; OrderedJoinStage stage[kMaxChain];
   u32 n_out_cols; u32 n_rec; ColRef out_ref[kMaxCols]; u32* out[kMaxCols];   // src 0 = table row, 1 = slice row, 2 + t = stage t's row
   // everything an output row takes from the table row or its stage rows, packed per table row (n_rec x 16 B, written by

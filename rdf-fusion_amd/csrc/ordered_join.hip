@@ -52,10 +52,11 @@ __global__ __launch_bounds__(256) void oj_probe_kernel(const OrderedJoinArgs a) 
   }
   a.trec[r * a.n_rec] = make_uint4(w[0], w[1], w[2], w[3]);
   if (a.n_rec > 1) a.trec[r * a.n_rec + 1] = make_uint4(w[4], w[5], w[6], w[7]);
-  a.next[r] = atomicExch(&a.head[d].x, (u32)r);
-  atomicAdd(&a.head[d].y, 1u);                    // (0xFFFFFFFF + 1 = 0: the stored value is the chain's length - 1) — the count pass reads
-}                                                  // head and length with ONE 8-byte gather: its gathers are what it is bound by
-
+  const u32 old = atomicExch(&a.head[d].x, (u32)r);
+  a.next[r] = old;
+  if (old != kNil) atomicAdd(&a.head[d].y, 1u);    // rows of a key beyond its first (0xFFFFFFFF + 1 = 0): the count pass reads chain head
+}                                                  // and length with ONE 8-byte gather (its gathers are what it is bound by); a key with
+                                                   // one row — the common case — costs one atomic here
 __global__ __launch_bounds__(kOjBlock) void oj_count_kernel(const OrderedJoinArgs a) {
   __shared__ u32 wave_tot[kOjBlock / 64];
   const u64 base = (u64)blockIdx.x * kOjTile;
@@ -71,7 +72,7 @@ __global__ __launch_bounds__(kOjBlock) void oj_count_kernel(const OrderedJoinArg
     const u64 row = base + (u64)it * kOjBlock + threadIdx.x;
     const u32 d = keys[it] - a.kmin;
     const uint2 hc = (keys[it] != 0 && d < a.kn) ? a.head[d] : make_uint2(kNil, 0xFFFFFFFFu);
-    const u32 hd = hc.x, c = hc.y + 1u;
+    const u32 hd = hc.x, c = hc.x != kNil ? hc.y + 2u : 0u;   // 1 + the rows beyond the first (stored - 1)
     if (row < a.n_build) { a.row_head[row] = hd; a.row_cnt[row] = (unsigned char)(c < 255u ? c : 255u); }
     tot += c;
   }
