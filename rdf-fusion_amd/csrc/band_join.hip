@@ -88,6 +88,12 @@ __device__ __forceinline__ uint2 band_interval(long long lo, long long hi, long 
   const u32 hi_b = dh >= 0xFFFFFFF0ull ? 0xFFFFFFF0u : (u32)dh + 1u;
   return make_uint2(lo_b, hi_b - lo_b);
 }
+// [lo, lo + w] over 32-bit biased values -> the same interval over 16 bits (values are <= 65533 when this form is chosen)
+__device__ __forceinline__ void band_pack_interval(u32 lo, u32 w, u32& lo16, u32& w16) {
+  if (lo > 65534u) { lo16 = 0xFFFFu; w16 = 0u; return; }           // empty (or the "nothing passes" marker): (x - 0xFFFF) mod 2^16 >= 1 > 0
+  const u64 hi = (u64)lo + w;
+  lo16 = lo; w16 = (u32)(hi < 65534ull ? hi : 65534ull) - lo;      // a dead entry (x = 0) gives 65536 - lo > w16: never passes
+}
 // One atomic per RUN of equal keys among neighbouring lanes of a wave instead of one per lane: the re-sharded probe side of
 // a sharded step arrives as N sorted runs, so neighbouring rows share their key (any input is handled: a lane whose
 // neighbours differ is a run of one).  Every lane of the wave calls it; returns the lane's own position (counter value
@@ -148,6 +154,12 @@ __global__ __launch_bounds__(256) void band_decode_kernel(const BandArgs b) {
   u32 rv[kBandMaxRowCols] = {0u, 0u};
 #pragma unroll
   for (u32 u = 0; u < kBandMaxRowCols; u++) if (u < b.n_row_cols) rv[u] = b.row_col[u][j];
+  if (b.pack16) {   // the pair test's packed form: both windows' {lo, width} as 2 x 16 bits each — once per row here, not once per row and block there
+    u32 l0, w0, l1, w1;
+    band_pack_interval(rec.x, rec.y, l0, w0);
+    band_pack_interval(rec.z, rec.w, l1, w1);
+    rec = make_uint4(l0 | (l1 << 16), w0 | (w1 << 16), 0u, 0u);
+  }
   if (b.presorted) { b.rec_s[j] = rec; b.aux_s[j] = make_uint4(x, flags, rv[0], rv[1]); return; }   // row order IS the sorted order
   b.rec[2 * j] = rec;
   b.rec[2 * j + 1] = make_uint4(x, flags, rv[0], rv[1]);
@@ -317,12 +329,6 @@ __global__ __launch_bounds__(256) void band_desc_kernel(const BandArgs b) {
 // NWIN = window stages (1..2; no window = one trivial window); NEQ = base filter: 0 none / 1 `!=` / 2 `=`.
 struct BandEntry8 { uint4 a[8]; };
 typedef unsigned short us2 __attribute__((ext_vector_type(2)));
-// [lo, lo + w] over 32-bit biased values -> the same interval over 16 bits (values are <= 65533 when this form is chosen)
-__device__ __forceinline__ void band_pack_interval(u32 lo, u32 w, u32& lo16, u32& w16) {
-  if (lo > 65534u) { lo16 = 0xFFFFu; w16 = 0u; return; }           // empty (or the "nothing passes" marker): (x - 0xFFFF) mod 2^16 >= 1 > 0
-  const u64 hi = (u64)lo + w;
-  lo16 = lo; w16 = (u32)(hi < 65534ull ? hi : 65534ull) - lo;      // a dead entry (x = 0) gives 65536 - lo > w16: never passes
-}
 template <int NWIN, int NEQ, bool PACK>
 __global__ __launch_bounds__(256) void band_mask_kernel(const BandArgs b) {
   __shared__ uint4 ent[4][64];
@@ -335,7 +341,7 @@ __global__ __launch_bounds__(256) void band_mask_kernel(const BandArgs b) {
   const uint4 d = b.bdesc[blk];
   const u32 eb = __builtin_amdgcn_readfirstlane(d.x), ne = __builtin_amdgcn_readfirstlane(d.y);
   const u32 rb = __builtin_amdgcn_readfirstlane(d.z), nr = __builtin_amdgcn_readfirstlane(d.w);
-  uint4 rec = make_uint4(kBandInvalidLo, 0u, 1u, 0u);
+  uint4 rec = PACK ? make_uint4(0x0001FFFFu, 0u, 0u, 0u) : make_uint4(kBandInvalidLo, 0u, 1u, 0u);   // (nothing passes; PACK: the decode pass stored the packed form)
   u32 x = 0;
   if (lane < nr) { rec = b.rec_s[rb + lane]; if (NEQ) x = b.aux_s[rb + lane].x; }
   // The block's 64 entries go through LDS: lane e fetches entry e (one coalesced 1 KB load per block), every test then reads
@@ -347,10 +353,7 @@ __global__ __launch_bounds__(256) void band_mask_kernel(const BandArgs b) {
     uint4 q = b.et[eb + lane];                          // the table is padded: reading past the group is harmless
     if (PACK) {
       q.x = (q.x & 0xFFFFu) | (q.y << 16);              // both windows' operands in one word
-      u32 l0, w0, l1, w1;
-      band_pack_interval(rec.x, rec.y, l0, w0);
-      band_pack_interval(rec.z, rec.w, l1, w1);
-      plo = l0 | (l1 << 16); pw = w0 | (w1 << 16);
+      plo = rec.x; pw = rec.y;
     }
     ent[wave][lane] = q;
   }
