@@ -265,6 +265,23 @@ join_lowering_cases = [
     dict(src="L/join/rewrite.rs:419-439 optional_non_overlapping_variables_produces_left_join_with_empty_filter", left=["a"], right=["b"],
          join_type="Left", plan=["Left Join: ", "  EmptyRelation: rows=0", "  EmptyRelation: rows=0"]),
 ]
+# Join ROW results the reference holds as a fixture: testsuite/oxigraph-tests/sparql/nested_anonymous.{rq,ttl,srx}
+# (manifest.ttl:129-134).  Data (.ttl):  [ :p1 "t1" ; :p2 [ :p3 :foo ] ] .  [ :p1 "t2" ; :p2 [ :p3 :bar ] ] .
+# Query (.rq):  SELECT ?a WHERE { [ :p1 ?a ; :p2 [ :p3 :foo ] ] }  = the BGP  _:x :p1 ?a . _:x :p2 _:y . _:y :p3 :foo
+# (blank nodes in a query pattern are variables, quad_pattern/logical.rs:56-68) = two equi-joins (on x, then on y).
+# Expected (.srx): exactly one solution, ?a = "t1".
+# Terms are numbered in order of first use in the .ttl (any bijection is an equally valid dictionary).
+_NA = {":p1": 1, '"t1"': 2, ":p2": 3, ":p3": 4, ":foo": 5, "_:x1": 6, "_:y1": 7, '"t2"': 8, ":bar": 9, "_:x2": 10, "_:y2": 11}
+_na = lambda s, p, o: [0, _NA[s], _NA[p], _NA[o]]
+join_fixture_cases = [
+    dict(name="nested_anonymous", src="testsuite/oxigraph-tests/sparql/nested_anonymous.{rq,ttl,srx} (manifest.ttl:129-134)",
+         terms=_NA,
+         quads_gspo=[_na("_:x1", ":p1", '"t1"'), _na("_:x1", ":p2", "_:y1"), _na("_:y1", ":p3", ":foo"),
+                     _na("_:x2", ":p1", '"t2"'), _na("_:x2", ":p2", "_:y2"), _na("_:y2", ":p3", ":bar")],
+         # subject / predicate / object per triple pattern: str = variable, int = constant object id; default graph
+         patterns=[["x", _NA[":p1"], "a"], ["x", _NA[":p2"], "y"], ["y", _NA[":p3"], _NA[":foo"]]],
+         select=["a"], rows=[[_NA['"t1"']]]),
+]
 # bench/tests/plans/snapshots/r#mod__plans__bsbm_explore__BSBM Explore - Q{1,5} (Execution Plan).snap: the operator subtree
 # below the SortExec (the path this library executes), line for line; IRIs and the masked object id are written <c>, and the
 # `additional_filters=[DynamicFilter ...]` annotations (a run-time superset filter, never changes results) are dropped.
@@ -309,7 +326,8 @@ out = dict(
     pushdown_display=pushdown_display_cases, rowgroups=rowgroup_cases, dedupe=dedupe_cases,
     prune=prune_cases, find_range=find_range_cases, numeric_arith=numeric_arith_cases,
     decimal_to_double=decimal_to_double_cases, compare=compare_cases, decimal_to_float=decimal_to_float_cases,
-    ebv=ebv_cases, type_ids=type_id_cases, join_lowering=join_lowering_cases, plan_snapshots=plan_snapshot_cases)
+    ebv=ebv_cases, type_ids=type_id_cases, join_lowering=join_lowering_cases, join_fixtures=join_fixture_cases,
+    plan_snapshots=plan_snapshot_cases)
 
 if __name__ == "__main__":
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "reference_kats.json")

@@ -261,3 +261,33 @@ def string_dictionary(strings, n_other=5, lang_every=5, lang_id=7):
         tv["lo"][i] = i
         offsets[i + 1] = len(heap)
     return tv, offsets, bytes(heap)
+
+
+def bgp_plan(patterns, select, order=None):
+    """A basic graph pattern as the reference plans it: one DataSourceExec per triple pattern (default graph), joined
+    left-deep in textual order on ALL shared variables (logical_plan_builder_context.rs:239-250 + SparqlJoinLoweringRule,
+    join/rewrite.rs:126-168), then the SELECT projection.  `order` = another association order of the same patterns
+    (inner joins: the multiset of solutions does not depend on it).  Returns (PlanBuilder, root)."""
+    from rdf_fusion_amd.plan import PlanBuilder, quad_pattern
+    pb = PlanBuilder()
+    order = list(range(len(patterns))) if order is None else list(order)
+    node = None
+    for i in order:
+        s, p, o = patterns[i]
+        src = pb.data_source(quad_pattern(s, p, o))
+        node = src if node is None else pb.sparql_join(node, src)
+    root = pb.projection(node, [pb.names[node].index(v) for v in select])
+    return pb, root
+
+
+def scaled_join_fixture(case, copies):
+    """`copies` disjoint renamings of a join fixture's data (every non-predicate, non-query-constant term of copy k shifted
+    by k * stride): the expected rows are the fixture's rows once per copy, shifted alike.  A derived vector — it keeps the
+    fixture's join shape while the inputs grow past the sizes at which the engine changes its join table form."""
+    consts = {t for pat in case["patterns"] for t in pat if isinstance(t, int)}
+    preds = {q[2] for q in case["quads_gspo"]}
+    stride = max(case["terms"].values()) + 1
+    shift = lambda t, k: t if (t in consts or t in preds or t == 0) else t + k * stride
+    quads = [[q[0], shift(q[1], k), q[2], shift(q[3], k)] for k in range(copies) for q in case["quads_gspo"]]
+    rows = [[shift(v, k) for v in r] for k in range(copies) for r in case["rows"]]
+    return quads, rows
