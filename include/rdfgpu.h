@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define RDFGPU_ABI_VERSION 2u
+#define RDFGPU_ABI_VERSION 3u
 
 /* ------------------------------------------------------------------------------------ */
 /* 0. Status codes                                                                       */
@@ -164,6 +164,12 @@ int rdfgpu_store_clear(rdfgpu_store* store);
 int rdfgpu_store_remove_graph(rdfgpu_store* store, uint32_t graph, uint64_t* removed);
 /* QuadStorage::len (quad_storage.rs:71). */
 int rdfgpu_store_len(const rdfgpu_store* store, uint64_t* out);
+/* Cache control (no counterpart in the reference, whose HashJoinExec builds its table per query): forgets every join table
+   cached on the store (direct-address / CSR / hash tables of predicate slices, decoded value tables, band-join entries) and
+   bumps the store version — exactly what every extend / remove / clear does to the caches, without touching the quads.  The
+   next execution of any plan locates its ranges and builds the tables it needs again, inside that execution.  Used to
+   measure the "tables rebuilt in the step" figure (bench.py: config.cold_start.fused_rebuild). */
+int rdfgpu_store_drop_tables(rdfgpu_store* store);
 
 /*
  * Installs the id -> typed value table (MemObjectIdMapping::decode_array_to_typed_value,
@@ -272,6 +278,29 @@ enum {
                                  [u .. u + lo), each with its object id (rdfgpu_regex.pattern_id) and the constant flags; they are
                                  compiled at plan time and a row picks its program by the pattern's id.  A row whose pattern was not
                                  announced fails the execute (RDFGPU_ERR_UNSUPPORTED), it is never answered as "no match".            */
+  /* ---- ABI 3: string-valued expressions.  A string value on the device is a VIEW: the lexical form of an object
+     id in the store's string heap (rdfgpu_store_set_strings) or a constant of the plan, with a byte window (SUBSTR) and an ASCII
+     case mapping (UCASE / LCASE) applied on the fly; nothing is materialised per row.  Views are consumed by REGEX / CONTAINS /
+     STRSTARTS / STRENDS (whose operand may now be any string value, not only ENC_TV of a column), STRLEN, EBV and the
+     comparisons (two strings of which at least one is a view compare byte-wise — `str` order — when their languages agree). */
+  RDFGPU_EX_STR = 29,         /* ID -> TV(simple literal)  STR(term), scalar/terms/str.rs:42: over an object-id column the reference
+                                 plans STR in the plain-term encoding (decide_input_encoding, expr_builder_context.rs:557-582:
+                                 ObjectId is not supported, PlainTerm is the first that is), i.e. the lexical form AS WRITTEN of IRIs,
+                                 blank nodes and every literal ("010"^^xsd:int -> "010", lib/functions/tests/snapshots/
+                                 unary__STR(PLAIN_TERM).snap).  Null / an id without a lexical form in the heap => the error value. */
+  RDFGPU_EX_LIT_STR = 30,     /* -> TV(string)  a string constant WITH its bytes: `u` indexes rdfgpu_plan_desc.regexes (the entry's
+                                 pattern is the text), `lo` = its language id (0 = simple literal).  What a view is compared with:
+                                 an RDFGPU_EX_LIT_TV string carries only its rank in the dictionary's order.                     */
+  RDFGPU_EX_STRLEN = 31,      /* TV -> TV(integer)  STRLEN, scalar/strings/strlen.rs: characters (code points) of a simple or
+                                 language-tagged string; anything else => error.                                                  */
+  RDFGPU_EX_SUBSTR = 32,      /* TV TV [TV] -> TV(string)  SUBSTR(str, start[, length]), scalar/strings/sub_str.rs:83-121: `u` = 2 or 3
+                                 operands; 1-based character positions; start < 1 or a negative length => error; a start beyond the
+                                 end => ""; the language of the source is kept.  start / length must be xsd:int / xsd:integer values
+                                 (a float / double / decimal argument fails the execute with RDFGPU_ERR_UNSUPPORTED).             */
+  RDFGPU_EX_UCASE = 33,       /* TV -> TV(string)  UCASE, scalar/strings/ucase.rs (str::to_uppercase), language kept.  ASCII letters are
+                                 mapped on the device; a string with a non-ASCII byte under a case mapping fails the execute with
+                                 RDFGPU_ERR_UNSUPPORTED (Unicode case tables are not restated; never answered differently).      */
+  RDFGPU_EX_LCASE = 34,       /* same: LCASE, scalar/strings/lcase.rs (str::to_lowercase)                                        */
   RDFGPU_EX__COUNT
 };
 
@@ -386,6 +415,12 @@ typedef struct rdfgpu_metrics {
   double elapsed_compute_ms; /* device time of the last execute (HIP events)              */
   uint32_t kernels_launched;
   uint32_t host_syncs;
+  /* ABI 3: why an execution was slow, when it was */
+  uint32_t exact_reruns;     /* speculative sizes did not fit: the execution ran again with exact sizes (0 or 1)            */
+  uint32_t device_mallocs;   /* hipMalloc calls the store's pools had to make during this execution (0 in steady state)     */
+  double device_malloc_ms;   /* .. and the host time spent inside them                                                      */
+  uint32_t tables_built;     /* join tables of store slices built (not found cached) during this execution                  */
+  uint32_t reserved;
 } rdfgpu_metrics;
 
 /* Validates the description, chooses an index per data source (IndexPermutations::choose_index,

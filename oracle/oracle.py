@@ -80,6 +80,10 @@ def lib():
         l.orc_last_error.restype = C.c_char_p
         l.orc_eval_bool.argtypes = [vp, C.POINTER(abi.ExprNode), C.c_uint32, C.POINTER(vp), C.c_uint32,
                                     C.c_uint64, vp]
+        l.orc_eval_set_table.argtypes = [C.POINTER(abi.Regex), C.c_uint32]
+        l.orc_eval_set_table.restype = None
+        l.orc_eval_str.argtypes = [vp, C.POINTER(abi.ExprNode), C.c_uint32, C.POINTER(abi.Regex), C.c_uint32, C.POINTER(vp), C.c_uint32,
+                                   C.c_uint64, vp, vp, vp, vp, C.c_uint64]
         l.orc_eval_tv.argtypes = [vp, C.POINTER(abi.ExprNode), C.c_uint32, C.POINTER(vp), C.c_uint32,
                                   C.c_uint64, vp, vp]
         _LIB = l
@@ -332,9 +336,20 @@ class OracleStore:
         self._l.orc_table_free(C.byref(out))
         return cols, n_rows, m
 
+    def _program(self, expr):
+        """ctypes nodes of an expression, its string-table references resolved like a plan resolves them (and the table handed
+        to this thread's evaluator)."""
+        from rdf_fusion_amd.plan import PlanBuilder
+        pb = PlanBuilder()
+        pb._expr(abi.PlanNode(), expr)
+        nodes = (abi.ExprNode * max(1, len(pb.exprs)))(*pb.exprs)
+        keep = [(bytes(r[0]), bytes(r[1]), int(r[2]) if len(r) > 2 else 0) for r in pb.regexes]
+        regexes = (abi.Regex * max(1, len(keep)))(*[abi.Regex(p, f, len(p), len(f), pid, 0) for p, f, pid in keep])
+        self._l.orc_eval_set_table(regexes, len(keep))
+        return nodes, (keep, regexes)
+
     def eval_bool(self, expr, cols, n_rows=None):
-        nodes = (abi.ExprNode * len(expr.nodes))(*[abi.ExprNode(op, tag, fl, 0, u, lo, hi)
-                                                    for (op, tag, fl, u, lo, hi) in expr.nodes])
+        nodes, _keep = self._program(expr)
         cols = [np.ascontiguousarray(c, dtype=np.uint32) for c in cols]
         n = n_rows if n_rows is not None else (len(cols[0]) if cols else 1)
         ptrs = (C.c_void_p * max(1, len(cols)))(*[c.ctypes.data_as(C.c_void_p) for c in cols])
@@ -343,10 +358,30 @@ class OracleStore:
             raise _err()
         return out
 
+    def eval_str(self, expr, cols, n_rows=None):
+        """A string-valued expression row by row: [None (the error value / not a string) | (bytes, language id)]."""
+        from rdf_fusion_amd.plan import PlanBuilder
+        pb = PlanBuilder()
+        node = abi.PlanNode()
+        pb._expr(node, expr)                                  # resolves the string-table references like a plan does
+        nodes = (abi.ExprNode * max(1, len(pb.exprs)))(*pb.exprs)
+        keep = [(bytes(r[0]), bytes(r[1])) for r in pb.regexes]
+        regexes = (abi.Regex * max(1, len(keep)))(*[abi.Regex(p, f, len(p), len(f), 0, 0) for p, f in keep])
+        cols = [np.ascontiguousarray(c, dtype=np.uint32) for c in cols]
+        n = n_rows if n_rows is not None else (len(cols[0]) if cols else 1)
+        ptrs = (C.c_void_p * max(1, len(cols)))(*[c.ctypes.data_as(C.c_void_p) for c in cols])
+        state, lang, off = np.zeros(n, np.uint8), np.zeros(n, np.uint32), np.zeros(n + 1, np.uint64)
+        cap = 1 << 24
+        buf = np.zeros(cap, np.uint8)
+        if self._l.orc_eval_str(self._h, nodes, len(pb.exprs), regexes, len(keep), ptrs, len(cols), n, state.ctypes.data_as(C.c_void_p),
+                                lang.ctypes.data_as(C.c_void_p), off.ctypes.data_as(C.c_void_p), buf.ctypes.data_as(C.c_void_p), cap):
+            raise _err()
+        raw = buf.tobytes()
+        return [(raw[int(off[i]):int(off[i + 1])], int(lang[i])) if state[i] else None for i in range(n)]
+
     def eval_tv(self, expr, cols, n_rows=None):
         from rdf_fusion_amd.engine import TV_DTYPE
-        nodes = (abi.ExprNode * len(expr.nodes))(*[abi.ExprNode(op, tag, fl, 0, u, lo, hi)
-                                                    for (op, tag, fl, u, lo, hi) in expr.nodes])
+        nodes, _keep = self._program(expr)
         cols = [np.ascontiguousarray(c, dtype=np.uint32) for c in cols]
         n = n_rows if n_rows is not None else (len(cols[0]) if cols else 1)
         ptrs = (C.c_void_p * max(1, len(cols)))(*[c.ctypes.data_as(C.c_void_p) for c in cols])

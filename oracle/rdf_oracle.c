@@ -469,7 +469,15 @@ typedef struct {
   uint8_t tag, flags, b; /* b: BOOL 0/1/2(null) */
   u32 aux; u32 id;
   int64_t lo; i128 dec;
+  /* a COMPUTED string (STR / SUBSTR / UCASE / LCASE / a constant with bytes): materialised in the per-row arena; it has no
+     rank in the dictionary's order, so comparisons with it go by bytes */
+  const unsigned char* sp; u32 sl; uint8_t computed;
 } val;
+static __thread unsigned char g_arena[1 << 16]; static __thread size_t g_arena_used;
+static unsigned char* arena_take(size_t n) {
+  if (g_arena_used + n > sizeof g_arena) return NULL;
+  unsigned char* p = g_arena + g_arena_used; g_arena_used += n; return p;
+}
 
 static const i128 DEC_POW = (i128)1000000000000000000LL; /* decimal.rs:9-11 */
 
@@ -620,12 +628,29 @@ static uint8_t tv_ebv(const val* v) {
   }
 }
 
+/* the bytes of a string value: a computed string's own, a dictionary string's lexical form from the heap */
+static int str_bytes(const orc_store* s, const val* v, const unsigned char** p, size_t* n) {
+  if (v->tag != RDFGPU_TV_STRING) return 0;
+  if (v->computed) { *p = v->sp; *n = v->sl; return 1; }
+  if (v->id == 0 || v->id >= s->n_str_ids) return 0;
+  *p = s->heap + s->str_off[v->id]; *n = (size_t)(s->str_off[v->id + 1] - s->str_off[v->id]);
+  return 1;
+}
+static val tv_computed_string(const unsigned char* p, size_t n, u32 lang) {
+  val v = tv_null();
+  v.tag = RDFGPU_TV_STRING; v.computed = 1; v.sp = p; v.sl = (u32)n; v.aux = lang; v.flags = n == 0 ? RDFGPU_TVF_EMPTY_STRING : 0;
+  return v;
+}
+/* length in bytes of the UTF-8 sequence a lead byte starts (the heap holds valid UTF-8) */
+static size_t utf8_len(unsigned char b) { return b < 0x80 ? 1 : (b >> 5) == 6 ? 2 : (b >> 4) == 14 ? 3 : 4; }
+
 typedef struct { const u32* const* lc; u32 nl; u64 li; const u32* const* rc; u32 nr; u64 ri; } rowctx;
 static inline u32 row_col(const rowctx* r, u32 c) { return c < r->nl ? r->lc[c][r->li] : r->rc[c - r->nl][r->ri]; }
 
 #define STK 32
 static int eval_prog(const orc_store* s, const rdfgpu_expr_node* p, u32 n, const rowctx* row, val* result) {
   val st[STK]; int sp = 0;
+  g_arena_used = 0;
   for (u32 i = 0; i < n; i++) {
     const rdfgpu_expr_node* e = &p[i];
     val v; memset(&v, 0, sizeof v);
@@ -640,7 +665,17 @@ static int eval_prog(const orc_store* s, const rdfgpu_expr_node* p, u32 n, const
       case RDFGPU_EX_GT: case RDFGPU_EX_LT: case RDFGPU_EX_GEQ: case RDFGPU_EX_LEQ: case RDFGPU_EX_EQ: case RDFGPU_EX_NEQ: {
         if (sp < 2 || st[sp - 1].kind != 1 || st[sp - 2].kind != 1) FAIL("comparison needs two typed values");
         val b = st[--sp], a = st[--sp];
-        int o = tv_partial_cmp(&a, &b);
+        int o;
+        if (a.tag == RDFGPU_TV_STRING && b.tag == RDFGPU_TV_STRING && (a.computed || b.computed)) {
+          /* partial_cmp_literals typed_value.rs:184-196: simple with simple, language-tagged with the same language: the values, as `str` */
+          const unsigned char *pa, *pb; size_t na, nb;
+          if (a.aux != b.aux) o = ORD_NONE;
+          else {
+            if (!str_bytes(s, &a, &pa, &na) || !str_bytes(s, &b, &pb, &nb)) FAIL("a computed string is compared with a string that has no bytes here (pass the literal as RDFGPU_EX_LIT_STR)");
+            int c = memcmp(pa, pb, na < nb ? na : nb);
+            o = c < 0 ? -1 : c > 0 ? 1 : na < nb ? -1 : na > nb;
+          }
+        } else o = tv_partial_cmp(&a, &b);
         if (o == ORD_NONE) { v = tv_null(); break; } /* ThinError => null (greater_than.rs:52-60) */
         int r = e->op == RDFGPU_EX_GT ? o > 0 : e->op == RDFGPU_EX_LT ? o < 0 : e->op == RDFGPU_EX_GEQ ? o >= 0 :
                 e->op == RDFGPU_EX_LEQ ? o <= 0 : e->op == RDFGPU_EX_EQ ? o == 0 : o != 0;
@@ -653,10 +688,10 @@ static int eval_prog(const orc_store* s, const rdfgpu_expr_node* p, u32 n, const
         if (e->u >= g_n_regexes) FAIL("REGEX pattern %u out of range", e->u);
         val a = st[--sp];
         v = tv_null();
-        if (a.tag != RDFGPU_TV_STRING || a.id == 0 || a.id >= s->n_str_ids) break;
+        const unsigned char* subj; size_t subj_n;
+        if (!str_bytes(s, &a, &subj, &subj_n)) break;
         const rdfgpu_regex* rx = &g_regexes[e->u];
-        int m = orc_regex_is_match(rx->pattern, rx->pattern_len, rx->flags ? rx->flags : "", rx->flags ? rx->flags_len : 0,
-                                   s->heap + s->str_off[a.id], (size_t)(s->str_off[a.id + 1] - s->str_off[a.id]));
+        int m = orc_regex_is_match(rx->pattern, rx->pattern_len, rx->flags ? rx->flags : "", rx->flags ? rx->flags_len : 0, subj, subj_n);
         if (m == -2) FAIL("REGEX with \\d \\w \\s or \\b over a string with non-ASCII characters needs the regex crate's Unicode tables");
         if (m >= 0) v = tv_bool(m);
         break; }
@@ -666,12 +701,12 @@ static int eval_prog(const orc_store* s, const rdfgpu_expr_node* p, u32 n, const
         if (e->u >= g_n_regexes) FAIL("REGEX pattern table %u out of range", e->u);
         val pat = st[--sp]; val a = st[--sp];
         v = tv_null();
-        if (pat.tag != RDFGPU_TV_STRING || pat.aux != 0 || pat.id == 0 || pat.id >= s->n_str_ids) break;
-        if (a.tag != RDFGPU_TV_STRING || a.id == 0 || a.id >= s->n_str_ids) break;
+        if (pat.tag != RDFGPU_TV_STRING || pat.aux != 0 || pat.computed || pat.id == 0 || pat.id >= s->n_str_ids) break;
+        const unsigned char* subj; size_t subj_n;
+        if (!str_bytes(s, &a, &subj, &subj_n)) break;
         const rdfgpu_regex* rx = &g_regexes[e->u];      /* the flags are the plan's constant third argument */
         int m = orc_regex_is_match((const char*)(s->heap + s->str_off[pat.id]), (size_t)(s->str_off[pat.id + 1] - s->str_off[pat.id]),
-                                   rx->flags ? rx->flags : "", rx->flags ? rx->flags_len : 0,
-                                   s->heap + s->str_off[a.id], (size_t)(s->str_off[a.id + 1] - s->str_off[a.id]));
+                                   rx->flags ? rx->flags : "", rx->flags ? rx->flags_len : 0, subj, subj_n);
         if (m == -2) FAIL("REGEX with \\d \\w \\s or \\b over a string with non-ASCII characters needs the regex crate's Unicode tables");
         if (m >= 0) v = tv_bool(m);
         break; }
@@ -682,11 +717,11 @@ static int eval_prog(const orc_store* s, const rdfgpu_expr_node* p, u32 n, const
         if (e->u >= g_n_regexes) FAIL("string constant %u out of range", e->u);
         val a = st[--sp];
         v = tv_null();
-        if (a.tag != RDFGPU_TV_STRING || a.id == 0 || a.id >= s->n_str_ids) break;
+        const unsigned char* hay; size_t hl;
+        if (!str_bytes(s, &a, &hay, &hl)) break;
         if (e->lo > 0 && (int64_t)a.aux != e->lo) break;
         const rdfgpu_regex* rx = &g_regexes[e->u];
-        const unsigned char* hay = s->heap + s->str_off[a.id];
-        const size_t hl = (size_t)(s->str_off[a.id + 1] - s->str_off[a.id]), nl = rx->pattern_len;
+        const size_t nl = rx->pattern_len;
         int r = 0;
         if (nl <= hl) {
           if (e->op == RDFGPU_EX_STRSTARTS) r = memcmp(hay, rx->pattern, nl) == 0;
@@ -705,6 +740,66 @@ static int eval_prog(const orc_store* s, const rdfgpu_expr_node* p, u32 n, const
         const rdfgpu_regex* rx = &g_regexes[e->u];
         if (lang >= rx->pattern_len) break;
         v = tv_bool(rx->pattern[lang] != 0);
+        break; }
+      case RDFGPU_EX_STR: {   /* str.rs:42 in the plain-term encoding (the encoding an object-id argument is converted to): the lexical form as written */
+        if (sp < 1 || st[sp - 1].kind != 0) FAIL("STR needs an id");
+        u32 id = st[--sp].id;
+        v = tv_null();
+        if (id == 0 || id >= s->n_str_ids) break;
+        size_t len = (size_t)(s->str_off[id + 1] - s->str_off[id]);
+        unsigned char* buf = arena_take(len);
+        if (!buf) FAIL("string arena exhausted");
+        memcpy(buf, s->heap + s->str_off[id], len);
+        v = tv_computed_string(buf, len, 0);
+        break; }
+      case RDFGPU_EX_LIT_STR:
+        if (e->u >= g_n_regexes) FAIL("string constant %u out of range", e->u);
+        v = tv_computed_string((const unsigned char*)g_regexes[e->u].pattern, g_regexes[e->u].pattern_len, e->lo < 0 ? 0 : (u32)e->lo);
+        break;
+      case RDFGPU_EX_STRLEN: {   /* strlen.rs: chars().count() */
+        if (sp < 1 || st[sp - 1].kind != 1) FAIL("STRLEN needs a typed value");
+        val a = st[--sp]; const unsigned char* q; size_t qn;
+        v = tv_null();
+        if (!str_bytes(s, &a, &q, &qn)) break;
+        int64_t chars = 0;
+        for (size_t i = 0; i < qn; i += utf8_len(q[i])) chars++;
+        v.tag = RDFGPU_TV_INTEGER; v.lo = chars;
+        break; }
+      case RDFGPU_EX_SUBSTR: {   /* sub_str.rs:83-121 */
+        if (e->u != 2 && e->u != 3) FAIL("SUBSTR takes 2 or 3 operands");
+        if (sp < (int)e->u) FAIL("SUBSTR: stack underflow");
+        val len_v = tv_null(); if (e->u == 3) len_v = st[--sp];
+        val from = st[--sp], a = st[--sp];
+        v = tv_null();
+        const unsigned char* q; size_t qn;
+        if (!str_bytes(s, &a, &q, &qn)) break;
+        /* Integer::try_from(typed value): numerics only; float / double / decimal go through Decimal (not restated: refused) */
+        if (num_kind(from.tag) != NK_NONE && from.tag != RDFGPU_TV_INT && from.tag != RDFGPU_TV_INTEGER) FAIL("SUBSTR with a float / double / decimal position is not restated");
+        if (e->u == 3 && num_kind(len_v.tag) != NK_NONE && len_v.tag != RDFGPU_TV_INT && len_v.tag != RDFGPU_TV_INTEGER) FAIL("SUBSTR with a float / double / decimal length is not restated");
+        if (num_kind(from.tag) == NK_NONE || (e->u == 3 && num_kind(len_v.tag) == NK_NONE)) break;
+        if (from.lo < 1 || (e->u == 3 && len_v.lo < 0)) break;           /* usize::try_from(negative) / index 0: errors */
+        size_t starts[4096]; size_t nch = 0;                              /* byte offset of every character */
+        for (size_t i = 0; i < qn; i += utf8_len(q[i])) { if (nch >= 4096) FAIL("SUBSTR over more than 4096 characters"); starts[nch++] = i; }
+        size_t c0 = (size_t)(from.lo - 1), b0, b1;
+        if (c0 >= nch) { b0 = b1 = qn; }
+        else { b0 = starts[c0]; size_t c1 = e->u == 3 ? c0 + (size_t)len_v.lo : nch; b1 = c1 >= nch ? qn : starts[c1]; }
+        unsigned char* buf = arena_take(b1 - b0);
+        if (!buf) FAIL("string arena exhausted");
+        memcpy(buf, q + b0, b1 - b0);
+        v = tv_computed_string(buf, b1 - b0, a.aux);
+        break; }
+      case RDFGPU_EX_UCASE: case RDFGPU_EX_LCASE: {   /* ucase.rs / lcase.rs: str::to_uppercase / to_lowercase, language kept */
+        if (sp < 1 || st[sp - 1].kind != 1) FAIL("UCASE / LCASE needs a typed value");
+        val a = st[--sp]; const unsigned char* q; size_t qn;
+        v = tv_null();
+        if (!str_bytes(s, &a, &q, &qn)) break;
+        unsigned char* buf = arena_take(qn);
+        if (!buf) FAIL("string arena exhausted");
+        for (size_t i = 0; i < qn; i++) {
+          if (q[i] >= 0x80) FAIL("UCASE / LCASE over a string with non-ASCII characters needs Unicode case tables (not restated)");
+          buf[i] = e->op == RDFGPU_EX_UCASE ? (unsigned char)((q[i] >= 'a' && q[i] <= 'z') ? q[i] - 32 : q[i]) : (unsigned char)((q[i] >= 'A' && q[i] <= 'Z') ? q[i] + 32 : q[i]);
+        }
+        v = tv_computed_string(buf, qn, a.aux);
         break; }
       case RDFGPU_EX_EBV: if (sp < 1 || st[sp - 1].kind != 1) FAIL("EBV needs a typed value"); { val a = st[--sp]; v.kind = 2; v.b = tv_ebv(&a); } break;
       case RDFGPU_EX_ID_EQ: case RDFGPU_EX_ID_NEQ: {
@@ -751,6 +846,28 @@ int orc_eval_tv(const orc_store* s, const rdfgpu_expr_node* prog, u32 n, const u
     out[i].tag = v.tag; out[i].flags = v.flags; out[i].aux = v.aux; out[i].lo = v.lo; out_hi[i] = 0;
     if (v.tag == RDFGPU_TV_DECIMAL) { out[i].lo = (int64_t)(u64)v.dec; out_hi[i] = (int64_t)(v.dec >> 64); }
   }
+  return 0;
+}
+
+/* the string table (REGEX patterns / string constants) the next orc_eval_* calls of this thread refer to */
+void orc_eval_set_table(const rdfgpu_regex* regexes, u32 n_regexes) { g_regexes = regexes; g_n_regexes = n_regexes; }
+int orc_eval_str(const orc_store* s, const rdfgpu_expr_node* prog, u32 n, const rdfgpu_regex* regexes, u32 n_regexes,
+                 const u32* const* cols, u32 n_cols, u64 n_rows, uint8_t* out_state, u32* out_lang, u64* out_off, uint8_t* out_bytes, u64 cap) {
+  g_regexes = regexes; g_n_regexes = n_regexes;
+  u64 at = 0;
+  for (u64 i = 0; i < n_rows; i++) {
+    rowctx r = {cols, n_cols, i, NULL, 0, 0}; val v;
+    out_off[i] = at;
+    if (eval_prog(s, prog, n, &r, &v)) return -1;
+    if (v.kind != 1) FAIL("program does not yield a typed value");
+    const unsigned char* p; size_t len;
+    out_state[i] = 0; out_lang[i] = 0;
+    if (!str_bytes(s, &v, &p, &len)) continue;
+    if (at + len > cap) FAIL("orc_eval_str: output buffer of %llu bytes is too small", (unsigned long long)cap);
+    memcpy(out_bytes + at, p, len); at += len;
+    out_state[i] = 1; out_lang[i] = v.aux;
+  }
+  out_off[n_rows] = at;
   return 0;
 }
 

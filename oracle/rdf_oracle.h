@@ -110,6 +110,14 @@ int orc_eval_bool(const orc_store* s, const rdfgpu_expr_node* prog, uint32_t n, 
 int orc_eval_tv(const orc_store* s, const rdfgpu_expr_node* prog, uint32_t n, const uint32_t* const* cols,
                 uint32_t n_cols, uint64_t n_rows, rdfgpu_typed_value* out, int64_t* out_hi);
 
+void orc_eval_set_table(const rdfgpu_regex* regexes, uint32_t n_regexes);
+/* A program that leaves a STRING on the stack, with the plan's string table (REGEX patterns / string constants) it refers to:
+   out_state[i] = 0 the error value / not a string, 1 a string whose bytes are out_bytes[out_off[i] .. out_off[i + 1]); out_lang[i] =
+   its language id.  out_off has n_rows + 1 entries; returns -1 (orc_last_error) when out_bytes (cap bytes) is too small. */
+int orc_eval_str(const orc_store* s, const rdfgpu_expr_node* prog, uint32_t n, const rdfgpu_regex* regexes, uint32_t n_regexes,
+                 const uint32_t* const* cols, uint32_t n_cols, uint64_t n_rows, uint8_t* out_state, uint32_t* out_lang,
+                 uint64_t* out_off, uint8_t* out_bytes, uint64_t cap);
+
 #ifdef __cplusplus
 }
 #endif

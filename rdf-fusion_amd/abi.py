@@ -5,7 +5,7 @@ test-only CPU checker binding can describe a plan with the same structs.
 """
 import ctypes as C
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 # status codes
 OK, END = 0, 1
@@ -27,7 +27,8 @@ TVF_EMPTY_STRING = 1
 # expression ops
 (EX_COLUMN, EX_LIT_ID, EX_LIT_TV, EX_ENC_TV, EX_GT, EX_LT, EX_GEQ, EX_LEQ, EX_EQ, EX_ADD, EX_SUB,
  EX_EBV, EX_ID_EQ, EX_ID_NEQ, EX_AND, EX_OR, EX_NOT, EX_IS_COMPATIBLE, EX_BOUND, EX_BOOL_AS_TV,
- EX_LIT_BOOL, EX_NEQ, EX_REGEX, EX_CONTAINS, EX_STRSTARTS, EX_STRENDS, EX_LANG_IN, EX_REGEX_VAR) = range(1, 29)
+ EX_LIT_BOOL, EX_NEQ, EX_REGEX, EX_CONTAINS, EX_STRSTARTS, EX_STRENDS, EX_LANG_IN, EX_REGEX_VAR,
+ EX_STR, EX_LIT_STR, EX_STRLEN, EX_SUBSTR, EX_UCASE, EX_LCASE) = range(1, 35)
 
 # plan nodes
 (NODE_DATA_SOURCE, NODE_FILTER, NODE_HASH_JOIN, NODE_CROSS_JOIN, NODE_NESTED_LOOP_JOIN,
@@ -92,7 +93,8 @@ class Metrics(C.Structure):
     _fields_ = [("output_rows", C.c_uint64), ("input_rows", C.c_uint64),
                 ("intermediate_rows", C.c_uint64), ("device_bytes", C.c_uint64),
                 ("elapsed_compute_ms", C.c_double), ("kernels_launched", C.c_uint32),
-                ("host_syncs", C.c_uint32)]
+                ("host_syncs", C.c_uint32), ("exact_reruns", C.c_uint32), ("device_mallocs", C.c_uint32),
+                ("device_malloc_ms", C.c_double), ("tables_built", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class KernelStat(C.Structure):
@@ -141,7 +143,7 @@ assert C.sizeof(ExprNode) == 24
 EXPORTED_SYMBOLS = [
     "rdfgpu_last_error", "rdfgpu_abi_version",
     "rdfgpu_store_create", "rdfgpu_store_destroy", "rdfgpu_store_extend", "rdfgpu_store_extend_device",
-    "rdfgpu_store_remove", "rdfgpu_store_clear", "rdfgpu_store_remove_graph", "rdfgpu_store_len", "rdfgpu_store_set_typed_values", "rdfgpu_store_set_strings",
+    "rdfgpu_store_remove", "rdfgpu_store_clear", "rdfgpu_store_drop_tables", "rdfgpu_store_remove_graph", "rdfgpu_store_len", "rdfgpu_store_set_typed_values", "rdfgpu_store_set_strings",
     "rdfgpu_store_read_index",
     "rdfgpu_plan_compile", "rdfgpu_plan_destroy", "rdfgpu_plan_bind_table", "rdfgpu_plan_execute",
     "rdfgpu_plan_result_info", "rdfgpu_plan_result_device", "rdfgpu_plan_fetch", "rdfgpu_plan_next",

@@ -67,6 +67,7 @@ int rdfgpu_store_remove(rdfgpu_store* store, const uint32_t* g, const uint32_t* 
   ABI_END
 }
 int rdfgpu_store_clear(rdfgpu_store* store) { ABI_BEGIN S(store)->clear(); ABI_END }
+int rdfgpu_store_drop_tables(rdfgpu_store* store) { ABI_BEGIN S(store)->drop_tables(); ABI_END }
 int rdfgpu_store_remove_graph(rdfgpu_store* store, uint32_t graph, uint64_t* removed) {
   ABI_BEGIN
   const u64 r = S(store)->remove_graph(graph);

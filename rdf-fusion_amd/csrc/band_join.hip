@@ -36,6 +36,7 @@
 
 namespace rdfgpu {
 
+static inline dim3 grid256(u64 n) { const u64 g = (n + 255) / 256; return dim3((unsigned)(g ? g : 1)); }
 constexpr u32 kBandInvalidLo = 0xFFFFFFFFu;   // a row / window that nothing can pass: (x - 0xFFFFFFFF) <= 0 never holds for x < 2^32 - 1
 
 // ---- partition of the probe side by key ----------------------------------------------------------------------------
@@ -94,6 +95,31 @@ __device__ __forceinline__ void band_pack_interval(u32 lo, u32 w, u32& lo16, u32
   const u64 hi = (u64)lo + w;
   lo16 = lo; w16 = (u32)(hi < 65534ull ? hi : 65534ull) - lo;      // a dead entry (x = 0) gives 65536 - lo > w16: never passes
 }
+// What the pair test needs of ONE probe row: its windows as biased intervals (packed to 2 x 16 bits when the plan says so), given
+// the ids of the window operands and the id operand x of the base join's filter.  flags: 1 = some operand is not an xsd:integer
+// (the row takes the full typed-value semantics, its record passes nothing), 2 = x is null.
+__device__ __forceinline__ void band_row_record(const BandArgs& b, const u32 iy0[2], const u32 iy1[2], u32 x, uint4& rec, u32& flags) {
+  rec = make_uint4(1u, 0u, 1u, 0u);              // no window: entries carry x_b = 1 (0 when the entry is dead)
+  flags = 0;
+#pragma unroll
+  for (u32 w = 0; w < 2; w++) {
+    if (w >= b.n_win) continue;
+    const BandWin& bw = b.win[w];
+    long long lo, hi;
+    uint2 iv = make_uint2(kBandInvalidLo, 0u);
+    if (band_window_of(b.tt, bw, iy0[w], iy1[w], lo, hi)) iv = band_interval(lo, hi, bw.vbase);
+    else flags |= 1u;                                  // slow row: full semantics per pair
+    if (w == 0) { rec.x = iv.x; rec.y = iv.y; } else { rec.z = iv.x; rec.w = iv.y; }
+  }
+  if (b.has_neq && x == 0) { rec.x = kBandInvalidLo; rec.y = 0u; flags = 2u; }   // null => the comparison is not `true`
+  if (flags & 1u) { rec.x = kBandInvalidLo; rec.y = 0u; }   // the register test must not pass a slow row
+  if (b.pack16) {   // the pair test's packed form: both windows' {lo, width} as 2 x 16 bits each — once per row here, not once per row and block there
+    u32 l0, w0, l1, w1;
+    band_pack_interval(rec.x, rec.y, l0, w0);
+    band_pack_interval(rec.z, rec.w, l1, w1);
+    rec = make_uint4(l0 | (l1 << 16), w0 | (w1 << 16), 0u, 0u);
+  }
+}
 // One atomic per RUN of equal keys among neighbouring lanes of a wave instead of one per lane: the re-sharded probe side of
 // a sharded step arrives as N sorted runs, so neighbouring rows share their key (any input is handled: a lane whose
 // neighbours differ is a run of one).  Every lane of the wave calls it; returns the lane's own position (counter value
@@ -136,34 +162,49 @@ __global__ __launch_bounds__(256) void band_decode_kernel(const BandArgs b) {
   if (j >= b.n_probe_cap) return;
   b.skey_in[j] = k; b.sval_in[j] = (u32)j;
   if (k == b.kn) return;
-  uint4 rec = make_uint4(1u, 0u, 1u, 0u);              // no window: entries carry x_b = 1 (0 when the entry is dead)
-  u32 flags = 0;
+  u32 iy0[2] = {0u, 0u}, iy1[2] = {0u, 0u};
 #pragma unroll
-  for (u32 w = 0; w < 2; w++) {
-    if (w >= b.n_win) continue;
-    const BandWin& bw = b.win[w];
-    long long lo, hi;
-    uint2 iv = make_uint2(kBandInvalidLo, 0u);
-    if (band_window_of(b.tt, bw, bw.y0[j], bw.y1[j], lo, hi)) iv = band_interval(lo, hi, bw.vbase);
-    else flags |= 1u;                                  // slow row: full semantics per pair
-    if (w == 0) { rec.x = iv.x; rec.y = iv.y; } else { rec.z = iv.x; rec.w = iv.y; }
-  }
-  u32 x = 0;
-  if (b.has_neq) { x = b.neq_probe[j]; if (x == 0) { rec.x = kBandInvalidLo; rec.y = 0u; flags = 2u; } }   // null => the comparison is not `true`
-  if (flags & 1u) { rec.x = kBandInvalidLo; rec.y = 0u; atomicAdd(b.slow_rows, 1u); }   // the register test must not pass a slow row
+  for (u32 w = 0; w < 2; w++) if (w < b.n_win) { iy0[w] = b.win[w].y0[j]; iy1[w] = b.win[w].y1[j]; }
+  const u32 x = b.has_neq ? b.neq_probe[j] : 0u;
   u32 rv[kBandMaxRowCols] = {0u, 0u};
 #pragma unroll
   for (u32 u = 0; u < kBandMaxRowCols; u++) if (u < b.n_row_cols) rv[u] = b.row_col[u][j];
-  if (b.pack16) {   // the pair test's packed form: both windows' {lo, width} as 2 x 16 bits each — once per row here, not once per row and block there
-    u32 l0, w0, l1, w1;
-    band_pack_interval(rec.x, rec.y, l0, w0);
-    band_pack_interval(rec.z, rec.w, l1, w1);
-    rec = make_uint4(l0 | (l1 << 16), w0 | (w1 << 16), 0u, 0u);
-  }
+  uint4 rec; u32 flags;
+  band_row_record(b, iy0, iy1, x, rec, flags);
+  if (flags & 1u) atomicAdd(b.slow_rows, 1u);
   if (b.presorted) { b.rec_s[j] = rec; b.aux_s[j] = make_uint4(x, flags, rv[0], rv[1]); return; }   // row order IS the sorted order
   b.rec[2 * j] = rec;
   b.rec[2 * j + 1] = make_uint4(x, flags, rv[0], rv[1]);
 }
+// The probe side comes out of an ordered slice join (ordered_join.hip) whose write pass emits these records itself: everything
+// a record holds is a function of the TABLE row of that join (window operands, id operand, output values travel in its packed
+// record `trec`), so it is decoded here once per table row — 262 144 instances, not 4.85 M matches — and a match copies it.
+__global__ __launch_bounds__(256) void oj_band_records_kernel(const OrderedJoinArgs a, const BandArgs b, const OjBandFuse f) {
+  const u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  for (u64 z = r; z <= f.max_blocks; z += (u64)gridDim.x * blockDim.x) f.bcount[z] = 0u;   // (what the decode pass does on the way)
+  const u64 n = live_rows(a.n_probe_dev, a.n_probe_cap);
+  if (r >= n) return;
+  const u32 key = a.probe_key[r];
+  bool linked = key != 0 && key - a.kmin < a.kn;      // the rows oj_probe_kernel hung into the multimap (only they have a packed record)
+#pragma unroll
+  for (u32 t = 0; t < (u32)kMaxChain; t++) if (t < a.n_stages) linked = linked && a.stage[t].row[r] != kNil;
+  if (!linked) return;
+  const u32* words = reinterpret_cast<const u32*>(a.trec) + r * 4ull * a.n_rec;
+  auto word = [&](u8 slot) { return slot == 0xFFu ? 0u : words[slot]; };
+  u32 iy0[2], iy1[2];
+#pragma unroll
+  for (u32 w = 0; w < 2; w++) { iy0[w] = word(f.y0_slot[w]); iy1[w] = word(f.y1_slot[w]); }
+  const u32 x = word(f.neq_slot);
+  uint4 rec; u32 flags;
+  band_row_record(b, iy0, iy1, x, rec, flags);
+  if (flags & 1u) atomicAdd(b.slow_rows, 1u);
+  f.brec[2 * r] = rec;
+  f.brec[2 * r + 1] = make_uint4(x, flags, word(f.row_slot[0]), word(f.row_slot[1]));
+}
+void launch_oj_band_records(const OrderedJoinArgs& a, const BandArgs& b, const OjBandFuse& f, hipStream_t s) {
+  if (a.n_probe_cap) hipLaunchKernelGGL(oj_band_records_kernel, grid256(a.n_probe_cap), dim3(256), 0, s, a, b, f);
+}
+
 // The records in sorted order: the one random access per probe row (32 contiguous bytes); everything downstream streams.
 __global__ __launch_bounds__(256) void band_rows_kernel(const BandArgs b) {
   const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -538,7 +579,6 @@ __global__ __launch_bounds__(256) void band_emit_kernel(const BandArgs b) {
 }
 
 // ---- host side -------------------------------------------------------------------------------------------------------
-static inline dim3 grid256(u64 n) { const u64 g = (n + 255) / 256; return dim3((unsigned)(g ? g : 1)); }
 void launch_band_decode(const BandArgs& b, hipStream_t s) {
   if (b.n_probe_cap) hipLaunchKernelGGL(band_decode_kernel, grid256(b.n_probe_cap + 1), dim3(256), 0, s, b);   // (+ 1: the row after the last closes the key boundaries)
 }
@@ -599,6 +639,16 @@ struct BandBlocksOfKey {
     const u32 e = csr_off[k + 1] - csr_off[k], r = poff[k + 1] - poff[k];
     return (e && r) ? ((e + 63) >> 6) * ((r + 63) >> 6) : 0u;
   }
+  __device__ __forceinline__ uint4 group(u32 g, u32 n) const {   // (the one-workgroup scan's input: four consecutive keys)
+    const u32 k = 4u * g;
+    if (k + 4u <= kn && !((reinterpret_cast<uintptr_t>(csr_off) | reinterpret_cast<uintptr_t>(poff)) & 15u)) {   // five neighbouring offsets of each array: one 16-byte load + one word
+      const uint4 c = reinterpret_cast<const uint4*>(csr_off)[g], p = reinterpret_cast<const uint4*>(poff)[g];
+      const u32 c4 = csr_off[k + 4u], p4 = poff[k + 4u];
+      auto blocks = [](u32 e, u32 r) { return (e && r) ? ((e + 63u) >> 6) * ((r + 63u) >> 6) : 0u; };
+      return make_uint4(blocks(c.y - c.x, p.y - p.x), blocks(c.z - c.y, p.z - p.y), blocks(c.w - c.z, p.w - p.z), blocks(c4 - c.w, p4 - p.w));
+    }
+    return make_uint4(k < n ? (*this)(k) : 0u, k + 1u < n ? (*this)(k + 1u) : 0u, k + 2u < n ? (*this)(k + 2u) : 0u, k + 3u < n ? (*this)(k + 3u) : 0u);
+  }
 };
 size_t band_blocks_scan_temp_bytes(u32 kn) {
   size_t bytes = 0;
@@ -607,6 +657,7 @@ size_t band_blocks_scan_temp_bytes(u32 kn) {
   return bytes + 256;
 }
 void band_blocks_scan(const u32* csr_off, const u32* poff, u32 kn, u32* boff, void* temp, size_t temp_bytes, hipStream_t s) {
+  if (launch_small_scan<false>(BandBlocksOfKey{csr_off, poff, kn}, boff, (u64)kn + 1, s)) return;
   auto in = rocprim::make_transform_iterator(rocprim::make_counting_iterator<u32>(0u), BandBlocksOfKey{csr_off, poff, kn});
   RDFGPU_HIP(rocprim::exclusive_scan(temp, temp_bytes, in, boff, 0u, (size_t)kn + 1, rocprim::plus<u32>(), s));
 }

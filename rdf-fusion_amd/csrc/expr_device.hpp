@@ -26,6 +26,7 @@ struct ExprProgram {
   uint32_t pad;
   rdfgpu_expr_node nodes[kMaxExpr];
   const RegexProg* regex;        // the plan's compiled REGEX patterns (device memory), indexed by REGEX nodes' `u`
+  const uint8_t* str_consts;     // bytes of the plan's string constants (RDFGPU_EX_LIT_STR): entry u = [regex[u].first, + regex[u].n_pos)
 };
 
 struct TypedTable {
@@ -37,7 +38,9 @@ struct TypedTable {
   const uint8_t* heap;
   uint64_t n_str_ids;
   uint32_t* rt_error;            // the executing plan's run-time error flags (null outside a plan): bit 0 a REGEX with a Perl
-                                 // class / word boundary met a non-ASCII subject, bit 1 a per-row REGEX pattern was not announced
+                                 // class / word boundary met a non-ASCII subject, bit 1 a per-row REGEX pattern was not announced,
+                                 // bit 2 a string expression met what the device does not restate (case mapping of a non-ASCII
+                                 // string, a non-integer SUBSTR argument)
 };
 
 // Value kinds on the evaluation stack.
@@ -49,6 +52,13 @@ struct Val {
   uint32_t aux;   // TV: language id / datatype id
   uint8_t kind, tag, flags, pad;
 };
+// String VIEWS (RDFGPU_EX_STR / LIT_STR / SUBSTR / UCASE / LCASE): tag STRING with `pad` saying where the bytes are —
+//   0  a dictionary string as ENC_TV delivers it: lo = rank in `str` order, hi = object id (its lexical form is in the heap)
+//   1  a window of the heap's lexical form of object id (u32)hi:   lo = (first byte << 32) | bytes
+//   2  a window of the plan's string constant (u32)hi:             lo = (first byte << 32) | bytes
+// and flags bits 4 / 5 an ASCII upper / lower case mapping applied when a byte is read.  Nothing is materialised.
+constexpr uint8_t kStrUpper = 0x10, kStrLower = 0x20;
+constexpr uint32_t kRtStringUnsupported = 4u;
 
 typedef __int128 i128_t;
 typedef unsigned __int128 u128_t;
@@ -251,23 +261,46 @@ __device__ __forceinline__ uint32_t tv_ebv(const Val& v) {
 // The error value with aux = kRegexNeedsUnicode: "a Perl class / word boundary met a non-ASCII subject" — a per-term
 // verdict pass (no plan to fail) records it as verdict 3; a row that actually reads such a verdict raises the run-time error.
 constexpr uint32_t kRegexNeedsUnicode = 0xFFFFFFFFu;
-__device__ __forceinline__ Val tv_regex(const RegexProg& p, const TypedTable& t, const Val& v, int64_t rhs_lang = -1) {
+// The bytes of a string value: false when it has none on the device (not a string; an id without a lexical form in the heap).
+struct StrBytes { const uint8_t* p; uint64_t len; uint32_t xf; };   // xf: 0 as stored, 1 ASCII upper, 2 ASCII lower
+__device__ __forceinline__ bool str_bytes(const ExprProgram* prog, const TypedTable& t, const Val& v, StrBytes& s) {
+  if (v.tag != RDFGPU_TV_STRING) return false;
+  s.xf = (v.flags & kStrUpper) ? 1u : (v.flags & kStrLower) ? 2u : 0u;
+  if (v.pad == 2) {
+    if (prog == nullptr || prog->str_consts == nullptr) return false;
+    s.p = prog->str_consts + prog->regex[(uint32_t)v.hi].first + ((uint64_t)v.lo >> 32); s.len = (uint32_t)v.lo;
+    return true;
+  }
+  const uint64_t id = (uint64_t)(uint32_t)v.hi;
+  if (t.str_off == nullptr || id == 0 || id >= t.n_str_ids) return false;   // (a string literal of the plan given by rank only has no bytes here)
+  const uint64_t b0 = t.str_off[id];
+  if (v.pad == 0) { s.p = t.heap + b0; s.len = t.str_off[id + 1] - b0; }
+  else { s.p = t.heap + b0 + ((uint64_t)v.lo >> 32); s.len = (uint32_t)v.lo; }
+  return true;
+}
+__device__ __forceinline__ uint8_t str_at(const StrBytes& s, uint64_t i) {
+  uint8_t b = s.p[i];
+  if (s.xf == 1u && b >= 'a' && b <= 'z') b -= 32;
+  if (s.xf == 2u && b >= 'A' && b <= 'Z') b += 32;
+  return b;
+}
+__device__ __forceinline__ Val tv_regex(const RegexProg& p, const TypedTable& t, const Val& v, int64_t rhs_lang = -1, const ExprProgram* prog = nullptr) {
   if (v.tag != RDFGPU_TV_STRING || p.always_error || t.str_off == nullptr) return val_tv_null();
   if (rhs_lang > 0 && (int64_t)v.aux != rhs_lang) return val_tv_null();
-  const uint64_t id = (uint64_t)v.hi;
-  if (id == 0 || id >= t.n_str_ids) return val_tv_null();   // a string literal of the plan has no lexical form on the device
-  const uint64_t b0 = t.str_off[id], len = t.str_off[id + 1] - b0;
-  const uint8_t* s = t.heap + b0;
+  StrBytes sb;
+  if (!str_bytes(prog, t, v, sb)) return val_tv_null();   // a string literal of the plan has no lexical form on the device
+  const uint64_t len = sb.len;
+  auto at = [&](uint64_t i) -> uint8_t { return sb.xf ? str_at(sb, i) : sb.p[i]; };
   if (p.ascii_only) {   // `\d \w \s \b` are compiled with their ASCII members: exact on ASCII subjects only
     bool non_ascii = false;
-    for (uint64_t i = 0; i < len; i++) non_ascii = non_ascii || s[i] >= 0x80;
+    for (uint64_t i = 0; i < len; i++) non_ascii = non_ascii || sb.p[i] >= 0x80;
     if (non_ascii) {
       if (t.rt_error) atomicOr(t.rt_error, 1u);
       Val e = val_tv_null(); e.aux = kRegexNeedsUnicode; return e;
     }
   }
-  auto start_ok = [&](uint64_t i) { return !p.anchor_start || i == 0 || (p.ml_start && s[i - 1] == '\n'); };
-  auto end_ok = [&](uint64_t i) { return !p.anchor_end || i == len || (p.ml_end && s[i] == '\n'); };
+  auto start_ok = [&](uint64_t i) { return !p.anchor_start || i == 0 || (p.ml_start && at(i - 1) == '\n'); };
+  auto end_ok = [&](uint64_t i) { return !p.anchor_end || i == len || (p.ml_end && at(i) == '\n'); };
   if (!p.has_assert) {
     if (p.nullable) {
       if (!p.anchor_start && !p.anchor_end) return val_tv_bool(true);
@@ -277,14 +310,14 @@ __device__ __forceinline__ Val tv_regex(const RegexProg& p, const TypedTable& t,
     for (uint64_t i = 0; i < len; i++) {
       uint64_t nxt = start_ok(i) ? p.first : 0;
       for (uint64_t c = cur; c; c &= c - 1) nxt |= p.follow[__builtin_ctzll(c)];
-      cur = nxt & p.byte_mask[s[i]];
+      cur = nxt & p.byte_mask[at(i)];
       if ((cur & p.last) && end_ok(i + 1)) return val_tv_bool(true);
     }
     return val_tv_bool(false);
   }
   // with `\b` / `\B`: every crossing also looks at the word-boundary flag of the point it crosses (ASCII word characters)
   auto isw = [](uint8_t c) { return (c >= '0' && c <= '9') || (c >= 'a' && c <= 'z') || (c >= 'A' && c <= 'Z') || c == '_'; };
-  auto bnd = [&](uint64_t i) { const bool a = i > 0 && isw(s[i - 1]), b = i < len && isw(s[i]); return a != b; };
+  auto bnd = [&](uint64_t i) { const bool a = i > 0 && isw(at(i - 1)), b = i < len && isw(at(i)); return a != b; };
   for (uint64_t i = 0; i <= len; i++)
     if (start_ok(i) && end_ok(i) && (p.nullable || (bnd(i) ? p.nullable_b : p.nullable_nb))) return val_tv_bool(true);
   uint64_t cur = 0;
@@ -292,18 +325,85 @@ __device__ __forceinline__ Val tv_regex(const RegexProg& p, const TypedTable& t,
     const bool bi = bnd(i);
     uint64_t nxt = start_ok(i) ? (p.first | (bi ? p.first_b : p.first_nb)) : 0;
     for (uint64_t c = cur; c; c &= c - 1) { const int k = __builtin_ctzll(c); nxt |= p.follow[k] | (bi ? p.follow_b[k] : p.follow_nb[k]); }
-    cur = nxt & p.byte_mask[s[i]];
+    cur = nxt & p.byte_mask[at(i)];
     if ((cur & (p.last | (bnd(i + 1) ? p.last_b : p.last_nb))) && end_ok(i + 1)) return val_tv_bool(true);
   }
   return val_tv_bool(false);
 }
+// ---- string-valued expressions over views ----------------------------------------------------------------------------
+__device__ __forceinline__ Val val_str_view(uint8_t where, uint32_t src, uint64_t first, uint64_t bytes, uint32_t lang, uint8_t case_bits) {
+  Val v = val_tv_null();
+  v.tag = RDFGPU_TV_STRING; v.pad = where; v.hi = (int64_t)(uint64_t)src; v.lo = (int64_t)((first << 32) | (bytes & 0xFFFFFFFFull));
+  v.aux = lang; v.flags = (uint8_t)((bytes == 0 ? RDFGPU_TVF_EMPTY_STRING : 0u) | case_bits);
+  return v;
+}
+// STR(term) over an object id: the lexical form as written (str.rs:42 in the plain-term encoding)
+__device__ __forceinline__ Val tv_str_of_id(const TypedTable& t, uint32_t id) {
+  if (t.str_off == nullptr || id == 0 || (uint64_t)id >= t.n_str_ids) return val_tv_null();
+  return val_str_view(1, id, 0, t.str_off[id + 1] - t.str_off[id], 0u, 0);
+}
+// STRLEN, strlen.rs: `chars().count()` = bytes that do not continue a UTF-8 sequence
+__device__ __forceinline__ Val tv_strlen(const ExprProgram* prog, const TypedTable& t, const Val& v) {
+  StrBytes s;
+  if (!str_bytes(prog, t, v, s)) return val_tv_null();
+  int64_t n = 0;
+  for (uint64_t i = 0; i < s.len; i++) n += (s.p[i] & 0xC0u) != 0x80u;
+  Val r = val_tv_null(); r.tag = RDFGPU_TV_INTEGER; r.lo = n; return r;
+}
+// SUBSTR(source, start[, length]), sub_str.rs:83-121: 1-based characters; usize::try_from of a negative argument, and start 0, are errors
+__device__ __forceinline__ Val tv_substr(const ExprProgram* prog, const TypedTable& t, const Val& v, const Val& start, const Val* length) {
+  StrBytes s;
+  if (!str_bytes(prog, t, v, s)) return val_tv_null();
+  auto as_int = [&](const Val& x, int64_t& out) {
+    if (x.tag == RDFGPU_TV_INT || x.tag == RDFGPU_TV_INTEGER) { out = x.lo; return true; }
+    if (num_kind(x.tag) != NK_NONE && t.rt_error) atomicOr(t.rt_error, kRtStringUnsupported);   // float / double / decimal -> Integer::try_from is not restated
+    return false;
+  };
+  int64_t st = 0, ln = 0;
+  if (!as_int(start, st) || st < 1) return val_tv_null();
+  if (length && (!as_int(*length, ln) || ln < 0)) return val_tv_null();
+  uint64_t chars = 0, b0 = s.len, b1 = s.len;                  // byte offsets of character (st - 1) and of character (st - 1 + ln)
+  const uint64_t c0 = (uint64_t)st - 1, c1 = length ? c0 + (uint64_t)ln : ~0ull;
+  for (uint64_t i = 0; i < s.len; i++) {
+    if ((s.p[i] & 0xC0u) == 0x80u) continue;
+    if (chars == c0) b0 = i;
+    if (chars == c1) { b1 = i; break; }
+    chars++;
+  }
+  if (b0 > b1) b0 = b1;
+  const uint64_t base = v.pad == 0 ? 0ull : ((uint64_t)v.lo >> 32);
+  return val_str_view(v.pad == 0 ? 1 : v.pad, (uint32_t)v.hi, base + b0, b1 - b0, v.aux, (uint8_t)(v.flags & (kStrUpper | kStrLower)));
+}
+// UCASE / LCASE: ASCII letters on the device; any non-ASCII byte raises the plan's run-time error (Unicode case tables are not restated)
+__device__ __forceinline__ Val tv_case(const ExprProgram* prog, const TypedTable& t, const Val& v, bool upper) {
+  StrBytes s;
+  if (!str_bytes(prog, t, v, s)) return val_tv_null();
+  bool non_ascii = false;
+  for (uint64_t i = 0; i < s.len; i++) non_ascii = non_ascii || s.p[i] >= 0x80;
+  if (non_ascii) { if (t.rt_error) atomicOr(t.rt_error, kRtStringUnsupported); return val_tv_null(); }
+  const uint64_t base = v.pad == 0 ? 0ull : ((uint64_t)v.lo >> 32);
+  return val_str_view(v.pad == 0 ? 1 : v.pad, (uint32_t)v.hi, base, s.len, v.aux, upper ? kStrUpper : kStrLower);
+}
+// two strings of which at least one is a view: `str` order of their bytes (typed_value.rs:184-196 compares the values), same language only
+__device__ __forceinline__ bool str_is_view(const Val& v) { return v.tag == RDFGPU_TV_STRING && (v.pad != 0 || (v.flags & (kStrUpper | kStrLower))); }
+__device__ __forceinline__ int tv_cmp_string_views(const ExprProgram* prog, const TypedTable& t, const Val& a, const Val& b) {
+  if (a.aux != b.aux) return ORD_NONE;
+  StrBytes x, y;
+  if (!str_bytes(prog, t, a, x) || !str_bytes(prog, t, b, y)) {   // one side has no bytes on the device: refused loudly, not answered as an error value
+    if (t.rt_error) atomicOr(t.rt_error, kRtStringUnsupported);
+    return ORD_NONE;
+  }
+  const uint64_t n = x.len < y.len ? x.len : y.len;
+  for (uint64_t i = 0; i < n; i++) { const uint8_t p = str_at(x, i), q = str_at(y, i); if (p != q) return p < q ? -1 : 1; }
+  return x.len < y.len ? -1 : x.len > y.len;
+}
 // REGEX(value, ?pattern): the pattern is a per-row simple literal (regex.rs:59-76, compiled per row there); here every
 // DISTINCT pattern the host announced was compiled at plan time and the row picks its program by the pattern's object id.
 // A pattern that was not announced raises the plan's run-time error (never answered as if it did not match).
-__device__ __forceinline__ Val tv_regex_var(const RegexProg* progs, uint32_t first, uint32_t count, const TypedTable& t, const Val& v, const Val& pat) {
-  if (pat.tag != RDFGPU_TV_STRING || pat.aux != 0) return val_tv_null();   // the pattern must be a simple literal
+__device__ __forceinline__ Val tv_regex_var(const RegexProg* progs, uint32_t first, uint32_t count, const TypedTable& t, const Val& v, const Val& pat, const ExprProgram* prog = nullptr) {
+  if (pat.tag != RDFGPU_TV_STRING || pat.aux != 0 || pat.pad != 0) return val_tv_null();   // the pattern must be a simple literal of the dictionary
   const uint32_t pid = (uint32_t)pat.hi;
-  for (uint32_t k = 0; k < count; k++) if (progs[first + k].pattern_id == pid) return tv_regex(progs[first + k], t, v);
+  for (uint32_t k = 0; k < count; k++) if (progs[first + k].pattern_id == pid) return tv_regex(progs[first + k], t, v, -1, prog);
   if (t.rt_error) atomicOr(t.rt_error, 2u);
   return val_tv_null();
 }
@@ -323,16 +423,24 @@ __device__ __forceinline__ Val eval_program(const ExprProgram& prog, const Typed
       case RDFGPU_EX_ENC_TV: v = enc_tv(tt, (uint32_t)st[--sp].lo); break;
       case RDFGPU_EX_GT: case RDFGPU_EX_LT: case RDFGPU_EX_GEQ: case RDFGPU_EX_LEQ: case RDFGPU_EX_EQ: case RDFGPU_EX_NEQ: {
         const Val b = st[--sp]; const Val a = st[--sp];
-        const int o = tv_partial_cmp(a, b);
+        const int o = (a.tag == RDFGPU_TV_STRING && b.tag == RDFGPU_TV_STRING && (str_is_view(a) || str_is_view(b))) ? tv_cmp_string_views(&prog, tt, a, b) : tv_partial_cmp(a, b);
         if (o == ORD_NONE) { v = val_tv_null(); break; }
         const bool r = e.op == RDFGPU_EX_GT ? o > 0 : e.op == RDFGPU_EX_LT ? o < 0 : e.op == RDFGPU_EX_GEQ ? o >= 0
                      : e.op == RDFGPU_EX_LEQ ? o <= 0 : e.op == RDFGPU_EX_EQ ? o == 0 : o != 0;
         v = val_tv_bool(r); break; }
       case RDFGPU_EX_ADD: case RDFGPU_EX_SUB: { const Val b = st[--sp]; const Val a = st[--sp]; v = tv_arith(a, b, e.op == RDFGPU_EX_SUB); break; }
       case RDFGPU_EX_EBV: v = val_bool(tv_ebv(st[--sp])); break;
-      case RDFGPU_EX_REGEX: v = tv_regex(prog.regex[e.u], tt, st[--sp]); break;
-      case RDFGPU_EX_REGEX_VAR: { const Val pat = st[--sp]; const Val val = st[--sp]; v = tv_regex_var(prog.regex, e.u, (uint32_t)e.lo, tt, val, pat); break; }
-      case RDFGPU_EX_CONTAINS: case RDFGPU_EX_STRSTARTS: case RDFGPU_EX_STRENDS: v = tv_regex(prog.regex[e.u], tt, st[--sp], e.lo < 0 ? 0 : e.lo); break;
+      case RDFGPU_EX_REGEX: v = tv_regex(prog.regex[e.u], tt, st[--sp], -1, &prog); break;
+      case RDFGPU_EX_REGEX_VAR: { const Val pat = st[--sp]; const Val val = st[--sp]; v = tv_regex_var(prog.regex, e.u, (uint32_t)e.lo, tt, val, pat, &prog); break; }
+      case RDFGPU_EX_CONTAINS: case RDFGPU_EX_STRSTARTS: case RDFGPU_EX_STRENDS: v = tv_regex(prog.regex[e.u], tt, st[--sp], e.lo < 0 ? 0 : e.lo, &prog); break;
+      case RDFGPU_EX_STR: v = tv_str_of_id(tt, (uint32_t)st[--sp].lo); break;
+      case RDFGPU_EX_LIT_STR: v = val_str_view(2, e.u, 0, prog.regex[e.u].n_pos, (uint32_t)(e.lo < 0 ? 0 : e.lo), 0); break;
+      case RDFGPU_EX_STRLEN: v = tv_strlen(&prog, tt, st[--sp]); break;
+      case RDFGPU_EX_SUBSTR: {
+        if (e.u == 3) { const Val ln = st[--sp]; const Val from = st[--sp]; const Val src = st[--sp]; v = tv_substr(&prog, tt, src, from, &ln); }
+        else { const Val from = st[--sp]; const Val src = st[--sp]; v = tv_substr(&prog, tt, src, from, nullptr); }
+        break; }
+      case RDFGPU_EX_UCASE: case RDFGPU_EX_LCASE: v = tv_case(&prog, tt, st[--sp], e.op == RDFGPU_EX_UCASE); break;
       case RDFGPU_EX_LANG_IN: {   // LANGMATCHES(LANG(v), range): one verdict bit per language id (bit 0 = no language)
         const Val a = st[--sp];
         const RegexProg& p = prog.regex[e.u];

@@ -49,6 +49,75 @@ __device__ __forceinline__ u32 wave_incl_scan(u32 v) {
   v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast31 into rows 2 and 3
   return v;
 }
+// ---- scan of up to 64 K counts by ONE workgroup ---------------------------------------------------------------------
+// The scans inside a plan run over tile / key / block COUNTS (5 k - 64 k elements), not over rows: rocPRIM's device scan
+// is two launches with a look-back between them (11 - 15 us each time, a tenth of a BGP scan + FILTER over 2^26 rows; three
+// of them per 0.5 ms Q5 step).  One workgroup of 1024 lanes does it in one launch: lane t loads the 16-byte groups
+// j * 1024 + t (coalesced, all J loads in flight), every wave scans its group sums with DPP moves, the J x 16 wave totals
+// meet in LDS, wave 0 scans those, and the prefixes go back out as 16-byte stores.  Two barriers in all.
+// `In` yields element i (a plain array, or a count computed on the fly from other arrays).
+struct ScanArrayIn {
+  const u32* p;
+  __device__ __forceinline__ uint4 group(u32 g, u32 n) const {
+    if (4u * g + 4u <= n) return reinterpret_cast<const uint4*>(p)[g];
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (4u * g < n) v.x = p[4u * g];
+    if (4u * g + 1u < n) v.y = p[4u * g + 1u];
+    if (4u * g + 2u < n) v.z = p[4u * g + 2u];
+    return v;
+  }
+};
+template <int J, bool INCLUSIVE, class In>
+__global__ __launch_bounds__(1024) void small_scan_kernel(const In in, u32* out, u32 n) {
+  static_assert(J == 4 || J == 8 || J == 16, "J x 16 wave totals are scanned by one wave, J / 4 per lane");
+  __shared__ u32 wt[J * 16];
+  const u32 t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+  uint4 x[J]; u32 sum[J], incl[J];
+#pragma unroll
+  for (int j = 0; j < J; j++) x[j] = in.group((u32)j * 1024u + t, n);
+#pragma unroll
+  for (int j = 0; j < J; j++) {
+    sum[j] = x[j].x + x[j].y + x[j].z + x[j].w;
+    incl[j] = wave_incl_scan(sum[j]);
+    if (lane == 63u) wt[j * 16 + (int)wave] = incl[j];
+  }
+  __syncthreads();
+  if (wave == 0) {   // exclusive scan of the J x 16 totals, in (j, wave) order = element order
+    constexpr int Q = J / 4;
+    u32 a[Q], local = 0;
+#pragma unroll
+    for (int q = 0; q < Q; q++) { a[q] = wt[lane * Q + q]; local += a[q]; }
+    u32 run = wave_incl_scan(local) - local;
+#pragma unroll
+    for (int q = 0; q < Q; q++) { wt[lane * Q + q] = run; run += a[q]; }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < J; j++) {
+    const u32 g = (u32)j * 1024u + t;
+    u32 b = wt[j * 16 + (int)wave] + incl[j] - sum[j];
+    uint4 o;
+    if (INCLUSIVE) { o.x = b + x[j].x; o.y = o.x + x[j].y; o.z = o.y + x[j].z; o.w = o.z + x[j].w; }
+    else { o.x = b; o.y = b + x[j].x; o.z = o.y + x[j].y; o.w = o.z + x[j].z; }
+    if (4u * g + 4u <= n) reinterpret_cast<uint4*>(out)[g] = o;
+    else {
+      if (4u * g < n) out[4u * g] = o.x;
+      if (4u * g + 1u < n) out[4u * g + 1u] = o.y;
+      if (4u * g + 2u < n) out[4u * g + 2u] = o.z;
+    }
+  }
+}
+// true: scanned by one workgroup; false: too many elements (or `out` not 16-byte aligned) — the caller takes rocPRIM's scan
+template <bool INCLUSIVE, class In>
+static inline bool launch_small_scan(const In& in, u32* out, u64 n, hipStream_t s) {
+  if (n == 0) return true;
+  if (n > kSmallScanElems || (reinterpret_cast<uintptr_t>(out) & 15u)) return false;
+  if (n <= 4ull * 4096ull) hipLaunchKernelGGL((small_scan_kernel<4, INCLUSIVE, In>), dim3(1), dim3(1024), 0, s, in, out, (u32)n);
+  else if (n <= 8ull * 4096ull) hipLaunchKernelGGL((small_scan_kernel<8, INCLUSIVE, In>), dim3(1), dim3(1024), 0, s, in, out, (u32)n);
+  else hipLaunchKernelGGL((small_scan_kernel<16, INCLUSIVE, In>), dim3(1), dim3(1024), 0, s, in, out, (u32)n);
+  return true;
+}
+
 // A build-side column at candidate `i`.  Normally i is the build row.  In range-index mode (LdsJoinArgs::range_link) a
 // candidate carries its POSITION in the value-ordered CSR instead: the link column (the stage key, e.g. ?product) is
 // then read from its value-ordered copy — consecutive positions, coalesced — and any other build column through the

@@ -42,6 +42,28 @@ __device__ __forceinline__ u64 wave_partition_point(const u32* c, u64 lo, u64 hi
   return lo + (u64)__popcll(__ballot(below));
 }
 
+// The same with 128 pivots per step (two per lane, both in flight): 129-ary — four dependent memory round trips over 2^26 rows
+// where the 65-ary form takes five.  For kernels whose time IS those round trips (value_runs_kernel: one search per wave,
+// thousands of waves; 512 pivots per step were tried too: three round trips, but eight fully divergent gathers per lane and
+// step cost more than the two round trips they save, 10 -> 19 us).
+template <bool UPPER>
+__device__ __forceinline__ u64 wave_partition_point2(const u32* c, u64 lo, u64 hi, u32 key) {
+  const u32 lane = threadIdx.x & 63;
+  while (hi - lo > 128) {
+    const u64 step = (hi - lo + 128) / 129;
+    const u64 i0 = lo + (u64)(lane + 1u) * step - 1, i1 = lo + (u64)(lane + 65u) * step - 1;   // pivot p sits at lo + (p + 1) step - 1
+    const bool in0 = i0 < hi, in1 = i1 < hi;
+    const u32 v0 = in0 ? c[i0] : 0u, v1 = in1 ? c[i1] : 0u;
+    const u32 cnt = (u32)__popcll(__ballot(in0 && (UPPER ? v0 <= key : v0 < key))) + (u32)__popcll(__ballot(in1 && (UPPER ? v1 <= key : v1 < key)));
+    const u64 nlo = cnt ? lo + (u64)cnt * step : lo;               // pivots are sorted: the ones left of the partition point are a prefix
+    const u64 nhi = cnt < 128 ? lo + (u64)(cnt + 1) * step - 1 : hi;
+    lo = nlo; hi = nhi < hi ? nhi : hi;
+  }
+  const u64 j0 = lo + lane, j1 = lo + 64 + lane;
+  const u32 w0 = j0 < hi ? c[j0] : 0u, w1 = j1 < hi ? c[j1] : 0u;
+  return lo + (u32)__popcll(__ballot(j0 < hi && (UPPER ? w0 <= key : w0 < key))) + (u32)__popcll(__ballot(j1 < hi && (UPPER ? w1 <= key : w1 < key)));
+}
+
 __global__ __launch_bounds__(64) void locate_kernel(const LocateJob* jobs, u32 n_jobs, u64* lo_hi) {
   const u32 j = blockIdx.x;
   if (j >= n_jobs) return;
@@ -432,6 +454,39 @@ __global__ __launch_bounds__(kBlock) void filter_bits_kernel(const FilterStreamA
         bits |= (u32)stream_pred<2>(a, v) << k;
       }
     }
+  } else if constexpr (SHAPE == 4) {
+    // One verdict bit per id of the slice's id range.  The column is the slice's SORTED column: the four ids of a 16-byte group
+    // are neighbours in the id range and almost always share their 32-bit verdict word — two word loads per group (the first id's
+    // and the last id's; they are the same cache line, usually the same word) instead of four, any other word only when an id in
+    // between falls on neither (never, for sorted ids whose ends are at most a word apart; the general case is kept for ids out of
+    // range / unsorted tails).
+    const u32* words = reinterpret_cast<const u32*>(a.verdict);
+    const u64 nvd = a.n_verdict;
+    u32 wx[kStreamRounds], ww[kStreamRounds];
+#pragma unroll
+    for (int it = 0; it < kStreamRounds; it++) {
+      const u32 dx = pv[it].x - a.id_lit, dw = pv[it].w - a.id_lit;
+      wx[it] = (u64)dx < nvd ? words[dx >> 5] : 0u;
+      ww[it] = (u64)dw < nvd ? words[dw >> 5] : 0u;
+    }
+#pragma unroll
+    for (int it = 0; it < kStreamRounds; it++) {
+      const u64 v0 = base + (u64)it * kTile + (u64)threadIdx.x * 4;
+      const u32 val[4] = {pv[it].x, pv[it].y, pv[it].z, pv[it].w};
+      const u32 ix = (val[0] - a.id_lit) >> 5, iw = (val[3] - a.id_lit) >> 5;
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const u32 d = val[r] - a.id_lit;
+        bool keep = false;
+        if ((u64)d < nvd) {
+          const u32 i = d >> 5;
+          const u32 word = (r == 0 || i == ix) ? wx[it] : (r == 3 || i == iw) ? ww[it] : words[i];
+          keep = (word >> (d & 31u)) & 1u;
+        }
+        const u64 v = v0 + r;
+        bits |= (u32)(keep && v >= mis && v < nv) << (it * 4 + r);
+      }
+    }
   } else {
 #pragma unroll
     for (int it = 0; it < kStreamRounds; it++) {
@@ -473,7 +528,7 @@ __global__ __launch_bounds__(256) void value_runs_kernel(const FilterStreamArgs 
   // searches are chains of dependent HBM loads, and two per qualifying id were most of this kernel's time
   const u32 i = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (i > span) return;                                    // wave-uniform
-  const u64 l = i < span ? wave_partition_point<false>(a.pcol, 0, n, first + i) : wave_partition_point<true>(a.pcol, 0, n, first + span - 1u);
+  const u64 l = i < span ? wave_partition_point2<false>(a.pcol, 0, n, first + i) : wave_partition_point2<true>(a.pcol, 0, n, first + span - 1u);
   const bool ok = i < span && stream_pred<2>(a, first + i);   // the same answer in every lane
   if ((threadIdx.x & 63) == 0) { run_lo[i] = (u32)l; if (i < span) run_cnt[i] = ok ? 1u : 0u; }
 }
@@ -543,6 +598,8 @@ __global__ __launch_bounds__(256) void run_copy_kernel(const u32* c_lo, const u3
     k++;
   }
 }
+// (requesting the output columns before the verdict bits have arrived — no dependent round trip bits -> columns, for filters
+//  that keep a good part of their rows — was tried: 85 us against 83, the 8 resident workgroups per CU hide that latency already)
 template <int NOUT>
 __global__ __launch_bounds__(kBlock) void filter_write_kernel(const FilterStreamArgs a) {
   __shared__ u32 rcnt[kStreamRounds][kBlock / 64];
@@ -1127,10 +1184,12 @@ size_t scan_temp_bytes(u64 n) {
 }
 void exclusive_scan_u32(const u32* in, u32* out, u64 n, void* temp, size_t temp_bytes, hipStream_t s) {
   if (!n) return;
+  if (!(reinterpret_cast<uintptr_t>(in) & 15u) && launch_small_scan<false>(ScanArrayIn{in}, out, n, s)) return;   // counts, not rows: one workgroup
   RDFGPU_HIP(rocprim::exclusive_scan(temp, temp_bytes, in, out, 0u, (size_t)n, rocprim::plus<u32>(), s));
 }
 void inclusive_scan_u32(const u32* in, u32* out, u64 n, void* temp, size_t temp_bytes, hipStream_t s) {
   if (!n) return;
+  if (!(reinterpret_cast<uintptr_t>(in) & 15u) && launch_small_scan<true>(ScanArrayIn{in}, out, n, s)) return;
   RDFGPU_HIP(rocprim::inclusive_scan(temp, temp_bytes, in, out, (size_t)n, rocprim::plus<u32>(), s));
 }
 size_t sort_temp_bytes(u64 n) {

@@ -246,6 +246,21 @@ struct OrderedJoinArgs {
   u32* tile_count; u32* tile_off;                                      // per 1024-row tile of the slice (+ 1) and their exclusive scan
   u32* row_head; unsigned char* row_cnt;                               // per slice row, from the count pass: first table row of its chain, chain length (capped at 255: longer chains are re-walked)
 };
+struct BandArgs;
+// The ordered slice join feeding a band join (band_join.hip) writes the band join's ROW RECORDS itself: the windows, the id
+// operand and the row's output values depend on the TABLE row (the query instance) only, so they are decoded once per table
+// row (oj_band_records_kernel) and a match copies 32 bytes — the intermediate table between the two joins is never written,
+// the band join's decode pass (a pass over every match with two typed-value gathers each) does not run.
+struct OjBandFuse {
+  uint4* brec;                       // per table row: {record, aux} as band_decode_kernel would write them for a match of that row
+  uint4* rec_s; uint4* aux_s;        // the band join's row records, in match order (= sorted by the band join's key)
+  u32* poff; u32* bcount; u32 max_blocks;   // key boundaries of the matches; the block counts the decode pass zeroes
+  u32 kmin, kn;                      // the band join's key range
+  const u32* key_col;                // the slice's sorted column: the band join's key of a slice row
+  u8 y0_slot[2], y1_slot[2], neq_slot, row_slot[2], pad;   // words of the packed table record holding the window operands / id operand / output values (0xFF: none)
+};
+void launch_oj_band_records(const OrderedJoinArgs& a, const BandArgs& b, const OjBandFuse& f, hipStream_t s);
+void launch_ordered_join_write_band(const OrderedJoinArgs& a, const OjBandFuse& f, hipStream_t s);
 u64 ordered_join_tiles(u64 n_build);
 void launch_ordered_join_probe(const OrderedJoinArgs& a, hipStream_t s);
 void launch_ordered_join_count(const OrderedJoinArgs& a, hipStream_t s);
@@ -401,6 +416,7 @@ void launch_unique_flags(const u32* c0, const u32* c1, const u32* c2, const u32*
 void launch_scatter_if(const u32* src, const u32* flags, const u32* excl, u32* dst, u64 n, hipStream_t s);
 void launch_mark_removed(const u32* const ix[4], u64 n_ix, const u32* const rm[4], u64 n_rm, u32* keep, hipStream_t s);
 // device-wide scans (rocPRIM; load path + per-join offsets)
+constexpr u64 kSmallScanElems = 16ull * 4096ull;   // scans of up to this many counts run in one workgroup (join_device.hpp: small_scan_kernel)
 size_t scan_temp_bytes(u64 n);
 void exclusive_scan_u32(const u32* in, u32* out, u64 n, void* temp, size_t temp_bytes, hipStream_t s);
 void inclusive_scan_u32(const u32* in, u32* out, u64 n, void* temp, size_t temp_bytes, hipStream_t s);

@@ -173,6 +173,82 @@ __global__ __launch_bounds__(kOjBlock) void oj_write_kernel(const OrderedJoinArg
   }
 }
 
+// Pass 2 when the matches feed a band join (OjBandFuse, kernels.hpp): a match is the 32-byte record of its table row, copied to
+// its position in match order; the key boundaries of the matches (the band join's partition of its probe side: poff[k] = first
+// match whose key is >= k) fall out of the slice's sorted column — a slice row whose key differs from its predecessor's starts
+// the keys in between at its own first match.  Same numbering of matches as oj_write_kernel.
+__global__ __launch_bounds__(kOjBlock) void oj_write_band_kernel(const OrderedJoinArgs a, const OjBandFuse f) {
+  __shared__ u32 starts[kOjTile];
+  __shared__ u32 heads[kOjTile];
+  __shared__ u32 rcnt[kOjRounds][kOjBlock / 64];
+  const u64 base = (u64)blockIdx.x * kOjTile;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const u64 total = a.tile_off[gridDim.x];
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    *a.n_out_dev = total;
+    if (total > a.out_cap) *a.overflow = 1u;
+  }
+  const u32 tile_total = a.tile_count[blockIdx.x];
+  const u64 tile_base = a.tile_off[blockIdx.x];
+  auto key_of = [&](u64 row) { u32 kk = f.kn; if (row < a.n_build) { const u32 v = f.key_col[row]; const u32 d = v - f.kmin; if (v != 0 && d < f.kn) kk = d; } return kk; };
+  auto bounds = [&](u64 row, u64 first_match) {           // the keys that start at slice row `row` (row == n_build closes the table)
+    if (row > a.n_build) return;
+    const u32 from = row > 0 ? key_of(row - 1) + 1u : 0u, to = key_of(row);
+    for (u32 q = from; q <= to && q <= f.kn; q++) f.poff[q] = (u32)(first_match < a.out_cap ? first_match : a.out_cap);
+  };
+  if (tile_total == 0) {                                   // no match in this tile: every row "starts" at the tile's offset
+#pragma unroll
+    for (int it = 0; it < kOjRounds; it++) bounds(base + (u64)it * kOjBlock + threadIdx.x, tile_base);
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0 && base + kOjTile == a.n_build) bounds(a.n_build, total);
+    return;                                                // uniform per workgroup
+  }
+  u32 cnt[kOjRounds], hd[kOjRounds], incl[kOjRounds];
+#pragma unroll
+  for (int it = 0; it < kOjRounds; it++) {
+    const u64 row = base + (u64)it * kOjBlock + threadIdx.x;
+    hd[it] = row < a.n_build ? a.row_head[row] : kNil;
+    cnt[it] = row < a.n_build ? (u32)a.row_cnt[row] : 0u;
+  }
+#pragma unroll
+  for (int it = 0; it < kOjRounds; it++) {
+    u32 c = cnt[it];
+    if (c == 255u) { c = 0; for (u32 r = hd[it]; r != kNil; r = a.next[r]) c++; }
+    cnt[it] = c;
+    incl[it] = wave_incl_scan(c);
+    if (lane == 63) rcnt[it][wave] = incl[it];
+  }
+  __syncthreads();
+  u32 off = 0;
+#pragma unroll
+  for (int it = 0; it < kOjRounds; it++) {
+    u32 woff = off;
+    for (int w = 0; w < wave; w++) woff += rcnt[it][w];
+    off += rcnt[it][0] + rcnt[it][1] + rcnt[it][2] + rcnt[it][3];
+    const u32 st = woff + (incl[it] - cnt[it]);
+    starts[it * kOjBlock + threadIdx.x] = st;
+    heads[it * kOjBlock + threadIdx.x] = hd[it];
+    bounds(base + (u64)it * kOjBlock + threadIdx.x, tile_base + st);
+  }
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0 && base + kOjTile == a.n_build) bounds(a.n_build, total);
+  __syncthreads();
+  const u64 out_cap = a.out_cap;
+  for (u32 j = threadIdx.x; j < tile_total; j += kOjBlock) {
+    u32 lo = 0, hi = kOjTile;
+#pragma unroll
+    for (int step = 0; step < 10; step++) { const u32 mid = (lo + hi) >> 1; if (starts[mid] <= j) lo = mid; else hi = mid; }
+    u32 r = heads[lo];
+    for (u32 k = j - starts[lo]; k; k--) r = a.next[r];
+    const u64 pos = tile_base + j;
+    if (pos >= out_cap) continue;                          // the count stays exact: the plan re-runs with room for all
+    const uint4 r0 = f.brec[2ull * r], r1 = f.brec[2ull * r + 1];
+    f.rec_s[pos] = r0;
+    f.aux_s[pos] = r1;
+  }
+}
+void launch_ordered_join_write_band(const OrderedJoinArgs& a, const OjBandFuse& f, hipStream_t s) {
+  hipLaunchKernelGGL(oj_write_band_kernel, dim3((unsigned)ordered_join_tiles(a.n_build)), dim3(kOjBlock), 0, s, a, f);
+}
+
 void launch_ordered_join_probe(const OrderedJoinArgs& a, hipStream_t s) {
   if (!a.n_probe_cap) return;
   hipLaunchKernelGGL(oj_probe_kernel, dim3((unsigned)((a.n_probe_cap + 255) / 256)), dim3(256), 0, s, a);

@@ -33,6 +33,7 @@ bool is_cmp(u8 op) {
 u32 check_program(const rdfgpu_expr_node* p, u32 n, u32 n_cols, u32 n_regexes = 0) {
   if (n > (u32)kMaxExpr) fail(RDFGPU_ERR_UNSUPPORTED, "expression has %u nodes (max %d)", n, kMaxExpr);
   u32 st[kMaxStack]; int sp = 0;
+  bool views = false, rank_only_string = false;   // computed strings (views) / a string literal given by its rank in the dictionary only
   auto pop = [&](u32 kind, const char* what) {
     if (sp < 1) fail(RDFGPU_ERR_INVALID, "expression: stack underflow at %s", what);
     if (st[--sp] != kind) fail(RDFGPU_ERR_INVALID, "expression: %s got an operand of the wrong kind", what);
@@ -43,7 +44,8 @@ u32 check_program(const rdfgpu_expr_node* p, u32 n, u32 n_cols, u32 n_regexes = 
     switch (e.op) {
       case RDFGPU_EX_COLUMN: if (e.u >= n_cols) fail(RDFGPU_ERR_INVALID, "expression: column %u out of range (%u columns)", e.u, n_cols); out = VK_ID; break;
       case RDFGPU_EX_LIT_ID: out = VK_ID; break;
-      case RDFGPU_EX_LIT_TV: if (e.tag > RDFGPU_TV_OTHER) fail(RDFGPU_ERR_INVALID, "expression: bad literal tag %u", e.tag); out = VK_TV; break;
+      case RDFGPU_EX_LIT_TV: if (e.tag > RDFGPU_TV_OTHER) fail(RDFGPU_ERR_INVALID, "expression: bad literal tag %u", e.tag); out = VK_TV;
+        rank_only_string = rank_only_string || (e.tag == RDFGPU_TV_STRING && e.hi == 0); break;
       case RDFGPU_EX_LIT_BOOL: out = VK_BOOL; break;
       case RDFGPU_EX_ENC_TV: pop(VK_ID, "ENC_TV"); out = VK_TV; break;
       case RDFGPU_EX_GT: case RDFGPU_EX_LT: case RDFGPU_EX_GEQ: case RDFGPU_EX_LEQ: case RDFGPU_EX_EQ: case RDFGPU_EX_NEQ:
@@ -51,9 +53,18 @@ u32 check_program(const rdfgpu_expr_node* p, u32 n, u32 n_cols, u32 n_regexes = 
       case RDFGPU_EX_EBV: pop(VK_TV, "EBV"); out = VK_BOOL; break;
       case RDFGPU_EX_REGEX: case RDFGPU_EX_CONTAINS: case RDFGPU_EX_STRSTARTS: case RDFGPU_EX_STRENDS:
         if (e.u >= n_regexes) fail(RDFGPU_ERR_INVALID, "expression: REGEX pattern %u out of range (%u patterns)", e.u, n_regexes);
-        // the lexical form lives in HBM under the value's object id: the operand has to be ENC_TV(column)
-        if (i < 2 || p[i - 1].op != RDFGPU_EX_ENC_TV || p[i - 2].op != RDFGPU_EX_COLUMN) fail(RDFGPU_ERR_UNSUPPORTED, "REGEX / CONTAINS / STRSTARTS / STRENDS over anything but ENC_TV(column)");
+        // (the operand is any string value: ENC_TV of a column, or a view — STR / SUBSTR / UCASE / LCASE / a constant with bytes)
         pop(VK_TV, "REGEX"); out = VK_TV; break;
+      case RDFGPU_EX_STR: pop(VK_ID, "STR"); out = VK_TV; views = true; break;
+      case RDFGPU_EX_LIT_STR:
+        if (e.u >= n_regexes) fail(RDFGPU_ERR_INVALID, "expression: string constant %u out of range (%u entries)", e.u, n_regexes);
+        out = VK_TV; views = true; break;
+      case RDFGPU_EX_STRLEN: pop(VK_TV, "STRLEN"); out = VK_TV; break;
+      case RDFGPU_EX_SUBSTR:
+        if (e.u != 2 && e.u != 3) fail(RDFGPU_ERR_INVALID, "expression: SUBSTR takes 2 or 3 operands, not %u", e.u);
+        for (u32 k = 0; k < e.u; k++) pop(VK_TV, "SUBSTR");
+        out = VK_TV; views = true; break;
+      case RDFGPU_EX_UCASE: case RDFGPU_EX_LCASE: pop(VK_TV, "UCASE / LCASE"); out = VK_TV; views = true; break;
       case RDFGPU_EX_REGEX_VAR:
         if (e.lo < 1 || (u64)e.u + (u64)e.lo > n_regexes) fail(RDFGPU_ERR_INVALID, "expression: REGEX pattern table %u .. +%lld out of range (%u patterns)", e.u, (long long)e.lo, n_regexes);
         pop(VK_TV, "REGEX pattern"); pop(VK_TV, "REGEX"); out = VK_TV; break;
@@ -71,6 +82,8 @@ u32 check_program(const rdfgpu_expr_node* p, u32 n, u32 n_cols, u32 n_regexes = 
     st[sp++] = out;
   }
   if (sp != 1) fail(RDFGPU_ERR_INVALID, "expression leaves %d values on the stack", sp);
+  // a computed string compares byte-wise; a string literal that comes with its dictionary rank only has no bytes on the device
+  if (views && rank_only_string) fail(RDFGPU_ERR_UNSUPPORTED, "expression mixes computed strings (STR / SUBSTR / UCASE / LCASE) with a string literal given by rank: pass the literal as RDFGPU_EX_LIT_STR");
   return st[0];
 }
 
@@ -104,7 +117,7 @@ int detect_join_filter_shape(const ExprProgram& pr, bool force_vm) {
   return 1;
 }
 
-void load_program(NodeInfo& nd, const rdfgpu_plan_desc* d, u32 n_cols, const char* what, const RegexProg* regex_dev) {
+void load_program(NodeInfo& nd, const rdfgpu_plan_desc* d, u32 n_cols, const char* what, const RegexProg* regex_dev, const unsigned char* str_consts = nullptr) {
   const rdfgpu_plan_node& r = nd.d;
   nd.prog.n = 0;
   if (r.expr_len == 0) return;
@@ -113,6 +126,7 @@ void load_program(NodeInfo& nd, const rdfgpu_plan_desc* d, u32 n_cols, const cha
   nd.prog.n = r.expr_len;
   std::memcpy(nd.prog.nodes, d->exprs + r.expr_off, r.expr_len * sizeof(rdfgpu_expr_node));
   nd.prog.regex = regex_dev;
+  nd.prog.str_consts = str_consts;
 }
 
 void load_projection(NodeInfo& nd, const rdfgpu_plan_desc* d, u32 full, const char* what) {
@@ -157,14 +171,22 @@ Plan* plan_compile(Store* store, const rdfgpu_plan_desc* d) {
         for (int64_t k = 0; k < e.lo && (u64)e.u + (u64)k < d->n_regexes; k++) use[e.u + k] = RDFGPU_EX_REGEX;
         continue;
       }
-      if (e.op != RDFGPU_EX_REGEX && e.op != RDFGPU_EX_CONTAINS && e.op != RDFGPU_EX_STRSTARTS && e.op != RDFGPU_EX_STRENDS && e.op != RDFGPU_EX_LANG_IN) continue;
+      if (e.op != RDFGPU_EX_REGEX && e.op != RDFGPU_EX_CONTAINS && e.op != RDFGPU_EX_STRSTARTS && e.op != RDFGPU_EX_STRENDS && e.op != RDFGPU_EX_LANG_IN && e.op != RDFGPU_EX_LIT_STR) continue;
       if (e.u >= d->n_regexes) fail(RDFGPU_ERR_INVALID, "expression: string pattern %u out of range", e.u);
       if (use[e.u] >= 0 && use[e.u] != (int)e.op) fail(RDFGPU_ERR_INVALID, "string pattern %u is used by two different functions", e.u);
       use[e.u] = (int)e.op;
     }
     std::vector<RegexProg> progs(d->n_regexes);
+    std::vector<unsigned char> consts;   // the bytes of the string constants (RDFGPU_EX_LIT_STR), back to back
     for (u32 r = 0; r < d->n_regexes; r++) {
       const rdfgpu_regex& rx = d->regexes[r];
+      if (use[r] == RDFGPU_EX_LIT_STR) {   // not a pattern: raw bytes — the slot holds where they are
+        std::memset(&progs[r], 0, sizeof(RegexProg));
+        progs[r].first = consts.size(); progs[r].n_pos = rx.pattern_len;
+        if (rx.pattern_len && !rx.pattern) fail(RDFGPU_ERR_INVALID, "string constant %u: null text", r);
+        consts.insert(consts.end(), reinterpret_cast<const unsigned char*>(rx.pattern), reinterpret_cast<const unsigned char*>(rx.pattern) + rx.pattern_len);
+        continue;
+      }
       if (use[r] == RDFGPU_EX_LANG_IN) {   // not a pattern: one verdict byte per language id -> a bit set in the slot
         std::memset(&progs[r], 0, sizeof(RegexProg));
         if (rx.pattern_len > 256u * 64u) fail(RDFGPU_ERR_UNSUPPORTED, "language table %u: %u language ids (max 16384)", r, rx.pattern_len);
@@ -172,7 +194,7 @@ Plan* plan_compile(Store* store, const rdfgpu_plan_desc* d) {
         progs[r].n_pos = rx.pattern_len;
         continue;
       }
-      if (use[r] >= 0 && !store->str_off) fail(RDFGPU_ERR_INVALID, "plan uses REGEX but the store has no strings (rdfgpu_store_set_strings)");
+      if (use[r] >= 0 && !store->str_off) fail(RDFGPU_ERR_INVALID, "plan uses string functions but the store has no strings (rdfgpu_store_set_strings)");
       std::string why;
       const bool literal = use[r] == RDFGPU_EX_CONTAINS || use[r] == RDFGPU_EX_STRSTARTS || use[r] == RDFGPU_EX_STRENDS;
       const char* flags = literal ? "q" : (rx.flags ? rx.flags : "");
@@ -197,8 +219,17 @@ Plan* plan_compile(Store* store, const rdfgpu_plan_desc* d) {
     store->activate();
     RDFGPU_HIP(hipMalloc((void**)&plan->regex_dev, progs.size() * sizeof(RegexProg)));
     RDFGPU_HIP(hipMemcpy(plan->regex_dev, progs.data(), progs.size() * sizeof(RegexProg), hipMemcpyHostToDevice));
+    if (!consts.empty()) {
+      RDFGPU_HIP(hipMalloc((void**)&plan->str_consts_dev, consts.size()));
+      RDFGPU_HIP(hipMemcpy(plan->str_consts_dev, consts.data(), consts.size(), hipMemcpyHostToDevice));
+    }
   }
 
+  for (u32 i = 0; i < d->n_exprs; i++) {
+    const u8 op = d->exprs[i].op;
+    if ((op == RDFGPU_EX_STR || op == RDFGPU_EX_STRLEN || op == RDFGPU_EX_SUBSTR || op == RDFGPU_EX_UCASE || op == RDFGPU_EX_LCASE) && !store->str_off)
+      fail(RDFGPU_ERR_INVALID, "plan uses string functions but the store has no strings (rdfgpu_store_set_strings)");
+  }
   for (u32 i = 0; i < d->n_nodes; i++) {
     NodeInfo& nd = plan->nodes[i];
     nd.d = d->nodes[i];
@@ -220,7 +251,7 @@ Plan* plan_compile(Store* store, const rdfgpu_plan_desc* d) {
       }
       case RDFGPU_NODE_FILTER: {
         const NodeInfo& c = child(r.left, "input");
-        load_program(nd, d, c.width, "FilterExec", plan->regex_dev);
+        load_program(nd, d, c.width, "FilterExec", plan->regex_dev, plan->str_consts_dev);
         load_projection(nd, d, c.width, "FilterExec");
         nd.shape = detect_shape(nd.prog, plan->opt.on(RDFGPU_OPT_FORCE_GENERIC_VM));
         break;
@@ -241,7 +272,7 @@ Plan* plan_compile(Store* store, const rdfgpu_plan_desc* d) {
         }
         if (r.kind == RDFGPU_NODE_CROSS_JOIN && (r.expr_len || r.join_type != RDFGPU_JOIN_INNER)) fail(RDFGPU_ERR_INVALID, "node %u: CrossJoinExec takes no filter / join type", i);
         if (l.width + rr.width > 2u * kMaxCols) fail(RDFGPU_ERR_UNSUPPORTED, "node %u: too many columns", i);
-        load_program(nd, d, l.width + rr.width, "join filter", plan->regex_dev);
+        load_program(nd, d, l.width + rr.width, "join filter", plan->regex_dev, plan->str_consts_dev);
         load_projection(nd, d, l.width + rr.width, "join");
         nd.shape = detect_join_filter_shape(nd.prog, plan->opt.on(RDFGPU_OPT_FORCE_GENERIC_VM));
         if (l.width > (u32)kMaxCols || rr.width > (u32)kMaxCols) fail(RDFGPU_ERR_UNSUPPORTED, "node %u: too many columns", i);
@@ -349,6 +380,14 @@ Plan* plan_compile(Store* store, const rdfgpu_plan_desc* d) {
       if (nd.d.left >= 0) { plan->nodes[nd.d.left].refs++; stack.push_back((u32)nd.d.left); }
       if (binary && nd.d.right >= 0) { plan->nodes[nd.d.right].refs++; stack.push_back((u32)nd.d.right); }
     }
+  }
+  for (u32 i = 0; i < plan->nodes.size(); i++) {   // the one consumer of a node consumed once
+    const NodeInfo& nd = plan->nodes[i];
+    if (nd.d.kind == RDFGPU_NODE_DATA_SOURCE || nd.d.kind == RDFGPU_NODE_TABLE) continue;
+    const bool binary = nd.d.kind == RDFGPU_NODE_HASH_JOIN || nd.d.kind == RDFGPU_NODE_CROSS_JOIN || nd.d.kind == RDFGPU_NODE_NESTED_LOOP_JOIN || nd.d.kind == RDFGPU_NODE_UNION;
+    if (i != plan->root && nd.refs == 0) continue;   // (rewritten away: not an operator of this plan any more)
+    if (nd.d.left >= 0 && plan->nodes[nd.d.left].refs == 1) plan->nodes[nd.d.left].parent = (int)i;
+    if (binary && nd.d.right >= 0 && plan->nodes[nd.d.right].refs == 1) plan->nodes[nd.d.right].parent = (int)i;
   }
   // per-node byte accounting inputs: distinct columns read, typed gathers per row
   for (NodeInfo& nd : plan->nodes) {
@@ -475,11 +514,14 @@ Plan::~Plan() {
   release_intermediates();
   if (pool_dev) (void)hipFree(pool_dev);
   if (regex_dev) (void)hipFree(regex_dev);
+  if (str_consts_dev) (void)hipFree(str_consts_dev);
 
   if (store && ctx) store->release_context(ctx);
   if (store) store->release();
 }
 
+// which scan an n-element scan of counts takes (kernels.hip: one workgroup up to kSmallScanElems elements, rocPRIM's device scan beyond)
+static int scan_class(u64 n) { return n <= kSmallScanElems ? KC_SMALL_SCAN : KC_DEVICE_SCAN; }
 // Names as rocprofv3 --kernel-trace prints them (prefix up to the argument list).
 const char* kernel_class_name(int kc) {
   static const char* const fixed[KC_LDS_JOIN0] = {
@@ -497,7 +539,8 @@ const char* kernel_class_name(int kc) {
       "void rdfgpu::filter_bits_kernel<1>", "void rdfgpu::filter_bits_kernel<2>", "void rdfgpu::filter_bits_kernel<3>", "void rdfgpu::filter_bits_kernel<4>", "rdfgpu::value_verdict_kernel",
       "rdfgpu::value_runs_kernel", "rdfgpu::run_scan_kernel", "rdfgpu::run_copy_kernel",
       "rdfgpu::oj_probe_kernel", "rdfgpu::oj_count_kernel", "void rdfgpu::oj_write_kernel",
-      "void rdfgpu::filter_write_kernel", "rdfgpu::part_keys_kernel", "void rdfgpu::part_join_kernel"};
+      "void rdfgpu::filter_write_kernel", "rdfgpu::part_keys_kernel", "void rdfgpu::part_join_kernel",
+      "rdfgpu::oj_band_records_kernel", "rdfgpu::oj_write_band_kernel", "void rdfgpu::small_scan_kernel"};
   if (kc < KC_LDS_JOIN0) return fixed[kc];
   static std::string names[192];
   static std::once_flag once;
@@ -635,6 +678,8 @@ void Plan::execute() {
   store->pool.trim_to(2 * std::max(scratch_hist[0], scratch_hist[1]) + (1ull << 30));
   held = store->gen;         // ... and the generation it read until its next execute: the result may be zero-copy slices of it
   metrics = rdfgpu_metrics{};
+  const u64 mallocs0 = store->pool.mallocs() + store->table_pool.mallocs();
+  const double malloc_ms0 = store->pool.malloc_ms() + store->table_pool.malloc_ms();
   counters_used = 0;
   progs_used = 0;
   arg_slots_used = 0;
@@ -646,6 +691,7 @@ void Plan::execute() {
   RDFGPU_HIP(hipMemsetAsync(counters, 0, 256 * sizeof(u64), stream));
 
   spec_checks.clear();
+  pending_oj.active = false;
   band_block_counters.clear();
   memo.assign(nodes.size(), DevTable{}); memo_valid.assign(nodes.size(), 0);
   speculative = allow_speculation && !opt.on(RDFGPU_OPT_NO_SPECULATION);
@@ -702,6 +748,7 @@ void Plan::execute() {
   }
 
   result = exec_node(root);
+  flush_pending_oj();
   // one copy brings back every device-side cardinality (the result's and, for timing, the others')
   RDFGPU_HIP(hipMemcpyAsync(ctx->counters_host, counters, 256 * sizeof(u64), hipMemcpyDeviceToHost, stream));
   RDFGPU_HIP(hipEventRecord(ev_stop, stream));
@@ -709,6 +756,8 @@ void Plan::execute() {
   RDFGPU_HIP(hipGetLastError());
   if (const u32 rt = (u32)(ctx->counters_host[255] & 0xFFFFFFFFull)) {   // a row asked for something that is refused loudly, not answered differently
     if (rt & 1u) fail(RDFGPU_ERR_UNSUPPORTED, "REGEX with \\d \\w \\s or \\b over a string with non-ASCII characters needs the regex crate's Unicode tables (not restated)");
+    if (rt & 4u) fail(RDFGPU_ERR_UNSUPPORTED, "a string expression met what the device does not restate: UCASE / LCASE of a string with non-ASCII characters (Unicode case tables), "
+                                               "a float / double / decimal SUBSTR position, or a comparison with a string that has no bytes on the device");
     fail(RDFGPU_ERR_UNSUPPORTED, "REGEX with a per-row pattern: a row's pattern literal was not announced in the plan's pattern table");
   }
   bool slow_missed = false;
@@ -732,6 +781,7 @@ void Plan::execute() {
     allow_speculation = false;
     try { execute(); } catch (...) { allow_speculation = true; throw; }
     allow_speculation = true;
+    metrics.exact_reruns = 1;
     return;
   }
   result_rows = result.n_dev ? ctx->counters_host[result.n_dev - counters] : result.cap;
@@ -740,6 +790,8 @@ void Plan::execute() {
   RDFGPU_HIP(hipEventElapsedTime(&ms, ev_start, ev_stop));
   metrics.elapsed_compute_ms = ms;
   metrics.output_rows = result_rows;
+  metrics.device_mallocs = (u32)(store->pool.mallocs() + store->table_pool.mallocs() - mallocs0);
+  metrics.device_malloc_ms = store->pool.malloc_ms() + store->table_pool.malloc_ms() - malloc_ms0;
   resolve_timing();
   executed = true;
   scratch_hist[1] = scratch_hist[0]; scratch_hist[0] = metrics.device_bytes;
@@ -853,7 +905,7 @@ DevTable Plan::exec_source(NodeInfo& nd) {
   u32 n_pred_cols = 0;   // columns the residual predicates read
   for (int k = 0; k < 4; k++) n_pred_cols += job.pred[k].kind != RDFGPU_PRED_NONE && job.pred[k].kind != RDFGPU_PRED_FALSE;
   timed(KC_SCAN_COUNT, 0, n, nullptr, 4ull * n_pred_cols, nullptr, 0, 0, [&] { launch_scan_count(job, counts, stream); });
-  timed(KC_DEVICE_SCAN, 0, n_blocks + 1, nullptr, 8, nullptr, 0, 0, [&] { exclusive_scan_u32(counts, offs, n_blocks + 1, temp, tb, stream); });
+  timed(scan_class(n_blocks + 1), 0, n_blocks + 1, nullptr, 8, nullptr, 0, 0, [&] { exclusive_scan_u32(counts, offs, n_blocks + 1, temp, tb, stream); });
   u32 total = 0;
   RDFGPU_HIP(hipMemcpyAsync(&total, offs + n_blocks, 4, hipMemcpyDeviceToHost, stream));
   RDFGPU_HIP(hipStreamSynchronize(stream)); metrics.host_syncs++;
@@ -930,6 +982,8 @@ DevTable Plan::apply_filter(NodeInfo& nd, const DevTable& in) {
       a.stream_bits = reinterpret_cast<unsigned short*>(scratch<u32>(1)); a.stream_counts = scratch<u32>(1); a.stream_offs = a.stream_counts;   // (the argument block wants them non-null)
       RunCopyBuffers b{scratch<u32>(span + 1), scratch<u32>(span), scratch<u32>(span + 1), scratch<u32>(span + 1), scratch<u32>(span + 1), scratch<u32>(1)};   // (run_lo: one entry past the last id)
       timed(KC_VALUE_RUNS, 0, span, nullptr, 16, nullptr, 0, 0, [&] { launch_value_runs(a, b, stream); });
+      // (one launch for scan + copy — 2048 workgroups that each scan the run lengths in LDS and copy an equal share — was tried: 68 us
+      //  against 6 + 51: the big chunks do not hide their memory latency the way 16 K small workgroups do)
       timed(KC_RUN_SCAN, 0, span, nullptr, 8, nullptr, 0, 0, [&] { launch_run_scan(a, b, stream); });
       timed(KC_RUN_COPY, 0, 0, nullptr, 0, a.n_out_dev, 0, 8ull * nd.n_proj, [&] { launch_run_copy(a, b, stream); });
       t.cap = in.cap; t.n_dev = a.n_out_dev;
@@ -959,7 +1013,7 @@ DevTable Plan::apply_filter(NodeInfo& nd, const DevTable& in) {
     }
     const int kc1 = shape == 1 ? KC_FILTER_BITS_ID : shape == 2 ? KC_FILTER_BITS_TV : shape == 4 ? KC_FILTER_BITS_VALUE : KC_FILTER_BITS_VERDICT;
     timed(kc1, tiles * 4, in.cap, in.n_dev, 4, nullptr, 0, 0, [&] { launch_filter_bits(a, shape, stream); });
-    timed(KC_DEVICE_SCAN, 0, tiles + 1, nullptr, 8, nullptr, 0, 0, [&] { exclusive_scan_u32(a.stream_counts, a.stream_offs, tiles + 1, a.stream_temp, a.stream_temp_bytes, stream); });
+    timed(scan_class(tiles + 1), 0, tiles + 1, nullptr, 8, nullptr, 0, 0, [&] { exclusive_scan_u32(a.stream_counts, a.stream_offs, tiles + 1, a.stream_temp, a.stream_temp_bytes, stream); });
     timed(KC_FILTER_WRITE, tiles * 8, in.cap, in.n_dev, 4ull * nd.n_proj, a.n_out_dev, 0, 4ull * nd.n_proj, [&] { launch_filter_write(a, shape, stream); });
     t.cap = in.cap; t.n_dev = a.n_out_dev;
     return t;
@@ -1089,6 +1143,14 @@ bool Plan::plan_chain(NodeInfo& top, ChainRequest& req) {
       if (S.cap == 0 || S.stable_id == 0) continue;
       SliceKey sk; sk.n_keys = 1; sk.rows = S.cap; sk.key[0] = S.cols[side == 0 ? d.left_keys[0] : d.right_keys[0]];
       const SliceTable* st = store->find_slice_table(sk);
+      if ((!st || !st->dense_tried) && S.n_dev == nullptr && S.cap > std::min<u64>(opt.v[RDFGPU_OPT_LDS_MAX_BUILD], kLdsJoinMaxBuild) && !opt.on(RDFGPU_OPT_NO_DIRECT_TABLE)) {
+        // the store changed since this chain last ran (its history is still good): the slice's table is built here, inside
+        // the execution, and the chain stays fused — no un-fused execution just to get the tables back
+        SliceTable* fresh = store->slice_table(sk);
+        std::unique_lock<std::mutex> building(store->slice_build_mu);
+        if (!fresh->dense_tried) build_dense_table(fresh, sk.key[0], S.cap);
+        st = fresh;
+      }
       if (!st || !st->direct) continue;
       down.push_back(ChainLink{cur, side == 0, S, st});
       cur = &nodes[co];
@@ -1158,15 +1220,15 @@ bool Plan::apply_chain(const ChainRequest& req, NodeInfo& base, const DevTable& 
       for (auto& v : tab->values) if (v.col == st.f[0].ptr) vc = &v;
       if (!vc) {
         const u32 key_local = ln.slice_is_left ? N.d.left_keys[0] : N.d.right_keys[0];
-        long long* val = nullptr;
-        RDFGPU_HIP(hipMalloc((void**)&val, (size_t)tab->kn * sizeof(long long)));
+        long long* val = store->table_alloc<long long>(tab->kn);
+        metrics.tables_built++;
         u32* bad = reinterpret_cast<u32*>(new_counter());
         launch_fill_i64(val, INT64_MIN, tab->kn, stream);
         launch_direct_values(ln.slice.cols[key_local], st.f[0].ptr, ln.slice.cap, tab->kmin, tab->kn, typed_table(), val, bad, stream);
         u32 is_bad = 0;
         RDFGPU_HIP(hipMemcpyAsync(&is_bad, bad, sizeof(u32), hipMemcpyDeviceToHost, stream));
         RDFGPU_HIP(hipStreamSynchronize(stream)); metrics.host_syncs++;
-        if (is_bad) { RDFGPU_HIP(hipFree(val)); val = nullptr; }
+        if (is_bad) { store->table_free(val); val = nullptr; }
         SliceTable::ValueColumn fresh{st.f[0].ptr, val, val != nullptr};
         if (val) {   // value range: the bias of the band join's 32-bit window intervals
           long long* mm = reinterpret_cast<long long*>(new_counter()); (void)new_counter();
@@ -1271,15 +1333,16 @@ bool Plan::apply_chain(const ChainRequest& req, NodeInfo& base, const DevTable& 
         RDFGPU_HIP(hipStreamSynchronize(stream)); metrics.host_syncs++;
         if (got[0] <= got[1] && (unsigned long long)(got[1] - got[0]) < 0xFFFFFFF0ull && n < (1ull << 32)) {
           u64* key_in = scratch<u64>(n); u64* key_out = scratch<u64>(n); u32* rows_in = scratch<u32>(n);
-          RDFGPU_HIP(hipMalloc((void**)&fresh.rows, n * sizeof(u32)));
-          RDFGPU_HIP(hipMalloc((void**)&fresh.vals, n * sizeof(u32)));
+          fresh.rows = store->table_alloc<u32>(n);
+          fresh.vals = store->table_alloc<u32>(n);
+          metrics.tables_built++;
           fresh.vbase = got[0];
           launch_range_keys(a.build_key[0], a.direct_min, s0.key.ptr, a.csr_rows, n, s0.val, s0.kmin, s0.kn, got[0], key_in, rows_in, stream);
           const size_t tb = sort_temp_bytes(n);
           void* temp = scratch<unsigned char>(tb);
           sort_pairs_u64_u32(key_in, key_out, rows_in, fresh.rows, n, temp, tb, stream);
           launch_range_decode(key_out, n, fresh.vals, stream);
-          RDFGPU_HIP(hipMalloc((void**)&fresh.link, n * sizeof(u32)));
+          fresh.link = store->table_alloc<u32>(n);
           launch_gather_u32(s0.key.ptr, fresh.rows, fresh.link, n, stream);   // the link column in index order
           RDFGPU_HIP(hipStreamSynchronize(stream)); metrics.host_syncs++;
           fresh.usable = true;
@@ -1295,6 +1358,14 @@ bool Plan::apply_chain(const ChainRequest& req, NodeInfo& base, const DevTable& 
   for (size_t k = 0; k < cur.size(); k++) a.chain_out[k] = cur[k];
   a.n_out_cols = (u32)cur.size();
   return true;
+}
+
+// The held-back write pass of an ordered slice join, run after all: its consumer turned out not to take the band join's records.
+void Plan::flush_pending_oj() {
+  if (!pending_oj.active) return;
+  pending_oj.active = false;
+  const OrderedJoinArgs& o = pending_oj.o;
+  timed(KC_OJ_WRITE, 0, pending_oj.n_build, nullptr, 4, o.n_out_dev, 0, 8ull * o.n_out_cols, [&] { launch_ordered_join_write(o, stream); });
 }
 
 DevTable Plan::exec_join(NodeInfo& nd) {
@@ -1329,6 +1400,7 @@ DevTable Plan::exec_join(NodeInfo& nd) {
   DevTable L = lf ? exec_node((u32)nodes[nd.d.left].d.left) : exec_node((u32)nd.d.left);
   DevTable R = rf ? exec_node((u32)nodes[nd.d.right].d.left) : exec_node((u32)nd.d.right);
   pending_chain = for_this_join;
+  if (pending_oj.active && !(nd.band_takes_records && nd.d.kind == RDFGPU_NODE_HASH_JOIN && !left_join && !lf && !rf)) flush_pending_oj();
   const NodeInfo* post = nullptr;   // a build-side FilterExec kept as a conjunct of the join filter (see below)
   if (lf || rf) {
     // `col <=|!=> literal` over a store slice: if the join builds on that slice (index join through the slice's cached
@@ -1350,6 +1422,7 @@ DevTable Plan::exec_join(NodeInfo& nd) {
   t.n_cols = nd.n_proj;
 
   if (nd.d.kind == RDFGPU_NODE_CROSS_JOIN) {
+    flush_pending_oj();
     const u64 cap = L.cap * R.cap;
     if (cap == 0) { t.cap = 0; return t; }
     if (cap >= (1ull << 40)) fail(RDFGPU_ERR_UNSUPPORTED, "cross join of %llu x %llu rows", (unsigned long long)L.cap, (unsigned long long)R.cap);
@@ -1379,6 +1452,7 @@ DevTable Plan::exec_join(NodeInfo& nd) {
       return exec_lds_join(nd, L, R, build_left, pf, post);
     }
   }
+  flush_pending_oj();
   JoinArgs a{};
   for (u32 c = 0; c < L.n_cols; c++) a.left[c] = L.cols[c];
   for (u32 c = 0; c < R.n_cols; c++) a.right[c] = R.cols[c];
@@ -1420,7 +1494,7 @@ DevTable Plan::exec_join(NodeInfo& nd) {
     // count pass: 4·k·N_p keys + 8·N_p (head + first chain slot read per probe row)
     timed(hash ? KC_JOIN_COUNT : KC_NLJ_COUNT, 0, R.cap, R.n_dev, 4ull * a.n_keys + 8, nullptr, 0, 0,
           [&] { if (hash) launch_join_count(a, stream); else launch_nlj_count(a, stream); });
-    timed(KC_DEVICE_SCAN, 0, R.cap, nullptr, 8, nullptr, 0, 0, [&] { inclusive_scan_u32(counts, offs, R.cap, temp, tb, stream); });
+    timed(scan_class(R.cap), 0, R.cap, nullptr, 8, nullptr, 0, 0, [&] { inclusive_scan_u32(counts, offs, R.cap, temp, tb, stream); });
     u32 tot32 = 0;
     RDFGPU_HIP(hipMemcpyAsync(&tot32, offs + R.cap - 1, 4, hipMemcpyDeviceToHost, stream));
     RDFGPU_HIP(hipStreamSynchronize(stream)); metrics.host_syncs++;
@@ -1444,6 +1518,57 @@ DevTable Plan::exec_join(NodeInfo& nd) {
     t.n_dev = a.n_out_dev;
   }
   return t;
+}
+
+// The dense join tables of a single-key store slice (decided once per slice and store version, with `slice_build_mu` held):
+// direct-address if the keys are unique, CSR (offsets + row ids grouped by key; the identity when the slice is sorted by the
+// key) if not; `dense_failed` when the id range is not worth a 4-byte-per-id table.  Costs a few small kernels and host
+// syncs at that time, nothing afterwards.
+void Plan::build_dense_table(SliceTable* st, const u32* key, u64 n) {
+  u32* mm = reinterpret_cast<u32*>(new_counter());     // {min, max}
+  u32* flags = reinterpret_cast<u32*>(new_counter());  // {duplicate seen, unsorted seen}
+  const u32 init[2] = {0xFFFFFFFFu, 0u};
+  RDFGPU_HIP(hipMemcpyAsync(mm, init, sizeof(init), hipMemcpyHostToDevice, stream));
+  timed(KC_MINMAX, 4ull * n, 0, nullptr, 0, nullptr, 0, 0, [&] { launch_minmax_u32(key, n, mm, stream); });
+  u32 got[2];
+  RDFGPU_HIP(hipMemcpyAsync(got, mm, sizeof(got), hipMemcpyDeviceToHost, stream));
+  RDFGPU_HIP(hipStreamSynchronize(stream)); metrics.host_syncs++;
+  // "dense" = the id range is worth a 4-B-per-id table: up to 4 ids per row outright; up to 64 ids per row while
+  // the table stays small (16 M ids = 64 MB) — a subject-hash shard of a slice keeps the slice's id range with
+  // 1/G of its rows, and must not fall off the index-join path for that
+  const u64 range = got[0] <= got[1] ? (u64)(got[1] - got[0]) + 1 : ~0ull;
+  const bool dense = range <= 4 * n + 1024 || (range <= 64 * n + 1024 && range <= (16ull << 20));
+  if (!dense) { st->dense_failed = true; st->dense_tried = true; return; }
+  metrics.tables_built++;
+  const u32 kmin = got[0], kn = got[1] - got[0] + 1;
+  u32* direct = store->table_alloc<u32>(kn);
+  RDFGPU_HIP(hipMemsetAsync(direct, 0xFF, (size_t)kn * sizeof(u32), stream));
+  timed(KC_GDIRECT_BUILD, 0, n, nullptr, 8, nullptr, 0, 0, [&] { launch_gdirect_build(key, n, direct, kmin, kn, flags, stream); });
+  u32 is_dup = 0;
+  RDFGPU_HIP(hipMemcpyAsync(&is_dup, flags, sizeof(u32), hipMemcpyDeviceToHost, stream));
+  RDFGPU_HIP(hipStreamSynchronize(stream)); metrics.host_syncs++;
+  st->kmin = kmin; st->kn = kn;
+  if (!is_dup) { st->direct = direct; st->dense_tried = true; return; }
+  // duplicates: counting sort into CSR (offsets + row ids grouped by key)
+  store->table_free(direct);
+  u32* off = store->table_alloc<u32>((u64)kn + 1); u32* rows = nullptr;
+  u32* counts = scratch<u32>((u64)kn + 1);
+  RDFGPU_HIP(hipMemsetAsync(counts, 0, ((size_t)kn + 1) * sizeof(u32), stream));
+  timed(KC_CSR_HIST, 0, n, nullptr, 8, nullptr, 0, 0, [&] { launch_csr_hist(key, n, kmin, kn, counts, flags + 1, stream); });
+  const size_t tb = scan_temp_bytes((u64)kn + 1);
+  void* temp = scratch<unsigned char>(tb);
+  exclusive_scan_u32(counts, off, (u64)kn + 1, temp, tb, stream);
+  u32 unsorted = 0;
+  RDFGPU_HIP(hipMemcpyAsync(&unsorted, flags + 1, sizeof(u32), hipMemcpyDeviceToHost, stream));
+  RDFGPU_HIP(hipStreamSynchronize(stream)); metrics.host_syncs++;
+  if (unsorted) {   // else the slice is sorted by the key: rows[] is the identity and is never materialised
+    rows = store->table_alloc<u32>(n);
+    RDFGPU_HIP(hipMemcpyAsync(counts, off, (size_t)kn * sizeof(u32), hipMemcpyDeviceToDevice, stream));   // cursors
+    timed(KC_CSR_SCATTER, 0, n, nullptr, 12, nullptr, 0, 0, [&] { launch_csr_scatter(key, n, kmin, kn, counts, rows, stream); });
+    RDFGPU_HIP(hipStreamSynchronize(stream)); metrics.host_syncs++;   // complete before other plans may see it
+  }
+  st->csr_rows = rows; st->csr_off = off;
+  st->dense_tried = true;
 }
 
 // HashJoinExec whose build side fits one workgroup's LDS: one fused kernel, optimistic output capacity.
@@ -1495,56 +1620,7 @@ DevTable Plan::exec_lds_join(NodeInfo& nd, const DevTable& L, const DevTable& R,
       std::unique_lock<std::mutex> building(store->slice_build_mu);
       // Dense forms first (one single key over a dense id range): direct-address if the keys are unique, CSR if not.
       // Decided once per slice; costs a few small kernels and host syncs at that time, nothing afterwards.
-      if (!st->dense_tried && a.n_keys == 1 && !opt.on(RDFGPU_OPT_NO_DIRECT_TABLE)) {
-        u32* mm = reinterpret_cast<u32*>(new_counter());     // {min, max}
-        u32* flags = reinterpret_cast<u32*>(new_counter());  // {duplicate seen, unsorted seen}
-        const u32 init[2] = {0xFFFFFFFFu, 0u};
-        RDFGPU_HIP(hipMemcpyAsync(mm, init, sizeof(init), hipMemcpyHostToDevice, stream));
-        timed(KC_MINMAX, 4ull * B.cap, 0, nullptr, 0, nullptr, 0, 0, [&] { launch_minmax_u32(a.build_key[0], B.cap, mm, stream); });
-        u32 got[2];
-        RDFGPU_HIP(hipMemcpyAsync(got, mm, sizeof(got), hipMemcpyDeviceToHost, stream));
-        RDFGPU_HIP(hipStreamSynchronize(stream)); metrics.host_syncs++;
-        // "dense" = the id range is worth a 4-B-per-id table: up to 4 ids per row outright; up to 64 ids per row while
-        // the table stays small (16 M ids = 64 MB) — a subject-hash shard of a slice keeps the slice's id range with
-        // 1/G of its rows, and must not fall off the index-join path for that
-        const u64 range = got[0] <= got[1] ? (u64)(got[1] - got[0]) + 1 : ~0ull;
-        const bool dense = range <= 4 * B.cap + 1024 || (range <= 64 * B.cap + 1024 && range <= (16ull << 20));
-        if (!dense) st->dense_failed = true;
-        else {
-          const u32 kmin = got[0], kn = got[1] - got[0] + 1;
-          u32* direct = nullptr;
-          RDFGPU_HIP(hipMalloc((void**)&direct, (size_t)kn * sizeof(u32)));
-          RDFGPU_HIP(hipMemsetAsync(direct, 0xFF, (size_t)kn * sizeof(u32), stream));
-          timed(KC_GDIRECT_BUILD, 0, B.cap, nullptr, 8, nullptr, 0, 0, [&] { launch_gdirect_build(a.build_key[0], B.cap, direct, kmin, kn, flags, stream); });
-          u32 is_dup = 0;
-          RDFGPU_HIP(hipMemcpyAsync(&is_dup, flags, sizeof(u32), hipMemcpyDeviceToHost, stream));
-          RDFGPU_HIP(hipStreamSynchronize(stream)); metrics.host_syncs++;
-          st->kmin = kmin; st->kn = kn;
-          if (!is_dup) st->direct = direct;
-          else {   // duplicates: counting sort into CSR (offsets + row ids grouped by key)
-            RDFGPU_HIP(hipFree(direct));
-            u32* off = nullptr; u32* rows = nullptr;
-            RDFGPU_HIP(hipMalloc((void**)&off, ((size_t)kn + 1) * sizeof(u32)));
-            u32* counts = scratch<u32>((u64)kn + 1);
-            RDFGPU_HIP(hipMemsetAsync(counts, 0, ((size_t)kn + 1) * sizeof(u32), stream));
-            timed(KC_CSR_HIST, 0, B.cap, nullptr, 8, nullptr, 0, 0, [&] { launch_csr_hist(a.build_key[0], B.cap, kmin, kn, counts, flags + 1, stream); });
-            const size_t tb = scan_temp_bytes((u64)kn + 1);
-            void* temp = scratch<unsigned char>(tb);
-            exclusive_scan_u32(counts, off, (u64)kn + 1, temp, tb, stream);
-            u32 unsorted = 0;
-            RDFGPU_HIP(hipMemcpyAsync(&unsorted, flags + 1, sizeof(u32), hipMemcpyDeviceToHost, stream));
-            RDFGPU_HIP(hipStreamSynchronize(stream)); metrics.host_syncs++;
-            if (unsorted) {   // else the slice is sorted by the key: rows[] is the identity and is never materialised
-              RDFGPU_HIP(hipMalloc((void**)&rows, (size_t)B.cap * sizeof(u32)));
-              RDFGPU_HIP(hipMemcpyAsync(counts, off, (size_t)kn * sizeof(u32), hipMemcpyDeviceToDevice, stream));   // cursors
-              timed(KC_CSR_SCATTER, 0, B.cap, nullptr, 12, nullptr, 0, 0, [&] { launch_csr_scatter(a.build_key[0], B.cap, kmin, kn, counts, rows, stream); });
-              RDFGPU_HIP(hipStreamSynchronize(stream)); metrics.host_syncs++;   // complete before other plans may see it
-            }
-            st->csr_rows = rows; st->csr_off = off;
-          }
-        }
-        st->dense_tried = true;
-      }
+      if (!st->dense_tried && a.n_keys == 1 && !opt.on(RDFGPU_OPT_NO_DIRECT_TABLE)) build_dense_table(st, a.build_key[0], B.cap);
       if (st->csr_off) {
         a.csr_off = st->csr_off; a.csr_rows = st->csr_rows; a.direct_min = st->kmin; a.direct_n = st->kn;
         // lanes per probe row: a small probe side with a large fan-out is spread over the chip
@@ -1561,9 +1637,9 @@ DevTable Plan::exec_lds_join(NodeInfo& nd, const DevTable& L, const DevTable& R,
         a.direct = st->direct; a.direct_min = st->kmin; a.direct_n = st->kn;
       } else {
         if (!st->slots || st->mask != a.tbl_mask) {   // build the hash form now, under the lock, and publish it only when complete
-          if (st->slots) { RDFGPU_HIP(hipFree(st->slots)); st->slots = nullptr; }
-          void* mem = nullptr;
-          RDFGPU_HIP(hipMalloc(&mem, (size_t)slots * sizeof(uint2)));
+          if (st->slots) { store->table_free(st->slots); st->slots = nullptr; }
+          void* mem = store->table_alloc<uint2>(slots);
+          metrics.tables_built++;
           a.gslots = static_cast<uint2*>(mem);
           RDFGPU_HIP(hipMemsetAsync(a.gslots, 0xFF, (size_t)slots * sizeof(uint2), stream));
           timed(KC_GJOIN_BUILD, 0, B.cap, B.n_dev, 4ull * a.n_keys + 8, nullptr, 0, 0, [&] { launch_gjoin_build(a, stream); });
@@ -1648,6 +1724,7 @@ DevTable Plan::exec_lds_join(NodeInfo& nd, const DevTable& L, const DevTable& R,
   const u64 fixed = (4ull * (a.n_keys + build_payload) + 8) * B.cap;
 
   if (use_part) {
+    flush_pending_oj();
     prepare_partitions(a, B, P, part);   // the build half of this HashJoinExec: inside the operator, every execution
     // output of the previous execution (none: single pass): above ~50 M rows the reservations of a single pass (one
     // same-address atomic per 256 rows, ~88 per microsecond) cost more than walking every partition twice
@@ -1689,6 +1766,7 @@ DevTable Plan::exec_lds_join(NodeInfo& nd, const DevTable& L, const DevTable& R,
       size_node = pending_chain->top;
       t.n_cols = a.n_out_cols;
     }
+    if (!use_band) flush_pending_oj();   // (only the band join takes an ordered slice join's held-back write pass)
     const bool chained = a.n_chain != 0;
     const u64 spec_cap = nd.has_last ? std::max<u64>(1024, size_node->last_rows + size_node->last_rows / (size_node->last_scaled ? 2 : 4) + 256)   // 25 % head room over the previous run (50 % over an extrapolation)
                                      : std::max<u64>(1024, first_guess);
@@ -1739,8 +1817,13 @@ DevTable Plan::exec_lds_join(NodeInfo& nd, const DevTable& L, const DevTable& R,
       void* temp = scratch<unsigned char>(tb);
       timed(KC_OJ_PROBE, 0, P.cap, P.n_dev, 8 + 12ull * a.n_chain, nullptr, 0, 0, [&] { launch_ordered_join_probe(o, stream); });
       timed(KC_OJ_COUNT, 0, B.cap, nullptr, 4, nullptr, 0, 0, [&] { launch_ordered_join_count(o, stream); });
-      timed(KC_DEVICE_SCAN, 0, tiles + 1, nullptr, 8, nullptr, 0, 0, [&] { exclusive_scan_u32(o.tile_count, o.tile_off, tiles + 1, temp, tb, stream); });
-      timed(KC_OJ_WRITE, 0, B.cap, nullptr, 4, n_out, 0, 8ull * a.n_out_cols, [&] { launch_ordered_join_write(o, stream); });
+      timed(scan_class(tiles + 1), 0, tiles + 1, nullptr, 8, nullptr, 0, 0, [&] { exclusive_scan_u32(o.tile_count, o.tile_off, tiles + 1, temp, tb, stream); });
+      // the consumer is a band join that (last time) found this output sorted by its key and needed nothing else of it: the write
+      // pass is held back — that join has it write its row records instead of this table (exec_band_join), anything else flushes it
+      const int consumer = size_node->parent;
+      if (consumer >= 0 && nodes[consumer].band_takes_records && !pending_oj.active && t.sorted_col >= 0) {
+        pending_oj.active = true; pending_oj.o = o; pending_oj.first_col = a.out[0]; pending_oj.n_build = B.cap; pending_oj.n_chain = a.n_chain;
+      } else timed(KC_OJ_WRITE, 0, B.cap, nullptr, 4, n_out, 0, 8ull * a.n_out_cols, [&] { launch_ordered_join_write(o, stream); });
     }
     else if (use_band) { cur_band_node = &nd; exec_band_join(a, band, B, P, 4ull * (1 + build_payload), 4ull * probe_cols); cur_band_node = nullptr; }
     else launch_join(lds_join_class(a.has_filter, a.has_probe_filter, lds_join_items(P.cap << a.row_lanes_log2, global_table), use_part ? kJoinTableLds : lds_join_mode(a), chained),
@@ -1758,6 +1841,7 @@ DevTable Plan::exec_lds_join(NodeInfo& nd, const DevTable& L, const DevTable& R,
     }
     return t;
   }
+  flush_pending_oj();
   u64 out_cap = P.cap < 1024 ? 1024 : P.cap;   // optimistic: at most one match per probe row on average
   if (a.csr_off) out_cap = std::max<u64>(out_cap, 2 * P.cap * ((B.cap + a.direct_n - 1) / (a.direct_n ? a.direct_n : 1)) + 1024);   // CSR: twice the mean rows per key
   u64 total = 0;
@@ -1851,6 +1935,32 @@ void Plan::exec_band_join(LdsJoinArgs& a, BandArgs& b, const DevTable& B, const 
   bool presorted = false;
   if (P.sorted_col >= 0 && P.cols[P.sorted_col] == a.probe_key[0] && P.key_min >= std::max<u32>(1u, a.direct_min) && !opt.on(RDFGPU_OPT_NO_ORDERED_JOIN)) presorted = true;
   b.presorted = presorted ? 1u : 0u;
+  // the full-semantics pass is launched when the previous execution met a row that needed it (or there was none); a row that
+  // needs it after all is caught at the end of the plan like any failed speculation
+  const bool skip_slow = speculative && cur_band_node && cur_band_node->band_ran && cur_band_node->band_slow_rows == 0;
+  // The probe side is the held-back output of an ordered slice join (Plan::pending_oj): if everything this join reads of it
+  // travels in that join's packed table record — the window operands, the id operand, the rows' output values — and its key is
+  // the slice's sorted column, that join writes this join's row records itself (OjBandFuse) and the table in between is never
+  // written.  Otherwise its write pass runs now.
+  OjBandFuse fuse{}; bool fused = false;
+  if (pending_oj.active) {
+    const OrderedJoinArgs& o = pending_oj.o;
+    bool ok = presorted && skip_slow && P.cols[0] == pending_oj.first_col && P.n_cols == o.n_out_cols;
+    auto slot_of = [&](const u32* col, u8& slot) {      // the word of the packed record that holds output column `col`
+      slot = 0xFFu;
+      for (u32 c = 0; c < o.n_out_cols; c++) if (o.out[c] == col && o.out_slot[c] != 0xFFu) { slot = o.out_slot[c]; return true; }
+      return false;
+    };
+    fuse.y0_slot[0] = fuse.y0_slot[1] = fuse.y1_slot[0] = fuse.y1_slot[1] = fuse.neq_slot = fuse.row_slot[0] = fuse.row_slot[1] = 0xFFu;
+    for (u32 w = 0; ok && w < b.n_win; w++) ok = slot_of(b.win[w].y0, fuse.y0_slot[w]) && slot_of(b.win[w].y1, fuse.y1_slot[w]);
+    if (ok && b.has_neq) ok = slot_of(b.neq_probe, fuse.neq_slot);
+    for (u32 u = 0; ok && u < b.n_row_cols; u++) ok = slot_of(b.row_col[u], fuse.row_slot[u]);
+    fuse.key_col = nullptr;
+    for (u32 c = 0; ok && c < o.n_out_cols; c++) if (o.out[c] == a.probe_key[0] && o.out_slot[c] == 0xFFu && o.out_ref[c].src == 1) fuse.key_col = o.out_ref[c].ptr;
+    ok = ok && fuse.key_col != nullptr;
+    if (ok) fused = true; else flush_pending_oj();
+  }
+  if (cur_band_node) cur_band_node->band_takes_records = presorted && skip_slow && !opt.on(RDFGPU_OPT_NO_ORDERED_JOIN);
   // small probe side, not sorted: counting sort on the key (band_scatter_kernel) instead of rocPRIM's radix sort; a larger one
   // when the previous execution found it piecewise sorted (>= 4 rows per run of equal neighbouring keys: the N sorted runs
   // a repartition delivers) — one atomic per run, rows of a run scattered together
@@ -1916,8 +2026,9 @@ void Plan::exec_band_join(LdsJoinArgs& a, BandArgs& b, const DevTable& B, const 
   // the build side, once: per row its columns + stage look-ups read, 16 B of operands + the output values written
   const bool own_entries = cache_entries && cur_build_table->band_entries.size() < 8;
   if (own_entries) {
-    RDFGPU_HIP(hipMalloc((void**)&b.et, (nb + 64) * sizeof(uint4)));
-    for (u32 u = 0; u < b.n_entry_cols; u++) RDFGPU_HIP(hipMalloc((void**)&b.eo[u], nb * sizeof(u32)));
+    b.et = store->table_alloc<uint4>(nb + 64);
+    for (u32 u = 0; u < b.n_entry_cols; u++) b.eo[u] = store->table_alloc<u32>(nb);
+    metrics.tables_built++;
   } else {
     b.et = scratch<uint4>(nb + 64);                  // padded: the pair test reads whole groups of 8 entries
     for (u32 u = 0; u < b.n_entry_cols; u++) b.eo[u] = scratch<u32>(nb);
@@ -1939,15 +2050,23 @@ void Plan::exec_band_join(LdsJoinArgs& a, BandArgs& b, const DevTable& B, const 
   if (max_blocks >= (1ull << 31)) fail(RDFGPU_ERR_UNSUPPORTED, "band join of %llu blocks", (unsigned long long)max_blocks);
   b.max_blocks = (u32)max_blocks;
   b.bcount = scratch<u32>(max_blocks + 1); b.bofs = scratch<u32>(max_blocks + 1);   // (bcount is zeroed by the decode pass: a memset is two more launches, ~10 us of launch gap each on this part)
+  if (fused) {
+    const OrderedJoinArgs& o = pending_oj.o;
+    pending_oj.active = false;
+    fuse.brec = scratch<uint4>(2 * o.n_probe_cap);
+    fuse.rec_s = b.rec_s; fuse.aux_s = b.aux_s; fuse.poff = b.poff; fuse.bcount = b.bcount; fuse.max_blocks = b.max_blocks;
+    fuse.kmin = b.kmin; fuse.kn = b.kn;
+    // per table row: its packed record read + two typed-value gathers + 32 B written; per slice row the count pass's 5 bytes + its
+    // key; per match a 32-byte record gathered and stored
+    timed(KC_OJ_BAND_RECORDS, 0, o.n_probe_cap, o.n_probe_dev, 16ull * o.n_rec + 9ull * b.n_win + 32, nullptr, 0, 0, [&] { launch_oj_band_records(o, b, fuse, stream); });
+    timed(KC_OJ_WRITE_BAND, 0, pending_oj.n_build, nullptr, 4 + 1 + 4, a.n_probe_dev, 0, 64, [&] { launch_ordered_join_write_band(o, fuse, stream); });
+  } else
   timed(KC_BAND_DECODE, 0, np, P.n_dev, 4 + 4ull * (b.n_win + b.has_neq) + 9ull * b.n_win + 24 + 8, nullptr, 0, 0, [&] { launch_band_decode(b, stream); });
   // the partition pass: in the time, not in the algorithmic bytes
   if (!presorted && !counting) timed(KC_RADIX_SORT, 0, np, nullptr, 0, nullptr, 0, 0, [&] { sort_pairs_u32_u32(b.skey_in, skey, b.sval_in, perm, np, bits, stemp, stb, stream); });
   b.boff = scratch<u32>((u64)kn + 1);
   // the block kernels launch one wave per block: sized from the previous execution's count (+ 25 %), not from the upper bound
   b.n_blocks_out = new_counter();
-  // the full-semantics pass is launched when the previous execution met a row that needed it (or there was none); a row that
-  // needs it after all is caught at the end of the plan like any failed speculation
-  const bool skip_slow = speculative && cur_band_node && cur_band_node->band_ran && cur_band_node->band_slow_rows == 0;
   band_block_counters.push_back({cur_band_node, (u32)(b.n_blocks_out - counters), (u32)(reinterpret_cast<u64*>(b.slow_rows) - counters), (u32)(reinterpret_cast<u64*>(b.run_stats) - counters), skip_slow});
   const u64 hist = cur_band_node ? cur_band_node->band_blocks : 0;
   b.launch_blocks = (u32)std::min<u64>(max_blocks, hist ? hist + hist / 4 + 1024 : max_blocks);
@@ -1956,11 +2075,11 @@ void Plan::exec_band_join(LdsJoinArgs& a, BandArgs& b, const DevTable& B, const 
   const size_t tb = std::max(scan_temp_bytes(std::max<u64>((u64)kn + 1, max_blocks + 1)), band_blocks_scan_temp_bytes(kn));
   void* temp = scratch<unsigned char>(tb);
   if (counting) {   // poff = exclusive scan of the rows per key (entry kn = the rows that join something); then the scatter
-    timed(KC_DEVICE_SCAN, 0, (u64)kn + 1, nullptr, 8, nullptr, 0, 0, [&] { exclusive_scan_u32(b.key_hist, b.poff, (u64)kn + 1, temp, tb, stream); });
+    timed(scan_class((u64)kn + 1), 0, (u64)kn + 1, nullptr, 8, nullptr, 0, 0, [&] { exclusive_scan_u32(b.key_hist, b.poff, (u64)kn + 1, temp, tb, stream); });
     RDFGPU_HIP(hipMemcpyAsync(b.key_cursor, b.poff, ((size_t)kn + 1) * sizeof(u32), hipMemcpyDeviceToDevice, stream));
     timed(KC_BAND_ROWS, 0, np, P.n_dev, 8 + 32 + 32, nullptr, 0, 0, [&] { launch_band_scatter(b, stream); });
   } else if (!presorted) timed(KC_BAND_BOUNDS, 0, np, nullptr, 4, nullptr, 0, 0, [&] { launch_band_bounds(skey, np, kn, b.poff, stream); });   // (presorted: the decode pass wrote poff)
-  timed(KC_DEVICE_SCAN, 12ull * kn, (u64)kn + 1, nullptr, 4, nullptr, 0, 0, [&] { band_blocks_scan(a.csr_off, b.poff, kn, b.boff, temp, tb, stream); });   // (blocks per key: the scan's input iterator)
+  timed(scan_class((u64)kn + 1), 12ull * kn, (u64)kn + 1, nullptr, 4, nullptr, 0, 0, [&] { band_blocks_scan(a.csr_off, b.poff, kn, b.boff, temp, tb, stream); });   // (blocks per key: the scan's input iterator)
   timed(KC_BAND_DESC, 12ull * kn, 0, nullptr, 0, nullptr, 0, 0, [&] { launch_band_desc(b, stream); });
   if (!presorted && !counting) timed(KC_BAND_ROWS, 0, np, P.n_dev, 4 + 32 + 32, nullptr, 0, 0, [&] { launch_band_rows(b, stream); });
   // per probe row 4 (sorted position) + 24 (record) read, per entry 16 B read, per pair one bit written; the pair count
@@ -1976,7 +2095,7 @@ void Plan::exec_band_join(LdsJoinArgs& a, BandArgs& b, const DevTable& B, const 
     RDFGPU_HIP(hipMemcpyAsync(a_dev, a_host, sizeof(LdsJoinArgs), hipMemcpyHostToDevice, stream));
     timed(KC_BAND_SLOW, 0, 0, nullptr, 0, nullptr, 0, 0, [&] { launch_band_slow(a_dev, b, stream); });
   }
-  timed(KC_DEVICE_SCAN, 0, max_blocks + 1, nullptr, 8, nullptr, 0, 0, [&] { exclusive_scan_u32(b.bcount, b.bofs, max_blocks + 1, temp, tb, stream); });
+  timed(scan_class(max_blocks + 1), 0, max_blocks + 1, nullptr, 8, nullptr, 0, 0, [&] { exclusive_scan_u32(b.bcount, b.bofs, max_blocks + 1, temp, tb, stream); });
   timed(KC_BAND_EMIT, 4ull * b.n_entry_cols * nb, np, P.n_dev, 4 + 4ull * b.n_row_cols, a.n_out_dev, 0, 4ull * a.n_out_cols, [&] { launch_band_emit(b, stream); });
 }
 

@@ -40,6 +40,8 @@ struct NodeInfo {
   bool last_scaled = false;
   u64 band_blocks = 0;                         // blocks of the band join based on this node in its previous execution (launch sizing)
   u64 band_run_stats = 0;                      // sampled rows << 32 | runs of equal neighbouring probe keys (a piecewise sorted probe side takes the counting partition)
+  int parent = -1;                             // the one operator consuming this node (-1: the root, or several)
+  bool band_takes_records = false;             // this node's band join found its probe side presorted by an ordered slice join below and needed no slow pass: next time that join may write the row records itself
   bool band_ran = false; u64 band_slow_rows = 0;   // .. and how many of its probe rows needed the full typed-value semantics                    // .. extrapolated from a priming run over a prefix of the bound tables
 };
 struct SpecCheck { NodeInfo* node; u32 counter; bool left_join; };   // counter = n_out slot, counter+1 = overflow flag
@@ -48,6 +50,10 @@ struct SpecCheck { NodeInfo* node; u32 counter; bool left_join; };   // counter 
 // tables: handed to the base join, which runs them inside its resolve phase (kernels.hpp ChainStage).
 struct ChainLink { NodeInfo* node; bool slice_is_left; DevTable slice; const SliceTable* table; };
 struct ChainRequest { NodeInfo* top = nullptr; NodeInfo* base = nullptr; std::vector<ChainLink> links /* bottom-up */; bool consumed = false; };
+
+// An ordered slice join whose write pass is held back: its consumer, a band join, may have it write the band join's row
+// records instead of the output table (OjBandFuse); anything else flushes it (Plan::flush_pending_oj) first.
+struct PendingOj { bool active = false; OrderedJoinArgs o{}; const u32* first_col = nullptr; u64 n_build = 0; u32 n_chain = 0; };
 
 struct BoundTable { std::vector<const u32*> cols; u64 n_rows = 0; bool bound = false; };
 
@@ -61,7 +67,7 @@ enum KernelClass {
   KC_FILTER_VERDICT, KC_REGEX_VERDICTS, KC_UNION,
   KC_BAND_SLOW, KC_RADIX_SORT, KC_BAND_BOUNDS, KC_BAND_BLOCKS, KC_BAND_DECODE, KC_BAND_MASK, KC_BAND_EMIT, KC_BAND_ENTRIES, KC_BAND_DESC, KC_BAND_PT, KC_BAND_ROWS,
   KC_FILTER_BITS_ID, KC_FILTER_BITS_TV, KC_FILTER_BITS_VERDICT, KC_FILTER_BITS_VALUE, KC_VALUE_VERDICTS, KC_VALUE_RUNS, KC_RUN_SCAN, KC_RUN_COPY, KC_OJ_PROBE, KC_OJ_COUNT, KC_OJ_WRITE, KC_FILTER_WRITE,
-  KC_PART_KEYS, KC_PART_JOIN,
+  KC_PART_KEYS, KC_PART_JOIN, KC_OJ_BAND_RECORDS, KC_OJ_WRITE_BAND, KC_SMALL_SCAN,
   KC_LDS_JOIN0,                      // 192 names: lds_join_kernel<FS in {0..3}, PFS in {0,1,2}, ITEMS in {4,1}, MODE in {0,1,2,3}, CHAIN>
   KC__N = KC_LDS_JOIN0 + 192
 };
@@ -93,6 +99,7 @@ struct Plan {
   std::vector<u32> pool;          // IN-set ids of residual predicates (host copy)
   u32* pool_dev = nullptr;        // same, on device
   RegexProg* regex_dev = nullptr; // compiled REGEX patterns of the plan (device)
+  unsigned char* str_consts_dev = nullptr;   // bytes of the plan's string constants (RDFGPU_EX_LIT_STR)
   std::vector<std::string> regex_strings; std::vector<rdfgpu_regex> regex_text;   // their texts (pattern, flags per entry)
   u32 root = 0;
   ExecContext* ctx = nullptr;     // stream, events, counters (pooled per store)
@@ -124,6 +131,8 @@ struct Plan {
   std::vector<DevTable> memo; std::vector<char> memo_valid;   // node results of the current execution
   ChainRequest* pending_chain = nullptr;                        // set while the base join of a fusable chain executes
   SliceTable* cur_build_table = nullptr;                        // the store-level table of the join being set up (if any)
+  PendingOj pending_oj;
+  void flush_pending_oj();
   u32 events_used = 0;
   KernelStat kstats[KC__N];
   // Arrow batch stream over a host copy of the result
@@ -148,6 +157,7 @@ struct Plan {
   DevTable apply_filter(NodeInfo& nd, const DevTable& in);
   DevTable exec_lds_join(NodeInfo& nd, const DevTable& L, const DevTable& R, bool build_left, const NodeInfo* probe_filter, const NodeInfo* post_filter = nullptr);
   bool plan_chain(NodeInfo& top, ChainRequest& req);
+  void build_dense_table(SliceTable* st, const u32* key, u64 n);
   bool apply_chain(const ChainRequest& req, NodeInfo& base, const DevTable& L, const DevTable& R, bool build_left, LdsJoinArgs& a, u64& stage_bytes, BandArgs* band, bool* use_band);
   void prepare_partitions(const LdsJoinArgs& a, const DevTable& B, const DevTable& P, PartArgs& pa);
   void exec_band_join(LdsJoinArgs& a, BandArgs& b, const DevTable& B, const DevTable& P, u64 build_bytes_per_row, u64 probe_bytes_per_row);

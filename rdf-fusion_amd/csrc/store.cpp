@@ -1,6 +1,7 @@
 // store.cpp — see store.hpp.  Index build = device radix sort of three permutations + dedupe.
 #include "store.hpp"
 
+#include <chrono>
 #include <cstdlib>
 #include <string>
 #include <vector>
@@ -39,12 +40,14 @@ void* DevicePool::alloc(size_t bytes) {
   if (it == free_.end()) { it = free_.upper_bound(b); if (it != free_.end() && it->first > b + b / 2) it = free_.end(); }
   void* p = nullptr;
   size_t got = b;
-  if (it != free_.end()) { p = it->second; got = it->first; free_.erase(it); cached_ -= got; }
+  if (it != free_.end()) { p = it->second.p; got = it->first; free_.erase(it); cached_ -= got; }
   else {
+    const auto t0 = std::chrono::steady_clock::now();
+    struct Tally { DevicePool* self; std::chrono::steady_clock::time_point t0; ~Tally() { self->n_mallocs_++; self->malloc_ns_ += (u64)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); } } tally{this, t0};
     hipError_t e = hipMalloc(&p, b);
     if (e != hipSuccess) {
       // give cached blocks back (this pool's, then every other pool's) and retry once
-      for (auto& kv : free_) (void)hipFree(kv.second);
+      for (auto& kv : free_) (void)hipFree(kv.second.p);
       free_.clear(); cached_ = 0;
       (void)hipGetLastError();
       e = hipMalloc(&p, b);
@@ -52,7 +55,7 @@ void* DevicePool::alloc(size_t bytes) {
         (void)hipGetLastError();
         std::lock_guard<std::mutex> gp(g_pools_mu);
         for (DevicePool* other : g_pools) if (other != this && other->mu_.try_lock()) {
-          for (auto& kv : other->free_) (void)hipFree(kv.second);
+          for (auto& kv : other->free_) (void)hipFree(kv.second.p);
           other->free_.clear(); other->cached_ = 0;
           other->mu_.unlock();
         }
@@ -78,22 +81,28 @@ void DevicePool::free(void* p) {
   if (it == live_.end()) return;
   in_use_ -= it->second;
   cached_ += it->second;
-  free_.emplace(it->second, p);
+  free_.emplace(it->second, Cached{p, epoch_});
   live_.erase(it);
 }
+// Gives cached blocks back to the device until at most keep_bytes stay cached — the ones that have gone unused longest first
+// (handed back in the oldest trim round), the larger of two equally old ones first.  Largest-first regardless of age freed
+// exactly the blocks the next execution wanted again: two multi-GB hipMallocs per step of a plan whose output is a few GB.
 void DevicePool::trim_to(u64 keep_bytes) {
   std::lock_guard<std::mutex> g(mu_);
+  epoch_++;
   while (cached_ > keep_bytes && !free_.empty()) {
-    auto it = std::prev(free_.end());           // the largest block
-    (void)hipFree(it->second);
-    cached_ -= it->first;
-    free_.erase(it);
+    auto victim = free_.begin();
+    for (auto it = free_.begin(); it != free_.end(); ++it)
+      if (it->second.epoch < victim->second.epoch || (it->second.epoch == victim->second.epoch && it->first > victim->first)) victim = it;
+    (void)hipFree(victim->second.p);
+    cached_ -= victim->first;
+    free_.erase(victim);
   }
 }
 void DevicePool::trim() {
   std::lock_guard<std::mutex> g(mu_);
   cached_ = 0;
-  for (auto& kv : free_) (void)hipFree(kv.second);
+  for (auto& kv : free_) (void)hipFree(kv.second.p);
   free_.clear();
 }
 
@@ -229,15 +238,19 @@ void Store::drop_slice_tables() {
   std::lock_guard<std::mutex> lock(slice_mu);
   for (auto& kv : slice_tables) {
     SliceTable& t = kv.second;
-    if (t.direct) (void)hipFree(t.direct);
-    if (t.csr_off) (void)hipFree(t.csr_off);
-    if (t.csr_rows) (void)hipFree(t.csr_rows);
-    if (t.slots) (void)hipFree(t.slots);
-    for (auto& v : t.values) if (v.val) (void)hipFree(v.val);
-    for (auto& r : t.ranges) { if (r.rows) (void)hipFree(r.rows); if (r.vals) (void)hipFree(r.vals); if (r.link) (void)hipFree(r.link); }
-    for (auto& e : t.band_entries) { if (e.et) (void)hipFree(e.et); for (u32* p : e.eo) if (p) (void)hipFree(p); }
+    table_free(t.direct); table_free(t.csr_off); table_free(t.csr_rows); table_free(t.slots);
+    for (auto& v : t.values) table_free(v.val);
+    for (auto& r : t.ranges) { table_free(r.rows); table_free(r.vals); table_free(r.link); }
+    for (auto& e : t.band_entries) { table_free(e.et); for (u32* p : e.eo) table_free(p); }
   }
   slice_tables.clear();
+}
+void Store::drop_tables() {
+  std::unique_lock<std::shared_mutex> lock(mu);   // like a mutation: no plan is running
+  activate();
+  RDFGPU_HIP(hipDeviceSynchronize());
+  version++;
+  drop_slice_tables();
 }
 
 void Store::drop_string_verdicts() {

@@ -27,12 +27,18 @@ class DevicePool {
   void trim_to(u64 keep_bytes);     // largest cached blocks back to the device until at most keep_bytes stay cached
   u64 bytes_in_use() const { return in_use_; }
   u64 bytes_cached() const { return cached_; }
+  // hipMalloc calls this pool had to make (a steady-state execution makes none) and the host time they took
+  u64 mallocs() const { return n_mallocs_.load(); }
+  double malloc_ms() const { return (double)malloc_ns_.load() * 1e-6; }
 
  private:
   std::mutex mu_;
-  std::multimap<size_t, void*> free_;
+  struct Cached { void* p; u64 epoch; };
+  std::multimap<size_t, Cached> free_;   // by size; `epoch` = the trim round in which the block was handed back
+  u64 epoch_ = 0;
   std::map<void*, size_t> live_;
   u64 in_use_ = 0, cached_ = 0;
+  std::atomic<u64> n_mallocs_{0}, malloc_ns_{0};
 };
 
 // Per-plan execution resources (a HIP stream, a grow-on-demand event pool, the device counters and
@@ -123,6 +129,12 @@ struct Store {
   // lexical forms of string ids (the slice of the dictionary string builtins read): offsets[n_str_ids + 1] + UTF-8 heap
   u64* str_off = nullptr; unsigned char* heap = nullptr; u64 n_str_ids = 0;
   DevicePool pool;
+  // the slice join tables' own pool: a mutation drops every table, the next executions build them again — out of the blocks
+  // the dropped ones gave back, not out of fresh hipMalloc calls (a store that is updated between queries pays kernels, not
+  // the allocator, for its tables)
+  DevicePool table_pool;
+  template <class T> T* table_alloc(u64 n) { return static_cast<T*>(table_pool.alloc((n ? n : 1) * sizeof(T))); }
+  void table_free(void* p) { table_pool.free(p); }
   hipStream_t stream = nullptr;  // load-path stream
   std::shared_mutex mu;   // readers = running plans (a snapshot), writers = extend / remove / clear
   // Shared ownership like the reference's Arc<...>: the handle holds one reference, every compiled plan one more; the
@@ -143,6 +155,7 @@ struct Store {
   SliceTable* slice_table(const SliceKey& k);
   const SliceTable* find_slice_table(const SliceKey& k);
   void drop_slice_tables();
+  void drop_tables();   // rdfgpu_store_drop_tables: what a mutation does to the caches, without one
   std::mutex ctx_mu;
   std::vector<ExecContext*> free_ctx;
   ExecContext* acquire_context(u32 n_sources);

@@ -54,6 +54,7 @@ def load_library():
     lib.rdfgpu_store_extend_device.argtypes = [vp, vp, vp, vp, vp, C.c_uint64, u64p]
     lib.rdfgpu_store_remove.argtypes = [vp, vp, vp, vp, vp, C.c_uint64, u64p]
     lib.rdfgpu_store_clear.argtypes = [vp]
+    lib.rdfgpu_store_drop_tables.argtypes = [vp]
     lib.rdfgpu_store_remove_graph.argtypes = [vp, C.c_uint32, u64p]
     lib.rdfgpu_store_len.argtypes = [vp, u64p]
     lib.rdfgpu_store_set_typed_values.argtypes = [vp, vp, C.c_uint64, vp, C.c_uint64]
@@ -247,6 +248,11 @@ class GpuQuadStore:
 
     def clear(self):
         _check(self._lib.rdfgpu_store_clear(self._h))
+
+    def drop_tables(self):
+        """rdfgpu_store_drop_tables: forget every cached join table and bump the store version (what any mutation does to the
+        caches); the next execution of a plan builds what it needs again."""
+        _check(self._lib.rdfgpu_store_drop_tables(self._h))
 
     def remove_graph(self, graph_id):
         """QuadStorage::clear_graph / the quads of drop_named_graph: every quad of one graph (0 = default graph)."""

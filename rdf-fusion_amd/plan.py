@@ -212,6 +212,36 @@ def _string_fn(op):
 CONTAINS, STRSTARTS, STRENDS = _string_fn(abi.EX_CONTAINS), _string_fn(abi.EX_STRSTARTS), _string_fn(abi.EX_STRENDS)
 
 
+# String-valued expressions (include/rdfgpu.h, ABI 3).  STR takes the column itself (an object id): over an object-id column
+# the reference evaluates STR in the plain-term encoding, i.e. on the lexical form as written (scalar/terms/str.rs:42).
+def STR(e):
+    return e._un(abi.EX_STR)
+
+
+def lit_str(text, language_id=0):
+    """A string constant with its bytes (what a computed string is compared with); language_id as in the typed-value table."""
+    b = text.encode("utf-8") if isinstance(text, str) else bytes(text)
+    return Expr([(abi.EX_LIT_STR, 0, 0, (b, b"", abi.EX_LIT_STR), int(language_id), 0)])
+
+
+def STRLEN(e):
+    return e._un(abi.EX_STRLEN)
+
+
+def SUBSTR(e, start, length=None):
+    """SUBSTR(str, start[, length]) — scalar/strings/sub_str.rs; start / length are expressions (e.g. integer(2))."""
+    nodes = e.nodes + start.nodes + (length.nodes if length is not None else [])
+    return Expr(nodes + [(abi.EX_SUBSTR, 0, 0, 3 if length is not None else 2, 0, 0)])
+
+
+def UCASE(e):
+    return e._un(abi.EX_UCASE)
+
+
+def LCASE(e):
+    return e._un(abi.EX_LCASE)
+
+
 def lang_matches(language_tag, language_range):
     """LANGMATCHES on two plain strings, as scalar/strings/lang_matches.rs:52-69 evaluates it: "*" matches every
     non-empty tag; otherwise the subtags ('-' separated) are zipped with the longer side padded: a range subtag that is
@@ -310,7 +340,7 @@ class PlanBuilder:
                 for pid, txt in table:
                     self._regex_keys.append(("var", pid, txt, fl))
                     self.regexes.append((txt, fl, pid))
-            elif op in (abi.EX_REGEX, abi.EX_CONTAINS, abi.EX_STRSTARTS, abi.EX_STRENDS, abi.EX_LANG_IN):
+            elif op in (abi.EX_REGEX, abi.EX_CONTAINS, abi.EX_STRSTARTS, abi.EX_STRENDS, abi.EX_LANG_IN, abi.EX_LIT_STR):
                 # u carries (pattern, flags, op): register the plan constant (one entry per function), keep its index
                 if u not in self._regex_keys:
                     self._regex_keys.append(u)

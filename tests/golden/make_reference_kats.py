@@ -282,6 +282,29 @@ join_fixture_cases = [
          patterns=[["x", _NA[":p1"], "a"], ["x", _NA[":p2"], "y"], ["y", _NA[":p3"], _NA[":foo"]]],
          select=["a"], rows=[[_NA['"t1"']]]),
 ]
+# STR over plain terms: lib/functions/tests/unary.rs:91-125 (the test vector) and lib/functions/tests/snapshots/
+# unary__STR(PLAIN_TERM).snap (the answers): [term kind, lexical form, datatype IRI suffix or language tag] -> STR's value.
+# (Over an object-id column the reference evaluates STR in this encoding: decide_input_encoding, expr_builder_context.rs:557-582.)
+_xsd = lambda lex, dt: ["literal", lex, "xsd:" + dt]
+str_cases = [
+    dict(term=["iri", "http://example.org/foo"], str="http://example.org/foo"),
+    dict(term=["bnode", "myBlank"], str="myBlank"),
+    dict(term=["bnode", "4e15c8ff3a72491a92c64e7415a11d90"], str="4e15c8ff3a72491a92c64e7415a11d90"),
+    dict(term=["literal", "", None], str=""),
+    dict(term=["literal", "Plain Literal", None], str="Plain Literal"),
+    dict(term=["literal", "\U0001F916\U0001F980\U0001F916 Bee Boo Boo Ba Bee Bee \U0001F916\U0001F980\U0001F916", None],
+         str="\U0001F916\U0001F980\U0001F916 Bee Boo Boo Ba Bee Bee \U0001F916\U0001F980\U0001F916"),
+    dict(term=["literal", "\u00c4pfel", "@de-at"], str="\u00c4pfel"),
+    dict(term=["literal", "\u043f\u0440\u0438\u0432\u0456\u0442", "@uk-ukr"], str="\u043f\u0440\u0438\u0432\u0456\u0442"),
+    dict(term=_xsd("true", "boolean"), str="true"), dict(term=_xsd("false", "boolean"), str="false"),
+    dict(term=_xsd("10", "int"), str="10"), dict(term=_xsd("010", "int"), str="010"), dict(term=_xsd("0", "int"), str="0"),
+    dict(term=_xsd("10", "integer"), str="10"), dict(term=_xsd("010", "integer"), str="010"), dict(term=_xsd("0", "integer"), str="0"),
+    dict(term=_xsd("10", "float"), str="10"), dict(term=_xsd("10.0", "float"), str="10.0"), dict(term=_xsd("0", "float"), str="0"),
+    dict(term=_xsd("10", "double"), str="10"), dict(term=_xsd("10.0", "double"), str="10.0"), dict(term=_xsd("0", "double"), str="0"),
+    dict(term=_xsd("10", "decimal"), str="10"), dict(term=_xsd("10.0", "decimal"), str="10.0"), dict(term=_xsd("0", "decimal"), str="0"),
+]
+# testsuite/oxigraph-tests/sparql/small_iri_str.{rq,srx}: ASK { FILTER(STR(<ex:a>) = "ex:a") } => true
+str_query_cases = [dict(src="testsuite/oxigraph-tests/sparql/small_iri_str.{rq,srx}", term=["iri", "ex:a"], equals="ex:a", answer=True)]
 # bench/tests/plans/snapshots/r#mod__plans__bsbm_explore__BSBM Explore - Q{1,5} (Execution Plan).snap: the operator subtree
 # below the SortExec (the path this library executes), line for line; IRIs and the masked object id are written <c>, and the
 # `additional_filters=[DynamicFilter ...]` annotations (a run-time superset filter, never changes results) are dropped.
@@ -326,7 +349,7 @@ out = dict(
     pushdown_display=pushdown_display_cases, rowgroups=rowgroup_cases, dedupe=dedupe_cases,
     prune=prune_cases, find_range=find_range_cases, numeric_arith=numeric_arith_cases,
     decimal_to_double=decimal_to_double_cases, compare=compare_cases, decimal_to_float=decimal_to_float_cases,
-    ebv=ebv_cases, type_ids=type_id_cases, join_lowering=join_lowering_cases, join_fixtures=join_fixture_cases,
+    ebv=ebv_cases, type_ids=type_id_cases, join_lowering=join_lowering_cases, join_fixtures=join_fixture_cases, str_plain_term=str_cases, str_queries=str_query_cases,
     plan_snapshots=plan_snapshot_cases)
 
 if __name__ == "__main__":

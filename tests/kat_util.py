@@ -291,3 +291,42 @@ def scaled_join_fixture(case, copies):
     quads = [[q[0], shift(q[1], k), q[2], shift(q[3], k)] for k in range(copies) for q in case["quads_gspo"]]
     rows = [[shift(v, k) for v in r] for k in range(copies) for r in case["rows"]]
     return quads, rows
+
+
+def term_dictionary(terms, languages=("",)):
+    """Typed values + string heap for ids 1..len(terms); a term is [kind, lexical, datatype-or-language] with kind in
+    iri / bnode / literal, the third entry None (simple literal), "@tag" (language-tagged) or "xsd:<type>".  The heap holds
+    the lexical form AS WRITTEN of every term (what the host dictionary stores); `languages` numbers the language tags
+    (index 0 = no language).  Numeric payloads: int / integer parsed, everything else opaque here."""
+    from rdf_fusion_amd import abi
+    from rdf_fusion_amd.engine import TV_DTYPE
+    languages = list(languages)
+    n_ids = 1 + len(terms)
+    tv = np.zeros(n_ids, dtype=TV_DTYPE)
+    strings = sorted({t[1] for t in terms})
+    rank = {s: r for r, s in enumerate(strings)}
+    offsets = np.zeros(n_ids + 1, dtype=np.uint64)
+    heap = bytearray()
+    for k, t in enumerate(terms):
+        i = 1 + k
+        kind, lex, extra = t[0], t[1], (t[2] if len(t) > 2 else None)
+        b = lex.encode("utf-8")
+        offsets[i] = len(heap); heap += b; offsets[i + 1] = len(heap)
+        if kind == "iri":
+            tv["tag"][i] = abi.TV_NAMED_NODE; tv["lo"][i] = rank[lex]
+        elif kind == "bnode":
+            tv["tag"][i] = abi.TV_BLANK_NODE; tv["lo"][i] = rank[lex]
+        elif extra is None or extra.startswith("@"):
+            tv["tag"][i] = abi.TV_STRING; tv["lo"][i] = rank[lex]
+            if extra:
+                if extra[1:] not in languages:
+                    languages.append(extra[1:])
+                tv["aux"][i] = languages.index(extra[1:])
+            tv["flags"][i] = abi.TVF_EMPTY_STRING if not b else 0
+        elif extra in ("xsd:int", "xsd:integer"):
+            tv["tag"][i] = abi.TV_INT if extra == "xsd:int" else abi.TV_INTEGER; tv["lo"][i] = int(lex)
+        elif extra == "xsd:boolean":
+            tv["tag"][i] = abi.TV_BOOLEAN; tv["lo"][i] = 1 if lex in ("true", "1") else 0
+        else:
+            tv["tag"][i] = abi.TV_OTHER; tv["lo"][i] = rank[lex]
+    return tv, offsets, bytes(heap), languages

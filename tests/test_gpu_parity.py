@@ -491,14 +491,14 @@ def test_streaming_filter_matches_oracle(torch_cuda, n):
             mask = os_.eval_bool(e, scan_cols) == 1                    # the row-wise evaluator over the scan's rows, in index order
             exp = [scan_cols[c][mask] for c in projection]
             names = [st[0] for st in plan.kernel_stats()]
-            ordered = any("filter_write_kernel" in x or "run_copy_kernel" in x for x in names)
+            ordered = any("filter_write_kernel" in x or "run_copy" in x for x in names)
             assert ordered or ENGINE_TOGGLED
             if ordered:
                 for c in range(len(projection)):
                     np.testing.assert_array_equal(got[c], exp[c])      # the streaming / run-copy forms keep the rows in index order
             if k < 4 and not ENGINE_TOGGLED:
                 # few ids under many rows: the qualifying runs are copied; then the two fallbacks, each forced
-                assert any("run_copy_kernel" in x for x in names) and any("value_runs_kernel" in x for x in names)
+                assert any("run_copy" in x for x in names) and any("value_runs_kernel" in x for x in names)
                 for option, kernel in (("NO_RUN_COPY", "filter_bits_kernel<4>"), ("NO_VALUE_VERDICTS", "filter_bits_kernel<2>")):
                     p2 = gs.plan(desc).set_option(option).enable_kernel_timing(True)
                     got2 = p2.execute().fetch()
@@ -934,6 +934,78 @@ def test_string_functions_match_oracle(torch_cuda):
         gs.plan(pb.build(pb.filter(pb.table(0, 2), EBV(CONTAINS(ENC_TV(col(0)), "y" * 65)))))
 
 
+def test_string_valued_expressions_match_oracle(torch_cuda, kats):
+    """STR / STRLEN / SUBSTR / UCASE / LCASE inside plan expressions: string VIEWS over the heap on the device against
+    the oracle's materialised strings; the reference's STR vectors (unary__STR(PLAIN_TERM).snap, small_iri_str.rq) through the GPU;
+    what the device does not restate fails the execute loudly."""
+    from rdf_fusion_amd.plan import STR, STRLEN, SUBSTR, UCASE, LCASE, lit_str
+    # the reference's vectors: STR(term) = its lexical form as written, for every kind of term
+    cases = kats["str_plain_term"]
+    tv, off, heap, _ = ku.term_dictionary([c["term"] for c in cases])
+    gs, os_ = both_stores((np.zeros(0, np.uint32),) * 4, typed=tv)
+    gs.set_strings(off, heap); os_.set_strings(off, heap)
+    for k, c in enumerate(cases):
+        one = [np.array([k + 1], np.uint32)]
+        got = check_filter(torch_cuda, gs, os_, EBV(EQ(STR(col(0)), lit_str(c["str"]))), one)
+        assert got[0].tolist() == [k + 1], c
+        check_filter(torch_cuda, gs, os_, EBV(EQ(STRLEN(STR(col(0))), integer(len(c["str"])))), one)
+    for c in kats["str_queries"]:
+        tv1, off1, heap1, _ = ku.term_dictionary([c["term"]])
+        g1, o1 = both_stores((np.zeros(0, np.uint32),) * 4, typed=tv1)
+        g1.set_strings(off1, heap1); o1.set_strings(off1, heap1)
+        got = check_filter(torch_cuda, g1, o1, EBV(EQ(STR(col(0)), lit_str(c["equals"]))), [np.array([1], np.uint32)])
+        assert (len(got[0]) == 1) == c["answer"]
+    # random dictionary: ASCII words, non-ASCII words, language tags, IRIs, integers
+    rng = np.random.default_rng(17)
+    alphabet = list("abcdeABC019 _-.")
+    ascii_words = ["".join(rng.choice(alphabet, rng.integers(0, 14))) for _ in range(400)]
+    words = ascii_words + ["äpfel", "日本語テキスト", "🤖 robot", "naïve café", "Ünïcode"]
+    terms = [["literal", w, None if k % 4 else "@en"] for k, w in enumerate(words)] + [["iri", "http://example.org/" + w.strip()] for w in ascii_words[:40]] + \
+            [["literal", str(k), "xsd:integer"] for k in range(10)]
+    tv, off, heap, langs = ku.term_dictionary(terms)
+    gs, os_ = both_stores((np.zeros(0, np.uint32),) * 4, typed=tv)
+    gs.set_strings(off, heap); os_.set_strings(off, heap)
+    n_ascii = len(ascii_words)
+    ids = rng.integers(0, len(tv) + 2, 6000).astype(np.uint32)
+    ascii_ids = np.concatenate([rng.integers(1, n_ascii + 1, 3000), rng.integers(len(words) + 1, len(tv), 500)]).astype(np.uint32)   # (case mapping: ASCII strings, IRIs, integers)
+    en = langs.index("en")
+    exprs_any = [
+        EBV(EQ(STR(col(0)), lit_str(ascii_words[3]))), EBV(LT(STR(col(0)), lit_str("b"))), EBV(GEQ(STR(col(0)), lit_str("http://example.org/c"))),
+        EBV(CONTAINS(STR(col(0)), "example.org/a")), EBV(STRSTARTS(STR(col(0)), "http://")), EBV(REGEX(STR(col(0)), "^[0-9]+$")),
+        EBV(GT(STRLEN(ENC_TV(col(0))), integer(5))), EBV(EQ(STRLEN(STR(col(0))), integer(7))),
+        EBV(EQ(SUBSTR(ENC_TV(col(0)), integer(2), integer(3)), lit_str("bc"))), EBV(EQ(SUBSTR(ENC_TV(col(0)), integer(2), integer(3)), lit_str("bc", en))),
+        EBV(STRENDS(SUBSTR(STR(col(0)), integer(3)), "a")), EBV(SUBSTR(ENC_TV(col(0)), integer(4))), EBV(SUBSTR(ENC_TV(col(0)), integer(0))),
+        EBV(LT(SUBSTR(ENC_TV(col(0)), integer(1), integer(2)), SUBSTR(ENC_TV(col(0)), integer(2), integer(2)))),
+        EBV(EQ(SUBSTR(STR(col(0)), integer(8), integer(40)), STR(col(0)))),
+        NOT(EBV(EQ(STRLEN(SUBSTR(ENC_TV(col(0)), integer(2), integer(300))), integer(0)))),
+    ]
+    for e in exprs_any:
+        check_filter(torch_cuda, gs, os_, e, [ids])
+    exprs_ascii = [
+        EBV(EQ(UCASE(ENC_TV(col(0))), lit_str(ascii_words[5].upper()))), EBV(CONTAINS(LCASE(ENC_TV(col(0))), "ab")),
+        EBV(REGEX(UCASE(STR(col(0))), "^HTTP://EXAMPLE")), EBV(LT(LCASE(STR(col(0))), lit_str("c"))),
+        EBV(EQ(UCASE(SUBSTR(LCASE(ENC_TV(col(0))), integer(2), integer(2))), lit_str("BC"))),
+        EBV(EQ(LCASE(ENC_TV(col(0))), UCASE(ENC_TV(col(0))))),
+    ]
+    for e in exprs_ascii:
+        check_filter(torch_cuda, gs, os_, e, [ascii_ids])
+    # not restated on the device: never answered differently, the execute fails (and the oracle refuses the same)
+    for e, rows in ((EBV(EQ(UCASE(ENC_TV(col(0))), lit_str("X"))), np.array([n_ascii + 1], np.uint32)),
+                    (EBV(SUBSTR(ENC_TV(col(0)), double(2.0))), np.array([1, 2], np.uint32))):
+        pb = PlanBuilder()
+        desc = pb.build(pb.filter(pb.table(0, 1), e))
+        keep, ptrs = table_on_device(torch_cuda, [rows])
+        plan = gs.plan(desc); plan.bind_table(0, ptrs, len(rows))
+        with pytest.raises(rf.RdfGpuError) as err:
+            plan.execute()
+        assert err.value.status == abi.ERR_UNSUPPORTED
+        with pytest.raises(RuntimeError):
+            os_.execute(desc, [[rows]])
+    pb = PlanBuilder()                       # a string literal given by rank only next to computed strings: refused at compile time
+    with pytest.raises(rf.RdfGpuError):
+        gs.plan(pb.build(pb.filter(pb.table(0, 1), EBV(EQ(STR(col(0)), lit_tv(abi.TV_STRING, 3))))))
+
+
 def test_regex_perl_classes_and_word_boundaries(torch_cuda):
     """`\\d \\w \\s \\D \\W \\S` (alone and inside classes) and `\\b \\B`: device automaton vs the oracle's Pike VM and vs
     Python's `re` (re.ASCII) over an all-ASCII dictionary — both the per-term verdict table and the per-row VM."""
@@ -1325,7 +1397,7 @@ def test_engine_toggles_do_not_change_results(bsbm_stores, torch_cuda, request, 
     run_both(gs, os_, bsbm.q4_plan(ds, ds.type_base + ds.n_types - 1, int(feats[0]), int(feats[1]), int(feats[2]), 300, 400))
     desc = bsbm.q5_batch_plan(ds)
     plan = gs.plan(desc)
-    for batch in (60, 90, 75):                                   # re-executions: speculative sizes, cached tables, fusion
+    for batch in (60, 90, 75, 80, 70, 85):                       # re-executions: speculative sizes, cached tables, fusion, the record-writing ordered join
         prods = np.array([ds.product(i) for i in rng.choice(ds.n_products, batch, replace=False)], dtype=np.uint32)
         params = [np.arange(1, batch + 1, dtype=np.uint32), prods]
         keep, ptrs = table_on_device(torch_cuda, params)
@@ -1393,6 +1465,46 @@ def test_plan_outlives_its_store_handle(torch_cuda):
     got = plan.execute().fetch()
     np.testing.assert_array_equal(ku.multiset(got), ku.multiset(exp, n_exp))
     plan.close()
+
+
+def test_tables_rebuilt_inside_a_fused_execution(torch_cuda):
+    """rdfgpu_store_drop_tables (what any extend / remove does to the cached join tables): a plan with history keeps its fused
+    form — the tables it needs are built inside the next execution, which still runs the ordered slice join + band join and
+    still answers like the oracle; an extend / remove pair does the same through a real mutation."""
+    ds = bsbm.generate(2000)
+    gs, os_ = both_stores((ds.g, ds.s, ds.p, ds.o), typed=ds.typed_values, decimals=ds.decimals)
+    rng = np.random.default_rng(77)
+    desc = bsbm.q5_batch_plan(ds)
+    plan = gs.plan(desc).enable_kernel_timing(True)
+    def run(batch):
+        prods = np.array([ds.product(i) for i in rng.choice(ds.n_products, batch, replace=False)], dtype=np.uint32)
+        params = [np.arange(1, batch + 1, dtype=np.uint32), prods]
+        keep, ptrs = table_on_device(torch_cuda, params)
+        plan.bind_table(0, ptrs, batch)
+        got = plan.execute().fetch()
+        exp, n_exp, _ = os_.execute(desc, [params])
+        np.testing.assert_array_equal(ku.multiset(got), ku.multiset(exp, n_exp))
+        return plan.metrics(), {k[0] for k in plan.kernel_stats()}
+    run(1500); run(1400); run(1420); run(1460)
+    m, ran = run(1450)
+    if not ENGINE_TOGGLED:
+        assert any("oj_write_band_kernel" in k for k in ran), sorted(ran)
+    if not ENGINE_TOGGLED:
+        assert m.tables_built == 0 and m.host_syncs == 1 and any("band_mask_kernel" in k for k in ran), (m.tables_built, m.host_syncs, sorted(ran))
+    gs.drop_tables()
+    m, ran = run(1480)
+    if not ENGINE_TOGGLED:
+        assert m.tables_built >= 4 and m.exact_reruns == 0, (m.tables_built, m.exact_reruns)
+        assert any("band_mask_kernel" in k for k in ran) and any("band_entries_kernel" in k for k in ran), sorted(ran)
+    m, ran = run(1500)
+    if not ENGINE_TOGGLED:
+        assert m.tables_built == 0 and m.host_syncs == 1
+    # a real mutation: one foreign quad in and out again
+    q = [np.array([0], np.uint32), np.array([ds.product(0)], np.uint32), np.array([ds.pred["rdfs:label"]], np.uint32), np.array([ds.product(1)], np.uint32)]
+    assert gs.extend(*q) == os_.extend(*q) == 1
+    run(1300)
+    assert gs.remove(*q) == os_.remove(*q) == 1
+    run(1350)
 
 
 def test_topk_distinct_matches_oracle(torch_cuda):
@@ -1537,16 +1649,18 @@ def test_bsbm_100m_timed_path_answers_to_the_oracle(torch_cuda):
     expected = ku.multiset(list(np.concatenate(expected).T))
     plan = gs.plan(bsbm.q5_batch_plan(ds)).enable_kernel_timing(True)
     plan.bind_table(0, ptrs, batch)
-    counts = []
-    for run in range(3):
-        got = plan.execute().fetch()
+    counts, forms = [], []
+    for run in range(6):      # 1: exact (primed); 2, 3: speculative, fused (ordered slice join -> table C -> band join); from 4 on the ordered
+        got = plan.execute().fetch()      # join writes the band join's row records itself (no table C, no decode pass)
         counts.append(len(got[0]))
         sel = np.isin(got[0], tags)
         np.testing.assert_array_equal(ku.multiset([c[sel] for c in got]), expected)
-    assert counts[0] == counts[1] == counts[2] and counts[0] > 100 * batch // 2
-    if not ENGINE_TOGGLED:
         ran = {k[0] for k in plan.kernel_stats()}
-        assert any("band_mask_kernel" in k for k in ran) and any("oj_write_kernel" in k for k in ran), sorted(ran)
+        forms.append("records" if any("oj_write_band_kernel" in k for k in ran) else "table" if any("band_decode_kernel" in k for k in ran) else "unfused")
+    assert len(set(counts)) == 1 and counts[0] > 100 * batch // 2
+    if not ENGINE_TOGGLED:
+        assert any("band_mask_kernel" in k for k in ran), sorted(ran)
+        assert "table" in forms and forms[-1] == "records", forms
         assert plan.metrics().host_syncs == 1
 
 
