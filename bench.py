@@ -112,7 +112,7 @@ def scan_roofline(rf, device, log2_rows=26, threshold=1000, reps=10, distinct=20
     return out
 
 
-def pmc_traffic(kernels, workload):
+def pmc_traffic(kernels, workload, profiles_dir=None):
     """HBM bytes per launch of `kernels` (one name or several: summed) from the committed rocprofv3 PMC passes of THIS
     command (FETCH_SIZE and WRITE_SIZE in separate runs, gfx950 corrections applied by profiles/summarize.py) —
     counters cannot be read from inside the benchmark process, so the newest summary under profiles/ whose recorded
@@ -121,7 +121,8 @@ def pmc_traffic(kernels, workload):
     import re
     if isinstance(kernels, str):
         kernels = [kernels]
-    files = glob.glob(os.path.join(ROOT, "profiles", "*_pmc_fetch_write_per_kernel.json"))
+    profiles_dir = profiles_dir or os.path.join(ROOT, "profiles")
+    files = glob.glob(os.path.join(profiles_dir, "*_pmc_fetch_write_per_kernel.json"))
     files.sort(key=lambda f: [int(x) for x in re.findall(r"\d+", os.path.basename(f))])
     for f in reversed(files):
         try:
@@ -131,10 +132,14 @@ def pmc_traffic(kernels, workload):
         w = d.get("_workload") or {}
         if any(w.get(k) != v for k, v in workload.items()):
             continue
-        # only the NEWEST summary of the workload counts: an older one describes kernels that have changed since
-        found = [next((v for k, v in d.items() if k != "_workload" and k.startswith(kn.split("(")[0])), None) for kn in kernels]
+        # only the NEWEST summary of the workload counts: an older one describes kernels that have changed since — and it counts
+        # only while the device sources still hash to what it was collected on (a summary without the stamp predates it: stale)
+        import rdf_fusion_amd
+        if d.get("_source_sha16") != rdf_fusion_amd.kernel_source_sha16():
+            return None, f"{os.path.basename(f)} is stale: collected on other kernel sources"
+        found = [next((v for k, v in d.items() if not k.startswith("_") and k.startswith(kn.split("(")[0])), None) for kn in kernels]
         if all(e and "hbm_bytes_per_launch" in e for e in found):
-            return int(sum(e["hbm_bytes_per_launch"] for e in found)), os.path.relpath(f, ROOT)
+            return int(sum(e["hbm_bytes_per_launch"] for e in found)), os.path.join("profiles", os.path.basename(f))
         return None, None
     return None, None
 

@@ -137,6 +137,7 @@ enum {
   RDFGPU_TV_DATE = 12, RDFGPU_TV_DURATION = 13, RDFGPU_TV_OTHER = 14
 };
 #define RDFGPU_TVF_EMPTY_STRING 1u
+#define RDFGPU_TVF_NEEDS_HOST 0x80u   /* rdfgpu_ntriples_decoded only: the literal's value is left to the host's parser (see there) */
 
 /* MemQuadStorage::new (mem_storage.rs:31-65): creates the store on `cfg->device`. */
 int rdfgpu_store_create(const rdfgpu_config* cfg, rdfgpu_store** out);
@@ -676,9 +677,9 @@ uint32_t rdfgpu_shard_of(uint32_t id, uint32_t world);
  * object_id_mapping.rs:106-116).  rdfgpu_ntriples_parse does the per-triple half on the device: line and term splitting,
  * one id per DISTINCT term (first_id .. first_id + n_terms - 1; a bijection, not the reference's insertion order — no query
  * can observe the difference), and the s / p / o id columns in HBM, ready for rdfgpu_store_extend_device (graph column =
- * zeros = the default graph).  The distinct terms come back exactly as written in the file (`<iri>`, `_:b1`, `"lex"`,
- * `"lex"@en`, `"lex"^^<dt>`; escapes are kept, not rewritten): the host builds its dictionary and the typed values of the
- * new literals from them — per distinct term, not per triple.  Text: UTF-8, one triple per line, blank lines and `#`
+ * zeros = the default graph).  The distinct terms come back as written in the file (`<iri>`, `_:b1`, `"lex"`, `"lex"@en`,
+ * `"lex"^^<dt>`: rdfgpu_ntriples_terms) and decoded + typed (rdfgpu_ntriples_decoded): the host builds its dictionary from them —
+ * per distinct term, not per triple.  Text: UTF-8, one triple per line, blank lines and `#`
  * comment lines allowed.  A malformed line is RDFGPU_ERR_INVALID with its number; two different terms with one 64-bit
  * hash (probability ~ n_terms^2 / 2^65) is RDFGPU_ERR_UNSUPPORTED — loud, never a wrong id.
  */
@@ -687,6 +688,25 @@ int rdfgpu_ntriples_parse(int32_t device, const char* text, uint64_t text_bytes,
 int rdfgpu_ntriples_info(const rdfgpu_ntriples* nt, uint64_t* n_triples, uint32_t* n_terms, uint64_t* term_bytes);
 /* offsets[n_terms + 1] and the terms' bytes (term t has id first_id + t); either pointer may be null */
 int rdfgpu_ntriples_terms(const rdfgpu_ntriples* nt, uint64_t* offsets, uint8_t* bytes);
+/*
+ * The distinct terms as the reference's parser hands them to its dictionary (oxttl -> oxrdf: escapes decoded) and the typed values
+ * of the literals (ABI 3).  Terms are interned by this CANONICAL form: `"a\u0041"` and `"aA"`, `"x"^^xsd:string` and `"x"`, `"v"@EN`
+ * and `"v"@en` are one term with one id (rdfgpu_ntriples_terms hands out one of its spellings).  Per term t (id first_id + t):
+ *   kind[t]    1 IRI, 2 blank node, 3 simple literal, 4 language-tagged literal, 5 typed literal
+ *   lex        the lexical form, ECHAR / UCHAR escapes decoded to UTF-8: lex_bytes[lex_off[t] .. lex_off[t + 1])
+ *   suffix     the language tag in lower case / the datatype IRI (decoded): suffix_bytes[suffix_off[t] .. suffix_off[t + 1])
+ *   typed[t]   the typed-value row the device derives (encoding/typed_value.rs:27-83, lib/model/src/typed_value.rs:349-411): tag;
+ *              IRIs / blank nodes / strings carry lo = 0 (their rank in `str` order is the dictionary's to give) and aux = 0 (the
+ *              host numbers languages / datatypes); xsd:integer and its derived types, xsd:int, xsd:boolean, xsd:decimal (low
+ *              64 bits in lo, high in dec_hi[t]: the host's decimal side table) are parsed here, an invalid lexical form gives
+ *              RDFGPU_TV_NULL like the reference's Invalid; xsd:double / xsd:float are parsed when the conversion is exact in one
+ *              IEEE operation (<= 15 / 7 digits, |exponent| <= 22 / 10), otherwise — and for dateTime / time / date / durations —
+ *              flags carries RDFGPU_TVF_NEEDS_HOST and the tag says what to parse the lexical form as.
+ * Any pointer may be null.  Sizes: rdfgpu_ntriples_decoded_info.
+ */
+int rdfgpu_ntriples_decoded_info(const rdfgpu_ntriples* nt, uint64_t* lex_bytes, uint64_t* suffix_bytes);
+int rdfgpu_ntriples_decoded(const rdfgpu_ntriples* nt, uint8_t* kind, uint64_t* lex_off, uint8_t* lex_bytes, uint64_t* suffix_off,
+                            uint8_t* suffix_bytes, rdfgpu_typed_value* typed, int64_t* dec_hi);
 /* device pointers of the id columns (n_triples each, file order); valid until rdfgpu_ntriples_destroy */
 int rdfgpu_ntriples_columns(const rdfgpu_ntriples* nt, const uint32_t** s, const uint32_t** p, const uint32_t** o);
 void rdfgpu_ntriples_destroy(rdfgpu_ntriples* nt);

@@ -164,11 +164,163 @@ def ntriples_encode(text):
         if not rest.startswith(b".") or (rest[1:].strip(b" \t\r") and not rest[1:].strip(b" \t\r").startswith(b"#")):
             raise ValueError(n_line)
         for k, t in enumerate(got):
-            if t not in ids:
-                ids[t] = len(terms) + 1
+            try:
+                key = ntriples_decode_term(t)          # interned by what the parser hands the dictionary, not by spelling
+            except ValueError:
+                raise ValueError(n_line)
+            if key not in ids:
+                ids[key] = len(terms) + 1
                 terms.append(t)
-            cols[k].append(ids[t])
+            cols[k].append(ids[key])
     return terms, cols[0], cols[1], cols[2]
+
+
+_NT_ECHAR = {b"t": b"\t", b"b": b"\b", b"n": b"\n", b"r": b"\r", b"f": b"\f", b'"': b'"', b"'": b"'", b"\\": b"\\"}
+_XSD = b"http://www.w3.org/2001/XMLSchema#"
+_XSD_INTEGERS = {b"integer", b"byte", b"short", b"long", b"unsignedByte", b"unsignedShort", b"unsignedInt", b"unsignedLong",
+                 b"positiveInteger", b"negativeInteger", b"nonPositiveInteger", b"nonNegativeInteger"}
+
+
+def _nt_unescape(raw, echar):
+    """ECHAR / UCHAR of the N-Triples grammar -> UTF-8 (what oxttl's lexer hands on).  ValueError on a malformed escape."""
+    import re
+
+    def one(m):
+        body = m.group(1)
+        if body[:1] in (b"u", b"U"):
+            want = 4 if body[:1] == b"u" else 8
+            if len(body) != 1 + want:
+                raise ValueError("bad UCHAR")
+            cp = int(body[1:], 16)
+            if cp > 0x10FFFF or 0xD800 <= cp <= 0xDFFF:
+                raise ValueError("not a Unicode scalar value")
+            return chr(cp).encode("utf-8")
+        if not echar or body not in _NT_ECHAR:
+            raise ValueError("bad ECHAR")
+        return _NT_ECHAR[body]
+
+    out = re.sub(rb"\\(u[0-9A-Fa-f]{0,4}|U[0-9A-Fa-f]{0,8}|.|$)", one, raw, flags=re.S)
+    return out
+
+
+def ntriples_decode_term(term):
+    """One term as written -> (kind, lexical form, suffix), the canonical form the reference's parser produces (oxttl + oxrdf):
+    escapes decoded, the language tag in lower case, the datatype IRI decoded, `"x"^^xsd:string` = the simple literal "x".
+    kind: 1 IRI, 2 blank node, 3 simple literal, 4 language-tagged literal, 5 typed literal (abi.NT_*)."""
+    t = bytes(term)
+    if t.startswith(b"<"):
+        return 1, _nt_unescape(t[1:-1], False), b""
+    if t.startswith(b"_:"):
+        return 2, t[2:], b""
+    q = 1                                              # the closing quote: the first unescaped one
+    while t[q:q + 1] != b'"':
+        q += 2 if t[q:q + 1] == b"\\" else 1
+    lex, rest = _nt_unescape(t[1:q], True), t[q + 1:]
+    if rest.startswith(b"@"):
+        return 4, lex, rest[1:].lower()
+    if rest.startswith(b"^^<"):
+        dt = _nt_unescape(rest[3:-1], False)
+        return (3, lex, b"") if dt == _XSD + b"string" else (5, lex, dt)
+    return 3, lex, b""
+
+
+def _nearest_float(frac, single):
+    """frac (a Fraction) rounded to the nearest binary32 / binary64, ties to even — Rust's f32 / f64::from_str on a decimal string."""
+    import struct
+    from fractions import Fraction
+    cand = float(frac)                                   # correctly rounded to binary64 by Python
+    if not single:
+        return cand
+    c32 = np.float32(cand)
+    best, best_err = None, None
+    for nb in (np.nextafter(c32, np.float32(-np.inf)), c32, np.nextafter(c32, np.float32(np.inf))):
+        if not np.isfinite(nb):
+            continue
+        err = abs(Fraction(float(nb)) - frac)
+        even = (struct.unpack("<I", struct.pack("<f", float(nb)))[0] & 1) == 0
+        if best is None or err < best_err or (err == best_err and even):
+            best, best_err = nb, err
+    return float(best)
+
+
+def ntriples_typed_value(kind, lex, suffix):
+    """The typed-value row of one decoded term (lib/model/src/typed_value.rs:349-411 + the xsd FromStr impls), independent of the
+    device code: returns (tag, lo, flags, dec_hi, host) — `host` True where the DEVICE is allowed to leave the value to the host's
+    parser (off Clinger's fast path, dateTime / durations); for those `lo` is not compared."""
+    import re
+    import struct
+    from fractions import Fraction
+    from rdf_fusion_amd import abi
+    if kind == 1:
+        return abi.TV_NAMED_NODE, 0, 0, 0, False
+    if kind == 2:
+        return abi.TV_BLANK_NODE, 0, 0, 0, False
+    if kind in (3, 4):
+        return abi.TV_STRING, 0, abi.TVF_EMPTY_STRING if not lex else 0, 0, False
+    if not suffix.startswith(_XSD):
+        return abi.TV_OTHER, 0, 0, 0, False
+    name = suffix[len(_XSD):]
+    if name in _XSD_INTEGERS or name == b"int":
+        ok = re.fullmatch(rb"[+-]?[0-9]+", lex) is not None        # i64::from_str / i32::from_str
+        v = int(lex) if ok else 0
+        lo_b, hi_b = (-2**31, 2**31 - 1) if name == b"int" else (-2**63, 2**63 - 1)
+        if not ok or not lo_b <= v <= hi_b:
+            return abi.TV_NULL, 0, 0, 0, False
+        return (abi.TV_INT if name == b"int" else abi.TV_INTEGER), v, 0, 0, False
+    if name == b"boolean":
+        if lex in (b"true", b"1"):
+            return abi.TV_BOOLEAN, 1, 0, 0, False
+        if lex in (b"false", b"0"):
+            return abi.TV_BOOLEAN, 0, 0, 0, False
+        return abi.TV_NULL, 0, 0, 0, False
+    if name == b"decimal":
+        m = re.fullmatch(rb"([+-]?)([0-9]*)(?:\.([0-9]*))?", lex)      # (\+|-)?([0-9]+(\.[0-9]*)?|\.[0-9]+), decimal.rs:501
+        if not m or (not m.group(2) and not m.group(3)):
+            return abi.TV_NULL, 0, 0, 0, False
+        frac_digits = (m.group(3) or b"").rstrip(b"0")
+        if len(frac_digits) > 18:
+            return abi.TV_NULL, 0, 0, 0, False                       # underflow
+        scaled = int((m.group(2) or b"0") + frac_digits + b"0" * (18 - len(frac_digits)))
+        if m.group(1) == b"-":
+            scaled = -scaled
+        # the reference accumulates digit by digit in a checked i128, then multiplies by 10^(18 - fractional digits)
+        unscaled = int((m.group(2) or b"0") + frac_digits or b"0")
+        if not -2**127 <= (-unscaled if m.group(1) == b"-" else unscaled) <= 2**127 - 1 or not -2**127 <= scaled <= 2**127 - 1:
+            return abi.TV_NULL, 0, 0, 0, False
+        u = scaled & ((1 << 128) - 1)
+        to_i64 = lambda x: x - (1 << 64) if x >= (1 << 63) else x
+        return abi.TV_DECIMAL, to_i64(u & ((1 << 64) - 1)), 0, to_i64(u >> 64), False
+    if name in (b"double", b"float"):
+        single = name == b"float"
+        tag = abi.TV_FLOAT if single else abi.TV_DOUBLE
+        bits = (lambda x: struct.unpack("<I", struct.pack("<f", x))[0]) if single else (lambda x: struct.unpack("<q", struct.pack("<d", x))[0])
+        low = lex.lower()
+        if low in (b"inf", b"+inf"):
+            return tag, bits(float("inf")), 0, 0, False
+        if low == b"-inf":
+            return tag, bits(float("-inf")), 0, 0, False
+        if low == b"nan":
+            return tag, 0, 0, 0, None                                # (the payload of a NaN is not pinned: compared as "is NaN")
+        m = re.fullmatch(rb"([+-]?)([0-9]*)(?:\.([0-9]*))?(?:[eE]([+-]?[0-9]+))?", lex)
+        if not m or (not m.group(2) and not m.group(3)):
+            return tag, 0, abi.TVF_NEEDS_HOST, 0, True               # not this grammar: the host's parser decides
+        digits = ((m.group(2) or b"") + (m.group(3) or b"")).lstrip(b"0")
+        mant = int(digits or b"0")
+        scale = int(m.group(4) or b"0") - len(m.group(3) or b"")
+        fast = len(digits) <= 19 and mant < (1 << (24 if single else 53)) and abs(scale) <= (10 if single else 22) and abs(int(m.group(4) or b"0")) <= 10000
+        if mant == 0:
+            fast = len(digits) <= 19 and abs(int(m.group(4) or b"0")) <= 10000
+        if not fast:
+            return tag, 0, abi.TVF_NEEDS_HOST, 0, True
+        val = _nearest_float(Fraction(mant) * Fraction(10) ** scale, single) if mant else 0.0
+        if m.group(1) == b"-":
+            val = -val
+        return tag, bits(val), 0, 0, False
+    host_tags = {b"dateTime": abi.TV_DATE_TIME, b"time": abi.TV_TIME, b"date": abi.TV_DATE, b"duration": abi.TV_DURATION,
+                 b"yearMonthDuration": abi.TV_DURATION, b"dayTimeDuration": abi.TV_DURATION}
+    if name in host_tags:
+        return host_tags[name], 0, abi.TVF_NEEDS_HOST, 0, True
+    return abi.TV_OTHER, 0, 0, 0, False
 
 
 def decode_terms(ids, typed_values, offsets, heap):

@@ -1,7 +1,8 @@
 """Turns rocprofv3 output directories into the small per-kernel summaries committed next to this file.
 
   python profiles/summarize.py stats <dir with *_kernel_stats.csv> <out.csv>
-  python profiles/summarize.py pmc   <fetch dir> <write dir> <out.json> [key=value ...]   (key=value -> "_workload", what bench.py matches on)
+  python profiles/summarize.py pmc   <fetch dir> <write dir> <out.json> [key=value ...]   (key=value -> "_workload", what bench.py matches on;
+                                                                                            "_source_sha16" = the device sources' hash, stamped here)
   python profiles/summarize.py counters <out.json> <kernel substring> <dir> [<dir> ...]
 
 The pmc form reads *_counter_collection.csv of two separate passes (FETCH_SIZE and WRITE_SIZE cannot share a
@@ -64,6 +65,10 @@ def main():
                   "hbm_bytes_per_launch": int(1024 * (factor * statistics.median(f) + statistics.median(w)))}
     if len(sys.argv) > 5:
         res["_workload"] = {kv.split("=", 1)[0]: (int(kv.split("=", 1)[1]) if kv.split("=", 1)[1].lstrip("-").isdigit() else kv.split("=", 1)[1]) for kv in sys.argv[5:]}
+    # which kernel code these counters were collected on: bench.py quotes a summary only while the device sources still hash to this
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import rdf_fusion_amd
+    res["_source_sha16"] = rdf_fusion_amd.kernel_source_sha16()
     json.dump(res, open(sys.argv[4], "w"), indent=1, sort_keys=True)
 
 

@@ -5,9 +5,9 @@ runs radix-partitioned with LDS-staged hash tables (part_join.hip).  Reported: H
 passes of both sides + join kernel), the SURVEY 8d hash-join bytes (partition passes in the time, not in the bytes), the
 fraction of 8 TB/s; beside it the same join against the store slice's cached table and through one HBM hash table; all three
 must agree on count and checksum.
-  python scratch/lubm_join_bench.py [universities]"""
+  python profiles/tools/lubm_join_bench.py [universities]"""
 import sys, os, time, json
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import rdf_fusion_amd as rf
 from rdf_fusion_amd import lubm, abi

@@ -2,9 +2,9 @@
 The oracle cannot follow to this size; checked instead: (1) every result row is a triangle of the raw triples (sample),
 (2) the bindings (count + order-independent checksum) are the same with the engine's index joins / direct tables / LDS
 joins switched off — different join algorithms, same answer.
-  python scratch/lubm_scale.py [universities]"""
+  python profiles/tools/lubm_scale.py [universities]"""
 import sys, os, time, json
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import rdf_fusion_amd as rf
 from rdf_fusion_amd import lubm

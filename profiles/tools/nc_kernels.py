@@ -1,6 +1,6 @@
 """Kernel breakdown of one steady-state Q5 batch step with NO cached join table (every HashJoinExec builds inside the step)."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import rdf_fusion_amd as rf
 from rdf_fusion_amd import bsbm

@@ -1,7 +1,7 @@
 """N-Triples -> ids on the device: throughput on a synthetic file (2 M triples by default)."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests"))
 import numpy as np, torch
 import rdf_fusion_amd as rf
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 2_000_000

@@ -1,6 +1,6 @@
 """Send-side cost of rdfgpu_exchange_repartition on one GPU (one-rank RCCL communicator: count, scan, stable scatter, send/recv to self)."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import rdf_fusion_amd as rf
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4_850_000

@@ -1,6 +1,6 @@
 """Q5 batch steps with one or two batches in flight (two plans, two host threads): does overlapping steps fill the launch bubbles?"""
 import sys, os, time, threading
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import rdf_fusion_amd as rf
 from rdf_fusion_amd import bsbm

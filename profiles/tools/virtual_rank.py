@@ -1,9 +1,9 @@
 """One rank's work of an N-way sharded batched Q5 step, on one GPU: phase A (constants of the rank's instances on its shard),
 the re-sharded C table (computed here from the full graph and cut to the rank's features: what the repartition delivers), phase B on the shard.
-    python scratch/virtual_rank.py <N> <instances>
+    python profiles/tools/virtual_rank.py <N> <instances>
 Everything but xGMI; prints per-phase device + wall times of the steady state."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import rdf_fusion_amd as rf
 from rdf_fusion_amd import bsbm, sharding

@@ -23,6 +23,8 @@ PRED_NONE, PRED_FALSE, PRED_IN, PRED_BETWEEN, PRED_EQUAL_TO = 0, 1, 2, 3, 4
 (TV_NULL, TV_NAMED_NODE, TV_BLANK_NODE, TV_STRING, TV_BOOLEAN, TV_FLOAT, TV_DOUBLE, TV_DECIMAL,
  TV_INT, TV_INTEGER, TV_DATE_TIME, TV_TIME, TV_DATE, TV_DURATION, TV_OTHER) = range(15)
 TVF_EMPTY_STRING = 1
+TVF_NEEDS_HOST = 0x80
+NT_IRI, NT_BNODE, NT_SIMPLE, NT_LANG, NT_TYPED = 1, 2, 3, 4, 5   # rdfgpu_ntriples_decoded: kind of a distinct term
 
 # expression ops
 (EX_COLUMN, EX_LIT_ID, EX_LIT_TV, EX_ENC_TV, EX_GT, EX_LT, EX_GEQ, EX_LEQ, EX_EQ, EX_ADD, EX_SUB,
@@ -147,7 +149,7 @@ EXPORTED_SYMBOLS = [
     "rdfgpu_store_read_index",
     "rdfgpu_plan_compile", "rdfgpu_plan_destroy", "rdfgpu_plan_bind_table", "rdfgpu_plan_execute",
     "rdfgpu_plan_result_info", "rdfgpu_plan_result_device", "rdfgpu_plan_fetch", "rdfgpu_plan_next",
-    "rdfgpu_plan_rewind", "rdfgpu_plan_decode_terms", "rdfgpu_ntriples_parse", "rdfgpu_ntriples_info", "rdfgpu_ntriples_terms", "rdfgpu_ntriples_columns", "rdfgpu_ntriples_destroy", "rdfgpu_plan_metrics", "rdfgpu_plan_selected_index", "rdfgpu_plan_stream",
+    "rdfgpu_plan_rewind", "rdfgpu_plan_decode_terms", "rdfgpu_ntriples_parse", "rdfgpu_ntriples_info", "rdfgpu_ntriples_terms", "rdfgpu_ntriples_decoded_info", "rdfgpu_ntriples_decoded", "rdfgpu_ntriples_columns", "rdfgpu_ntriples_destroy", "rdfgpu_plan_metrics", "rdfgpu_plan_selected_index", "rdfgpu_plan_stream",
     "rdfgpu_plan_enable_kernel_timing", "rdfgpu_plan_kernel_stats",
     "rdfgpu_plan_pushdown_filters", "rdfgpu_plan_set_dynamic_filters", "rdfgpu_plan_source_predicate",
     "rdfgpu_store_set_option", "rdfgpu_store_get_option", "rdfgpu_plan_set_option", "rdfgpu_option_name",

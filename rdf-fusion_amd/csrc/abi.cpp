@@ -555,6 +555,21 @@ int rdfgpu_ntriples_terms(const rdfgpu_ntriples* nt, uint64_t* offsets, uint8_t*
   ntriples_terms(reinterpret_cast<const NTriples*>(nt), offsets, bytes);
   ABI_END
 }
+int rdfgpu_ntriples_decoded_info(const rdfgpu_ntriples* nt, uint64_t* lex_bytes, uint64_t* suffix_bytes) {
+  ABI_BEGIN
+  if (!nt) fail(RDFGPU_ERR_INVALID, "null handle");
+  const NTriples* t = reinterpret_cast<const NTriples*>(nt);
+  if (lex_bytes) *lex_bytes = t->lex_total;
+  if (suffix_bytes) *suffix_bytes = t->sfx_total;
+  ABI_END
+}
+int rdfgpu_ntriples_decoded(const rdfgpu_ntriples* nt, uint8_t* kind, uint64_t* lex_off, uint8_t* lex_bytes, uint64_t* suffix_off,
+                            uint8_t* suffix_bytes, rdfgpu_typed_value* typed, int64_t* dec_hi) {
+  ABI_BEGIN
+  if (!nt) fail(RDFGPU_ERR_INVALID, "null handle");
+  ntriples_decoded(reinterpret_cast<const NTriples*>(nt), kind, lex_off, lex_bytes, suffix_off, suffix_bytes, typed, dec_hi);
+  ABI_END
+}
 int rdfgpu_ntriples_columns(const rdfgpu_ntriples* nt, const uint32_t** s, const uint32_t** p, const uint32_t** o) {
   ABI_BEGIN
   if (!nt) fail(RDFGPU_ERR_INVALID, "null handle");

@@ -42,28 +42,6 @@ __device__ __forceinline__ u64 wave_partition_point(const u32* c, u64 lo, u64 hi
   return lo + (u64)__popcll(__ballot(below));
 }
 
-// The same with 128 pivots per step (two per lane, both in flight): 129-ary — four dependent memory round trips over 2^26 rows
-// where the 65-ary form takes five.  For kernels whose time IS those round trips (value_runs_kernel: one search per wave,
-// thousands of waves; 512 pivots per step were tried too: three round trips, but eight fully divergent gathers per lane and
-// step cost more than the two round trips they save, 10 -> 19 us).
-template <bool UPPER>
-__device__ __forceinline__ u64 wave_partition_point2(const u32* c, u64 lo, u64 hi, u32 key) {
-  const u32 lane = threadIdx.x & 63;
-  while (hi - lo > 128) {
-    const u64 step = (hi - lo + 128) / 129;
-    const u64 i0 = lo + (u64)(lane + 1u) * step - 1, i1 = lo + (u64)(lane + 65u) * step - 1;   // pivot p sits at lo + (p + 1) step - 1
-    const bool in0 = i0 < hi, in1 = i1 < hi;
-    const u32 v0 = in0 ? c[i0] : 0u, v1 = in1 ? c[i1] : 0u;
-    const u32 cnt = (u32)__popcll(__ballot(in0 && (UPPER ? v0 <= key : v0 < key))) + (u32)__popcll(__ballot(in1 && (UPPER ? v1 <= key : v1 < key)));
-    const u64 nlo = cnt ? lo + (u64)cnt * step : lo;               // pivots are sorted: the ones left of the partition point are a prefix
-    const u64 nhi = cnt < 128 ? lo + (u64)(cnt + 1) * step - 1 : hi;
-    lo = nlo; hi = nhi < hi ? nhi : hi;
-  }
-  const u64 j0 = lo + lane, j1 = lo + 64 + lane;
-  const u32 w0 = j0 < hi ? c[j0] : 0u, w1 = j1 < hi ? c[j1] : 0u;
-  return lo + (u32)__popcll(__ballot(j0 < hi && (UPPER ? w0 <= key : w0 < key))) + (u32)__popcll(__ballot(j1 < hi && (UPPER ? w1 <= key : w1 < key)));
-}
-
 __global__ __launch_bounds__(64) void locate_kernel(const LocateJob* jobs, u32 n_jobs, u64* lo_hi) {
   const u32 j = blockIdx.x;
   if (j >= n_jobs) return;
@@ -525,10 +503,12 @@ __global__ __launch_bounds__(256) void value_verdict_kernel(const FilterStreamAr
 // SURVIVING row and column (8 sigma N instead of 8 N + 4 sigma N).  Output order = index order, as in the streaming form.
 __global__ __launch_bounds__(256) void value_runs_kernel(const FilterStreamArgs a, u32 first, u32 span, u64 n, u32* run_lo, u32* run_cnt) {
   // ONE search per id (where its run starts; it ends where the next id's starts; entry `span` = where the last one ends): the
-  // searches are chains of dependent HBM loads, and two per qualifying id were most of this kernel's time
+  // searches are chains of dependent HBM loads, and two per qualifying id were most of this kernel's time.  (More pivots per step
+  // — 2 or 8 per lane: 129-ary / 513-ary, one or two round trips fewer — were tried: 13.8 and 18.9 us against 10.3; the
+  // fully divergent gathers cost more than the round trips they save.)
   const u32 i = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (i > span) return;                                    // wave-uniform
-  const u64 l = i < span ? wave_partition_point2<false>(a.pcol, 0, n, first + i) : wave_partition_point2<true>(a.pcol, 0, n, first + span - 1u);
+  const u64 l = i < span ? wave_partition_point<false>(a.pcol, 0, n, first + i) : wave_partition_point<true>(a.pcol, 0, n, first + span - 1u);
   const bool ok = i < span && stream_pred<2>(a, first + i);   // the same answer in every lane
   if ((threadIdx.x & 63) == 0) { run_lo[i] = (u32)l; if (i < span) run_cnt[i] = ok ? 1u : 0u; }
 }
@@ -539,7 +519,9 @@ __global__ __launch_bounds__(1024) void run_scan_kernel(const u32* run_lo, const
   const u32 per = (span + 1023) / 1024;
   const u32 i0 = threadIdx.x * per, i1 = i0 + per < span ? i0 + per : span;
   u32 rows = 0, runs = 0;
-  for (u32 i = i0; i < i1; i++) { const u32 c = run_cnt[i] ? run_lo[i + 1] - run_lo[i] : 0u; rows += c; runs += c != 0; }   // (run_cnt: the id qualifies)
+  // (every load unconditional: `run_cnt[i] ? run_lo[i + 1] - run_lo[i] : 0` made the second load wait for the first one's verdict — two
+  //  dependent round trips per id in a kernel that is nothing but latency)
+  for (u32 i = i0; i < i1; i++) { const u32 q = run_cnt[i], lo = run_lo[i], hi = run_lo[i + 1]; const u32 c = q ? hi - lo : 0u; rows += c; runs += c != 0; }   // (run_cnt: the id qualifies)
   u32 inc_rows = rows, inc_runs = runs;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
@@ -553,8 +535,9 @@ __global__ __launch_bounds__(1024) void run_scan_kernel(const u32* run_lo, const
   for (int w = 0; w < wave; w++) { base_rows += w_rows[w]; base_runs += w_runs[w]; }
   u32 off = base_rows + inc_rows - rows, k = base_runs + inc_runs - runs;
   for (u32 i = i0; i < i1; i++) {
-    const u32 c = run_cnt[i] ? run_lo[i + 1] - run_lo[i] : 0u;
-    if (c) { c_lo[k] = run_lo[i]; c_off[k] = off; c_val[k] = first + i; k++; off += c; }
+    const u32 q = run_cnt[i], lo = run_lo[i], hi = run_lo[i + 1];
+    const u32 c = q ? hi - lo : 0u;
+    if (c) { c_lo[k] = lo; c_off[k] = off; c_val[k] = first + i; k++; off += c; }
   }
   if (threadIdx.x == 1023) { c_off[k] = off; *n_runs = k; *n_out = off; }
 }

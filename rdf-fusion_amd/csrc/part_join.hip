@@ -104,6 +104,10 @@ __global__ __launch_bounds__(256) void part_range_bounds_kernel(const u32* col, 
   pstart[p] = (u32)lower_bound_u32(col, n, first);
 }
 
+#ifndef RDFGPU_PART_PREFETCH_ROUNDS
+#define RDFGPU_PART_PREFETCH_ROUNDS 4
+#endif
+constexpr u32 kPartPrefetchRounds = RDFGPU_PART_PREFETCH_ROUNDS;
 template <int FS>
 __global__ __launch_bounds__(kLdsBlock) __attribute__((amdgpu_waves_per_eu(4))) void part_join_kernel(const LdsJoinArgs a, const PartArgs pa) {
   extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -187,9 +191,64 @@ __global__ __launch_bounds__(kLdsBlock) __attribute__((amdgpu_waves_per_eu(4))) 
     qn = 0;
   };
 
+  // one probe row of the partition against the chunk's table: walk its chain, queue the key-equal candidates
+  auto load_probe = [&](u32 ps, u32 t, bool live) -> uint4 {
+    uint4 r = make_uint4(kNil, 0u, 0u, 0u);
+    if (live) {
+      if (pa.ppart) { const PartRec q = pa.ppart[ps + t]; r = make_uint4(q.row, q.k0, q.k1, 0u); }
+      else {                                         // range mode: the slice itself, in place
+        r.x = ps + t; r.y = pa.pcol0[ps + t]; r.z = a.n_keys > 1 ? pa.pcol1[ps + t] : 0u;
+        if (r.y == 0 || (a.n_keys > 1 && r.z == 0)) r.x = kNil;   // NullEqualsNothing
+      }
+    }
+    return r;
+  };
+  auto probe_one = [&](const uint4 r, bool live, bool counting) {
+    Keys key; key.k[0] = r.y; key.k[1] = r.z; key.k[2] = 0; key.k[3] = 0;
+    u32 h = hash_keys4(key, a.n_keys) & pa.tbl_mask;
+    bool walking = live && r.x != kNil;
+    for (;;) {
+      u32 hit = kNil;
+      while (walking) {
+        const uint2 c = slots[h];
+        if (c.y == kNil) { walking = false; break; }
+        h = (h + 1) & pa.tbl_mask;
+        if (c.x != r.y) continue;
+        if (a.n_keys > 1 && k1s[c.y] != r.z) continue;
+        hit = rows[c.y];
+        break;
+      }
+      const unsigned long long found = __ballot(hit != kNil);
+      if (found == 0) break;
+      const u32 n_found = (u32)__popcll(found);
+      if (qn + n_found > qcap) flush(counting);      // wave-uniform: the queue is empty afterwards and 64 <= qcap
+      if (hit != kNil) wq[qn + lane_prefix(found)] = make_uint2(hit, r.x);
+      qn += n_found;
+    }
+  };
+  // Every memory round trip of a partition used to be exposed: `load a round of records -> use it`, ~3 build rounds and ~7 probe rounds
+  // per partition, with two workgroups per CU (the LDS table) to hide them behind — most of the 26 us a partition took.  Now the
+  // records of the first kPfBuild build rounds and the first kPfProbe probe rounds are requested TOGETHER, before the table is even
+  // cleared, and sit in registers (36 VGPRs) while the LDS phases run: one round trip per partition instead of ten.  Rounds beyond
+  // the prefetch (big partitions, later chunks) load in the loop as before.
+  // Only for the join without a VM / window filter (FS 0, 2: 40 VGPRs without the prefetch): the filtered forms sit at ~100 VGPRs already
+  // and would spill the prefetched records into scratch inside the probe loop (measured at compile time: 107 spilled VGPRs for FS 1).
+  // Depth: kPartPrefetchRounds probe rounds — deep enough for the usual partition (~3.5 k probe rows = 7 rounds of 512), shallow enough
+  // to stay under 84 VGPRs = 6 waves per SIMD = the three workgroups per CU a 52 KB-LDS join fits (108 VGPRs at depth 8: two).
+  constexpr u32 kPfProbe = (FS == 0 || FS == 2) ? kPartPrefetchRounds : 0u, kPfBuild = (FS == 0 || FS == 2) ? 4u : 0u;
+
   for (u32 p = blockIdx.x; p < pa.n_parts; p += gridDim.x) {
     const u32 bs = pa.bstart[p], be = pa.bstart[p + 1], ps = pa.pstart[p], pe = pa.pstart[p + 1];
     if (bs >= be || ps >= pe) continue;              // uniform per workgroup
+    const u32 n_probe = pe - ps;
+    PartRec pf_b[kPfBuild ? kPfBuild : 1]; uint4 pf_p[kPfProbe ? kPfProbe : 1];
+    {
+      const u32 nb0 = be - bs < pa.chunk ? be - bs : pa.chunk;
+#pragma unroll
+      for (u32 r = 0; r < kPfBuild; r++) { const u32 i = r * kLdsBlock + tid; pf_b[r] = i < nb0 ? pa.bpart[bs + i] : PartRec{kNil, 0u, 0u}; }
+#pragma unroll
+      for (u32 r = 0; r < kPfProbe; r++) { const u32 t = r * kLdsBlock + tid; pf_p[r] = load_probe(ps, t, t < n_probe); }
+    }
     __syncthreads();
     if (tid == 0) { wg_count = 0; wg_cursor = 0; }
     for (int pass = pa.two_pass ? 0 : 1; pass < 2; pass++) {
@@ -199,52 +258,31 @@ __global__ __launch_bounds__(kLdsBlock) __attribute__((amdgpu_waves_per_eu(4))) 
         __syncthreads();                             // every wave is done with the previous table
         for (u32 s = tid; s <= pa.tbl_mask; s += kLdsBlock) slots[s] = make_uint2(0u, kNil);
         __syncthreads();
-        for (u32 i = tid; i < nb; i += kLdsBlock) {
-          const PartRec q = pa.bpart[cb + i];
-          const uint4 r = make_uint4(q.row, q.k0, q.k1, 0u);   // {row, key0, key1, -}
-          k1s[i] = r.z; rows[i] = r.x;
-          if (r.x == kNil) continue;                 // a row that joins nothing
-          Keys key; key.k[0] = r.y; key.k[1] = r.z; key.k[2] = 0; key.k[3] = 0;
+        auto insert = [&](const PartRec q, u32 i) {
+          k1s[i] = q.k1; rows[i] = q.row;
+          if (q.row == kNil) return;                 // a row that joins nothing
+          Keys key; key.k[0] = q.k0; key.k[1] = q.k1; key.k[2] = 0; key.k[3] = 0;
           u32 h = hash_keys4(key, a.n_keys) & pa.tbl_mask;
           for (;;) {
-            if (atomicCAS(&slots[h].y, kNil, i) == kNil) { slots[h].x = r.y; break; }
+            if (atomicCAS(&slots[h].y, kNil, i) == kNil) { slots[h].x = q.k0; break; }
             h = (h + 1) & pa.tbl_mask;
           }
-        }
+        };
+        if (cb == bs) {                              // the first chunk: its first rounds are in registers already
+#pragma unroll
+          for (u32 r = 0; r < kPfBuild; r++) { const u32 i = r * kLdsBlock + tid; if (i < nb) insert(pf_b[r], i); }
+          for (u32 i = kPfBuild * kLdsBlock + tid; i < nb; i += kLdsBlock) insert(pa.bpart[cb + i], i);
+        } else for (u32 i = tid; i < nb; i += kLdsBlock) insert(pa.bpart[cb + i], i);
         __syncthreads();
-        const u32 n_probe = pe - ps;
-        for (u32 t0 = 0; t0 < n_probe; t0 += kLdsBlock) {   // uniform trip count per workgroup
+#pragma unroll
+        for (u32 r = 0; r < kPfProbe; r++) {         // uniform trip count per workgroup
+          if (r * kLdsBlock >= n_probe) break;
+          probe_one(pf_p[r], r * kLdsBlock + tid < n_probe, counting);
+        }
+        for (u32 t0 = kPfProbe * kLdsBlock; t0 < n_probe; t0 += kLdsBlock) {
           const u32 t = t0 + tid;
           const bool live = t < n_probe;
-          uint4 r = make_uint4(0u, 0u, 0u, 0u);
-          if (live) {
-            if (pa.ppart) { const PartRec q = pa.ppart[ps + t]; r = make_uint4(q.row, q.k0, q.k1, 0u); }
-            else {                                   // range mode: the slice itself, in place
-              r.x = ps + t; r.y = pa.pcol0[ps + t]; r.z = a.n_keys > 1 ? pa.pcol1[ps + t] : 0u;
-              if (r.y == 0 || (a.n_keys > 1 && r.z == 0)) r.x = kNil;   // NullEqualsNothing
-            }
-          }
-          Keys key; key.k[0] = r.y; key.k[1] = r.z; key.k[2] = 0; key.k[3] = 0;
-          u32 h = hash_keys4(key, a.n_keys) & pa.tbl_mask;
-          bool walking = live && r.x != kNil;
-          for (;;) {
-            u32 hit = kNil;
-            while (walking) {
-              const uint2 c = slots[h];
-              if (c.y == kNil) { walking = false; break; }
-              h = (h + 1) & pa.tbl_mask;
-              if (c.x != r.y) continue;
-              if (a.n_keys > 1 && k1s[c.y] != r.z) continue;
-              hit = rows[c.y];
-              break;
-            }
-            const unsigned long long found = __ballot(hit != kNil);
-            if (found == 0) break;
-            const u32 n_found = (u32)__popcll(found);
-            if (qn + n_found > qcap) flush(counting);   // wave-uniform: the queue is empty afterwards and 64 <= qcap
-            if (hit != kNil) wq[qn + lane_prefix(found)] = make_uint2(hit, r.x);
-            qn += n_found;
-          }
+          probe_one(load_probe(ps, t, live), live, counting);
         }
       }
       if (pa.two_pass) flush(counting);              // what is still queued belongs to this partition's range (single pass: the queue carries over)

@@ -32,20 +32,29 @@ bool is_cmp(u8 op) {
 // Type-checks a postfix program against `n_cols` input columns; returns the kind it leaves.
 u32 check_program(const rdfgpu_expr_node* p, u32 n, u32 n_cols, u32 n_regexes = 0) {
   if (n > (u32)kMaxExpr) fail(RDFGPU_ERR_UNSUPPORTED, "expression has %u nodes (max %d)", n, kMaxExpr);
-  u32 st[kMaxStack]; int sp = 0;
+  u32 st[kMaxStack]; bool no_bytes[kMaxStack]; int sp = 0;
   bool views = false, rank_only_string = false;   // computed strings (views) / a string literal given by its rank in the dictionary only
+  bool out_no_bytes = false;                      // the value being pushed is such a literal: it has no lexical form on the device
   auto pop = [&](u32 kind, const char* what) {
     if (sp < 1) fail(RDFGPU_ERR_INVALID, "expression: stack underflow at %s", what);
     if (st[--sp] != kind) fail(RDFGPU_ERR_INVALID, "expression: %s got an operand of the wrong kind", what);
   };
+  // an operand whose BYTES the op reads (REGEX / CONTAINS / STRSTARTS / STRENDS / STRLEN / SUBSTR / UCASE / LCASE): a string literal
+  // that came with its rank only would be the error value on every row — refused here, loudly, instead
+  auto pop_bytes = [&](const char* what) {
+    if (sp >= 1 && no_bytes[sp - 1]) fail(RDFGPU_ERR_UNSUPPORTED, "%s over a string literal given by its dictionary rank only: it has no lexical form on the device (pass it as RDFGPU_EX_LIT_STR)", what);
+    pop(VK_TV, what);
+  };
   for (u32 i = 0; i < n; i++) {
     const rdfgpu_expr_node& e = p[i];
     u32 out;
+    out_no_bytes = false;
     switch (e.op) {
       case RDFGPU_EX_COLUMN: if (e.u >= n_cols) fail(RDFGPU_ERR_INVALID, "expression: column %u out of range (%u columns)", e.u, n_cols); out = VK_ID; break;
       case RDFGPU_EX_LIT_ID: out = VK_ID; break;
       case RDFGPU_EX_LIT_TV: if (e.tag > RDFGPU_TV_OTHER) fail(RDFGPU_ERR_INVALID, "expression: bad literal tag %u", e.tag); out = VK_TV;
-        rank_only_string = rank_only_string || (e.tag == RDFGPU_TV_STRING && e.hi == 0); break;
+        out_no_bytes = e.tag == RDFGPU_TV_STRING && e.hi == 0;
+        rank_only_string = rank_only_string || out_no_bytes; break;
       case RDFGPU_EX_LIT_BOOL: out = VK_BOOL; break;
       case RDFGPU_EX_ENC_TV: pop(VK_ID, "ENC_TV"); out = VK_TV; break;
       case RDFGPU_EX_GT: case RDFGPU_EX_LT: case RDFGPU_EX_GEQ: case RDFGPU_EX_LEQ: case RDFGPU_EX_EQ: case RDFGPU_EX_NEQ:
@@ -54,20 +63,21 @@ u32 check_program(const rdfgpu_expr_node* p, u32 n, u32 n_cols, u32 n_regexes = 
       case RDFGPU_EX_REGEX: case RDFGPU_EX_CONTAINS: case RDFGPU_EX_STRSTARTS: case RDFGPU_EX_STRENDS:
         if (e.u >= n_regexes) fail(RDFGPU_ERR_INVALID, "expression: REGEX pattern %u out of range (%u patterns)", e.u, n_regexes);
         // (the operand is any string value: ENC_TV of a column, or a view — STR / SUBSTR / UCASE / LCASE / a constant with bytes)
-        pop(VK_TV, "REGEX"); out = VK_TV; break;
+        pop_bytes("REGEX / CONTAINS / STRSTARTS / STRENDS"); out = VK_TV; break;
       case RDFGPU_EX_STR: pop(VK_ID, "STR"); out = VK_TV; views = true; break;
       case RDFGPU_EX_LIT_STR:
         if (e.u >= n_regexes) fail(RDFGPU_ERR_INVALID, "expression: string constant %u out of range (%u entries)", e.u, n_regexes);
         out = VK_TV; views = true; break;
-      case RDFGPU_EX_STRLEN: pop(VK_TV, "STRLEN"); out = VK_TV; break;
+      case RDFGPU_EX_STRLEN: pop_bytes("STRLEN"); out = VK_TV; break;
       case RDFGPU_EX_SUBSTR:
         if (e.u != 2 && e.u != 3) fail(RDFGPU_ERR_INVALID, "expression: SUBSTR takes 2 or 3 operands, not %u", e.u);
-        for (u32 k = 0; k < e.u; k++) pop(VK_TV, "SUBSTR");
+        for (u32 k = 0; k + 1 < e.u; k++) pop(VK_TV, "SUBSTR position / length");
+        pop_bytes("SUBSTR");
         out = VK_TV; views = true; break;
-      case RDFGPU_EX_UCASE: case RDFGPU_EX_LCASE: pop(VK_TV, "UCASE / LCASE"); out = VK_TV; views = true; break;
+      case RDFGPU_EX_UCASE: case RDFGPU_EX_LCASE: pop_bytes("UCASE / LCASE"); out = VK_TV; views = true; break;
       case RDFGPU_EX_REGEX_VAR:
         if (e.lo < 1 || (u64)e.u + (u64)e.lo > n_regexes) fail(RDFGPU_ERR_INVALID, "expression: REGEX pattern table %u .. +%lld out of range (%u patterns)", e.u, (long long)e.lo, n_regexes);
-        pop(VK_TV, "REGEX pattern"); pop(VK_TV, "REGEX"); out = VK_TV; break;
+        pop(VK_TV, "REGEX pattern"); pop_bytes("REGEX"); out = VK_TV; break;
       case RDFGPU_EX_LANG_IN:
         if (e.u >= n_regexes) fail(RDFGPU_ERR_INVALID, "expression: language table %u out of range (%u tables)", e.u, n_regexes);
         pop(VK_TV, "LANGMATCHES(LANG())"); out = VK_TV; break;
@@ -79,6 +89,7 @@ u32 check_program(const rdfgpu_expr_node* p, u32 n, u32 n_cols, u32 n_regexes = 
       default: fail(RDFGPU_ERR_INVALID, "expression: unknown op %u", e.op);
     }
     if (sp >= kMaxStack) fail(RDFGPU_ERR_UNSUPPORTED, "expression: stack deeper than %d", kMaxStack);
+    no_bytes[sp] = out_no_bytes;
     st[sp++] = out;
   }
   if (sp != 1) fail(RDFGPU_ERR_INVALID, "expression leaves %d values on the stack", sp);
@@ -219,9 +230,11 @@ Plan* plan_compile(Store* store, const rdfgpu_plan_desc* d) {
     store->activate();
     RDFGPU_HIP(hipMalloc((void**)&plan->regex_dev, progs.size() * sizeof(RegexProg)));
     RDFGPU_HIP(hipMemcpy(plan->regex_dev, progs.data(), progs.size() * sizeof(RegexProg), hipMemcpyHostToDevice));
-    if (!consts.empty()) {
-      RDFGPU_HIP(hipMalloc((void**)&plan->str_consts_dev, consts.size()));
-      RDFGPU_HIP(hipMemcpy(plan->str_consts_dev, consts.data(), consts.size(), hipMemcpyHostToDevice));
+    bool any_const = false;
+    for (int u_ : use) any_const = any_const || u_ == RDFGPU_EX_LIT_STR;
+    if (any_const) {   // (at least one byte: the empty string is a constant too, and a null base would read as "no bytes on the device")
+      RDFGPU_HIP(hipMalloc((void**)&plan->str_consts_dev, consts.size() + 1));
+      if (!consts.empty()) RDFGPU_HIP(hipMemcpy(plan->str_consts_dev, consts.data(), consts.size(), hipMemcpyHostToDevice));
     }
   }
 

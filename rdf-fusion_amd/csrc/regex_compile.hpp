@@ -11,9 +11,16 @@
 //   `\d \w \s` and `\D \W \S` (also inside classes) and the word boundaries `\b \B` outside repetitions — with their
 //   ASCII members: on an all-ASCII subject that IS the crate's Unicode class; a subject with a non-ASCII byte raises the
 //   plan's run-time error (RegexProg::ascii_only) instead of being answered without the Unicode tables;
-//   flags: `i` (ASCII letters, incl. the two non-ASCII simple folds K <-> U+212A and s <-> U+017F), `s`, `m`, `x`, `q`.
-// Not supported: `\p{..}` (Unicode tables), class set operations, inline flags, non-ASCII class members, non-ASCII
-// letters under `i`, anchors elsewhere, `\b` under a repetition, > 64 positions.
+//   flags: `i` (ASCII letters, incl. the two non-ASCII simple folds K <-> U+212A and s <-> U+017F), `s`, `m`, `x`, `q` — as the
+//   SPARQL flags argument and INLINE: `(?i)`, `(?s-i)`, `(?imsx-imsx:...)` (a flag group applies to the rest of the enclosing
+//   group, `(?flags:...)` to its own; `U` = swap greediness is accepted and irrelevant for is_match);
+//   classes: nested `[a[bc]]`, ASCII POSIX classes `[[:alpha:]]` / `[[:^digit:]]`, the set operations `&&` `--` `~~`
+//   (left to right, operands unions — regex-syntax's precedence), negation of the whole;
+//   Unicode general categories `\p{L}` `\pL` `\p{Lu}` `\P{N}` `\p{^P}` ... (short and long names) with their ASCII members,
+//   under the same rule as the Perl classes (ASCII assignments are the same in every Unicode version; a non-ASCII subject
+//   raises the run-time error).
+// Not supported: scripts / binary properties other than Any / ASCII / Alphabetic, `(?-u)` / `(?R)`, non-ASCII class members,
+// non-ASCII letters under `i`, anchors elsewhere, `\b` under a repetition, > 64 positions.
 #pragma once
 #include <cstdint>
 #include <cstring>
@@ -62,8 +69,8 @@ inline NodeP bytes_seq(const unsigned char* b, size_t n) {
 
 struct Parser {
   const unsigned char* p; size_t n, i = 0;
-  bool f_i = false, f_s = false, f_x = false;
-  bool ascii_only = false;          // a Perl class or a word boundary was used
+  bool f_i = false, f_s = false, f_x = false, f_m = false;
+  bool ascii_only = false;          // a Perl / Unicode class or a word boundary was used
   std::string err;
   bool fail(const char* m) { if (err.empty()) err = m; return false; }
   bool eof() const { return i >= n; }
@@ -144,42 +151,206 @@ struct Parser {
     }
   }
 
-  NodeP parse_class() {   // after '['
+  // A class as a set over ASCII + the two non-ASCII partners of simple case folding (KELVIN SIGN, LATIN SMALL LETTER LONG S)
+  // + "every other non-ASCII scalar": the universe in which union / intersection / difference / complement are exact.
+  struct CSet {
+    ByteSet a; bool kelvin = false, long_s = false, other = false;
+    void fold() {   // simple case folding, as regex-syntax applies it to both operands of a set operation and to the finished class
+      for (unsigned c = 'a'; c <= 'z'; c++) if (a.has(c) || a.has(c - 32)) { a.add(c); a.add(c - 32); }
+      if (a.has('k') || kelvin) { a.add('k'); a.add('K'); kelvin = true; }
+      if (a.has('s') || long_s) { a.add('s'); a.add('S'); long_s = true; }
+    }
+    void complement() { for (int w = 0; w < 2; w++) a.w[w] = ~a.w[w]; a.w[2] = a.w[3] = 0; kelvin = !kelvin; long_s = !long_s; other = !other; }
+    void unite(const CSet& o) { for (int w = 0; w < 2; w++) a.w[w] |= o.a.w[w]; kelvin |= o.kelvin; long_s |= o.long_s; other |= o.other; }
+    void intersect(const CSet& o) { for (int w = 0; w < 2; w++) a.w[w] &= o.a.w[w]; kelvin &= o.kelvin; long_s &= o.long_s; other &= o.other; }
+    void subtract(const CSet& o) { for (int w = 0; w < 2; w++) a.w[w] &= ~o.a.w[w]; kelvin &= !o.kelvin; long_s &= !o.long_s; other &= !o.other; }
+    void sym_diff(const CSet& o) { for (int w = 0; w < 2; w++) a.w[w] ^= o.a.w[w]; kelvin ^= o.kelvin; long_s ^= o.long_s; other ^= o.other; }
+  };
+  NodeP cset_node(const CSet& c) {
+    std::vector<NodeP> alts;
+    ByteSet ascii = c.a; ascii.w[2] = ascii.w[3] = 0;
+    if (ascii.w[0] | ascii.w[1]) alts.push_back(leaf(ascii));
+    static const unsigned char kelvin[3] = {0xE2, 0x84, 0xAA}, long_s[2] = {0xC5, 0xBF};
+    if (c.other) {
+      if (!c.kelvin || !c.long_s) { fail("class that excludes the non-ASCII case partner of k / s but keeps other non-ASCII characters"); return nullptr; }
+      alts.push_back(non_ascii_char());
+    } else {
+      if (c.kelvin) alts.push_back(bytes_seq(kelvin, 3));
+      if (c.long_s) alts.push_back(bytes_seq(long_s, 2));
+    }
+    if (alts.empty()) { ByteSet none; return leaf(none); }   // the empty class: a position no byte enters
+    return alt(std::move(alts));
+  }
+  // ASCII POSIX classes `[:name:]` (regex-syntax: ASCII-only by definition)
+  static bool posix_class(const std::string& name, ByteSet& m) {
+    auto r = [&](unsigned a, unsigned b) { m.add_range(a, b); };
+    if (name == "alnum") { r('0', '9'); r('A', 'Z'); r('a', 'z'); }
+    else if (name == "alpha") { r('A', 'Z'); r('a', 'z'); }
+    else if (name == "ascii") r(0, 0x7F);
+    else if (name == "blank") { m.add(' '); m.add('\t'); }
+    else if (name == "cntrl") { r(0, 0x1F); m.add(0x7F); }
+    else if (name == "digit") r('0', '9');
+    else if (name == "graph") r('!', '~');
+    else if (name == "lower") r('a', 'z');
+    else if (name == "print") r(' ', '~');
+    else if (name == "punct") { r('!', '/'); r(':', '@'); r('[', '`'); r('{', '~'); }
+    else if (name == "space") { m.add('\t'); m.add('\n'); m.add('\v'); m.add('\f'); m.add('\r'); m.add(' '); }
+    else if (name == "upper") r('A', 'Z');
+    else if (name == "word") { r('0', '9'); r('A', 'Z'); r('a', 'z'); m.add('_'); }
+    else if (name == "xdigit") { r('0', '9'); r('A', 'F'); r('a', 'f'); }
+    else return false;
+    return true;
+  }
+  // The ASCII members of a Unicode general category (or of Any / ASCII / Alphabetic), by short or long name.  The ASCII block's
+  // assignments are the same in every version of the Unicode tables.
+  static bool unicode_class_ascii(std::string name, ByteSet& m) {
+    std::string k;
+    for (char ch : name) if (ch != '_' && ch != ' ' && ch != '-') k.push_back((char)(ch >= 'A' && ch <= 'Z' ? ch + 32 : ch));   // loose matching (UAX44-LM3)
+    auto r = [&](unsigned a, unsigned b) { m.add_range(a, b); };
+    auto add = [&](const char* cs) { for (; *cs; cs++) m.add((unsigned char)*cs); };
+    auto Lu = [&] { r('A', 'Z'); }; auto Ll = [&] { r('a', 'z'); }; auto Nd = [&] { r('0', '9'); };
+    auto Pc = [&] { m.add('_'); }; auto Pd = [&] { m.add('-'); }; auto Ps = [&] { add("([{"); }; auto Pe = [&] { add(")]}"); };
+    auto Po = [&] { add("!\"#%&'*,./:;?@\\"); };
+    auto Sm = [&] { add("+<=>|~"); }; auto Sc = [&] { m.add('$'); }; auto Sk = [&] { add("^`"); };
+    auto Zs = [&] { m.add(' '); }; auto Cc = [&] { r(0, 0x1F); m.add(0x7F); };
+    if (k == "any") r(0, 0x7F);
+    else if (k == "ascii") r(0, 0x7F);
+    else if (k == "alphabetic" || k == "alpha") { Lu(); Ll(); }
+    else if (k == "l" || k == "letter") { Lu(); Ll(); }
+    else if (k == "lu" || k == "uppercaseletter") Lu();
+    else if (k == "ll" || k == "lowercaseletter") Ll();
+    else if (k == "lc" || k == "casedletter") { Lu(); Ll(); }
+    else if (k == "lt" || k == "titlecaseletter" || k == "lm" || k == "modifierletter" || k == "lo" || k == "otherletter") {}
+    else if (k == "m" || k == "mark" || k == "mn" || k == "nonspacingmark" || k == "mc" || k == "spacingmark" || k == "me" || k == "enclosingmark") {}
+    else if (k == "n" || k == "number" || k == "nd" || k == "decimalnumber") Nd();
+    else if (k == "nl" || k == "letternumber" || k == "no" || k == "othernumber") {}
+    else if (k == "p" || k == "punctuation") { Pc(); Pd(); Ps(); Pe(); Po(); }
+    else if (k == "pc" || k == "connectorpunctuation") Pc();
+    else if (k == "pd" || k == "dashpunctuation") Pd();
+    else if (k == "ps" || k == "openpunctuation") Ps();
+    else if (k == "pe" || k == "closepunctuation") Pe();
+    else if (k == "pi" || k == "initialpunctuation" || k == "pf" || k == "finalpunctuation") {}
+    else if (k == "po" || k == "otherpunctuation") Po();
+    else if (k == "s" || k == "symbol") { Sm(); Sc(); Sk(); }
+    else if (k == "sm" || k == "mathsymbol") Sm();
+    else if (k == "sc" || k == "currencysymbol") Sc();
+    else if (k == "sk" || k == "modifiersymbol") Sk();
+    else if (k == "so" || k == "othersymbol") {}
+    else if (k == "z" || k == "separator" || k == "zs" || k == "spaceseparator") Zs();
+    else if (k == "zl" || k == "lineseparator" || k == "zp" || k == "paragraphseparator") {}
+    else if (k == "c" || k == "other" || k == "cc" || k == "control") Cc();
+    else if (k == "cf" || k == "format" || k == "cs" || k == "surrogate" || k == "co" || k == "privateuse" || k == "cn" || k == "unassigned") {}
+    else return false;
+    return true;
+  }
+  // `\p{..}` / `\P{..}` / `\pL` at p[i] (the 'p' / 'P'): the class's ASCII members into `s` (complemented for \P / {^..});
+  // like the Perl classes, exact on ASCII subjects only
+  bool unicode_class(ByteSet& s) {
+    if (eof() || (p[i] != 'p' && p[i] != 'P')) return false;
+    bool neg = p[i] == 'P';
+    i++;
+    std::string name;
+    if (eof()) { fail("bad \\p escape"); return true; }
+    if (p[i] == '{') {
+      i++;
+      if (!eof() && p[i] == '^') { neg = !neg; i++; }
+      while (!eof() && p[i] != '}') name.push_back((char)p[i++]);
+      if (eof()) { fail("bad \\p escape"); return true; }
+      i++;
+    } else name.push_back((char)p[i++]);
+    const size_t eq = name.find('=');
+    if (eq != std::string::npos) {   // gc=Lu / General_Category=Lu; any other property (scripts ...) needs the tables
+      std::string prop;
+      for (char ch : name.substr(0, eq)) if (ch != '_' && ch != ' ' && ch != '-') prop.push_back((char)(ch >= 'A' && ch <= 'Z' ? ch + 32 : ch));
+      if (prop != "gc" && prop != "generalcategory") { fail("Unicode property other than the general category"); return true; }
+      name = name.substr(eq + 1);
+    }
+    ByteSet m;
+    if (!unicode_class_ascii(name, m)) { fail("Unicode class that needs the Unicode tables (script / property)"); return true; }
+    ascii_only = true;
+    if (f_i) for (unsigned c = 'a'; c <= 'z'; c++) if (m.has(c) || m.has(c - 32)) { m.add(c); m.add(c - 32); }   // regex-syntax folds the class, THEN negates it
+    for (unsigned c = 0; c < 0x80; c++) if (m.has(c) != neg) s.add(c);
+    return true;
+  }
+
+  // after '[': items and set operations up to the matching ']' (regex-syntax precedence: ranges, then union, then && -- ~~ left to right)
+  bool parse_class_set(CSet& out) {
     bool neg = false;
     if (!eof() && p[i] == '^') { neg = true; i++; }
-    ByteSet s; bool first = true;
+    CSet acc; bool have_acc = false; int pending_op = 0;   // 0 none, 1 &&, 2 --, 3 ~~
+    CSet cur; bool first = true;
+    auto close_operand = [&]() {
+      if (f_i) cur.fold();
+      if (!have_acc) { acc = cur; have_acc = true; }
+      else if (pending_op == 1) acc.intersect(cur);
+      else if (pending_op == 2) acc.subtract(cur);
+      else acc.sym_diff(cur);
+      cur = CSet();
+    };
     for (;;) {
-      if (eof()) { fail("unclosed class"); return nullptr; }
+      if (eof()) return fail("unclosed class");
       unsigned c = p[i];
       if (c == ']' && !first) { i++; break; }
+      if (c == '[') {
+        if (i + 1 < n && p[i + 1] == ':') {          // POSIX class [:name:] / [:^name:]
+          size_t j = i + 2; bool pneg = false;
+          if (j < n && p[j] == '^') { pneg = true; j++; }
+          std::string name;
+          while (j < n && p[j] != ':' && p[j] != ']') name.push_back((char)p[j++]);
+          if (j + 1 < n && p[j] == ':' && p[j + 1] == ']') {
+            ByteSet m;
+            if (!posix_class(name, m)) return fail("unknown POSIX class");
+            CSet item; item.a = m;
+            if (pneg) item.complement();
+            cur.unite(item);
+            i = j + 2; first = false;
+            continue;
+          }
+        }
+        i++;                                          // nested class
+        CSet inner;
+        if (!parse_class_set(inner)) return false;
+        cur.unite(inner);
+        first = false;
+        continue;
+      }
+      if ((c == '&' || c == '-' || c == '~') && i + 1 < n && p[i + 1] == c && !(c == '-' && first)) {
+        // `--` right before the closing bracket is two literal dashes in regex-syntax? It is a set operation with an empty right side there; refused here
+        if (i + 2 < n && p[i + 2] == ']') return fail("set operation without a right operand");
+        close_operand();
+        pending_op = c == '&' ? 1 : c == '-' ? 2 : 3;
+        i += 2; first = false;
+        continue;
+      }
       first = false;
-      if (c == '[') { fail("nested / POSIX classes"); return nullptr; }
-      if (c >= 0x80) { fail("non-ASCII class member"); return nullptr; }
-      if ((c == '&' || c == '-' || c == '~') && i + 1 < n && p[i + 1] == c && c != '-') { fail("class set operation"); return nullptr; }
+      if (c >= 0x80) return fail("non-ASCII class member");
       i++;
       if (c == '\\') {
-        if (perl_class(s)) continue;        // `[\d_-]`: a class inside the class (no range from / to it)
-        if (!escape_byte(c)) return nullptr;
+        if (perl_class(cur.a)) continue;              // `[\d_-]`: a class inside the class (no range from / to it)
+        { const size_t before = i; if (unicode_class(cur.a)) { if (!err.empty()) return false; continue; } i = before; }
+        if (!escape_byte(c)) return false;
       }
       unsigned hi = c;
-      if (!eof() && p[i] == '-' && i + 1 < n && p[i + 1] != ']') {   // range
-        if (p[i + 1] == '-') { fail("class set operation"); return nullptr; }
+      if (!eof() && p[i] == '-' && i + 1 < n && p[i + 1] != ']' && !(p[i + 1] == '-')) {   // range (a dash before `--` is not one)
         i++;
         hi = p[i];
-        if (hi >= 0x80 || hi == '[') { fail("non-ASCII class member"); return nullptr; }
+        if (hi >= 0x80 || hi == '[') return fail("non-ASCII class member");
         i++;
-        if (hi == '\\') { if (!escape_byte(hi)) return nullptr; }
-        if (hi < c) { fail("invalid class range"); return nullptr; }
+        if (hi == '\\') { if (!escape_byte(hi)) return false; }
+        if (hi < c) return fail("invalid class range");
       }
-      s.add_range(c, hi);
+      cur.a.add_range(c, hi);
     }
-    if (!neg) return ascii_set_node(s);
-    if (f_i) {
-      for (unsigned c = 'a'; c <= 'z'; c++) if (s.has(c) || s.has(c - 32)) { s.add(c); s.add(c - 32); }
-      if (s.has('k') || s.has('s')) { fail("negated class with k / s under the `i` flag"); return nullptr; }
-    }
-    ByteSet inv; for (unsigned c = 0; c < 0x80; c++) if (!s.has(c)) inv.add(c);
-    return alt({leaf(inv), non_ascii_char()});
+    close_operand();
+    if (f_i) acc.fold();
+    if (neg) acc.complement();
+    out = acc;
+    return true;
+  }
+  NodeP parse_class() {   // after '['
+    CSet c;
+    if (!parse_class_set(c)) return nullptr;
+    return cset_node(c);
   }
 
   NodeP parse_atom() {
@@ -194,9 +365,34 @@ struct Parser {
           while (!eof() && p[i] != '>') i++;
           if (eof()) { fail("bad group name"); return nullptr; }
           i++;
-        } else { fail("inline flags"); return nullptr; }
+        } else {   // inline flags: (?flags) for the rest of the enclosing group, (?flags:...) for this one
+          i++;
+          bool on = true, any = false;
+          const bool s_i = f_i, s_s = f_s, s_x = f_x, s_m = f_m;
+          for (;; i++) {
+            if (eof()) { fail("unclosed flag group"); return nullptr; }
+            const unsigned fc = p[i];
+            if (fc == ')' || fc == ':') break;
+            if (fc == '-') { if (!on) { fail("bad flag group"); return nullptr; } on = false; continue; }
+            if (fc == 'i') f_i = on; else if (fc == 's') f_s = on; else if (fc == 'x') f_x = on; else if (fc == 'm') f_m = on;
+            else if (fc == 'U') {}   // swap greediness: the same language
+            else { fail("inline flag other than i m s x U"); return nullptr; }
+            any = true;
+          }
+          if (!any) { fail("empty flag group"); return nullptr; }
+          if (p[i] == ')') { i++; auto e = mk(EMPTY); e->set.add(3); return e; }   // (set bit 3: a flag directive, not an expression)
+          i++;                                          // ':' — a group with its own flags
+          NodeP inner = parse_alt();
+          f_i = s_i; f_s = s_s; f_x = s_x; f_m = s_m;
+          if (!inner) return nullptr;
+          if (eof() || p[i] != ')') { fail("unclosed group"); return nullptr; }
+          i++;
+          return inner;
+        }
       }
+      const bool s_i = f_i, s_s = f_s, s_x = f_x, s_m = f_m;   // a (?flags) directive inside ends with its group
       NodeP inner = parse_alt();
+      f_i = s_i; f_s = s_s; f_x = s_x; f_m = s_m;
       if (!inner) return nullptr;
       if (eof() || p[i] != ')') { fail("unclosed group"); return nullptr; }
       i++;
@@ -209,14 +405,15 @@ struct Parser {
       if (!f_s) s.w[0] &= ~(1ull << '\n');
       return alt({leaf(s), non_ascii_char()});
     }
-    if (c == '^') { i++; return mk(A_START); }
-    if (c == '$') { i++; return mk(A_END); }
+    if (c == '^') { i++; auto a = mk(A_START); if (f_m) a->set.add(2); return a; }   // set bit 2: under `m` (also matches after a line feed)
+    if (c == '$') { i++; auto a = mk(A_END); if (f_m) a->set.add(2); return a; }
     if (c == '\\') {
       i++;
       if (!eof() && p[i] == 'A') { i++; auto a = mk(A_START); a->set.add(1); return a; }   // set bit 1: not affected by `m`
       if (!eof() && p[i] == 'z') { i++; auto a = mk(A_END); a->set.add(1); return a; }
       if (!eof() && (p[i] == 'b' || p[i] == 'B')) { const bool nb = p[i] == 'B'; i++; ascii_only = true; return mk(nb ? A_NWORDB : A_WORDB); }
       { ByteSet ps_; if (perl_class(ps_)) return ascii_set_node(ps_); }
+      { ByteSet pu_; if (unicode_class(pu_)) { if (!err.empty()) return nullptr; return ascii_set_node(pu_); } }
       unsigned b;
       if (!escape_byte(b)) return nullptr;
       ByteSet s; s.add(b);
@@ -281,6 +478,7 @@ struct Parser {
       if (eof() || p[i] == '|' || p[i] == ')') break;
       NodeP r = parse_repeat();
       if (!r) return nullptr;
+      if (r->kind == EMPTY && r->set.has(3)) continue;   // a (?flags) directive
       k.push_back(r);
     }
     return cat(std::move(k));
@@ -375,12 +573,12 @@ enum RegexStatus { REGEX_OK = 0, REGEX_UNSUPPORTED = 1 };
 inline RegexStatus regex_compile(const char* pattern, size_t n, const char* flags, size_t n_flags, RegexProg& out, std::string& why) {
   using namespace regex_detail;
   std::memset(&out, 0, sizeof out);
-  bool q = false, multiline = false;
+  bool q = false, multiline = false; (void)multiline;
   Parser ps{reinterpret_cast<const unsigned char*>(pattern), n};
   for (size_t k = 0; k < n_flags; k++) {
     switch (flags[k]) {
       case 's': ps.f_s = true; break;
-      case 'm': multiline = true; break;
+      case 'm': multiline = true; ps.f_m = true; break;
       case 'i': ps.f_i = true; break;
       case 'x': ps.f_x = true; break;
       case 'q': q = true; break;
@@ -411,11 +609,11 @@ inline RegexStatus regex_compile(const char* pattern, size_t n, const char* flag
   if (root->kind == A_START || root->kind == A_END) { auto c = mk(CAT); c->kids.push_back(root); root = c; }
   if (root->kind == CAT) {
     if (!root->kids.empty() && root->kids.front()->kind == A_START) {
-      out.anchor_start = 1; out.ml_start = multiline && !root->kids.front()->set.has(1);
+      out.anchor_start = 1; out.ml_start = root->kids.front()->set.has(2) && !root->kids.front()->set.has(1);
       root->kids.erase(root->kids.begin());
     }
     if (!root->kids.empty() && root->kids.back()->kind == A_END) {
-      out.anchor_end = 1; out.ml_end = multiline && !root->kids.back()->set.has(1);
+      out.anchor_end = 1; out.ml_end = root->kids.back()->set.has(2) && !root->kids.back()->set.has(1);
       root->kids.pop_back();
     }
   }

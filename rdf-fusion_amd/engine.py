@@ -24,6 +24,20 @@ def library_path():
     return os.path.join(_HERE, "lib", "librdfgpu.so")
 
 
+def kernel_source_sha16():
+    """First 16 hex digits of the SHA-256 over the device sources (csrc/*.hip, *.hpp, in name order): what a committed rocprofv3
+    counter summary is stamped with (profiles/summarize.py) and what bench.py compares before it quotes that summary as the HBM
+    traffic of the kernels it has just timed — counters measured on other kernel code are not quoted."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(_HERE, "csrc", "*.hip")) + glob.glob(os.path.join(_HERE, "csrc", "*.hpp"))):
+        h.update(os.path.basename(f).encode()); h.update(b"\0")
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def load_library():
     """Loads the in-tree HIP library; fails loudly when it has not been built."""
     global _LIB
@@ -73,6 +87,8 @@ def load_library():
     lib.rdfgpu_ntriples_parse.argtypes = [C.c_int32, C.c_char_p, C.c_uint64, C.c_uint32, C.POINTER(vp)]
     lib.rdfgpu_ntriples_info.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]
     lib.rdfgpu_ntriples_terms.argtypes = [vp, C.c_void_p, C.c_void_p]
+    lib.rdfgpu_ntriples_decoded_info.argtypes = [vp, u64p, u64p]
+    lib.rdfgpu_ntriples_decoded.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
     lib.rdfgpu_ntriples_columns.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
     lib.rdfgpu_ntriples_destroy.argtypes = [vp]
     lib.rdfgpu_ntriples_destroy.restype = None
@@ -401,6 +417,23 @@ class NTriples:
         _check(self._lib.rdfgpu_ntriples_terms(self._h, off.ctypes.data_as(C.c_void_p), buf.ctypes.data_as(C.c_void_p)))
         raw = buf.tobytes()
         return [raw[int(off[t]):int(off[t + 1])] for t in range(self.n_terms)]
+
+    def decoded(self):
+        """rdfgpu_ntriples_decoded: per distinct term (id first_id + t) a tuple (kind, lexical form, suffix) — escapes decoded, the
+        language tag in lower case / the datatype IRI as suffix — and the typed-value rows the device derived (TV_DTYPE array; flags &
+        abi.TVF_NEEDS_HOST: the host parses that literal) with the decimals' high words."""
+        nl, ns = C.c_uint64(), C.c_uint64()
+        _check(self._lib.rdfgpu_ntriples_decoded_info(self._h, C.byref(nl), C.byref(ns)))
+        n = self.n_terms
+        kind = np.zeros(max(1, n), np.uint8)
+        lo, so = np.zeros(n + 1, np.uint64), np.zeros(n + 1, np.uint64)
+        lex, sfx = np.zeros(max(1, nl.value), np.uint8), np.zeros(max(1, ns.value), np.uint8)
+        typed, hi = np.zeros(max(1, n), TV_DTYPE), np.zeros(max(1, n), np.int64)
+        p = lambda a: a.ctypes.data_as(C.c_void_p)
+        _check(self._lib.rdfgpu_ntriples_decoded(self._h, p(kind), p(lo), p(lex), p(so), p(sfx), p(typed), p(hi)))
+        lb, sb = lex.tobytes(), sfx.tobytes()
+        terms = [(int(kind[t]), lb[int(lo[t]):int(lo[t + 1])], sb[int(so[t]):int(so[t + 1])]) for t in range(n)]
+        return terms, typed[:n], hi[:n]
 
     def columns(self):
         s, p, o = C.c_void_p(), C.c_void_p(), C.c_void_p()

@@ -139,17 +139,94 @@ def _lit(ch):
     return ("\\" + ch) if ch in _META else ch
 
 
-def random_regex(rng, depth=0, perl=False):
+def _py_class(members, other):
+    """A Python character class for a set of ASCII code points (+ every non-ASCII character when `other`)."""
+    import re
+    if other:
+        missing = [c for c in range(128) if c not in members]
+        return "[^" + "".join(re.escape(chr(c)) for c in missing) + "]" if missing else "[\\s\\S]"
+    return "[" + "".join(re.escape(chr(c)) for c in sorted(members)) + "]" if members else "[^\\s\\S]"
+
+
+_POSIX = {"alpha": "A-Za-z", "digit": "0-9", "upper": "A-Z", "lower": "a-z", "alnum": "0-9A-Za-z", "xdigit": "0-9A-Fa-f", "word": "0-9A-Za-z_"}
+_UNI = {"L": "A-Za-z", "Lu": "A-Z", "Ll": "a-z", "N": "0-9", "Nd": "0-9", "Letter": "A-Za-z", "Pd": "\\-", "Zs": " "}
+
+
+def _expand(spec):
+    out, k = set(), 0
+    spec = spec.replace("\\-", "\x00")
+    while k < len(spec):
+        if k + 2 < len(spec) and spec[k + 1] == "-":
+            out |= set(range(ord(spec[k]), ord(spec[k + 2]) + 1)); k += 3
+        else:
+            out.add(ord("-") if spec[k] == "\x00" else ord(spec[k])); k += 1
+    return out
+
+
+def random_regex(rng, depth=0, perl=False, extended=False):
     """Returns (pattern, flags, python_pattern, python_flags).  `perl`: also draw `\\d \\w \\s \\D \\W \\S` (alone and inside
     classes) and `\\b \\B` — restated / compiled with their ASCII members, so pair them with all-ASCII subjects
-    (python_flags then carries re.ASCII)."""
+    (python_flags then carries re.ASCII).  `extended`: also inline flag groups `(?i:..)` `(?s:..)`, a leading `(?i)` / `(?s)`,
+    ASCII POSIX classes, class set operations `&& -- ~~` with nested (negated) classes — and, with `perl`, Unicode general
+    categories `\\p{..}`; their Python forms are spelled out sets (a third evaluation of the set algebra)."""
     import re
     flags = "".join(f for f in "ismx" if rng.random() < 0.25)
     # non-ASCII letters under `i` need the Unicode case-folding tables: outside the restated / supported subset
-    letters = [c for c in REGEX_ALPHABET if ord(c) < 0x80] if "i" in flags else REGEX_ALPHABET
+    all_letters = REGEX_ALPHABET
+    ascii_letters = [c for c in REGEX_ALPHABET if ord(c) < 0x80]
+    state = {"i": "i" in flags}
+
+    def class_operand():
+        """one operand of a set operation: (text, ASCII members, includes other non-ASCII)"""
+        kind = int(rng.integers(0, 4))
+        if kind == 0:
+            spec = ["a-f", "c-k", "0-9", "a-z", "b-dx", "aeiou"][int(rng.integers(0, 6))]
+            return spec, _expand(spec), False
+        if kind == 1:
+            spec = ["aeiou", "c", "0-4", "b-y"][int(rng.integers(0, 4))]
+            return f"[^{spec}]", set(range(128)) - _expand(spec), True
+        if kind == 2:
+            name = list(_POSIX)[int(rng.integers(0, len(_POSIX)))]
+            return f"[:{name}:]", _expand(_POSIX[name]), False
+        spec = ["abc", "x-z", "k"][int(rng.integers(0, 3))]
+        return f"[{spec}]q", _expand(spec) | {ord("q")}, False
 
     def atom(d):
         r = rng.random()
+        if extended and r < 0.3:
+            k = int(rng.integers(0, 6 if perl else 4))
+            if k == 0 and d < 2:                                   # a group with its own flags
+                fl = "i" if rng.random() < 0.5 else "s"
+                saved = state["i"]
+                state["i"] = state["i"] or fl == "i"
+                a, b = alt(d + 1)
+                state["i"] = saved
+                return f"(?{fl}:{a})", f"(?{fl}:{b})"
+            if k == 1:
+                name = list(_POSIX)[int(rng.integers(0, len(_POSIX)))]
+                extra = "_" if rng.random() < 0.3 else ""
+                return f"[[:{name}:]{extra}]", f"[{_POSIX[name]}{extra}]"
+            if k in (2, 3) and not state["i"]:                    # set operations (case folding of operands: left to the known answers)
+                text, members, other = class_operand()
+                for _ in range(int(rng.integers(1, 3))):
+                    op = ["&&", "--", "~~"][int(rng.integers(0, 3))]
+                    t2, m2, o2 = class_operand()
+                    text += op + t2
+                    if op == "&&":
+                        members, other = members & m2, other and o2
+                    elif op == "--":
+                        members, other = members - m2, other and not o2
+                    else:
+                        members, other = members ^ m2, other != o2
+                if rng.random() < 0.25:
+                    text, members, other = "^" + text, set(range(128)) - members, not other
+                return f"[{text}]", _py_class(members, other)
+            if k >= 4:
+                name = list(_UNI)[int(rng.integers(0, len(_UNI)))]
+                neg = rng.random() < 0.25
+                form = (f"\\P{{{name}}}" if neg else f"\\p{{{name}}}") if len(name) > 1 or rng.random() < 0.5 else (f"\\P{name}" if neg else f"\\p{name}")
+                return form, f"[{'^' if neg else ''}{_UNI[name]}]"
+        letters = ascii_letters if state["i"] else all_letters
         if perl and r < 0.25:
             k = int(rng.integers(0, 10))
             if k < 6:
@@ -206,6 +283,10 @@ def random_regex(rng, depth=0, perl=False):
         return "|".join(p[0] for p in parts), "|".join(p[1] for p in parts)
 
     top_alt = rng.random() < 0.2
+    lead = ""
+    if extended and rng.random() < 0.15:                           # a leading directive: the whole pattern (Python: the same, at the start only)
+        lead = "(?i)" if rng.random() < 0.5 else "(?s)"
+        state["i"] = state["i"] or lead == "(?i)"
     pat, py = alt(depth) if top_alt else cat(depth)
     if perl and not top_alt and rng.random() < 0.3:
         pat, py = pat + "\\b", py + "\\b"
@@ -219,6 +300,9 @@ def random_regex(rng, depth=0, perl=False):
     for f, v in (("i", re.I), ("s", re.S), ("m", re.M), ("x", re.X)):
         if f in flags:
             py_flags |= v
+    if lead:
+        pat = lead + pat
+        py_flags |= re.I if lead == "(?i)" else re.S
     return pat, flags, py, py_flags
 
 

@@ -859,10 +859,13 @@ def test_regex_filter_matches_oracle(torch_cuda, monkeypatch):
     ids = rng.integers(0, len(tv), 20_000).astype(np.uint32)              # includes 0 (null) and the non-string ids
     payload = np.arange(len(ids), dtype=np.uint32) + 1
     keep, ptrs = table_on_device(torch_cuda, [ids, payload])
-    fixed = [("^a$", ""), ("a.c", "s"), ("(ab|cd)+e", ""), ("k", "i"), ("^$", ""), ("b$", "m"), ("a", "z"), ("x{2,}", ""), (".", "q"), ("[^a]", "")]
+    fixed = [("^a$", ""), ("a.c", "s"), ("(ab|cd)+e", ""), ("k", "i"), ("^$", ""), ("b$", "m"), ("a", "z"), ("x{2,}", ""), (".", "q"), ("[^a]", ""),
+             # inline flags, nested / POSIX classes, class set operations (regex-syntax)
+             ("(?i)ab", ""), ("a(?i)b", ""), ("(?i:k)x", ""), ("(?s)a.b", ""), ("(?m)^b$", ""), ("(?i)a(?-i)b", ""), ("[a-z&&[^aeiou]]+", ""), ("[a-k--c-e]x", ""),
+             ("[a-c~~b-d]", ""), ("[[:alpha:]]+[[:digit:]]", ""), ("[^a[bc]]", ""), ("[[:^alpha:]]", ""), ("[A-Z&&[a-c]]", "i")]
     n_random, matched_some = 0, 0
-    while n_random < 150:
-        pat, flags, py, py_flags = ku.random_regex(rng)
+    while n_random < 220:
+        pat, flags, py, py_flags = ku.random_regex(rng, extended=n_random >= 150)
         try:
             rf.engine.regex_check(pat, flags)
         except rf.engine.RdfGpuError:
@@ -876,7 +879,7 @@ def test_regex_filter_matches_oracle(torch_cuda, monkeypatch):
             desc = pb.build(pb.filter(pb.table(0, 2), NOT(e) if negate else e))
             plan, got = run_both(gs, os_, desc, gpu_tables=[(ptrs, len(ids))], cpu_tables=[[ids, payload]])
             matched_some += plan.result_info()[0] > 0
-    assert matched_some > 100
+    assert matched_some > 130
     # per-distinct-term verdict table (filter_kernel<3>) vs per-row VM evaluation: same rows
     for pat, flags in fixed[:12]:
         pb = PlanBuilder()
@@ -1021,9 +1024,14 @@ def test_regex_perl_classes_and_word_boundaries(torch_cuda):
     keep, ptrs = table_on_device(torch_cuda, [ids, payload])
     is_str = (ids >= 1) & (ids <= len(strings))
     cases = [("\\d+", "", "\\d+", re.A), ("^\\w+$", "", "^\\w+\\Z", re.A), ("\\bfoo\\b", "", "\\bfoo\\b", re.A), ("\\Bfoo", "", "\\Bfoo", re.A),
-             ("[\\d\\s]x", "", "[\\d\\s]x", re.A), ("grad\\w*\\d{2}\\b", "i", "grad\\w*\\d{2}\\b", re.A | re.I), ("\\S\\s\\S", "", "\\S\\s\\S", re.A)]
-    while len(cases) < 130:
-        pat, flags, py, py_flags = ku.random_regex(rng, perl=True)
+             ("[\\d\\s]x", "", "[\\d\\s]x", re.A), ("grad\\w*\\d{2}\\b", "i", "grad\\w*\\d{2}\\b", re.A | re.I), ("\\S\\s\\S", "", "\\S\\s\\S", re.A),
+             # Unicode general categories: their ASCII members (all-ASCII subjects), folded before negation under `i`
+             ("\\p{L}+\\p{Nd}", "", "[A-Za-z]+[0-9]", re.A), ("^\\p{Lu}", "", "^[A-Z]", re.A), ("\\P{L}", "", "[^A-Za-z]", re.A), ("[\\p{Nd}x]\\pL", "", "[0-9x][A-Za-z]", re.A),
+             ("(?i)\\P{Lu}", "", "[^A-Za-z]", re.A), ("\\p{Pd}\\p{Zs}?", "", "-[ ]?", re.A), ("[\\w--\\d]+7", "", "[A-Za-z_]+7", re.A)]
+    while len(cases) < 190:
+        pat, flags, py, py_flags = ku.random_regex(rng, perl=True, extended=len(cases) >= 140)
+        if "x" in flags and len(cases) >= 140 and any(t in pat for t in ("[:", "&&", "--", "~~")):
+            continue                          # (Python's verbose mode reads the spelled-out classes its own way)
         try:
             rf.engine.regex_check(pat, flags)
             rx = re.compile(py, py_flags)
@@ -1043,7 +1051,7 @@ def test_regex_perl_classes_and_word_boundaries(torch_cuda):
         if k % 4 == 0:                    # the per-row VM path gives the same rows as the verdict table
             p2 = gs.plan(desc).set_option("NO_STRING_VERDICTS"); p2.bind_table(0, ptrs, len(ids))
             np.testing.assert_array_equal(np.sort(p2.execute().fetch()[0]), np.sort(got[0]))
-    assert matched_some > 60
+    assert matched_some > 90
 
 
 def test_regex_perl_class_over_non_ascii_subject_is_a_loud_error(torch_cuda):
@@ -1240,6 +1248,82 @@ def test_ntriples_to_ids_on_device(torch_cuda, n):
             orc.ntriples_encode(bad)
 
 
+def test_ntriples_escapes_and_typed_literals_on_device(torch_cuda):
+    """rdfgpu_ntriples_decoded: terms are interned by the canonical form the reference's parser produces (ECHAR / UCHAR
+    decoded, language tags lower-cased, `^^xsd:string` = simple literal), the decoded lexical forms and the typed-value rows of
+    xsd:integer / int / boolean / decimal / (exactly convertible) double / float literals come from the device — against an
+    independent Python restatement (oracle.ntriples_decode_term / ntriples_typed_value: re, int, Fraction)."""
+    X = "http://www.w3.org/2001/XMLSchema#"
+    lits = [
+        # one term, several spellings -> one id
+        '"aA\\n"', '"a\\u0041\\n"', '"\\u0061\\U00000041\\u000A"', '"x"', '"x"^^<%sstring>' % X, '"v"@en-GB', '"v"@EN-gb', '"v"@en-gb',
+        # escapes of every kind, quotes and delimiters inside strings
+        '"q\\"uote \\\\ back \\t tab \\b \\r \\f \\\' end"', '"\\U0001F600 and \\u20AC"', '"> . # <"', '""',
+        # typed literals
+        '"12"^^<%sinteger>' % X, '"012"^^<%sinteger>' % X, '"+7"^^<%sint>' % X, '"-9223372036854775808"^^<%slong>' % X, '"9223372036854775808"^^<%sinteger>' % X,
+        '"2147483648"^^<%sint>' % X, '"1 2"^^<%sinteger>' % X, '""^^<%sinteger>' % X, '"255"^^<%sunsignedByte>' % X, '"-"^^<%sinteger>' % X,
+        '"true"^^<%sboolean>' % X, '"0"^^<%sboolean>' % X, '"TRUE"^^<%sboolean>' % X,
+        '"1.50"^^<%sdecimal>' % X, '".5"^^<%sdecimal>' % X, '"-12."^^<%sdecimal>' % X, '"."^^<%sdecimal>' % X, '"1.0000000000000000001"^^<%sdecimal>' % X,
+        '"170141183460469231731.687303715884105727"^^<%sdecimal>' % X, '"170141183460469231732"^^<%sdecimal>' % X, '"1e3"^^<%sdecimal>' % X,
+        '"1.5E3"^^<%sdouble>' % X, '"0.1"^^<%sdouble>' % X, '"-0"^^<%sdouble>' % X, '"INF"^^<%sdouble>' % X, '"-inf"^^<%sdouble>' % X, '"NaN"^^<%sdouble>' % X,
+        '"1e22"^^<%sdouble>' % X, '"1e23"^^<%sdouble>' % X, '"9007199254740993"^^<%sdouble>' % X, '"123456789012345678901234"^^<%sdouble>' % X, '"1."^^<%sdouble>' % X,
+        '"abc"^^<%sdouble>' % X, '"0.000001"^^<%sdouble>' % X, '"1234.5e-7"^^<%sdouble>' % X,
+        '"0.1"^^<%sfloat>' % X, '"16777217"^^<%sfloat>' % X, '"3.5e10"^^<%sfloat>' % X, '"1e11"^^<%sfloat>' % X, '"2.5"^^<%sfloat>' % X,
+        '"2004-03-01T06:00:00Z"^^<%sdateTime>' % X, '"P1Y"^^<%sduration>' % X, '"x"^^<http://example.org/dt>', '"x"^^<http://example.org/d\\u0074>',
+    ]
+    iris = ["<http://example.org/s%d>" % i for i in range(40)] + ["<http://example.org/caf\\u00E9>", "<http://example.org/caf\u00e9>", "_:b1", "_:b2"]
+    rng = np.random.default_rng(8)
+    lines = []
+    for k, o_ in enumerate(lits * 3 + iris):
+        s_ = iris[int(rng.integers(0, len(iris)))]
+        lines.append("%s <http://example.org/p%d> %s ." % (s_ if not s_.startswith('"') else iris[0], k % 5, o_))
+    text = "\n".join(lines) + "\n"
+    terms_ref, s_ref, p_ref, o_ref = orc.ntriples_encode(text)
+    canon_ref = [orc.ntriples_decode_term(t) for t in terms_ref]
+    assert len(set(canon_ref)) == len(canon_ref)
+    nt = rf.NTriples(text, first_id=3)
+    assert nt.n_triples == len(s_ref) and nt.n_terms == len(terms_ref)
+    decoded, typed, dec_hi = nt.decoded()
+    assert sorted(decoded) == sorted(canon_ref)                       # the same distinct terms, decoded alike
+    assert len(set(decoded)) == nt.n_terms
+    # the spellings that must have merged
+    one = lambda lex, kind=3, sfx=b"": sum(1 for d in decoded if d == (kind, lex, sfx))
+    assert one(b"aA\n") == 1 and one(b"x") == 1 and one(b"v", 4, b"en-gb") == 1 and one("http://example.org/caf\u00e9".encode(), 1) == 1
+    assert one(b"x", 5, b"http://example.org/dt") == 1
+    # the triples, through the ids, are the restatement's triples
+    sp, pp, op = nt.columns()
+    gs = rf.GpuQuadStore()
+    zeros = torch_cuda.zeros(nt.n_triples, dtype=torch_cuda.int32, device="cuda")
+    gs.extend_device(zeros.data_ptr(), sp, pp, op, nt.n_triples)
+    g, s_, p_, o_ = gs.read_index(abi.GSPO)
+    got = sorted({(decoded[a - 3], decoded[b - 3], decoded[c - 3]) for a, b, c in zip(s_.tolist(), p_.tolist(), o_.tolist())})
+    exp = sorted({(canon_ref[a - 1], canon_ref[b - 1], canon_ref[c - 1]) for a, b, c in zip(s_ref, p_ref, o_ref)})
+    assert got == exp
+    # typed values
+    n_parsed = n_host = 0
+    for t, (kind, lex, sfx) in enumerate(decoded):
+        tag, lo, flags, hi, host = orc.ntriples_typed_value(kind, lex, sfx)
+        row = typed[t]
+        assert row["tag"] == tag, (lex, sfx, int(row["tag"]), tag)
+        if host:                                                   # the device may leave it to the host — or not: if it parsed it, the value must be right
+            assert row["flags"] & abi.TVF_NEEDS_HOST, (lex, sfx)
+            n_host += 1
+            continue
+        assert not (row["flags"] & abi.TVF_NEEDS_HOST), (lex, sfx)
+        if host is None:                                           # NaN: any payload
+            assert np.isnan(np.array([row["lo"]], np.int64).view(np.float64)[0])
+            continue
+        assert (int(row["lo"]), int(row["flags"]), int(dec_hi[t])) == (lo, flags, hi), (lex, sfx, int(row["lo"]), lo, int(dec_hi[t]), hi)
+        n_parsed += tag in (abi.TV_INTEGER, abi.TV_INT, abi.TV_BOOLEAN, abi.TV_DECIMAL, abi.TV_DOUBLE, abi.TV_FLOAT)
+    assert n_parsed >= 20 and n_host >= 6
+    nt.close()
+    for bad in ('<a> <b> "bad \\q escape" .\n', '<a> <b> "\\u12" .\n', '<a> <b> "\\uD800" .\n', '<a\\n> <b> <c> .\n', '<a> <b> "\\U00110000" .\n'):
+        with pytest.raises(rf.RdfGpuError, match="triple line 1"):
+            rf.NTriples(bad)
+        with pytest.raises(ValueError):
+            orc.ntriples_encode(bad)
+
+
 def test_regex_unsupported_is_refused_loudly(torch_cuda):
     tv, offsets, heap = string_dictionary(["abc"])
     gs, _ = both_stores((np.zeros(0, np.uint32),) * 4, typed=tv)
@@ -1249,13 +1333,20 @@ def test_regex_unsupported_is_refused_loudly(torch_cuda):
         gs.plan(desc)
     gs.set_strings(offsets, heap)
     gs.plan(desc)
-    for bad in ("\\p{L}", "(?i)a", "a|^b", "[é]"):
+    for bad in ("\\p{Greek}", "(?u)a", "a|^b", "[é]"):      # (\\p{L}, (?i)a, [a&&b] are inside the subset since ABI 3: tests/test_regex_cpu.py)
         pb = PlanBuilder()
         with pytest.raises(rf.RdfGpuError):
             gs.plan(pb.build(pb.filter(pb.table(0, 1), EBV(REGEX(ENC_TV(col(0)), bad, "")))))
     pb = PlanBuilder()
-    with pytest.raises(rf.RdfGpuError):          # REGEX over a literal has no lexical form on the device
+    with pytest.raises(rf.RdfGpuError, match="no lexical form on the device"):   # REGEX over a literal given by rank only: refused at compile
         gs.plan(pb.build(pb.filter(pb.table(0, 1), EBV(REGEX(lit_tv(abi.TV_STRING, 0), "a", "")))))
+    from rdf_fusion_amd.plan import STRLEN, UCASE, lit_str
+    for e in (EBV(EQ(STRLEN(lit_tv(abi.TV_STRING, 0)), integer(1))), EBV(CONTAINS(UCASE(lit_tv(abi.TV_STRING, 0)), "A"))):
+        pb = PlanBuilder()
+        with pytest.raises(rf.RdfGpuError, match="no lexical form on the device"):
+            gs.plan(pb.build(pb.filter(pb.table(0, 1), e)))
+    pb = PlanBuilder()                            # ... while the same literal WITH its bytes is an ordinary operand
+    gs.plan(pb.build(pb.filter(pb.table(0, 1), EBV(REGEX(lit_str("abc"), "a", "")))))
 
 
 def test_lubm_shaped_optional_plus_regex(torch_cuda):

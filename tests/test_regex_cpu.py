@@ -34,6 +34,24 @@ KATS = [  # (pattern, flags, subject, expected)   None = the SPARQL error value
     ("\\Bfoo", "", "foo", False), ("\\B", "", "", True), ("\\b", "", "", False), ("\\b", "", "a", True), ("a\\b|\\Bb", "", "ab", True), ("a\\b|\\Bb", "", "a-b", True), ("a\\B|\\Bb", "", "a-b", False),
     ("(\\b|x)+a", "", "-a", True), ("\\w\\b\\w", "", "ab", False), ("^\\b", "", " a", False), ("\\b$", "", "a ", False), ("\\d", "i", "5", True),
     ("grad\\w*\\d{2}\\b", "i", "GraduateStudent42 x", True),
+    # inline flags (regex-syntax: a directive holds to the end of the enclosing group; `(?flags:..)` for its own group)
+    ("(?i)abc", "", "xABCx", True), ("a(?i)bc", "", "aBC", True), ("a(?i)bc", "", "ABC", False), ("(?i:a)bc", "", "Abc", True), ("(?i:a)bc", "", "ABC", False),
+    ("(?i)a(?-i)b", "", "Ab", True), ("(?i)a(?-i)b", "", "AB", False), ("(a(?i)b)c", "", "aBc", True), ("(a(?i)b)c", "", "aBC", False),
+    ("(?s)a.b", "", "a\nb", True), ("(?s-s)a.b", "", "a\nb", False), ("(?m)^b$", "", "a\nb\nc", True), ("(?m:^b)", "", "a\nb", True), ("a(?x) b c # d\n e", "", "abce", True),
+    ("(?is)A.B", "", "a\nb", True), ("(?U)a+b", "", "aab", True), ("abc", "i", "(?-i)ABC", True), ("(?-i)abc", "i", "ABC", False), ("(?u)a", "", "a", None), ("(?)a", "", "a", None),
+    # classes: nesting, POSIX, set operations (left to right; operands are unions)
+    ("[a-z&&[^aeiou]]", "", "e", False), ("[a-z&&[^aeiou]]", "", "f", True), ("^[a-z--[aeiou]]+$", "", "xyz", True), ("^[a-z--[aeiou]]+$", "", "xaz", False),
+    ("[a-c~~b-d]", "", "a", True), ("[a-c~~b-d]", "", "b", False), ("[a-c~~b-d]", "", "d", True), ("[a-z&&b-y--m]", "", "m", False), ("[a-z&&b-y--m]", "", "n", True), ("[a-z&&b-y--m]", "", "z", False),
+    ("^[[:alpha:]]+[[:digit:]]$", "", "ab1", True), ("[[:^alpha:]]", "", "ab", False), ("[[:^alpha:]]", "", "a1", True), ("[[:alpha:][:digit:]_]+!", "", "a_1!", True),
+    ("[a[bc]]", "", "c", True), ("[^a[bc]]", "", "c", False), ("[^a[bc]]", "", "d", True), ("[^a[^bc]]", "", "b", True), ("[^a[^bc]]", "", "d", False),
+    ("[[:punct:]&&[^!]]", "", "!", False), ("[[:punct:]&&[^!]]", "", "?", True), ("[A-Z&&[a-c]]", "i", "b", True), ("[A-Z&&[a-c]]", "i", "d", False),
+    ("[\\w--\\d]", "", "5", False), ("[\\w--\\d]", "", "x", True), ("[^a&&b]", "", "a", True),
+    # Unicode general categories: ASCII members (like the Perl classes)
+    ("\\p{L}+", "", "12ab", True), ("^\\p{Lu}", "", "ab", False), ("^\\p{Lu}", "", "Ab", True), ("\\pN+", "", "ab", False), ("\\pN", "", "a7", True),
+    ("\\P{L}", "", "ab", False), ("\\P{L}", "", "a1", True), ("[\\p{Nd}x]", "", "x", True), ("\\p{^L}", "", "ab", False), ("\\p{gc=Lu}", "", "aB", True),
+    ("\\p{Letter}\\p{Decimal_Number}", "", "a1", True), ("\\p{P}", "", "a-b", True), ("\\p{P}", "", "a+b", False), ("\\p{S}", "", "a+b", True), ("\\p{Sc}", "", "$", True),
+    ("\\p{Zs}", "", "a b", True), ("\\p{Zs}", "", "a\tb", False), ("\\p{Cc}", "", "a\tb", True), ("\\p{Lu}", "i", "a", True), ("\\p{Lo}", "", "abc", False),
+    ("\\p{Greek}", "", "a", None), ("\\p{sc=Latin}", "", "a", None), ("\\p{Foo}", "", "a", None),
 ]
 
 
@@ -77,6 +95,30 @@ def test_oracle_perl_classes_agree_with_python_re():
     assert checked > 15_000
 
 
+def test_oracle_extended_syntax_agrees_with_python_re():
+    """Inline flag groups, a leading flag directive, POSIX classes, class set operations and (over ASCII subjects) Unicode general
+    categories: the oracle against Python's `re` on the same patterns with the set algebra spelled out."""
+    rng = np.random.default_rng(99)
+    checked = used = 0
+    for k in range(6000):
+        perl = k % 2 == 0
+        pat, flags, py, py_flags = ku.random_regex(rng, perl=perl, extended=True)
+        if "x" in flags and ("[:" in pat or "&&" in pat or "--" in pat or "~~" in pat or "#" in py):
+            continue                            # (Python's verbose mode treats '#' / spaces inside the spelled-out classes its own way)
+        try:
+            rx = re.compile(py, py_flags)
+        except re.error:
+            continue
+        used += any(t in pat for t in ("(?", "[:", "&&", "--", "~~", "\\p", "\\P"))
+        for _ in range(5):
+            s = ku.random_subject(rng, ascii_only=perl)
+            if s == "" and "\\B" in pat:
+                continue
+            assert orc.regex_is_match(pat, flags, s) == (rx.search(s) is not None), (pat, flags, py, s)
+            checked += 1
+    assert checked > 15_000 and used > 1500
+
+
 def test_oracle_perl_classes_refuse_non_ascii_subjects():
     for pat in ("\\d", "\\w+", "a\\b", "[\\s]"):
         with pytest.raises(orc.NeedsUnicodeTables):
@@ -100,6 +142,13 @@ def test_device_compiler_accepts_the_subset_and_refuses_the_rest():
             assert 0 <= engine.regex_check(pat, flags) <= 64
         except engine.RdfGpuError as e:
             assert "64 positions" in str(e) or "word boundary under a repetition" in str(e) or ku.regex_needs_unicode_fold_care(pat, flags), (pat, flags, str(e))
+    for k in range(3000):                                        # the extended syntax: accepted unless it is one of the documented refusals
+        pat, flags, _, _ = ku.random_regex(np.random.default_rng(10_000 + k), perl=k % 2 == 0, extended=True)
+        try:
+            assert 0 <= engine.regex_check(pat, flags) <= 64
+        except engine.RdfGpuError as e:
+            assert any(t in str(e) for t in ("64 positions", "word boundary under a repetition", "non-ASCII case partner", "non-ASCII literal under", "anchor that is not")) \
+                or ku.regex_needs_unicode_fold_care(pat, flags), (pat, flags, str(e))
     assert engine.regex_check("a", "z") == 0                     # invalid flag: a program that only yields the error value
     rng = np.random.default_rng(7)
     n_ok = 0
@@ -111,7 +160,7 @@ def test_device_compiler_accepts_the_subset_and_refuses_the_rest():
         except engine.RdfGpuError as e:
             assert "64 positions" in str(e) or ku.regex_needs_unicode_fold_care(pat, flags), (pat, flags, str(e))
     assert n_ok > 2000
-    for bad in ("\\p{L}", "\\pL", "[\\b]", "\\b*", "\\b+a", "\\<a", "[[:alpha:]]", "[a&&b]", "(?i)a", "a|^b", "x^", "[é]", "a{", "*a", "(", "a)", "\\"):
+    for bad in ("\\p{Greek}", "\\p{sc=Latin}", "\\p{Foo}", "[\\b]", "\\b*", "\\b+a", "\\<a", "[[:alfa:]]", "[a&&]", "(?u)a", "(?R)a", "(?)a", "(?i", "[^k]+(?i)[^k]", "a|^b", "x^", "[é]", "a{", "*a", "(", "a)", "\\"):
         with pytest.raises(engine.RdfGpuError):
             engine.regex_check(bad, "")
     with pytest.raises(engine.RdfGpuError):
