@@ -8,8 +8,8 @@
 //
 // Both sides are partitioned by the TOP bits of the key hash (rocPRIM radix sort of (partition, {row, key0, key1})
 // 12-byte records: the records travel with the sort, so neither side is gathered afterwards) into partitions of ~1 K build rows;
-// one workgroup owns one partition at a time: it builds the partition's {key0, index} open-addressing table in LDS (the
-// LOW hash bits pick the slot; second key and row id in LDS next to it), streams the partition's probe records
+// one workgroup owns one partition at a time: it builds the partition's {key0, key1} open-addressing table in LDS (the
+// LOW hash bits pick the slot; the build row id in a parallel array indexed by slot), streams the partition's probe records
 // (12-byte records, coalesced), and compacts the key-equal (build row, probe row) candidates with ballot + mbcnt into
 // wave-private LDS queues; a full queue runs the join filter on its candidates, reserves its output range with ONE
 // atomicAdd and writes consecutive rows (the resolve phase of the fused join kernel, join_device.hpp).
@@ -104,18 +104,18 @@ __global__ __launch_bounds__(256) void part_range_bounds_kernel(const u32* col, 
   pstart[p] = (u32)lower_bound_u32(col, n, first);
 }
 
-#ifndef RDFGPU_PART_PREFETCH_ROUNDS
-#define RDFGPU_PART_PREFETCH_ROUNDS 4
-#endif
-constexpr u32 kPartPrefetchRounds = RDFGPU_PART_PREFETCH_ROUNDS;
-template <int FS>
+template <int FS, bool RANGE>
 __global__ __launch_bounds__(kLdsBlock) __attribute__((amdgpu_waves_per_eu(4))) void part_join_kernel(const LdsJoinArgs a, const PartArgs pa) {
   extern __shared__ __align__(16) unsigned char lds_raw[];
-  // dynamic LDS: [slots: tbl_mask + 1 x {key0, local index}] [k1: chunk] [rows: chunk] [8 wave queues]
+  // dynamic LDS: [slots: tbl_mask + 1 x {key0, key1}; key0 == 0 = empty: a null key joins nothing and is never inserted]
+  //              [rowof: tbl_mask + 1 build row ids, by slot] [8 wave queues]
+  // One hop of a probe is ONE ds_read_b64 and two compares.  The first form kept {key0, local index} in the slot and the second
+  // key and the row id in arrays by index: two to four dependent LDS round trips per hop inside a divergent loop the compiler
+  // lowered to ~35 scalar instructions and 7 branches per hop — 1.0 G scalar against 0.53 G vector instructions for LUBM Q9's
+  // closing join, waves executing 26 % of their cycles (profiles/r03_lubm_part_join_sq_counters_before.json).
   uint2* slots = reinterpret_cast<uint2*>(lds_raw);
-  u32* k1s = reinterpret_cast<u32*>(slots + (pa.tbl_mask + 1u));
-  u32* rows = k1s + pa.chunk;
-  uint2* queues = reinterpret_cast<uint2*>(rows + pa.chunk);
+  u32* rowof = reinterpret_cast<u32*>(slots + (pa.tbl_mask + 1u));
+  uint2* queues = reinterpret_cast<uint2*>(rowof + (pa.tbl_mask + 1u));
   __shared__ u32 wg_count, wg_cursor;
   __shared__ u64 wg_base;
   const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -147,6 +147,9 @@ __global__ __launch_bounds__(kLdsBlock) __attribute__((amdgpu_waves_per_eu(4))) 
     }
     if (a.visited) for (u32 e = lane; e < qn; e += 64) a.visited[wq[e].x] = 1;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    // vmcnt(0): without it the compiler carries "a gather above may still be in flight" around the probe loop and waits for ALL
+    // memory operations — the prefetched next round included — in front of every slot read of every hop (this path is the rare one)
+    __builtin_amdgcn_s_waitcnt(0x0F70);
   };
   auto resolve = [&]() {   // join filter over the queued candidates, survivors compacted in place
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -191,98 +194,78 @@ __global__ __launch_bounds__(kLdsBlock) __attribute__((amdgpu_waves_per_eu(4))) 
     qn = 0;
   };
 
-  // one probe row of the partition against the chunk's table: walk its chain, queue the key-equal candidates
-  auto load_probe = [&](u32 ps, u32 t, bool live) -> uint4 {
-    uint4 r = make_uint4(kNil, 0u, 0u, 0u);
-    if (live) {
-      if (pa.ppart) { const PartRec q = pa.ppart[ps + t]; r = make_uint4(q.row, q.k0, q.k1, 0u); }
-      else {                                         // range mode: the slice itself, in place
-        r.x = ps + t; r.y = pa.pcol0[ps + t]; r.z = a.n_keys > 1 ? pa.pcol1[ps + t] : 0u;
-        if (r.y == 0 || (a.n_keys > 1 && r.z == 0)) r.x = kNil;   // NullEqualsNothing
-      }
-    }
-    return r;
+  // The record loads are PREFETCHES (a round is requested while the round before it is worked on), so they are unconditional and
+  // branch-free — the index is clamped into the partition, whether the lane has a row at all is decided when the record is used:
+  // a load under a branch made the compiler wait for it where it was issued.
+  const u32* pcol1x = a.n_keys > 1 ? pa.pcol1 : pa.pcol0;
+  auto load_probe = [&](u32 ps, u32 pe, u32 t) -> uint4 {   // {probe row, key0, key1, -} of row min(ps + t, pe - 1)
+    const u32 i = ps + t < pe ? ps + t : pe - 1;
+    if constexpr (RANGE) return make_uint4(i, pa.pcol0[i], pcol1x[i], 0u);   // range mode: the slice itself, in place
+    else { const PartRec q = pa.ppart[i]; return make_uint4(q.row, q.k0, q.k1, 0u); }
   };
-  auto probe_one = [&](const uint4 r, bool live, bool counting) {
+  // One round of probe rows (one per lane) against the chunk's table.  The wave walks in LOCKSTEP and keeps no per-lane state but
+  // its slot: a lane that has reached an empty slot (no further match) or a key-equal slot (a match) STAYS on it — reading it again
+  // gives the same answer — until every lane has stopped; the only branch of a hop is the wave-uniform "is any lane still walking".
+  // The lanes on a key-equal slot are queued and step past it, the next trip of the outer loop resumes there; a lane on an empty
+  // slot stops at once in every later trip.  Lanes without a row (beyond the partition, null key) never walk.
+  auto probe_round = [&](uint4 r, bool live, bool counting) {
+    if (a.n_keys < 2) r.z = 0u;
     Keys key; key.k[0] = r.y; key.k[1] = r.z; key.k[2] = 0; key.k[3] = 0;
     u32 h = hash_keys4(key, a.n_keys) & pa.tbl_mask;
-    bool walking = live && r.x != kNil;
+    const bool dead = !live | (r.x == kNil) | (r.y == 0u) | ((a.n_keys > 1) & (r.z == 0u));   // no row in this lane, or NullEqualsNothing
     for (;;) {
-      u32 hit = kNil;
-      while (walking) {
+      bool eq;
+      for (;;) {
         const uint2 c = slots[h];
-        if (c.y == kNil) { walking = false; break; }
-        h = (h + 1) & pa.tbl_mask;
-        if (c.x != r.y) continue;
-        if (a.n_keys > 1 && k1s[c.y] != r.z) continue;
-        hit = rows[c.y];
-        break;
+        eq = (c.x == r.y) & (c.y == r.z);
+        const bool stop = (c.x == 0u) | eq | dead;
+        if (__ballot(!stop) == 0) break;
+        h = stop ? h : (h + 1) & pa.tbl_mask;
       }
-      const unsigned long long found = __ballot(hit != kNil);
+      const bool hit = eq & !dead;                   // a live key is not 0: key-equal implies occupied
+      const unsigned long long found = __ballot(hit);
       if (found == 0) break;
       const u32 n_found = (u32)__popcll(found);
       if (qn + n_found > qcap) flush(counting);      // wave-uniform: the queue is empty afterwards and 64 <= qcap
-      if (hit != kNil) wq[qn + lane_prefix(found)] = make_uint2(hit, r.x);
+      if (hit) { wq[qn + lane_prefix(found)] = make_uint2(rowof[h], r.x); h = (h + 1) & pa.tbl_mask; }
       qn += n_found;
     }
   };
-  // Every memory round trip of a partition used to be exposed: `load a round of records -> use it`, ~3 build rounds and ~7 probe rounds
-  // per partition, with two workgroups per CU (the LDS table) to hide them behind — most of the 26 us a partition took.  Now the
-  // records of the first kPfBuild build rounds and the first kPfProbe probe rounds are requested TOGETHER, before the table is even
-  // cleared, and sit in registers (36 VGPRs) while the LDS phases run: one round trip per partition instead of ten.  Rounds beyond
-  // the prefetch (big partitions, later chunks) load in the loop as before.
-  // Only for the join without a VM / window filter (FS 0, 2: 40 VGPRs without the prefetch): the filtered forms sit at ~100 VGPRs already
-  // and would spill the prefetched records into scratch inside the probe loop (measured at compile time: 107 spilled VGPRs for FS 1).
-  // Depth: kPartPrefetchRounds probe rounds — deep enough for the usual partition (~3.5 k probe rows = 7 rounds of 512), shallow enough
-  // to stay under 84 VGPRs = 6 waves per SIMD = the three workgroups per CU a 52 KB-LDS join fits (108 VGPRs at depth 8: two).
-  constexpr u32 kPfProbe = (FS == 0 || FS == 2) ? kPartPrefetchRounds : 0u, kPfBuild = (FS == 0 || FS == 2) ? 4u : 0u;
 
   for (u32 p = blockIdx.x; p < pa.n_parts; p += gridDim.x) {
     const u32 bs = pa.bstart[p], be = pa.bstart[p + 1], ps = pa.pstart[p], pe = pa.pstart[p + 1];
     if (bs >= be || ps >= pe) continue;              // uniform per workgroup
     const u32 n_probe = pe - ps;
-    PartRec pf_b[kPfBuild ? kPfBuild : 1]; uint4 pf_p[kPfProbe ? kPfProbe : 1];
-    {
-      const u32 nb0 = be - bs < pa.chunk ? be - bs : pa.chunk;
-#pragma unroll
-      for (u32 r = 0; r < kPfBuild; r++) { const u32 i = r * kLdsBlock + tid; pf_b[r] = i < nb0 ? pa.bpart[bs + i] : PartRec{kNil, 0u, 0u}; }
-#pragma unroll
-      for (u32 r = 0; r < kPfProbe; r++) { const u32 t = r * kLdsBlock + tid; pf_p[r] = load_probe(ps, t, t < n_probe); }
-    }
     __syncthreads();
     if (tid == 0) { wg_count = 0; wg_cursor = 0; }
     for (int pass = pa.two_pass ? 0 : 1; pass < 2; pass++) {
       const bool counting = pass == 0;
       for (u32 cb = bs; cb < be; cb += pa.chunk) {
         const u32 nb = be - cb < pa.chunk ? be - cb : pa.chunk;
+        // the first round of both sides is requested before the table is cleared, every later round while the one before it is
+        // worked on: the loads of a partition overlap its LDS phases instead of heading each of them
+        PartRec bnext = pa.bpart[cb + (tid < nb ? tid : nb - 1)];
+        uint4 pnext = load_probe(ps, pe, tid);
         __syncthreads();                             // every wave is done with the previous table
-        for (u32 s = tid; s <= pa.tbl_mask; s += kLdsBlock) slots[s] = make_uint2(0u, kNil);
+        for (u32 s = tid; s <= pa.tbl_mask; s += kLdsBlock) slots[s] = make_uint2(0u, 0u);
         __syncthreads();
-        auto insert = [&](const PartRec q, u32 i) {
-          k1s[i] = q.k1; rows[i] = q.row;
-          if (q.row == kNil) return;                 // a row that joins nothing
+        for (u32 i0 = 0; i0 < nb; i0 += kLdsBlock) {  // uniform trip count per workgroup
+          const PartRec q = bnext;
+          const u32 in = i0 + kLdsBlock + tid;
+          bnext = pa.bpart[cb + (in < nb ? in : nb - 1)];
+          if (i0 + tid >= nb || q.row == kNil) continue;   // no row in this lane, or a row that joins nothing
           Keys key; key.k[0] = q.k0; key.k[1] = q.k1; key.k[2] = 0; key.k[3] = 0;
           u32 h = hash_keys4(key, a.n_keys) & pa.tbl_mask;
           for (;;) {
-            if (atomicCAS(&slots[h].y, kNil, i) == kNil) { slots[h].x = q.k0; break; }
+            if (atomicCAS(&slots[h].x, 0u, q.k0) == 0u) { slots[h].y = q.k1; rowof[h] = q.row; break; }
             h = (h + 1) & pa.tbl_mask;
           }
-        };
-        if (cb == bs) {                              // the first chunk: its first rounds are in registers already
-#pragma unroll
-          for (u32 r = 0; r < kPfBuild; r++) { const u32 i = r * kLdsBlock + tid; if (i < nb) insert(pf_b[r], i); }
-          for (u32 i = kPfBuild * kLdsBlock + tid; i < nb; i += kLdsBlock) insert(pa.bpart[cb + i], i);
-        } else for (u32 i = tid; i < nb; i += kLdsBlock) insert(pa.bpart[cb + i], i);
-        __syncthreads();
-#pragma unroll
-        for (u32 r = 0; r < kPfProbe; r++) {         // uniform trip count per workgroup
-          if (r * kLdsBlock >= n_probe) break;
-          probe_one(pf_p[r], r * kLdsBlock + tid < n_probe, counting);
         }
-        for (u32 t0 = kPfProbe * kLdsBlock; t0 < n_probe; t0 += kLdsBlock) {
-          const u32 t = t0 + tid;
-          const bool live = t < n_probe;
-          probe_one(load_probe(ps, t, live), live, counting);
+        __syncthreads();
+        for (u32 t0 = 0; t0 < n_probe; t0 += kLdsBlock) {   // uniform trip count per workgroup
+          const uint4 r = pnext;
+          pnext = load_probe(ps, pe, t0 + kLdsBlock + tid);
+          probe_round(r, t0 + tid < n_probe, counting);
         }
       }
       if (pa.two_pass) flush(counting);              // what is still queued belongs to this partition's range (single pass: the queue carries over)
@@ -329,14 +312,18 @@ void part_sort(const u32* kin, u32* kout, const PartRec* vin, PartRec* vout, u64
   RDFGPU_HIP(rocprim::radix_sort_pairs(temp, temp_bytes, kin, kout, vin, vout, (size_t)n, 0, bits, s));
 }
 size_t part_join_lds_bytes(const LdsJoinArgs& a, const PartArgs& pa) {
-  return (size_t)(pa.tbl_mask + 1) * sizeof(uint2) + 2ull * pa.chunk * sizeof(u32) + (size_t)(kLdsBlock / 64) * a.wave_q * sizeof(uint2);
+  return (size_t)(pa.tbl_mask + 1) * (sizeof(uint2) + sizeof(u32)) + (size_t)(kLdsBlock / 64) * a.wave_q * sizeof(uint2);
 }
-template <int FS> static void launch_part_join_fs(const LdsJoinArgs& a, const PartArgs& pa, dim3 g, size_t lds, hipStream_t s) {
+template <int FS, bool RANGE> static void launch_part_join_fr(const LdsJoinArgs& a, const PartArgs& pa, dim3 g, size_t lds, hipStream_t s) {
   static std::once_flag attr_once;
   std::call_once(attr_once, [] {
-    RDFGPU_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(part_join_kernel<FS>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
+    RDFGPU_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(part_join_kernel<FS, RANGE>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
   });
-  hipLaunchKernelGGL((part_join_kernel<FS>), g, dim3(kLdsBlock), lds, s, a, pa);
+  hipLaunchKernelGGL((part_join_kernel<FS, RANGE>), g, dim3(kLdsBlock), lds, s, a, pa);
+}
+template <int FS> static void launch_part_join_fs(const LdsJoinArgs& a, const PartArgs& pa, dim3 g, size_t lds, hipStream_t s) {
+  if (pa.ppart) launch_part_join_fr<FS, false>(a, pa, g, lds, s);
+  else launch_part_join_fr<FS, true>(a, pa, g, lds, s);   // range mode: the probe side is a sorted slice read in place
 }
 void launch_part_join(const LdsJoinArgs& a, const PartArgs& pa, hipStream_t s) {
   const size_t lds = part_join_lds_bytes(a, pa);
