@@ -116,8 +116,9 @@ __global__ __launch_bounds__(kLdsBlock) __attribute__((amdgpu_waves_per_eu(4))) 
   uint2* slots = reinterpret_cast<uint2*>(lds_raw);
   u32* rowof = reinterpret_cast<u32*>(slots + (pa.tbl_mask + 1u));
   uint2* queues = reinterpret_cast<uint2*>(rowof + (pa.tbl_mask + 1u));
-  __shared__ u32 wg_count, wg_cursor;
-  __shared__ u64 wg_base;
+  u64& wg_base = *reinterpret_cast<u64*>(queues + (size_t)(kLdsBlock / 64) * a.wave_q);   // (behind the queues: the table starts at LDS address 0)
+  u32& wg_count = reinterpret_cast<u32*>(&wg_base)[2];
+  u32& wg_cursor = reinterpret_cast<u32*>(&wg_base)[3];
   const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const u32 qcap = a.wave_q;
   uint2* wq = queues + (size_t)wave * qcap;
@@ -208,26 +209,30 @@ __global__ __launch_bounds__(kLdsBlock) __attribute__((amdgpu_waves_per_eu(4))) 
   // gives the same answer — until every lane has stopped; the only branch of a hop is the wave-uniform "is any lane still walking".
   // The lanes on a key-equal slot are queued and step past it, the next trip of the outer loop resumes there; a lane on an empty
   // slot stops at once in every later trip.  Lanes without a row (beyond the partition, null key) never walk.
+  // The slot of a key: the top bits of two multiplicative hashes (4 vector instructions).  The partition took the top bits of the
+  // general 4-round mix (part_keys_kernel) or an id range; this one only has to spread a partition's keys over its table.
+  const u32 slot_shift = 32u - (u32)__builtin_popcount(pa.tbl_mask);
+  auto slot_of = [&](u32 k0, u32 k1) -> u32 { return ((k0 * 0x9E3779B1u) ^ (k1 * 0x85EBCA77u)) >> slot_shift; };
   auto probe_round = [&](uint4 r, bool live, bool counting) {
     if (a.n_keys < 2) r.z = 0u;
-    Keys key; key.k[0] = r.y; key.k[1] = r.z; key.k[2] = 0; key.k[3] = 0;
-    u32 h = hash_keys4(key, a.n_keys) & pa.tbl_mask;
+    const u32 wrap = pa.tbl_mask << 3;
+    u32 hb = slot_of(r.y, r.z) << 3;                 // the walk keeps the slot's byte offset
     const bool dead = !live | (r.x == kNil) | (r.y == 0u) | ((a.n_keys > 1) & (r.z == 0u));   // no row in this lane, or NullEqualsNothing
+    const unsigned char* sb = reinterpret_cast<const unsigned char*>(slots);
     for (;;) {
       bool eq;
-      for (;;) {
-        const uint2 c = slots[h];
+      for (;;) {                                     // (divergent, but the body is one read, three compares and one exit)
+        const uint2 c = *reinterpret_cast<const uint2*>(sb + hb);
         eq = (c.x == r.y) & (c.y == r.z);
-        const bool stop = (c.x == 0u) | eq | dead;
-        if (__ballot(!stop) == 0) break;
-        h = stop ? h : (h + 1) & pa.tbl_mask;
+        if ((c.x == 0u) | eq | dead) break;
+        hb = (hb + 8u) & wrap;
       }
       const bool hit = eq & !dead;                   // a live key is not 0: key-equal implies occupied
-      const unsigned long long found = __ballot(hit);
+      const unsigned long long found = __builtin_amdgcn_ballot_w64(hit);
       if (found == 0) break;
       const u32 n_found = (u32)__popcll(found);
       if (qn + n_found > qcap) flush(counting);      // wave-uniform: the queue is empty afterwards and 64 <= qcap
-      if (hit) { wq[qn + lane_prefix(found)] = make_uint2(rowof[h], r.x); h = (h + 1) & pa.tbl_mask; }
+      if (hit) { wq[qn + lane_prefix(found)] = make_uint2(rowof[hb >> 3], r.x); hb = (hb + 8u) & wrap; }
       qn += n_found;
     }
   };
@@ -254,8 +259,7 @@ __global__ __launch_bounds__(kLdsBlock) __attribute__((amdgpu_waves_per_eu(4))) 
           const u32 in = i0 + kLdsBlock + tid;
           bnext = pa.bpart[cb + (in < nb ? in : nb - 1)];
           if (i0 + tid >= nb || q.row == kNil) continue;   // no row in this lane, or a row that joins nothing
-          Keys key; key.k[0] = q.k0; key.k[1] = q.k1; key.k[2] = 0; key.k[3] = 0;
-          u32 h = hash_keys4(key, a.n_keys) & pa.tbl_mask;
+          u32 h = slot_of(q.k0, a.n_keys > 1 ? q.k1 : 0u);
           for (;;) {
             if (atomicCAS(&slots[h].x, 0u, q.k0) == 0u) { slots[h].y = q.k1; rowof[h] = q.row; break; }
             h = (h + 1) & pa.tbl_mask;
@@ -312,7 +316,7 @@ void part_sort(const u32* kin, u32* kout, const PartRec* vin, PartRec* vout, u64
   RDFGPU_HIP(rocprim::radix_sort_pairs(temp, temp_bytes, kin, kout, vin, vout, (size_t)n, 0, bits, s));
 }
 size_t part_join_lds_bytes(const LdsJoinArgs& a, const PartArgs& pa) {
-  return (size_t)(pa.tbl_mask + 1) * (sizeof(uint2) + sizeof(u32)) + (size_t)(kLdsBlock / 64) * a.wave_q * sizeof(uint2);
+  return (size_t)(pa.tbl_mask + 1) * (sizeof(uint2) + sizeof(u32)) + (size_t)(kLdsBlock / 64) * a.wave_q * sizeof(uint2) + 16;
 }
 template <int FS, bool RANGE> static void launch_part_join_fr(const LdsJoinArgs& a, const PartArgs& pa, dim3 g, size_t lds, hipStream_t s) {
   static std::once_flag attr_once;
