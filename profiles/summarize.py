@@ -4,6 +4,8 @@
   python profiles/summarize.py pmc   <fetch dir> <write dir> <out.json> [key=value ...]   (key=value -> "_workload", what bench.py matches on;
                                                                                             "_source_sha16" = the device sources' hash, stamped here)
   python profiles/summarize.py counters <out.json> <kernel substring> <dir> [<dir> ...]
+  python profiles/summarize.py gaps  <dir with *_kernel_trace.csv> <out.json> <substring of a step's first kernel>   (busy time, span and
+                                                                                            launch gaps of the steady-state steps)
 
 The pmc form reads *_counter_collection.csv of two separate passes (FETCH_SIZE and WRITE_SIZE cannot share a
 pass on gfx950) and writes, per kernel: dispatches, median/max raw counter values in KB, and `hbm_bytes_per_launch`
@@ -28,6 +30,12 @@ def short(name):
     return name.split("(")[0].strip()
 
 
+def source_sha16():
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import rdf_fusion_amd
+    return rdf_fusion_amd.kernel_source_sha16()
+
+
 def pmc_values(d, counter):
     out = defaultdict(list)
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
@@ -41,6 +49,33 @@ def main():
     if sys.argv[1] == "stats":
         src = glob.glob(os.path.join(sys.argv[2], "**", "*kernel_stats.csv"), recursive=True)
         shutil.copy(src[0], sys.argv[3])
+        return
+    if sys.argv[1] == "gaps":       # summarize.py gaps <trace dir> <out.json> <first kernel substring> : device time line of the steady-state steps
+        import csv
+        src = glob.glob(os.path.join(sys.argv[2], "**", "*kernel_trace.csv"), recursive=True)
+        rows = []
+        for f in src:
+            for r in csv.DictReader(open(f)):
+                rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
+        rows.sort()
+        first = sys.argv[4]
+        starts = [i for i, r in enumerate(rows) if first in r[2]]
+        steps = []
+        for a, b in zip(starts, starts[1:]):           # a step = from one launch of the first kernel to the next
+            ks = rows[a:b]
+            busy = sum(e - s for s, e, _ in ks)
+            span = ks[-1][1] - ks[0][0]
+            gaps = [ks[i + 1][0] - ks[i][1] for i in range(len(ks) - 1)]
+            steps.append({"kernels": len(ks), "busy_us": busy / 1e3, "span_us": span / 1e3, "gaps_us": [g / 1e3 for g in gaps],
+                          "to_next_step_us": (rows[b][0] - ks[-1][1]) / 1e3, "names": [short(n) for _, _, n in ks]})
+        steady = steps[len(steps) // 2:]
+        med = lambda v: sorted(v)[len(v) // 2] if v else None
+        res = {"steps_seen": len(steps), "steady_steps": len(steady),
+               "median_busy_us": med([s["busy_us"] for s in steady]), "median_span_us": med([s["span_us"] for s in steady]),
+               "median_gap_sum_us": med([sum(s["gaps_us"]) for s in steady]), "median_between_steps_us": med([s["to_next_step_us"] for s in steady]),
+               "last_step": steady[-1] if steady else None, "_source_sha16": source_sha16()}
+        json.dump(res, open(sys.argv[3], "w"), indent=1)
+        print(json.dumps({k: v for k, v in res.items() if k != "last_step"}))
         return
     if sys.argv[1] == "counters":   # every counter found in the given pass directories, median per dispatch, for kernels matching the substring
         out, want = {}, sys.argv[3]

@@ -7,8 +7,8 @@ ds = bsbm.generate(int(os.environ.get("P", "285000")))
 st = rf.GpuQuadStore(); st.extend(ds.g, ds.s, ds.p, ds.o); st.set_typed_values(ds.typed_values, ds.decimals)
 B = int(os.environ.get("B", "256"))
 rng = np.random.default_rng(5)
-plan = st.plan(bsbm.q5_batch_plan(ds, topk=bool(int(os.environ.get("TOPK", "0"))))).enable_kernel_timing(True)
-for it in range(4):
+plan = st.plan(bsbm.q5_batch_plan(ds, topk=bool(int(os.environ.get("TOPK", "0"))))).enable_kernel_timing(bool(int(os.environ.get("TIMING", "1"))))   # TIMING=0: no event brackets (the launch-gap trace)
+for it in range(int(os.environ.get("STEPS", "4"))):
     prods = np.array([ds.product(i) for i in rng.choice(ds.n_products, B, replace=False)], dtype=np.uint32)
     flat = np.stack([np.arange(1, B + 1, dtype=np.uint32), prods])
     t = torch.from_numpy(flat.view(np.int32)).cuda()
