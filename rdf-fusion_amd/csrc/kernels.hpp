@@ -290,6 +290,23 @@ void launch_part_keys(const u32* k0, const u32* k1, u32 n_keys, const u64* n_dev
 void launch_part_equalise(const u32* sorted_col, u64 n, PartKeyRange kr, u32 n_parts, uint2* dir, hipStream_t s);
 void launch_part_range_bounds(const u32* sorted_col, u64 n, PartKeyRange kr, u32 n_parts, u32* pstart, hipStream_t s);
 void launch_sorted_bounds(const u32* sorted_keys, u64 n, u32 n_keys, u32* start, hipStream_t s);   // start[k] = first position with key >= k, k = 0 .. n_keys
+// the partition passes, hand-written (part_pass.hip): one or two MSD passes that recompute the partition from the keys they move —
+// no key array, 64 instead of 92 bytes per row; `start` comes out of the last pass's scanned histogram
+struct PartPassPlan { bool two; u32 nb_a, tiles_a, max_tiles_b; u64 hist_a, hist_b, tile_desc_bytes; };   // array sizes for n rows and `bits` partition bits
+struct PartPassBuffers {
+  PartRec* recs;                 // [n] the records grouped by partition (the result)
+  PartRec* recs_a;               // [n] the records after pass A (two passes only)
+  unsigned short* pid16;         // [n] the partition of every row (between pass A's histogram and its scatter)
+  unsigned char* digit;          // [n] partition & 255 of every record after pass A (two passes only)
+  u32* hist_a;                   // [hist_a] counts per (bin, tile) of pass A, scanned in place over a bin's tiles
+  u32* hist_b;                   // [hist_b] the same of pass B, per (bucket, bin, tile)
+  u32* total; u32* base_a;       // [max(nb_a, n_parts) + 1] rows per bin; [nb_a + 1] first record of every bucket of pass A
+  void* tiles_b; u32* tb; u32* n_tiles_b;   // [tile_desc_bytes] pass B's tiles, [nb_a + 1] first tile of every bucket, [1] their number
+  u32* start;                    // [n_parts + 1] first record of every partition
+};
+PartPassPlan part_pass_plan(u64 n, u32 bits);
+void part_pass_run(const PartPassBuffers& w, const PartPassPlan& pl, const u32* k0, const u32* k1, u32 n_keys, const u64* n_dev, u64 cap, u32 bits, u32 n_parts,
+                   PartKeyRange kr, void* scan_temp, size_t scan_temp_bytes, hipStream_t s);
 size_t part_sort_temp_bytes(u64 n, u32 bits);
 void part_sort(const u32* kin, u32* kout, const PartRec* vin, PartRec* vout, u64 n, u32 bits, void* temp, size_t temp_bytes, hipStream_t s);
 void launch_part_join(const LdsJoinArgs& a, const PartArgs& pa, hipStream_t s);

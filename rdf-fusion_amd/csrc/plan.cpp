@@ -553,7 +553,8 @@ const char* kernel_class_name(int kc) {
       "rdfgpu::value_runs_kernel", "rdfgpu::run_scan_kernel", "rdfgpu::run_copy_kernel",
       "rdfgpu::oj_probe_kernel", "rdfgpu::oj_count_kernel", "void rdfgpu::oj_write_kernel",
       "void rdfgpu::filter_write_kernel", "rdfgpu::part_keys_kernel", "void rdfgpu::part_join_kernel",
-      "rdfgpu::oj_band_records_kernel", "rdfgpu::oj_write_band_kernel", "void rdfgpu::small_scan_kernel"};
+      "rdfgpu::oj_band_records_kernel", "rdfgpu::oj_write_band_kernel", "void rdfgpu::small_scan_kernel",
+      "rdfgpu::part_pass (hist + scan + scatter)"};
   if (kc < KC_LDS_JOIN0) return fixed[kc];
   static std::string names[192];
   static std::once_flag once;
@@ -1917,9 +1918,28 @@ void Plan::prepare_partitions(const LdsJoinArgs& a, const DevTable& B, const Dev
       }
   auto side = [&](const DevTable& T, const u32* const* keys, const PartRec*& recs, const u32*& start, PartKeyRange r) {
     const u64 n = T.cap;
+    u32* st = scratch<u32>((u64)n_parts + 2);
+    if (!opt.on(RDFGPU_OPT_NO_OWN_PARTITION_PASS)) {   // hand-written MSD passes that recompute the partition from the keys (part_pass.hip)
+      const PartPassPlan pl = part_pass_plan(n, bits);
+      PartPassBuffers w{};
+      w.recs = scratch<PartRec>(n); w.recs_a = pl.two ? scratch<PartRec>(n) : nullptr;
+      w.pid16 = scratch<unsigned short>(n); w.digit = pl.two ? scratch<unsigned char>(n) : nullptr;
+      w.hist_a = scratch<u32>(pl.hist_a);
+      w.total = scratch<u32>((u64)std::max<u32>(pl.nb_a, n_parts) + 2); w.base_a = scratch<u32>((u64)pl.nb_a + 2);
+      if (pl.two) {
+        w.hist_b = scratch<u32>(pl.hist_b);
+        w.tiles_b = scratch<unsigned char>(pl.tile_desc_bytes); w.n_tiles_b = scratch<u32>(1);
+      }
+      w.tb = scratch<u32>((u64)pl.nb_a + 2);
+      w.start = st;
+      const size_t tb = scan_temp_bytes((u64)n_parts + 2);
+      void* temp = scratch<unsigned char>(tb);
+      timed(KC_PART_PASS, 0, n, T.n_dev, 0, nullptr, 0, 0, [&] { part_pass_run(w, pl, keys[0], a.n_keys > 1 ? keys[1] : nullptr, a.n_keys, T.n_dev, n, bits, n_parts, r, temp, tb, stream); });
+      recs = w.recs; start = st;
+      return;
+    }
     u32* skey_in = scratch<u32>(n); u32* skey = scratch<u32>(n);
     PartRec* sval_in = scratch<PartRec>(n); PartRec* sval = scratch<PartRec>(n);
-    u32* st = scratch<u32>((u64)n_parts + 2);
     const size_t tb = part_sort_temp_bytes(n, bits ? bits : 1);
     void* temp = scratch<unsigned char>(tb);
     timed(KC_PART_KEYS, 0, n, T.n_dev, 0, nullptr, 0, 0, [&] { launch_part_keys(keys[0], a.n_keys > 1 ? keys[1] : nullptr, a.n_keys, T.n_dev, n, bits, n_parts, r, skey_in, sval_in, stream); });

@@ -67,7 +67,7 @@ enum KernelClass {
   KC_FILTER_VERDICT, KC_REGEX_VERDICTS, KC_UNION,
   KC_BAND_SLOW, KC_RADIX_SORT, KC_BAND_BOUNDS, KC_BAND_BLOCKS, KC_BAND_DECODE, KC_BAND_MASK, KC_BAND_EMIT, KC_BAND_ENTRIES, KC_BAND_DESC, KC_BAND_PT, KC_BAND_ROWS,
   KC_FILTER_BITS_ID, KC_FILTER_BITS_TV, KC_FILTER_BITS_VERDICT, KC_FILTER_BITS_VALUE, KC_VALUE_VERDICTS, KC_VALUE_RUNS, KC_RUN_SCAN, KC_RUN_COPY, KC_OJ_PROBE, KC_OJ_COUNT, KC_OJ_WRITE, KC_FILTER_WRITE,
-  KC_PART_KEYS, KC_PART_JOIN, KC_OJ_BAND_RECORDS, KC_OJ_WRITE_BAND, KC_SMALL_SCAN,
+  KC_PART_KEYS, KC_PART_JOIN, KC_OJ_BAND_RECORDS, KC_OJ_WRITE_BAND, KC_SMALL_SCAN, KC_PART_PASS,
   KC_LDS_JOIN0,                      // 192 names: lds_join_kernel<FS in {0..3}, PFS in {0,1,2}, ITEMS in {4,1}, MODE in {0,1,2,3}, CHAIN>
   KC__N = KC_LDS_JOIN0 + 192
 };

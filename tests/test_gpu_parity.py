@@ -611,6 +611,12 @@ def test_partitioned_join_matches_oracle(torch_cuda, nb, npr, n_ids, min_build):
             assert plan.result_info()[0] == n_exp, (on, jt, rep)
             np.testing.assert_array_equal(ku.multiset(got, n_exp), want, err_msg=f"{on} {jt} rep {rep}")
             seen |= {k[0] for k in plan.kernel_stats()}
+        if nb <= 2_500_000:                   # the partition passes the other way: ids materialised + rocPRIM's radix sort instead of part_pass.hip
+            plan.set_option("NO_OWN_PARTITION_PASS", 1)
+            got = plan.execute().fetch()
+            assert any("rocprim radix sort" in k[0] for k in plan.kernel_stats()) or ENGINE_TOGGLED
+            np.testing.assert_array_equal(ku.multiset(got, n_exp), want)
+            plan.set_option("NO_OWN_PARTITION_PASS", 0)
         if not big:
             plan.set_option("NO_PARTITIONED_JOIN", 1)
             got = plan.execute().fetch()
@@ -618,6 +624,7 @@ def test_partitioned_join_matches_oracle(torch_cuda, nb, npr, n_ids, min_build):
             np.testing.assert_array_equal(ku.multiset(got, n_exp), want)
         plan.close()
     assert any("part_join_kernel" in k for k in seen) or ENGINE_TOGGLED, seen
+    assert any("part_pass" in k for k in seen) or ENGINE_TOGGLED, seen
     del kb, kp
 
 
@@ -666,7 +673,7 @@ def test_partitioned_join_over_sorted_slice(torch_cuda, n_quads, nb):
             assert plan.result_info()[0] == n_exp, (on, jt, mode)
             np.testing.assert_array_equal(ku.multiset(got, n_exp), want, err_msg=f"{on} {jt} {mode}")
             stats = {k[0]: k[1] for k in plan.kernel_stats()}
-            sorts[mode] = (stats.get("rocprim radix sort", 0), any("part_join_kernel" in k for k in stats))
+            sorts[mode] = (sum(v for k, v in stats.items() if "part_pass" in k), any("part_join_kernel" in k for k in stats))   # (sides that went through the partition passes)
         if not ENGINE_TOGGLED:
             in_place = 1 if any(r == 1 for _, r in on) else 2     # the slice of (?s <7> ?o) is sorted by ?o: a join on ?s alone partitions both sides
             assert sorts["range"] == (in_place, True) and sorts["range again"] == (in_place, True) and sorts["hash"] == (2, True) and not sorts["off"][1], (on, sorts)
