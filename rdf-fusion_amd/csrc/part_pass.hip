@@ -27,12 +27,13 @@
 // Reference behaviour is that of part_join.hip (HashJoinExec(CollectLeft), join/rewrite.rs:126-168): this file only decides where
 // a row waits for its partition's workgroup.
 #include <hip/hip_runtime.h>
+#include <algorithm>
 
 #include "join_device.hpp"
 
 namespace rdfgpu {
 
-constexpr u32 kPtBlock = 512, kPtItems = 8, kPtTile = kPtBlock * kPtItems;   // rows per tile
+constexpr u32 kPtBlock = 1024, kPtItems = 4, kPtTile = kPtBlock * kPtItems;   // rows per tile (4096: 59 KB of LDS staging in the scatter = two workgroups per CU, 32 waves)
 
 // partition of a key pair; joins = false: the row joins nothing (null key, outside the probe slice's id range) and rides in the
 // last partition with row = kNil
@@ -87,75 +88,116 @@ __device__ __forceinline__ bool part_tile_of(const PartPassArgs& a, u32 g, PartT
   return true;
 }
 
+// One count per `valid` lane into cnt[bin]; returns the lane's rank = the count before + its place among the wave's lanes of the same
+// bin.  Neighbouring rows often share their partition (a range-partitioned build side arrives clustered by key: LUBM's join output),
+// and 64 lanes adding to ONE LDS word serialise — pass B's histogram took 276 us on such rows against 95 us on hashed ones.  So the
+// lanes that share the first pending lane's bin are counted by that lane alone when they are a crowd (>= 16: one atomic for the group,
+// ranks from the ballot; at most two such rounds), everything else goes one atomic per lane — on hashed rows the test is a ballot and
+// a branch, no LDS round trip is added.  Every lane of the wave calls it.
+__device__ __forceinline__ u32 wave_bin_add(u32* cnt, u32 bin, bool valid) {
+  const u32 lane = threadIdx.x & 63u;
+  unsigned long long todo = __builtin_amdgcn_ballot_w64(valid);
+  u32 rank = 0;
+  for (int round = 0; round < 2 && todo; round++) {                       // wave-uniform
+    const int leader = __builtin_ctzll(todo);
+    const u32 b = (u32)__builtin_amdgcn_readlane((int)bin, leader);
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(valid && bin == b) & todo;
+    if (__popcll(m) < 16) break;                                          // no crowd (decided without touching LDS): one atomic per lane below
+    u32 base = 0;
+    if ((int)lane == leader) base = atomicAdd(&cnt[b], (u32)__popcll(m));
+    base = (u32)__builtin_amdgcn_readlane((int)base, leader);
+    if ((m >> lane) & 1ull) rank = base + (u32)__popcll(m & ((1ull << lane) - 1ull));
+    todo &= ~m;
+  }
+  if ((todo >> lane) & 1ull) rank = atomicAdd(&cnt[bin], 1u);
+  return rank;
+}
+
 constexpr u32 kPartDirMax = 4096;   // entries of the range directory (plan.cpp: n_coarse <= 4096)
+// Histogram workgroups are small (256 lanes x 16 rows of a tile) and PERSISTENT: a tile is 4 - 48 KB of input, a workgroup per tile
+// lived for its launch and its two memory round trips (pass B, 1 byte per row: 276 us for 98 MB), and pass A's workgroups staged the
+// 32 KB range directory once per tile — as many bytes as the tile's keys (444 us against 209 us in hash mode).
+constexpr u32 kPhBlock = 256, kPhItems = kPtTile / kPhBlock;
 template <bool PASS_B>
-__global__ __launch_bounds__(kPtBlock) void part_hist_kernel(const PartPassArgs a) {
+__global__ __launch_bounds__(kPhBlock) void part_hist_kernel(const PartPassArgs a) {
   __shared__ u32 cnt[256];
   __shared__ uint2 dir_l[PASS_B ? 1 : kPartDirMax];
-  PartTile t;
-  if (!part_tile_of<PASS_B>(a, blockIdx.x, t)) return;                   // pass B: the launch covers the upper bound of its tiles
-  if (threadIdx.x < 256) cnt[threadIdx.x] = 0u;
+  const u32 tid = threadIdx.x;
   const uint2* dir = a.pid.kr.dir;
   if constexpr (!PASS_B) {
     if (a.pid.kr.range >= 0 && a.pid.kr.n_coarse <= kPartDirMax) {       // the directory into LDS: every row reads one random entry of it
-      for (u32 c = threadIdx.x; c < a.pid.kr.n_coarse; c += kPtBlock) dir_l[c] = a.pid.kr.dir[c];
+      for (u32 c = tid; c < a.pid.kr.n_coarse; c += kPhBlock) dir_l[c] = a.pid.kr.dir[c];
       dir = dir_l;
     }
   }
-  __syncthreads();
-  u32 bin[kPtItems];
-  if constexpr (PASS_B) {
+  const u32 n_tiles = PASS_B ? *a.n_tiles_dev : a.n_tiles;
+  const u64 live = PASS_B ? 0 : live_rows(a.n_dev, a.cap);
+  for (u32 g = blockIdx.x; g < n_tiles; g += gridDim.x) {                 // uniform per workgroup
+    PartTile t;
+    (void)part_tile_of<PASS_B>(a, g, t);
+    cnt[tid] = 0u;
+    __syncthreads();
+    u32 bin[kPhItems];
+    if constexpr (PASS_B) {
 #pragma unroll
-    for (u32 it = 0; it < kPtItems; it++) {                               // (all loads of the tile in flight together, then the counting)
-      const u32 j = it * kPtBlock + threadIdx.x;
-      bin[it] = j < t.n ? (u32)a.digit[t.first + j] : 0u;
-    }
-  } else {
-    const u64 live = live_rows(a.n_dev, a.cap);
-    u32 k0[kPtItems], k1[kPtItems];
+      for (u32 it = 0; it < kPhItems; it++) {                             // (all loads of the tile in flight together, then the counting)
+        const u32 j = it * kPhBlock + tid;
+        bin[it] = j < t.n ? (u32)a.digit[t.first + j] : 0u;
+      }
+    } else {
+      u32 k0[kPhItems], k1[kPhItems];
 #pragma unroll
-    for (u32 it = 0; it < kPtItems; it++) {
-      const u32 i = t.first + it * kPtBlock + threadIdx.x;
-      const bool in = it * kPtBlock + threadIdx.x < t.n && i < live;
-      k0[it] = in ? a.k0[i] : 0u; k1[it] = (in && a.pid.n_keys > 1) ? a.k1[i] : 0u;
+      for (u32 it = 0; it < kPhItems; it++) {
+        const u32 i = t.first + it * kPhBlock + tid;
+        const bool in = it * kPhBlock + tid < t.n && i < live;
+        k0[it] = in ? a.k0[i] : 0u; k1[it] = (in && a.pid.n_keys > 1) ? a.k1[i] : 0u;
+      }
+#pragma unroll
+      for (u32 it = 0; it < kPhItems; it++) {
+        const u32 j = it * kPhBlock + tid;
+        const u32 p = a.pid.joins(k0[it], k1[it]) ? a.pid.of(k0[it], k1[it], dir) : a.pid.n_parts - 1;
+        if (j < t.n) a.pid16[t.first + j] = (unsigned short)p;
+        bin[it] = p >> a.shift;
+      }
     }
 #pragma unroll
-    for (u32 it = 0; it < kPtItems; it++) {
-      const u32 j = it * kPtBlock + threadIdx.x;
-      const u32 p = a.pid.joins(k0[it], k1[it]) ? a.pid.of(k0[it], k1[it], dir) : a.pid.n_parts - 1;
-      if (j < t.n) a.pid16[t.first + j] = (unsigned short)p;
-      bin[it] = p >> a.shift;
-    }
+    for (u32 it = 0; it < kPhItems; it++) (void)wave_bin_add(cnt, bin[it], it * kPhBlock + tid < t.n);
+    __syncthreads();
+    if (tid < a.nbins) a.hist[(u64)t.hbase + (u64)tid * t.stride] = cnt[tid];   // (lane `tid` zeroes cnt[tid] itself at the top of the next tile)
   }
-#pragma unroll
-  for (u32 it = 0; it < kPtItems; it++) if (it * kPtBlock + threadIdx.x < t.n) atomicAdd(&cnt[bin[it]], 1u);
-  __syncthreads();
-  if (threadIdx.x < a.nbins) a.hist[(u64)t.hbase + (u64)threadIdx.x * t.stride] = cnt[threadIdx.x];
 }
 
 // The counts of one bin over its tiles -> exclusive prefix in place + the bin's total.
-// Pass A: one workgroup of 1024 per bin (a row of cap / 4096 counts): every lane sums a contiguous piece, the 1024 sums are scanned,
-// the lane walks its piece again (L2) writing the running prefix.
+// Pass A: one workgroup of 1024 per bin (a row of cap / 4096 counts): every WAVE takes a contiguous sixteenth of the row and walks it
+// 64 counts at a time (coalesced) — once for its sum, and, after the 16 sums have met in LDS, again (L2) writing the running prefix.
 __global__ __launch_bounds__(1024) void part_row_scan_a_kernel(u32* hist, u32 tiles, u32 nbins, u32* total) {
   __shared__ u32 wt[16];
-  const u32 bin = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const u32 bin = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   u32* row = hist + (u64)bin * tiles;
-  const u32 c = (tiles + 1023u) / 1024u;
-  const u32 i0 = t * c < tiles ? t * c : tiles, i1 = i0 + c < tiles ? i0 + c : tiles;
+  const u32 seg = ((tiles + 15u) / 16u + 63u) & ~63u;                     // counts per wave, whole groups of 64
+  const u32 s0 = wave * seg < tiles ? wave * seg : tiles, s1 = s0 + seg < tiles ? s0 + seg : tiles;
   u32 sum = 0;
-  for (u32 i = i0; i < i1; i++) sum += row[i];
-  const u32 incl = wave_incl_scan(sum);
-  if (lane == 63) wt[wave] = incl;
+  for (u32 i = s0 + lane; i < s1; i += 64) sum += row[i];
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) sum += __shfl_xor(sum, d, 64);
+  if (lane == 0) wt[wave] = sum;
   __syncthreads();
-  u32 run = incl - sum, all = 0;
-  for (u32 w = 0; w < 16; w++) { const u32 v = wt[w]; if (w < wave) run += v; all += v; }
-  for (u32 i = i0; i < i1; i++) { const u32 v = row[i]; row[i] = run; run += v; }
-  if (t == 0) { total[bin] = all; if (bin == 0) total[nbins] = 0u; }   // (the extra element of the totals' scan: its exclusive prefix is the number of records)
+  u32 carry = 0, all = 0;
+  for (u32 w = 0; w < 16; w++) { const u32 v = wt[w]; if (w < wave) carry += v; all += v; }
+  for (u32 i0 = s0; i0 < s1; i0 += 64) {                                  // wave-uniform trip count
+    const u32 i = i0 + lane;
+    const u32 v = i < s1 ? row[i] : 0u;
+    const u32 incl = wave_incl_scan(v);
+    if (i < s1) row[i] = carry + incl - v;
+    carry += (u32)__builtin_amdgcn_readlane((int)incl, 63);
+  }
+  if (threadIdx.x == 0) { total[bin] = all; if (bin == 0) total[nbins] = 0u; }   // (the extra element of the totals' scan: its exclusive prefix is the number of records)
 }
 // Pass B: one wave per (bucket, bin) — a row of the bucket's tiles (~ records of the bucket / 4096 counts, a hundred for the LUBM
 // join); the totals, in (bucket, bin) order, are the partition sizes.
-__global__ __launch_bounds__(256) void part_row_scan_b_kernel(u32* hist, const u32* tb, u32 nb, u32* total) {
+__global__ __launch_bounds__(256) void part_row_scan_b_kernel(u32* hist, const u32* tb, u32 nb, u32* total, u32* start_end, u32 n_records) {
   const u32 lane = threadIdx.x & 63;
+  if (blockIdx.x == 0 && threadIdx.x == 0) *start_end = n_records;        // start[n_parts] = all records (every row has one); the totals' scan stops before it
   const u32 row_id = blockIdx.x * 4u + (threadIdx.x >> 6);                // bucket * 256 + bin
   if (row_id >= nb * 256u) return;                                        // (whole waves)
   const u32 b = row_id >> 8, bin = row_id & 255u;
@@ -206,10 +248,7 @@ __global__ __launch_bounds__(kPtBlock) void part_scatter_kernel(const PartPassAr
     }
   }
 #pragma unroll
-  for (u32 it = 0; it < kPtItems; it++) {
-    const u32 j = it * kPtBlock + tid;
-    if (j < t.n) rank[it] = atomicAdd(&cnt[bin[it]], 1u);                 // the row's place among the tile's rows of its bin
-  }
+  for (u32 it = 0; it < kPtItems; it++) rank[it] = wave_bin_add(cnt, bin[it], it * kPtBlock + tid < t.n);   // the row's place among the tile's rows of its bin
   __syncthreads();
   u32 c = 0, incl = 0;
   if (tid < 256) {                                                        // waves 0 - 3, whole: exclusive scan of the 256 counts
@@ -294,7 +333,7 @@ void part_pass_run(const PartPassBuffers& w, const PartPassPlan& pl, const u32* 
   a.n_tiles = pl.tiles_a; a.shift = pl.two ? 8u : 0u; a.nbins = pl.nb_a;
   a.hist = w.hist_a; a.base = base_a; a.out = pl.two ? w.recs_a : w.recs;
   a.pid16 = w.pid16; a.digit = pl.two ? w.digit : nullptr;
-  hipLaunchKernelGGL(part_hist_kernel<false>, dim3(pl.tiles_a), dim3(kPtBlock), 0, s, a);
+  hipLaunchKernelGGL(part_hist_kernel<false>, dim3(std::min<u32>(pl.tiles_a, 1024u)), dim3(kPhBlock), 0, s, a);   // (33 KB of LDS: four workgroups per CU)
   hipLaunchKernelGGL(part_row_scan_a_kernel, dim3(pl.nb_a), dim3(1024), 0, s, w.hist_a, pl.tiles_a, pl.nb_a, w.total);
   exclusive_scan_u32(w.total, base_a, (u64)pl.nb_a + 1, scan_temp, scan_temp_bytes, s);
   hipLaunchKernelGGL(part_scatter_kernel<false>, dim3(pl.tiles_a), dim3(kPtBlock), 0, s, a);
@@ -305,12 +344,10 @@ void part_pass_run(const PartPassBuffers& w, const PartPassPlan& pl, const u32* 
   b.in = w.recs_a; b.tiles = reinterpret_cast<const PartTile*>(w.tiles_b); b.n_tiles_dev = w.n_tiles_b; b.n_tiles = pl.max_tiles_b;
   b.shift = 0; b.nbins = 256;
   b.hist = w.hist_b; b.base = w.start; b.out = w.recs;
-  hipLaunchKernelGGL(part_hist_kernel<true>, dim3(pl.max_tiles_b), dim3(kPtBlock), 0, s, b);
-  hipLaunchKernelGGL(part_row_scan_b_kernel, dim3((pl.nb_a * 256u + 3) / 4), dim3(256), 0, s, w.hist_b, w.tb, pl.nb_a, w.total);
+  hipLaunchKernelGGL(part_hist_kernel<true>, dim3(std::min<u32>(pl.max_tiles_b, 2048u)), dim3(kPhBlock), 0, s, b);
+  hipLaunchKernelGGL(part_row_scan_b_kernel, dim3((pl.nb_a * 256u + 3) / 4), dim3(256), 0, s, w.hist_b, w.tb, pl.nb_a, w.total, w.start + n_parts, (u32)cap);
   // the (bucket, bin) totals are the partition sizes: their exclusive scan = the partitions' first records (n_parts <= 65536: one workgroup)
   exclusive_scan_u32(w.total, w.start, (u64)n_parts, scan_temp, scan_temp_bytes, s);
-  const u32 n32 = (u32)cap;
-  RDFGPU_HIP(hipMemcpyAsync(w.start + n_parts, &n32, sizeof(u32), hipMemcpyHostToDevice, s));   // start[n_parts] = all records (every row has one)
   hipLaunchKernelGGL(part_scatter_kernel<true>, dim3(pl.max_tiles_b), dim3(kPtBlock), 0, s, b);
 }
 
