@@ -628,6 +628,49 @@ def test_partitioned_join_matches_oracle(torch_cuda, nb, npr, n_ids, min_build):
     del kb, kp
 
 
+@pytest.mark.parametrize("nb,case", [(4096, "exact tile"), (4097, "tile + 1"), (8192, "two tiles"), (300_000, "all null"), (300_000, "one hot key"),
+                                     (262_144, "one pass / two pass boundary"), (262_400, "one pass / two pass boundary"), (1_048_576, "clustered")])
+def test_partition_passes_edge_cases(torch_cuda, nb, case):
+    """The hand-written partition passes (part_pass.hip) at their seams: row counts on / next to a tile boundary (4096 rows), a build
+    side on which NO row joins (every key null: all records ride in the last partition), one key on every row (one partition holds
+    everything, joined chunk by chunk; every wave's bins are a crowd), the build size where 256 partitions become 512 (one pass ->
+    two passes), and rows clustered by key (the wave-aggregated counting).  Two-column keys, inner join; the oracle's multiset and the
+    rocPRIM form of the passes."""
+    rng = np.random.default_rng(nb)
+    gs, os_ = both_stores((np.zeros(0, np.uint32),) * 4)
+    gs.set_option("PARTITION_MIN_BUILD", 1000)
+    npr = 50_000
+    n_ids = max(16, nb // 3)
+    B = [rng.integers(1, n_ids + 1, nb).astype(np.uint32), rng.integers(1, 5, nb).astype(np.uint32), np.arange(1, nb + 1, dtype=np.uint32)]
+    Pr = [rng.integers(1, n_ids + 1, npr).astype(np.uint32), rng.integers(1, 5, npr).astype(np.uint32), np.arange(1, npr + 1, dtype=np.uint32)]
+    if case == "all null":
+        B[0][:] = 0
+    elif case == "one hot key":
+        B[0][:] = 7; B[1][:] = 2; Pr[0][:40] = 7; Pr[1][:40] = 2          # 40 probe rows x nb build rows
+    elif case == "clustered":
+        B[0].sort()                                                         # neighbouring rows share their key (and so their partition)
+    kb, pbp = table_on_device(torch_cuda, B)
+    kp, ppp = table_on_device(torch_cuda, Pr)
+    pb = PlanBuilder()
+    desc = pb.build(pb.hash_join(pb.table(0, 3), pb.table(1, 3), on=[(0, 0), (1, 1)], join_type=abi.JOIN_INNER, projection=[2, 5]))
+    exp, n_exp, _ = os_.execute(desc, [B, Pr])
+    want = ku.multiset(exp, n_exp)
+    plan = gs.plan(desc)
+    plan.bind_table(0, pbp, nb); plan.bind_table(1, ppp, npr)
+    for own in (1, 0, 1):
+        plan.set_option("NO_OWN_PARTITION_PASS", 0 if own else 1)
+        plan.enable_kernel_timing(True)
+        got = plan.execute().fetch()
+        names = {k[0] for k in plan.kernel_stats()}
+        assert plan.result_info()[0] == n_exp, (case, own)
+        np.testing.assert_array_equal(ku.multiset(got, n_exp), want, err_msg=f"{case} own={own}")
+        if not ENGINE_TOGGLED:
+            assert any("part_join_kernel" in k for k in names), names
+            assert any("part_pass" in k for k in names) == bool(own), (own, names)
+    plan.close()
+    del kb, kp
+
+
 @pytest.mark.parametrize("n_quads,nb", [(300_000, 200_000), (2_500_000, 1_200_000)])
 def test_partitioned_join_over_sorted_slice(torch_cuda, n_quads, nb):
     """Partitioned join whose probe side is a store slice sorted by one of the join keys: the slice is read in place, its
