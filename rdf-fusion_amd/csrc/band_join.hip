@@ -198,6 +198,7 @@ __global__ __launch_bounds__(256) void oj_band_records_kernel(const OrderedJoinA
   uint4 rec; u32 flags;
   band_row_record(b, iy0, iy1, x, rec, flags);
   if (flags & 1u) atomicAdd(b.slow_rows, 1u);
+  if (f.compact) { f.brec[r] = make_uint4(rec.x, rec.y, x, word(f.row_slot[0])); return; }   // (packed form: rec.z / .w are unused; a flagged row's record passes nothing)
   f.brec[2 * r] = rec;
   f.brec[2 * r + 1] = make_uint4(x, flags, word(f.row_slot[0]), word(f.row_slot[1]));
 }
@@ -384,7 +385,7 @@ __global__ __launch_bounds__(256) void band_mask_kernel(const BandArgs b) {
   const u32 rb = __builtin_amdgcn_readfirstlane(d.z), nr = __builtin_amdgcn_readfirstlane(d.w);
   uint4 rec = PACK ? make_uint4(0x0001FFFFu, 0u, 0u, 0u) : make_uint4(kBandInvalidLo, 0u, 1u, 0u);   // (nothing passes; PACK: the decode pass stored the packed form)
   u32 x = 0;
-  if (lane < nr) { rec = b.rec_s[rb + lane]; if (NEQ) x = b.aux_s[rb + lane].x; }
+  if (lane < nr) { rec = b.rec_s[rb + lane]; if (NEQ) x = b.compact ? rec.z : b.aux_s[rb + lane].x; }   // (compact: the 16-byte record carries the id operand itself)
   // The block's 64 entries go through LDS: lane e fetches entry e (one coalesced 1 KB load per block), every test then reads
   // ITS entry with a broadcast ds_read_b128 (all lanes one address).  Scalar loads (s_load_dwordx8 from the entry table) looked
   // cheaper — no LDS, operands in SGPRs — but 200 k blocks x 1 KB through the scalar caches is what the kernel then waits
@@ -525,8 +526,8 @@ __global__ __launch_bounds__(256) void band_emit_kernel(const BandArgs b) {
   u32 ev[kBandMaxSideCols], rv[kBandMaxRowCols];   // output values of the entry (lane = entry) / of the probe row (lane = row)
   {
     uint4 aux = make_uint4(0u, 0u, 0u, 0u);
-    if (lane < nr) aux = b.aux_s[rb + lane];
-    rv[0] = aux.z; rv[1] = aux.w;
+    if (lane < nr) aux = b.compact ? b.rec_s[rb + lane] : b.aux_s[rb + lane];
+    rv[0] = b.compact ? aux.w : aux.z; rv[1] = b.compact ? 0u : aux.w;
   }
 #pragma unroll
   for (u32 u = 0; u < kBandMaxSideCols; u++) { ev[u] = 0; if (u < b.n_entry_cols && lane < ne) ev[u] = b.eo[u][eb + lane]; }

@@ -257,7 +257,8 @@ struct OjBandFuse {
   u32* poff; u32* bcount; u32 max_blocks;   // key boundaries of the matches; the block counts the decode pass zeroes
   u32 kmin, kn;                      // the band join's key range
   const u32* key_col;                // the slice's sorted column: the band join's key of a slice row
-  u8 y0_slot[2], y1_slot[2], neq_slot, row_slot[2], pad;   // words of the packed table record holding the window operands / id operand / output values (0xFF: none)
+  u8 y0_slot[2], y1_slot[2], neq_slot, row_slot[2];   // words of the packed table record holding the window operands / id operand / output values (0xFF: none)
+  u8 compact;                        // one 16-byte record per table row and match {lo pair, width pair, id operand, output value 0} instead of {record, aux} (BandArgs::compact)
 };
 void launch_oj_band_records(const OrderedJoinArgs& a, const BandArgs& b, const OjBandFuse& f, hipStream_t s);
 void launch_ordered_join_write_band(const OrderedJoinArgs& a, const OjBandFuse& f, hipStream_t s);
@@ -351,7 +352,9 @@ struct BandArgs {
   uint4* bdesc;               // per block {first entry, entries (<= 64), first sorted row, rows (<= 64)}
   u64* masks;                 // 64 x u64 per block: bit e of lane r = (entry e, row r) joins
   u32* bcount; u32* bofs;     // per block (+ 1): output rows / their exclusive scan
-  u32 pack16, pad4;             // every window's biased values fit 16 bits: the pair test checks both windows with packed 16-bit arithmetic
+  u32 pack16;                   // every window's biased values fit 16 bits: the pair test checks both windows with packed 16-bit arithmetic
+  u32 compact;                  // rec_s holds the WHOLE row record {lo pair, width pair, id operand, output value 0} (16 B; aux_s unused): packed form written
+                                // by the ordered slice join (OjBandFuse), at most one row output column, no full-semantics pass
   u32* key_hist; u32* key_cursor;   // counting-sort form of the partition pass (small probe sides): rows per key, counted by the decode pass; the scatter's cursors
   u32 launch_blocks; u32 pad3; u64* n_blocks_out;   // waves launched by the block kernels (>= the previous execution's blocks; they stride on if there are more); the count, for next time
   u32 max_blocks, presorted;  // presorted: the probe rows arrive sorted by key — no sort, records written in place

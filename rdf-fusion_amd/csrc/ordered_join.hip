@@ -240,6 +240,7 @@ __global__ __launch_bounds__(kOjBlock) void oj_write_band_kernel(const OrderedJo
     for (u32 k = j - starts[lo]; k; k--) r = a.next[r];
     const u64 pos = tile_base + j;
     if (pos >= out_cap) continue;                          // the count stays exact: the plan re-runs with room for all
+    if (f.compact) { f.rec_s[pos] = f.brec[r]; continue; }   // one 16-byte record per match
     const uint4 r0 = f.brec[2ull * r], r1 = f.brec[2ull * r + 1];
     f.rec_s[pos] = r0;
     f.aux_s[pos] = r1;

@@ -2086,13 +2086,17 @@ void Plan::exec_band_join(LdsJoinArgs& a, BandArgs& b, const DevTable& B, const 
   if (fused) {
     const OrderedJoinArgs& o = pending_oj.o;
     pending_oj.active = false;
-    fuse.brec = scratch<uint4>(2 * o.n_probe_cap);
+    // the packed pair test reads 8 bytes of window, the id operand and at most one output value per row: 16 bytes per match instead of 32
+    fuse.compact = (b.pack16 && b.n_row_cols <= 1 && skip_slow && !opt.on(RDFGPU_OPT_NO_BAND_COMPACT)) ? 1 : 0;
+    b.compact = fuse.compact;
+    fuse.brec = scratch<uint4>((fuse.compact ? 1 : 2) * o.n_probe_cap);
     fuse.rec_s = b.rec_s; fuse.aux_s = b.aux_s; fuse.poff = b.poff; fuse.bcount = b.bcount; fuse.max_blocks = b.max_blocks;
     fuse.kmin = b.kmin; fuse.kn = b.kn;
     // per table row: its packed record read + two typed-value gathers + 32 B written; per slice row the count pass's 5 bytes + its
     // key; per match a 32-byte record gathered and stored
-    timed(KC_OJ_BAND_RECORDS, 0, o.n_probe_cap, o.n_probe_dev, 16ull * o.n_rec + 9ull * b.n_win + 32, nullptr, 0, 0, [&] { launch_oj_band_records(o, b, fuse, stream); });
-    timed(KC_OJ_WRITE_BAND, 0, pending_oj.n_build, nullptr, 4 + 1 + 4, a.n_probe_dev, 0, 64, [&] { launch_ordered_join_write_band(o, fuse, stream); });
+    const u64 rec_bytes = fuse.compact ? 16 : 32;
+    timed(KC_OJ_BAND_RECORDS, 0, o.n_probe_cap, o.n_probe_dev, 16ull * o.n_rec + 9ull * b.n_win + rec_bytes, nullptr, 0, 0, [&] { launch_oj_band_records(o, b, fuse, stream); });
+    timed(KC_OJ_WRITE_BAND, 0, pending_oj.n_build, nullptr, 4 + 1 + 4, a.n_probe_dev, 0, 2 * rec_bytes, [&] { launch_ordered_join_write_band(o, fuse, stream); });
   } else
   timed(KC_BAND_DECODE, 0, np, P.n_dev, 4 + 4ull * (b.n_win + b.has_neq) + 9ull * b.n_win + 24 + 8, nullptr, 0, 0, [&] { launch_band_decode(b, stream); });
   // the partition pass: in the time, not in the algorithmic bytes
@@ -2117,7 +2121,7 @@ void Plan::exec_band_join(LdsJoinArgs& a, BandArgs& b, const DevTable& B, const 
   if (!presorted && !counting) timed(KC_BAND_ROWS, 0, np, P.n_dev, 4 + 32 + 32, nullptr, 0, 0, [&] { launch_band_rows(b, stream); });
   // per probe row 4 (sorted position) + 24 (record) read, per entry 16 B read, per pair one bit written; the pair count
   // is not known on the host
-  timed(KC_BAND_MASK, 16ull * nb, np, P.n_dev, 4 + 24, nullptr, 0, 0, [&] { launch_band_mask(b, stream); });
+  timed(KC_BAND_MASK, 16ull * nb, np, P.n_dev, b.compact ? 16 : 4 + 24, nullptr, 0, 0, [&] { launch_band_mask(b, stream); });
   if (!skip_slow) {
     // the full-semantics pass needs the chain's literals and columns: the fused join kernel's argument block, by pointer
     static_assert(sizeof(LdsJoinArgs) <= ExecContext::kArgBytes, "argument staging slot too small");

@@ -1803,6 +1803,13 @@ def test_bsbm_100m_timed_path_answers_to_the_oracle(torch_cuda):
         assert any("band_mask_kernel" in k for k in ran), sorted(ran)
         assert "table" in forms and forms[-1] == "records", forms
         assert plan.metrics().host_syncs == 1
+    # the 16-byte row records of the last runs (packed windows, one row output column, no full-semantics pass) against the 32-byte form
+    plan.set_option("NO_BAND_COMPACT", 1)
+    got32 = plan.execute().fetch()
+    sel = np.isin(got32[0], tags)
+    assert len(got32[0]) == counts[0]
+    np.testing.assert_array_equal(ku.multiset([c[sel] for c in got32]), expected)
+    np.testing.assert_array_equal(ku.multiset(got32), ku.multiset(got))      # the whole result, not only the sampled tags
 
 
 def test_fused_chain_with_mixed_numeric_kinds(torch_cuda):
