@@ -368,7 +368,7 @@ __global__ __launch_bounds__(256) void band_desc_kernel(const BandArgs b) {
 // range checks and one id compare (6 VALU instructions per pair), no vector memory and no LDS inside the loop.  Measured: the
 // kernel is NOT bound by those instructions (7 -> 6 per pair changed nothing; 200 k short waves with exposed scalar-load
 // latency are what it waits for; persistent waves made it slower, 240 -> 325 us).
-// NWIN = window stages (1..2; no window = one trivial window); NEQ = base filter: 0 none / 1 `!=` / 2 `=`.
+// NWIN = window stages (1..2; no window = one trivial window); NEQ = base filter: 0 none / 1 `!=` / 2 `=` / 3 `!=` by entry index (BandArgs::neq_self).
 struct BandEntry8 { uint4 a[8]; };
 typedef unsigned short us2 __attribute__((ext_vector_type(2)));
 template <int NWIN, int NEQ, bool PACK>
@@ -437,7 +437,8 @@ __global__ __launch_bounds__(256) void band_mask_kernel(const BandArgs b) {
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // the staging area is free for the wave's next block
   // entries past the group's end belong to the next key: their bits do not count
   const u64 live = ne >= 64 ? ~0ull : ((1ull << ne) - 1ull);
-  const u64 mask = ((((u64)m[1]) << 32) | m[0]) & live;
+  u64 mask = ((((u64)m[1]) << 32) | m[0]) & live;
+  if (NEQ == 3) { const u32 self = x - eb; if (self < 64u) mask &= ~(1ull << self); }   // the row's own entry, if it is in this chunk (x = its index)
   b.masks[(u64)blk * 64 + lane] = mask;
   const u32 c = wave_incl_scan((u32)__popcll(mask));      // (DPP: lane 63 holds the block's count)
   if (lane == 63) b.bcount[blk] = c;
@@ -602,7 +603,8 @@ void launch_band_desc(const BandArgs& b, hipStream_t s) {
   hipLaunchKernelGGL(band_desc_kernel, grid256(b.kn), dim3(256), 0, s, b);
 }
 template <int NWIN, bool PACK> static void launch_band_mask_w(const BandArgs& b, dim3 g, hipStream_t s) {
-  const int neq = b.has_neq ? (b.neq_is_eq ? 2 : 1) : 0;
+  const int neq = b.has_neq ? (b.neq_is_eq ? 2 : b.neq_self ? 3 : 1) : 0;
+  if (neq == 3) { if constexpr (PACK) { hipLaunchKernelGGL((band_mask_kernel<NWIN, 3, true>), g, dim3(256), 0, s, b); return; } }
   if (neq == 0) hipLaunchKernelGGL((band_mask_kernel<NWIN, 0, PACK>), g, dim3(256), 0, s, b);
   else if (neq == 1) hipLaunchKernelGGL((band_mask_kernel<NWIN, 1, PACK>), g, dim3(256), 0, s, b);
   else hipLaunchKernelGGL((band_mask_kernel<NWIN, 2, PACK>), g, dim3(256), 0, s, b);

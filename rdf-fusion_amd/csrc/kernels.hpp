@@ -258,6 +258,7 @@ struct OjBandFuse {
   u32 kmin, kn;                      // the band join's key range
   const u32* key_col;                // the slice's sorted column: the band join's key of a slice row
   u8 y0_slot[2], y1_slot[2], neq_slot, row_slot[2];   // words of the packed table record holding the window operands / id operand / output values (0xFF: none)
+  u8 self_index;                     // the record's id-operand word holds the match's SLICE ROW instead (BandArgs::neq_self)
   u8 compact;                        // one 16-byte record per table row and match {lo pair, width pair, id operand, output value 0} instead of {record, aux} (BandArgs::compact)
 };
 void launch_oj_band_records(const OrderedJoinArgs& a, const BandArgs& b, const OjBandFuse& f, hipStream_t s);
@@ -353,6 +354,9 @@ struct BandArgs {
   u64* masks;                 // 64 x u64 per block: bit e of lane r = (entry e, row r) joins
   u32* bcount; u32* bofs;     // per block (+ 1): output rows / their exclusive scan
   u32 pack16;                   // every window's biased values fit 16 bits: the pair test checks both windows with packed 16-bit arithmetic
+  u32 neq_self;                 // `entry id != row id` is `entry index != the row's own entry`: the band join's groups ARE the rows of the slice the ordered
+                                // slice join below streamed, the compared ids are that join's keys — the one entry whose id equals the row's is the slice
+                                // row the match came from; its index travels in the compact record (word z) and the pair loop drops the id compare
   u32 compact;                  // rec_s holds the WHOLE row record {lo pair, width pair, id operand, output value 0} (16 B; aux_s unused): packed form written
                                 // by the ordered slice join (OjBandFuse), at most one row output column, no full-semantics pass
   u32* key_hist; u32* key_cursor;   // counting-sort form of the partition pass (small probe sides): rows per key, counted by the decode pass; the scatter's cursors

@@ -240,7 +240,12 @@ __global__ __launch_bounds__(kOjBlock) void oj_write_band_kernel(const OrderedJo
     for (u32 k = j - starts[lo]; k; k--) r = a.next[r];
     const u64 pos = tile_base + j;
     if (pos >= out_cap) continue;                          // the count stays exact: the plan re-runs with room for all
-    if (f.compact) { f.rec_s[pos] = f.brec[r]; continue; }   // one 16-byte record per match
+    if (f.compact) {                                       // one 16-byte record per match
+      uint4 rc = f.brec[r];
+      if (f.self_index) rc.z = (u32)(base + lo);           // the slice row of this match = the index of the row's own entry in the band join's group
+      f.rec_s[pos] = rc;
+      continue;
+    }
     const uint4 r0 = f.brec[2ull * r], r1 = f.brec[2ull * r + 1];
     f.rec_s[pos] = r0;
     f.aux_s[pos] = r1;

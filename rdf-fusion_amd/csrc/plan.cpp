@@ -2089,6 +2089,15 @@ void Plan::exec_band_join(LdsJoinArgs& a, BandArgs& b, const DevTable& B, const 
     // the packed pair test reads 8 bytes of window, the id operand and at most one output value per row: 16 bytes per match instead of 32
     fuse.compact = (b.pack16 && b.n_row_cols <= 1 && skip_slow && !opt.on(RDFGPU_OPT_NO_BAND_COMPACT)) ? 1 : 0;
     b.compact = fuse.compact;
+    // `entry id != row id` by entry index: the band join's groups are the rows of the very slice the ordered join streamed (same sorted column, same
+    // rows, identity CSR), the entry's id is that join's build key, the row's id its probe key — equal keys are what made the match, and a store slice
+    // holds every (key, sorted column) pair once: the only entry of the group whose id equals the row's is the slice row the match came from
+    fuse.self_index = 0;
+    if (fuse.compact && b.has_neq && !b.neq_is_eq && b.csr_rows == nullptr && a.build_key[0] == fuse.key_col && B.cap == pending_oj.n_build &&
+        b.neq_build == o.build_key && B.stable_id != 0 && !opt.on(RDFGPU_OPT_NO_BAND_COMPACT))
+      for (u32 c = 0; c < o.n_out_cols; c++)
+        if (o.out[c] == b.neq_probe && o.out_slot[c] != 0xFFu && o.out_ref[c].src == 0 && o.out_ref[c].ptr == o.probe_key) fuse.self_index = 1;
+    b.neq_self = fuse.self_index;
     fuse.brec = scratch<uint4>((fuse.compact ? 1 : 2) * o.n_probe_cap);
     fuse.rec_s = b.rec_s; fuse.aux_s = b.aux_s; fuse.poff = b.poff; fuse.bcount = b.bcount; fuse.max_blocks = b.max_blocks;
     fuse.kmin = b.kmin; fuse.kn = b.kn;
