@@ -567,11 +567,12 @@ __global__ __launch_bounds__(256) void band_emit_kernel(const BandArgs b) {
       const u32 idx = t0 + lane;
       const u32 pr = idx < n_round ? (u32)list[wave][idx] : 0u;
       const u32 r = pr >> 6, e = pr & 63u;
+      u32 v[NCOLS];
 #pragma unroll
-      for (u32 oc = 0; oc < (u32)NCOLS; oc++) {
-        const u32 v = __shfl(srcv[oc], out_sel[oc] < 2 ? r : e, 64);
-        u32* base = outp[oc] + run_s;                                   // scalar
-        if (idx < lim) base[idx] = v;
+      for (u32 oc = 0; oc < (u32)NCOLS; oc++) v[oc] = __shfl(srcv[oc], out_sel[oc] < 2 ? r : e, 64);   // every column's permute in flight, then one wait
+      if (idx < lim) {
+#pragma unroll
+        for (u32 oc = 0; oc < (u32)NCOLS; oc++) (outp[oc] + run_s)[idx] = v[oc];                          // (scalar base + lane offset)
       }
     }
     run_s += n_round;
