@@ -61,8 +61,10 @@ def main():
         first = sys.argv[4]
         starts = [i for i, r in enumerate(rows) if first in r[2]]
         steps = []
-        for a, b in zip(starts, starts[1:]):           # a step = from one launch of the first kernel to the next
+        for a, b in zip(starts, starts[1:]):           # a step = from one launch of the first kernel to the next ...
             ks = rows[a:b]
+            for i in range(len(ks) - 1):               # ... or to the host's pause before it (the driver script prepares the next batch: > 1 ms)
+                if ks[i + 1][0] - ks[i][1] > 1_000_000: ks = ks[:i + 1]; b = a + i + 1; break
             busy = sum(e - s for s, e, _ in ks)
             span = ks[-1][1] - ks[0][0]
             gaps = [ks[i + 1][0] - ks[i][1] for i in range(len(ks) - 1)]
