@@ -512,16 +512,24 @@ __global__ __launch_bounds__(256) void value_runs_kernel(const FilterStreamArgs 
   const bool ok = i < span && stream_pred<2>(a, first + i);   // the same answer in every lane
   if ((threadIdx.x & 63) == 0) { run_lo[i] = (u32)l; if (i < span) run_cnt[i] = ok ? 1u : 0u; }
 }
-// one workgroup: qualifying runs compacted in id order, exclusive scan of their lengths (span <= kRunCopyMaxIds)
-__global__ __launch_bounds__(1024) void run_scan_kernel(const u32* run_lo, const u32* run_cnt, u32 span, u32 first,
+// one workgroup: qualifying runs compacted in id order, exclusive scan of their lengths (span <= kRunCopyMaxIds).
+// VERDICTS = true: the runs' starts come from the slice's cached table (SliceTable::ValueStarts) and the comparison of every id is
+// answered HERE (run_cnt unused) — the whole plan of the copy in one launch instead of value_runs_kernel's searches + this scan.
+template <bool VERDICTS>
+__global__ __launch_bounds__(1024) void run_scan_kernel(const FilterStreamArgs a, const u32* run_lo, const u32* run_cnt, u32 span, u32 first,
                                                          u32* c_lo, u32* c_off, u32* c_val, u32* n_runs, u64* n_out) {
   __shared__ u32 w_rows[16], w_runs[16];
-  const u32 per = (span + 1023) / 1024;
+  const u32 per = (span + 1023) / 1024;                   // <= 64 ids per lane (span <= kRunCopyMaxIds): their verdicts are one 64-bit word
   const u32 i0 = threadIdx.x * per, i1 = i0 + per < span ? i0 + per : span;
+  unsigned long long verdicts = 0;
+  if constexpr (VERDICTS) {
+    for (u32 i = i0; i < i1; i++) verdicts |= (unsigned long long)(stream_pred<2>(a, first + i) ? 1u : 0u) << (i - i0);
+  }
+  auto qualifies = [&](u32 i) -> u32 { if constexpr (VERDICTS) return (u32)((verdicts >> (i - i0)) & 1ull); else return run_cnt[i]; };
   u32 rows = 0, runs = 0;
   // (every load unconditional: `run_cnt[i] ? run_lo[i + 1] - run_lo[i] : 0` made the second load wait for the first one's verdict — two
   //  dependent round trips per id in a kernel that is nothing but latency)
-  for (u32 i = i0; i < i1; i++) { const u32 q = run_cnt[i], lo = run_lo[i], hi = run_lo[i + 1]; const u32 c = q ? hi - lo : 0u; rows += c; runs += c != 0; }   // (run_cnt: the id qualifies)
+  for (u32 i = i0; i < i1; i++) { const u32 q = qualifies(i), lo = run_lo[i], hi = run_lo[i + 1]; const u32 c = q ? hi - lo : 0u; rows += c; runs += c != 0; }   // (q: the id qualifies)
   u32 inc_rows = rows, inc_runs = runs;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
@@ -535,7 +543,7 @@ __global__ __launch_bounds__(1024) void run_scan_kernel(const u32* run_lo, const
   for (int w = 0; w < wave; w++) { base_rows += w_rows[w]; base_runs += w_runs[w]; }
   u32 off = base_rows + inc_rows - rows, k = base_runs + inc_runs - runs;
   for (u32 i = i0; i < i1; i++) {
-    const u32 q = run_cnt[i], lo = run_lo[i], hi = run_lo[i + 1];
+    const u32 q = qualifies(i), lo = run_lo[i], hi = run_lo[i + 1];
     const u32 c = q ? hi - lo : 0u;
     if (c) { c_lo[k] = lo; c_off[k] = off; c_val[k] = first + i; k++; off += c; }
   }
@@ -686,8 +694,10 @@ void launch_value_runs(const FilterArgs& a, const RunCopyBuffers& b, hipStream_t
   const u32 span = (u32)a.value_span;
   hipLaunchKernelGGL(value_runs_kernel, dim3((span + 1 + 3) / 4), dim3(256), 0, s, f, a.value_min, span, a.n_in_cap, b.run_lo, b.run_cnt);
 }
-void launch_run_scan(const FilterArgs& a, const RunCopyBuffers& b, hipStream_t s) {
-  hipLaunchKernelGGL(run_scan_kernel, dim3(1), dim3(1024), 0, s, b.run_lo, b.run_cnt, (u32)a.value_span, a.value_min, b.c_lo, b.c_off, b.c_val, b.n_runs, a.n_out_dev);
+void launch_run_scan(const FilterArgs& a, const RunCopyBuffers& b, bool verdicts_here, hipStream_t s) {
+  const FilterStreamArgs f = stream_args(a, 2);
+  if (verdicts_here) hipLaunchKernelGGL(run_scan_kernel<true>, dim3(1), dim3(1024), 0, s, f, b.run_lo, b.run_cnt, (u32)a.value_span, a.value_min, b.c_lo, b.c_off, b.c_val, b.n_runs, a.n_out_dev);
+  else hipLaunchKernelGGL(run_scan_kernel<false>, dim3(1), dim3(1024), 0, s, f, b.run_lo, b.run_cnt, (u32)a.value_span, a.value_min, b.c_lo, b.c_off, b.c_val, b.n_runs, a.n_out_dev);
 }
 void launch_run_copy(const FilterArgs& a, const RunCopyBuffers& b, hipStream_t s) {
   if (!a.n_out_cols) return;

@@ -81,7 +81,7 @@ u64 filter_stream_tiles(const FilterArgs& a);           // 4096-row tiles of the
 constexpr u64 kRunCopyMaxIds = 65536;
 struct RunCopyBuffers { u32* run_lo; u32* run_cnt; u32* c_lo; u32* c_off; u32* c_val; u32* n_runs; };
 void launch_value_runs(const FilterArgs& a, const RunCopyBuffers& b, hipStream_t s);
-void launch_run_scan(const FilterArgs& a, const RunCopyBuffers& b, hipStream_t s);
+void launch_run_scan(const FilterArgs& a, const RunCopyBuffers& b, bool verdicts_here, hipStream_t s);   // verdicts_here: b.run_lo is the slice's cached table, the comparison per id is answered in the scan kernel
 void launch_run_copy(const FilterArgs& a, const RunCopyBuffers& b, hipStream_t s);
 // shape 2's predicate once per id of [a.value_min, + a.value_span): bit (id - value_min) of `a.value_bits` (64-id words)
 void launch_value_verdicts(const FilterArgs& a, hipStream_t s);

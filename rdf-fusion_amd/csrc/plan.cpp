@@ -994,11 +994,32 @@ DevTable Plan::apply_filter(NodeInfo& nd, const DevTable& in) {
     if (span <= kRunCopyMaxIds && span * 1024 <= in.cap) {
       a.value_min = in.key_min; a.value_span = span;
       a.stream_bits = reinterpret_cast<unsigned short*>(scratch<u32>(1)); a.stream_counts = scratch<u32>(1); a.stream_offs = a.stream_counts;   // (the argument block wants them non-null)
-      RunCopyBuffers b{scratch<u32>(span + 1), scratch<u32>(span), scratch<u32>(span + 1), scratch<u32>(span + 1), scratch<u32>(span + 1), scratch<u32>(1)};   // (run_lo: one entry past the last id)
-      timed(KC_VALUE_RUNS, 0, span, nullptr, 16, nullptr, 0, 0, [&] { launch_value_runs(a, b, stream); });
+      // Where every id's run starts is a function of the slice alone: kept with the slice's other tables per store version (the searches
+      // that find them are five dependent HBM round trips per id: 10 of the operator's 68 us); with the table at hand the comparison of
+      // every id is answered in the scan kernel — one launch plans the copy.
+      const u32* pcol = in.cols[in.sorted_col];
+      const bool cacheable = in.stable_id != 0 && !opt.on(RDFGPU_OPT_NO_TABLE_CACHE);
+      u32* cached_lo = nullptr;
+      SliceTable* vst = nullptr;
+      std::unique_lock<std::mutex> building(store->slice_build_mu, std::defer_lock);
+      if (cacheable) {
+        SliceKey sk; sk.n_keys = 1; sk.rows = in.cap; sk.key[0] = pcol;
+        vst = store->slice_table(sk);
+        building.lock();
+        for (const auto& v : vst->value_starts) if (v.first == in.key_min && v.span == span) cached_lo = v.lo;
+      }
+      const bool own = cacheable && !cached_lo && vst->value_starts.size() < 4;
+      u32* run_lo = cached_lo ? cached_lo : own ? store->table_alloc<u32>(span + 1) : scratch<u32>(span + 1);   // (one entry past the last id)
+      RunCopyBuffers b{run_lo, scratch<u32>(span), scratch<u32>(span + 1), scratch<u32>(span + 1), scratch<u32>(span + 1), scratch<u32>(1)};
+      if (!cached_lo) timed(KC_VALUE_RUNS, 0, span, nullptr, 16, nullptr, 0, 0, [&] { launch_value_runs(a, b, stream); });
       // (one launch for scan + copy — 2048 workgroups that each scan the run lengths in LDS and copy an equal share — was tried: 68 us
       //  against 6 + 51: the big chunks do not hide their memory latency the way 16 K small workgroups do)
-      timed(KC_RUN_SCAN, 0, span, nullptr, 8, nullptr, 0, 0, [&] { launch_run_scan(a, b, stream); });
+      timed(KC_RUN_SCAN, 0, span, nullptr, cached_lo ? 16 + 8 : 8, nullptr, 0, 0, [&] { launch_run_scan(a, b, cached_lo != nullptr, stream); });
+      if (own) {   // publish only when complete
+        RDFGPU_HIP(hipStreamSynchronize(stream)); metrics.host_syncs++; metrics.tables_built++;
+        vst->value_starts.push_back(SliceTable::ValueStarts{in.key_min, span, run_lo});
+      }
+      if (building.owns_lock()) building.unlock();
       timed(KC_RUN_COPY, 0, 0, nullptr, 0, a.n_out_dev, 0, 8ull * nd.n_proj, [&] { launch_run_copy(a, b, stream); });
       t.cap = in.cap; t.n_dev = a.n_out_dev;
       return t;

@@ -242,6 +242,7 @@ void Store::drop_slice_tables() {
     for (auto& v : t.values) table_free(v.val);
     for (auto& r : t.ranges) { table_free(r.rows); table_free(r.vals); table_free(r.link); }
     for (auto& e : t.band_entries) { table_free(e.et); for (u32* p : e.eo) table_free(p); }
+    for (auto& v : t.value_starts) table_free(v.lo);
   }
   slice_tables.clear();
 }

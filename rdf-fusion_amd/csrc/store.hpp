@@ -105,6 +105,10 @@ struct SliceTable {
   // values, in CSR order): a function of the store's slices and the chain's constants only — `key` spells them out
   struct BandEntries { std::string key; uint4* et; u32* eo[4]; };
   std::vector<BandEntries> band_entries;
+  // the slice as the sorted input of a FILTER on its sort column (kernels.hip, run-copy form): lo[i] = first row whose id is >= first + i
+  // (i = 0 .. span): where every distinct id's run starts — a function of the slice alone
+  struct ValueStarts { u32 first; u64 span; u32* lo; };
+  std::vector<ValueStarts> value_starts;
 };
 struct SliceKey {
   const u32* key[RDFGPU_MAX_KEYS] = {}; u32 n_keys = 0; u64 rows = 0;

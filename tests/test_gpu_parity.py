@@ -498,7 +498,19 @@ def test_streaming_filter_matches_oracle(torch_cuda, n):
                     np.testing.assert_array_equal(got[c], exp[c])      # the streaming / run-copy forms keep the rows in index order
             if k < 4 and not ENGINE_TOGGLED:
                 # few ids under many rows: the qualifying runs are copied; then the two fallbacks, each forced
-                assert any("run_copy" in x for x in names) and any("value_runs_kernel" in x for x in names)
+                assert any("run_copy" in x for x in names)
+                # where the runs start is searched once per slice and store version (value_runs_kernel) and kept with the slice's tables:
+                # the next execution plans its copy in one launch (the comparison per id inside run_scan_kernel) — same rows, same order
+                again = plan.execute().fetch()
+                names2 = [st[0] for st in plan.kernel_stats()]
+                assert any("run_copy" in x for x in names2) and not any("value_runs_kernel" in x for x in names2), names2
+                for c in range(len(projection)):
+                    np.testing.assert_array_equal(again[c], exp[c])
+                p3 = gs.plan(desc).set_option("NO_TABLE_CACHE").enable_kernel_timing(True)     # ... and searched inside the execution when nothing may be kept
+                got3 = p3.execute().fetch()
+                assert any("value_runs_kernel" in st[0] for st in p3.kernel_stats())
+                for c in range(len(projection)):
+                    np.testing.assert_array_equal(got3[c], exp[c])
                 for option, kernel in (("NO_RUN_COPY", "filter_bits_kernel<4>"), ("NO_VALUE_VERDICTS", "filter_bits_kernel<2>")):
                     p2 = gs.plan(desc).set_option(option).enable_kernel_timing(True)
                     got2 = p2.execute().fetch()
