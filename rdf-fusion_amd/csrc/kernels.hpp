@@ -392,8 +392,6 @@ int lds_join_items(u64 n_probe_cap, bool global);   // rows per lane of the inst
 enum { kJoinTableLds = 0, kJoinTableHash = 1, kJoinTableDirect = 2, kJoinTableCsr = 3 };   // lds_join_kernel's MODE
 int lds_join_mode(const LdsJoinArgs& a);
 void launch_minmax_u32(const u32* col, u64 n, u32* out_dev /* {min, max}: preset to {~0, 0} */, hipStream_t s);   // nulls (0) skipped
-void launch_csr_hist(const u32* keys, u64 n, u32 kmin, u32 kn, u32* counts /* zeroed, kn + 1 */, u32* unsorted_dev, hipStream_t s);
-void launch_csr_scatter(const u32* keys, u64 n, u32 kmin, u32 kn, u32* cursor /* copy of the offsets */, u32* rows, hipStream_t s);
 // val[key - kmin] = xsd:integer value of valcol[row] for every row of a direct table's slice (val preset to INT64_MIN);
 // *bad is raised when a value is not an xsd:integer or equals the sentinel
 void launch_direct_values(const u32* keys, const u32* valcol, u64 n, u32 kmin, u32 kn, const TypedTable& tt, long long* val, u32* bad_dev, hipStream_t s);
@@ -435,6 +433,7 @@ void launch_fill_u32(u32* p, u32 v, u64 n, hipStream_t s);
 void launch_mark_not_equal(const u32* col, u32 value, u32* keep, u64 n, hipStream_t s);   // keep[i] = col[i] != value
 void launch_gather_u32(const u32* src, const u32* idx, u32* dst, u64 n, hipStream_t s);
 void launch_iota_u32(u32* p, u64 n, hipStream_t s);
+void launch_csr_rel_keys(const u32* keys, u64 n, u32 kmin, u32 kn, u32* rel, u32* unsorted_dev, hipStream_t s);   // rel = key - kmin (kn: joins nothing) + sortedness: the CSR build without atomics
 void launch_pack_key(const u32* hi, const u32* lo, const u32* idx /*nullable*/, u64* key, u64 n, hipStream_t s);
 void launch_unique_flags(const u32* c0, const u32* c1, const u32* c2, const u32* c3, u32* flags, u64 n, hipStream_t s);
 void launch_scatter_if(const u32* src, const u32* flags, const u32* excl, u32* dst, u64 n, hipStream_t s);

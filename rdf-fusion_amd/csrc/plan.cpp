@@ -543,7 +543,7 @@ const char* kernel_class_name(int kc) {
       "rdfgpu::cross_kernel", "rdfgpu::join_build_kernel", "void rdfgpu::join_probe_kernel<false>",
       "void rdfgpu::join_probe_kernel<true>", "rdfgpu::join_left_unmatched_kernel", "void rdfgpu::nlj_kernel<false>",
       "void rdfgpu::nlj_kernel<true>", "rocprim device scan", "rdfgpu::gjoin_build_kernel", "rdfgpu::gdirect_build_kernel",
-      "rdfgpu::minmax_u32_kernel", "rdfgpu::csr_hist_kernel", "rdfgpu::csr_scatter_kernel",
+      "rdfgpu::minmax_u32_kernel", "rdfgpu::csr_rel_keys_kernel", "rocprim radix sort (CSR rows)",
       "rdfgpu::topk_max_kernel", "rdfgpu::topk_hist_kernel", "rdfgpu::topk_scatter_kernel", "rdfgpu::topk_select_kernel",
       "rdfgpu::topk_write_kernel", "void rdfgpu::filter_kernel<3>", "rdfgpu::regex_verdict_kernel", "rdfgpu::union_kernel",
       "rdfgpu::band_slow_kernel", "rocprim radix sort", "rdfgpu::band_bounds_kernel", "rdfgpu::band_blocks_kernel",
@@ -1576,32 +1576,41 @@ void Plan::build_dense_table(SliceTable* st, const u32* key, u64 n) {
   if (!dense) { st->dense_failed = true; st->dense_tried = true; return; }
   metrics.tables_built++;
   const u32 kmin = got[0], kn = got[1] - got[0] + 1;
-  u32* direct = store->table_alloc<u32>(kn);
-  RDFGPU_HIP(hipMemsetAsync(direct, 0xFF, (size_t)kn * sizeof(u32), stream));
-  timed(KC_GDIRECT_BUILD, 0, n, nullptr, 8, nullptr, 0, 0, [&] { launch_gdirect_build(key, n, direct, kmin, kn, flags, stream); });
-  u32 is_dup = 0;
-  RDFGPU_HIP(hipMemcpyAsync(&is_dup, flags, sizeof(u32), hipMemcpyDeviceToHost, stream));
-  RDFGPU_HIP(hipStreamSynchronize(stream)); metrics.host_syncs++;
   st->kmin = kmin; st->kn = kn;
-  if (!is_dup) { st->direct = direct; st->dense_tried = true; return; }
-  // duplicates: counting sort into CSR (offsets + row ids grouped by key)
-  store->table_free(direct);
-  u32* off = store->table_alloc<u32>((u64)kn + 1); u32* rows = nullptr;
-  u32* counts = scratch<u32>((u64)kn + 1);
-  RDFGPU_HIP(hipMemsetAsync(counts, 0, ((size_t)kn + 1) * sizeof(u32), stream));
-  timed(KC_CSR_HIST, 0, n, nullptr, 8, nullptr, 0, 0, [&] { launch_csr_hist(key, n, kmin, kn, counts, flags + 1, stream); });
-  const size_t tb = scan_temp_bytes((u64)kn + 1);
-  void* temp = scratch<unsigned char>(tb);
-  exclusive_scan_u32(counts, off, (u64)kn + 1, temp, tb, stream);
+  // more rows than ids in the range: some key repeats (pigeonhole: null keys only make it more so when they are few; with many nulls the
+  // attempt below would have succeeded — then the CSR form is merely the more general table for the same join) — no direct-address attempt
+  if (n <= (u64)kn) {
+    u32* direct = store->table_alloc<u32>(kn);
+    RDFGPU_HIP(hipMemsetAsync(direct, 0xFF, (size_t)kn * sizeof(u32), stream));
+    timed(KC_GDIRECT_BUILD, 0, n, nullptr, 8, nullptr, 0, 0, [&] { launch_gdirect_build(key, n, direct, kmin, kn, flags, stream); });
+    u32 is_dup = 0;
+    RDFGPU_HIP(hipMemcpyAsync(&is_dup, flags, sizeof(u32), hipMemcpyDeviceToHost, stream));
+    RDFGPU_HIP(hipStreamSynchronize(stream)); metrics.host_syncs++;
+    if (!is_dup) { st->direct = direct; st->dense_tried = true; return; }
+    store->table_free(direct);
+  }
+  // duplicates: CSR (offsets + row ids grouped by key) — by boundary searches when the slice is sorted by the key, by one radix sort otherwise
+  u32* off = store->table_alloc<u32>((u64)kn + 2); u32* rows = nullptr;
+  if (n >= (1ull << 32)) fail(RDFGPU_ERR_UNSUPPORTED, "CSR table of %llu rows", (unsigned long long)n);
+  u32* rel = scratch<u32>(n);
+  timed(KC_CSR_HIST, 0, n, nullptr, 8, nullptr, 0, 0, [&] { launch_csr_rel_keys(key, n, kmin, kn, rel, flags + 1, stream); });
   u32 unsorted = 0;
   RDFGPU_HIP(hipMemcpyAsync(&unsorted, flags + 1, sizeof(u32), hipMemcpyDeviceToHost, stream));
   RDFGPU_HIP(hipStreamSynchronize(stream)); metrics.host_syncs++;
+  const u32* grouped = rel;
   if (unsorted) {   // else the slice is sorted by the key: rows[] is the identity and is never materialised
     rows = store->table_alloc<u32>(n);
-    RDFGPU_HIP(hipMemcpyAsync(counts, off, (size_t)kn * sizeof(u32), hipMemcpyDeviceToDevice, stream));   // cursors
-    timed(KC_CSR_SCATTER, 0, n, nullptr, 12, nullptr, 0, 0, [&] { launch_csr_scatter(key, n, kmin, kn, counts, rows, stream); });
-    RDFGPU_HIP(hipStreamSynchronize(stream)); metrics.host_syncs++;   // complete before other plans may see it
+    u32 bits = 1;
+    while ((1ull << bits) <= kn) bits++;             // keys 0 .. kn (kn = joins nothing: sorts to the end)
+    u32* rel_s = scratch<u32>(n); u32* iota = scratch<u32>(n);
+    const size_t stb = sort_u32_temp_bytes(n, bits);
+    void* stemp = scratch<unsigned char>(stb);
+    launch_iota_u32(iota, n, stream);
+    timed(KC_CSR_SCATTER, 0, n, nullptr, 12, nullptr, 0, 0, [&] { sort_pairs_u32_u32(rel, rel_s, iota, rows, n, bits, stemp, stb, stream); });
+    grouped = rel_s;
   }
+  launch_sorted_bounds(grouped, n, kn, off, stream);   // off[k] = first position with rel >= k, k = 0 .. kn (off[kn] = the rows that join something)
+  RDFGPU_HIP(hipStreamSynchronize(stream)); metrics.host_syncs++;   // complete before other plans may see it
   st->csr_rows = rows; st->csr_off = off;
   st->dense_tried = true;
 }
