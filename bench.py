@@ -137,7 +137,10 @@ def pmc_traffic(kernels, workload, profiles_dir=None):
         import rdf_fusion_amd
         if d.get("_source_sha16") != rdf_fusion_amd.kernel_source_sha16():
             return None, f"{os.path.basename(f)} is stale: collected on other kernel sources"
-        found = [next((v for k, v in d.items() if not k.startswith("_") and k.startswith(kn.split("(")[0])), None) for kn in kernels]
+        def pick(kn):        # a kernel class may have several instantiations in the summary (template arguments): the one that ran most often
+            m = [v for k, v in d.items() if not k.startswith("_") and k.startswith(kn.split("(")[0]) and isinstance(v, dict)]
+            return max(m, key=lambda v: v.get("dispatches", 0)) if m else None
+        found = [pick(kn) for kn in kernels]
         if all(e and "hbm_bytes_per_launch" in e for e in found):
             return int(sum(e["hbm_bytes_per_launch"] for e in found)), os.path.join("profiles", os.path.basename(f))
         return None, None

@@ -550,7 +550,7 @@ const char* kernel_class_name(int kc) {
       "rdfgpu::band_decode_kernel", "void rdfgpu::band_mask_kernel", "void rdfgpu::band_emit_kernel", "rdfgpu::band_entries_kernel",
       "rdfgpu::band_desc_kernel", "rdfgpu::band_pt_kernel", "rdfgpu::band_rows_kernel",
       "void rdfgpu::filter_bits_kernel<1>", "void rdfgpu::filter_bits_kernel<2>", "void rdfgpu::filter_bits_kernel<3>", "void rdfgpu::filter_bits_kernel<4>", "rdfgpu::value_verdict_kernel",
-      "rdfgpu::value_runs_kernel", "rdfgpu::run_scan_kernel", "rdfgpu::run_copy_kernel",
+      "rdfgpu::value_runs_kernel", "void rdfgpu::run_scan_kernel", "rdfgpu::run_copy_kernel",
       "rdfgpu::oj_probe_kernel", "rdfgpu::oj_count_kernel", "void rdfgpu::oj_write_kernel",
       "void rdfgpu::filter_write_kernel", "rdfgpu::part_keys_kernel", "void rdfgpu::part_join_kernel",
       "rdfgpu::oj_band_records_kernel", "rdfgpu::oj_write_band_kernel", "void rdfgpu::small_scan_kernel",
