@@ -1531,7 +1531,8 @@ TOGGLES = ["RDFGPU_NO_CHAIN_FUSION", "RDFGPU_NO_INDEX_JOIN", "RDFGPU_NO_TABLE_CA
            "RDFGPU_NO_FIRST_RUN_SPECULATION", "RDFGPU_NO_DIRECT_TABLE", "RDFGPU_FORCE_GENERIC_VM", "RDFGPU_NO_LDS_JOIN",
            "RDFGPU_NO_GLOBAL_TABLE_JOIN", "RDFGPU_NO_FILTER_FUSION", "RDFGPU_NO_VALUE_TABLES", "RDFGPU_NO_RANGE_INDEX",
            "RDFGPU_NO_BAND_JOIN", "RDFGPU_NO_PARTITIONED_JOIN", "RDFGPU_NO_JOIN_REORDER", "RDFGPU_NO_STRING_VERDICTS",
-           "RDFGPU_NO_VALUE_VERDICTS", "RDFGPU_NO_RUN_COPY", "RDFGPU_NO_PRIMING", "RDFGPU_NO_ORDERED_JOIN", "RDFGPU_NO_BAND_PACK16", "RDFGPU_NO_RANGE_PARTITION"]
+           "RDFGPU_NO_VALUE_VERDICTS", "RDFGPU_NO_RUN_COPY", "RDFGPU_NO_PRIMING", "RDFGPU_NO_ORDERED_JOIN", "RDFGPU_NO_BAND_PACK16", "RDFGPU_NO_RANGE_PARTITION",
+           "RDFGPU_NO_OWN_PARTITION_PASS", "RDFGPU_NO_BAND_COMPACT"]
 
 
 @pytest.mark.parametrize("toggle", TOGGLES)
