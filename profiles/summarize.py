@@ -51,7 +51,6 @@ def main():
         shutil.copy(src[0], sys.argv[3])
         return
     if sys.argv[1] == "gaps":       # summarize.py gaps <trace dir> <out.json> <first kernel substring> : device time line of the steady-state steps
-        import csv
         src = glob.glob(os.path.join(sys.argv[2], "**", "*kernel_trace.csv"), recursive=True)
         rows = []
         for f in src:

@@ -313,8 +313,13 @@ __device__ __forceinline__ bool load_keys(const u32* const* key_cols, u32 n_keys
 // only the value interval of its key's group that the first stage's window allows, and candidates carry index
 // positions (see bcol).
 
-template <int FS, int PFS, int ITEMS, int MODE, bool CHAIN>
-__global__ __launch_bounds__(kLdsBlock) __attribute__((amdgpu_waves_per_eu(ITEMS == 1 ? 5 : 4))) void lds_join_kernel(const LdsJoinArgs a) {
+// NK = 1: the join has ONE key column (every join of the BSBM plans, most others): key loads, the hash and the key compares are then
+// straight-line code instead of loops over a run-time count with a wave-uniform branch per key — the kernel issues 2.5 scalar
+// instructions per vector instruction (SQ counters, profiles/tools/join_micro_prof.sh), a good part of them exactly those branches;
+// 11 - 25 % of its time on 32 M probe rows (profiles/tools/join_micro.py).  NK = 0: the key count is a.n_keys.
+template <int FS, int PFS, int ITEMS, int MODE, bool CHAIN, int NK>
+__device__ __forceinline__ void lds_join_body(const LdsJoinArgs& a) {
+  const u32 n_keys = NK ? (u32)NK : a.n_keys;
   // candidates taken out of the queue per lane and resolve round: four keep more gathers in flight; the one-row-per-lane
   // variant takes two and fits 5 waves/SIMD without spills (95 VGPRs)
   constexpr int kResolveUnroll = ITEMS == 1 ? 2 : 4;
@@ -339,8 +344,8 @@ __global__ __launch_bounds__(kLdsBlock) __attribute__((amdgpu_waves_per_eu(ITEMS
     const u64 nb = live_rows(a.n_build_dev, a.n_build_cap);
     for (u64 i = tid; i < nb; i += kLdsBlock) {
       Keys key;
-      if (!load_keys(a.build_key, a.n_keys, i, key)) continue;
-      u32 h = hash_keys4(key, a.n_keys) & a.tbl_mask;
+      if (!load_keys(a.build_key, n_keys, i, key)) continue;
+      u32 h = hash_keys4(key, n_keys) & a.tbl_mask;
       for (;;) {
         if (atomicCAS(&lslots[h].y, kNil, (u32)i) == kNil) { lslots[h].x = key.k[0]; break; }
         h = (h + 1) & a.tbl_mask;
@@ -412,7 +417,7 @@ __global__ __launch_bounds__(kLdsBlock) __attribute__((amdgpu_waves_per_eu(ITEMS
 #pragma unroll
         for (int k = 0; k < ITEMS; k++) {
           const u64 j = base + (((u32)k * kLdsBlock + tid) >> rl);
-          walking[k] = j < np && load_keys(a.probe_key, a.n_keys, j, key[k]);
+          walking[k] = j < np && load_keys(a.probe_key, n_keys, j, key[k]);
         }
 #pragma unroll
         for (int k = 0; k < ITEMS; k++) {
@@ -474,7 +479,7 @@ __global__ __launch_bounds__(kLdsBlock) __attribute__((amdgpu_waves_per_eu(ITEMS
             }
             s[k].x += tid & ((1u << rl) - 1u);
           } else {
-            h[k] = hash_keys4(key[k], a.n_keys) & a.tbl_mask;
+            h[k] = hash_keys4(key[k], n_keys) & a.tbl_mask;
             if (walking[k]) s[k] = slots[h[k]];
           }
           pend[k] = kNil;
@@ -499,18 +504,22 @@ __global__ __launch_bounds__(kLdsBlock) __attribute__((amdgpu_waves_per_eu(ITEMS
               else walking[k] = false;
             }
           } else if (hit == kNil) {
-            while (walking[k]) {
-              if (s[k].y == kNil) { walking[k] = false; break; }
-              const uint2 c = s[k];
-              h[k] = (h[k] + 1) & a.tbl_mask;
-              s[k] = slots[h[k]];   // issued before the candidate is examined
-              if (c.x != key[k].k[0]) continue;
-              bool eq = true;
+            // The walk keeps no state but the slot in hand (s[k] = slots[h[k]]): a lane stops at an empty slot (no further match) or at
+            // a key-equal one; the loop body is one read, the compares and one exit.  (The `continue / break` form of this loop cost ~35
+            // scalar instructions and 7 branches per hop: what the partitioned join was bound by, part_join.hip.)
+            if (walking[k]) {
+              for (;;) {
+                const uint2 c = s[k];
+                if (c.y == kNil) { walking[k] = false; break; }
+                bool eq = c.x == key[k].k[0];
+                if (eq) {
 #pragma unroll
-              for (u32 q = 1; q < RDFGPU_MAX_KEYS; q++) if (q < a.n_keys) eq = eq && a.build_key[q][c.y] == key[k].k[q];
-              if (!eq) continue;
-              hit = c.y;
-              break;
+                  for (u32 q = 1; q < RDFGPU_MAX_KEYS; q++) if (q < n_keys) eq = eq && a.build_key[q][c.y] == key[k].k[q];
+                }
+                h[k] = (h[k] + 1) & a.tbl_mask;
+                s[k] = slots[h[k]];   // the next slot: what the walk resumes from after a match, and its next hop otherwise
+                if (eq) { hit = c.y; break; }
+              }
             }
           }
           const unsigned long long found = __ballot(hit != kNil);
@@ -702,13 +711,24 @@ __global__ __launch_bounds__(kLdsBlock) __attribute__((amdgpu_waves_per_eu(ITEMS
   write_out(out_base);
 }
 
-template <int FS, int PFS, int ITEMS, int MODE, bool CHAIN>
-static void launch_lds_join_tc(const LdsJoinArgs& a, dim3 g, size_t lds, hipStream_t s) {
+// (two kernels, not one kernel with a branch: a kernel's registers and occupancy are those of its larger body)
+template <int FS, int PFS, int ITEMS, int MODE, bool CHAIN, int NK>
+__global__ __launch_bounds__(kLdsBlock) __attribute__((amdgpu_waves_per_eu(ITEMS == 1 ? 5 : 4))) void lds_join_kernel(const LdsJoinArgs a) {
+  lds_join_body<FS, PFS, ITEMS, MODE, CHAIN, NK>(a);
+}
+
+template <int FS, int PFS, int ITEMS, int MODE, bool CHAIN, int NK>
+static void launch_lds_join_tk(const LdsJoinArgs& a, dim3 g, size_t lds, hipStream_t s) {
   static std::once_flag attr_once;   // dynamic LDS above 64 KiB has to be opted into, once per kernel instance (plans run on many host threads)
   std::call_once(attr_once, [] {
-    RDFGPU_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lds_join_kernel<FS, PFS, ITEMS, MODE, CHAIN>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
+    RDFGPU_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lds_join_kernel<FS, PFS, ITEMS, MODE, CHAIN, NK>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
   });
-  hipLaunchKernelGGL((lds_join_kernel<FS, PFS, ITEMS, MODE, CHAIN>), g, dim3(kLdsBlock), lds, s, a);
+  hipLaunchKernelGGL((lds_join_kernel<FS, PFS, ITEMS, MODE, CHAIN, NK>), g, dim3(kLdsBlock), lds, s, a);
+}
+template <int FS, int PFS, int ITEMS, int MODE, bool CHAIN>
+static void launch_lds_join_tc(const LdsJoinArgs& a, dim3 g, size_t lds, hipStream_t s) {
+  if (a.n_keys == 1) launch_lds_join_tk<FS, PFS, ITEMS, MODE, CHAIN, 1>(a, g, lds, s);
+  else launch_lds_join_tk<FS, PFS, ITEMS, MODE, CHAIN, 0>(a, g, lds, s);
 }
 template <int FS, int PFS, int ITEMS, int MODE>
 static void launch_lds_join_t(const LdsJoinArgs& a, dim3 g, size_t lds, hipStream_t s) {

@@ -562,7 +562,7 @@ const char* kernel_class_name(int kc) {
     const char* items[2] = {"4", "1"};
     for (int f = 0; f < 4; f++) for (int p = 0; p < 3; p++) for (int w = 0; w < 2; w++) for (int m = 0; m < 4; m++) for (int c = 0; c < 2; c++)
       names[(((f * 3 + p) * 2 + w) * 4 + m) * 2 + c] = "void rdfgpu::lds_join_kernel<" + std::to_string(f) + ", " + std::to_string(p) + ", " +
-                                                       items[w] + ", " + std::to_string(m) + ", " + (c ? "true" : "false") + ">";
+                                                       items[w] + ", " + std::to_string(m) + ", " + (c ? "true" : "false");   // (a prefix: the key-count argument follows)
   });
   return names[kc - KC_LDS_JOIN0].c_str();
 }

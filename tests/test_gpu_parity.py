@@ -160,14 +160,15 @@ def test_reference_join_lowering_kats(kats, torch_cuda):
 
 
 JOIN_TABLE_MODES = {
-    # name: (store options, copies of the fixture's data, substring of a kernel that has to have run)
+    # name: (store options, copies of the fixture's data, substring of a kernel that has to have run; the engine reports the fused join
+    #        kernel by its class `lds_join_kernel<FS, PFS, ITEMS, MODE, CHAIN` — the key-count argument that follows is not part of it)
     "lds_hash": ({}, 1, "lds_join_kernel<0, 0, "),                                  # every workgroup builds the table in LDS
-    "lds_hash_scaled": ({"NO_INDEX_JOIN": 1, "NO_TABLE_CACHE": 1, "LDS_MAX_BUILD": 1 << 20}, 300, ", 0, false>"),
+    "lds_hash_scaled": ({"NO_INDEX_JOIN": 1, "NO_TABLE_CACHE": 1, "LDS_MAX_BUILD": 1 << 20}, 300, ", 0, false"),
     "classic_hbm_chains": ({"NO_LDS_JOIN": 1}, 1, "join_probe_kernel"),             # heads / next chains in HBM, count + scan + write
-    "hbm_hash_built_per_run": ({"LDS_MAX_BUILD": 1, "NO_TABLE_CACHE": 1, "NO_PARTITIONED_JOIN": 1}, 3000, ", 1, false>"),
-    "hbm_hash_cached_slice": ({"LDS_MAX_BUILD": 1, "NO_DIRECT_TABLE": 1}, 3000, ", 1, false>"),
-    "direct_address": ({"LDS_MAX_BUILD": 1}, 3000, ", 2, false>"),                  # unique dense keys: row = direct[key - min]
-    "csr": ({"LDS_MAX_BUILD": 1}, 3000, ", 3, false>"),                             # (the data gets duplicate keys, see below)
+    "hbm_hash_built_per_run": ({"LDS_MAX_BUILD": 1, "NO_TABLE_CACHE": 1, "NO_PARTITIONED_JOIN": 1}, 3000, ", 1, false"),
+    "hbm_hash_cached_slice": ({"LDS_MAX_BUILD": 1, "NO_DIRECT_TABLE": 1}, 3000, ", 1, false"),
+    "direct_address": ({"LDS_MAX_BUILD": 1}, 3000, ", 2, false"),                  # unique dense keys: row = direct[key - min]
+    "csr": ({"LDS_MAX_BUILD": 1}, 3000, ", 3, false"),                             # (the data gets duplicate keys, see below)
     "radix_partitioned": ({"LDS_MAX_BUILD": 1, "NO_TABLE_CACHE": 1, "PARTITION_MIN_BUILD": 1}, 3000, "part_join_kernel"),
 }
 
@@ -1498,12 +1499,12 @@ def test_fused_lookup_chain_equals_unfused(bsbm_stores, torch_cuda, monkeypatch)
         exp, n_exp, _ = os_.execute(desc, [params])
         np.testing.assert_array_equal(ku.multiset(got), ku.multiset(exp, n_exp))
         names = [k[0] for k in plan.kernel_stats()]
-        fused_seen = fused_seen or any("lds_join_kernel" in n and n.endswith("true>") for n in names)
+        fused_seen = fused_seen or any("lds_join_kernel" in n and n.rstrip(">").endswith("true") for n in names)
         band_seen = band_seen or any("band_mask_kernel" in n for n in names)
         if it == 3:
             plan.set_option("NO_CHAIN_FUSION", 1)
             plain = plan.execute().fetch()
-            assert not any("lds_join_kernel" in k[0] and k[0].endswith("true>") for k in plan.kernel_stats())
+            assert not any("lds_join_kernel" in k[0] and k[0].rstrip(">").endswith("true") for k in plan.kernel_stats())
             np.testing.assert_array_equal(ku.multiset(plain), ku.multiset(got))
             plan.set_option("NO_CHAIN_FUSION", 0)
     assert fused_seen or ENGINE_TOGGLED, "the lookup chain was never fused"
@@ -1859,7 +1860,7 @@ def test_fused_chain_with_mixed_numeric_kinds(torch_cuda):
         got = plan.execute().fetch()
         exp, n_exp, _ = os_.execute(desc, [params])
         np.testing.assert_array_equal(ku.multiset(got), ku.multiset(exp, n_exp))
-    assert any("lds_join_kernel" in k[0] and k[0].endswith("true>") for k in plan.kernel_stats()) or ENGINE_TOGGLED
+    assert any("lds_join_kernel" in k[0] and k[0].rstrip(">").endswith("true") for k in plan.kernel_stats()) or ENGINE_TOGGLED
     for x in prods[:3]:
         run_both(gs, os_, bsbm.q5_plan(ds, int(x)))
 
@@ -2279,7 +2280,7 @@ def test_subject_hash_shard_keeps_the_index_join_path(torch_cuda, world):
         exp, n_exp, _ = os_.execute(desc, [c_tab])
         np.testing.assert_array_equal(ku.multiset(got), ku.multiset(exp, n_exp))
         # the fused chain: as a band join over the shard's CSR groups, or inside the candidate join's resolve phase
-        assert any(("lds_join_kernel" in k[0] and k[0].endswith("true>")) or "band_mask_kernel" in k[0] for k in plan.kernel_stats()) or ENGINE_TOGGLED
+        assert any(("lds_join_kernel" in k[0] and k[0].rstrip(">").endswith("true")) or "band_mask_kernel" in k[0] for k in plan.kernel_stats()) or ENGINE_TOGGLED
         union.append(ku.multiset(got))
     if world == 2:
         np.testing.assert_array_equal(ku.multiset(list(np.concatenate(union).T)), ku.multiset(exp_all, n_all))
