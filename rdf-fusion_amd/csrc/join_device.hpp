@@ -406,6 +406,9 @@ __device__ __forceinline__ void lds_join_body(const LdsJoinArgs& a) {
   bool q_exact = true;   // wave-uniform: every candidate in the queue comes from such a row => the first stage pass can be skipped
   u64 tile = blockIdx.x;
   bool tile_loaded = false, exhausted = false;   // wave-uniform
+  u32 nk0[ITEMS]; bool have_next = false;        // NK == 1: the next tile's keys, requested ahead
+#pragma unroll
+  for (int k = 0; k < ITEMS; k++) nk0[k] = 0;
   for (;;) {
     // ---- fill: walk tiles until the queue cannot take the next ballot's candidates or the tiles run out ----
     bool full = false;
@@ -414,10 +417,37 @@ __device__ __forceinline__ void lds_join_body(const LdsJoinArgs& a) {
         if (tile >= n_tiles) { exhausted = true; break; }
         const u64 base = tile * kTileRows;
         // the tile's probe keys first (independent coalesced loads in flight together), then the first table slot of every row
+        if constexpr (NK == 1) {
+          // one key column: the NEXT tile's keys are requested as soon as this tile's are in hand and stay in flight while it is walked
+          // (unconditional loads at a clamped row: a prefetch must not sit under a branch) — the waves of this kernel spent 81 % of
+          // their cycles waiting, at four per SIMD, with every tile's loads heading its work
+          const u32* pk0 = a.probe_key[0];
+#pragma unroll
+          for (int k = 0; k < ITEMS; k++) {
+            const u64 j = base + (((u32)k * kLdsBlock + tid) >> rl);
+            key[k].k[0] = have_next ? nk0[k] : pk0[j < np ? j : np - 1];
+            key[k].k[1] = 0; key[k].k[2] = 0; key[k].k[3] = 0;
+          }
+          const u64 nt = tile + gridDim.x;
+          have_next = nt < n_tiles;                        // wave-uniform
+          if (have_next) {
+#pragma unroll
+            for (int k = 0; k < ITEMS; k++) {
+              const u64 jn = nt * kTileRows + (((u32)k * kLdsBlock + tid) >> rl);
+              nk0[k] = pk0[jn < np ? jn : np - 1];
+            }
+          }
+#pragma unroll
+          for (int k = 0; k < ITEMS; k++) {
+            const u64 j = base + (((u32)k * kLdsBlock + tid) >> rl);
+            walking[k] = j < np && key[k].k[0] != 0;       // NullEqualsNothing
+          }
+        } else {
 #pragma unroll
         for (int k = 0; k < ITEMS; k++) {
           const u64 j = base + (((u32)k * kLdsBlock + tid) >> rl);
           walking[k] = j < np && load_keys(a.probe_key, n_keys, j, key[k]);
+        }
         }
 #pragma unroll
         for (int k = 0; k < ITEMS; k++) {
