@@ -24,6 +24,11 @@
 // then written out by consecutive lanes — runs of a bin are contiguous 12-byte records, not one 12-byte store per lane and line.
 // No global atomics, deterministic placement of the runs.
 //
+// Rows that join nothing (null key, outside the probe slice's id range, beyond the live row count of a filtered input) are DROPPED by pass
+// A: they have no record and no count.  (rocPRIM's sort had to place every element, so they rode in the last partition with row = kNil —
+// and a FILTER's output that kept 313 K of 2.13 M rows left 1.8 M dead records there, which ONE workgroup then "joined" chunk by chunk
+// against all of that partition's probe rows: LUBM Q9's OPTIONAL join took 11.5 ms instead of 3.)
+//
 // Reference behaviour is that of part_join.hip (HashJoinExec(CollectLeft), join/rewrite.rs:126-168): this file only decides where
 // a row waits for its partition's workgroup.
 #include <hip/hip_runtime.h>
@@ -137,12 +142,13 @@ __global__ __launch_bounds__(kPhBlock) void part_hist_kernel(const PartPassArgs 
     (void)part_tile_of<PASS_B>(a, g, t);
     cnt[tid] = 0u;
     __syncthreads();
-    u32 bin[kPhItems];
+    u32 bin[kPhItems]; bool live_item[kPhItems];
     if constexpr (PASS_B) {
 #pragma unroll
       for (u32 it = 0; it < kPhItems; it++) {                             // (all loads of the tile in flight together, then the counting)
         const u32 j = it * kPhBlock + tid;
         bin[it] = j < t.n ? (u32)a.digit[t.first + j] : 0u;
+        live_item[it] = true;                                             // (pass A kept only rows that join)
       }
     } else {
       u32 k0[kPhItems], k1[kPhItems];
@@ -155,13 +161,14 @@ __global__ __launch_bounds__(kPhBlock) void part_hist_kernel(const PartPassArgs 
 #pragma unroll
       for (u32 it = 0; it < kPhItems; it++) {
         const u32 j = it * kPhBlock + tid;
-        const u32 p = a.pid.joins(k0[it], k1[it]) ? a.pid.of(k0[it], k1[it], dir) : a.pid.n_parts - 1;
+        live_item[it] = a.pid.joins(k0[it], k1[it]);       // (a row beyond the live count has key 0: joins nothing)
+        const u32 p = live_item[it] ? a.pid.of(k0[it], k1[it], dir) : 0u;
         if (j < t.n) a.pid16[t.first + j] = (unsigned short)p;
         bin[it] = p >> a.shift;
       }
     }
 #pragma unroll
-    for (u32 it = 0; it < kPhItems; it++) (void)wave_bin_add(cnt, bin[it], it * kPhBlock + tid < t.n);
+    for (u32 it = 0; it < kPhItems; it++) (void)wave_bin_add(cnt, bin[it], it * kPhBlock + tid < t.n && live_item[it]);
     __syncthreads();
     if (tid < a.nbins) a.hist[(u64)t.hbase + (u64)tid * t.stride] = cnt[tid];   // (lane `tid` zeroes cnt[tid] itself at the top of the next tile)
   }
@@ -195,9 +202,9 @@ __global__ __launch_bounds__(1024) void part_row_scan_a_kernel(u32* hist, u32 ti
 }
 // Pass B: one wave per (bucket, bin) — a row of the bucket's tiles (~ records of the bucket / 4096 counts, a hundred for the LUBM
 // join); the totals, in (bucket, bin) order, are the partition sizes.
-__global__ __launch_bounds__(256) void part_row_scan_b_kernel(u32* hist, const u32* tb, u32 nb, u32* total, u32* start_end, u32 n_records) {
+__global__ __launch_bounds__(256) void part_row_scan_b_kernel(u32* hist, const u32* tb, u32 nb, u32* total, u32* start_end, const u32* n_records) {
   const u32 lane = threadIdx.x & 63;
-  if (blockIdx.x == 0 && threadIdx.x == 0) *start_end = n_records;        // start[n_parts] = all records (every row has one); the totals' scan stops before it
+  if (blockIdx.x == 0 && threadIdx.x == 0) *start_end = *n_records;       // start[n_parts] = all records (pass A's total: the rows that join something); the totals' scan stops before it
   const u32 row_id = blockIdx.x * 4u + (threadIdx.x >> 6);                // bucket * 256 + bin
   if (row_id >= nb * 256u) return;                                        // (whole waves)
   const u32 b = row_id >> 8, bin = row_id & 255u;
@@ -225,12 +232,12 @@ __global__ __launch_bounds__(kPtBlock) void part_scatter_kernel(const PartPassAr
   const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (tid < 256) cnt[tid] = 0u;
   __syncthreads();
-  PartRec rec[kPtItems]; u32 bin[kPtItems], rank[kPtItems], lo[kPtItems];
+  PartRec rec[kPtItems]; u32 bin[kPtItems], rank[kPtItems], lo[kPtItems]; bool valid[kPtItems];
   if constexpr (PASS_B) {
 #pragma unroll
     for (u32 it = 0; it < kPtItems; it++) {                               // (all loads of the tile in flight together)
       const u32 j = it * kPtBlock + tid;
-      bin[it] = 0; lo[it] = 0;
+      bin[it] = 0; lo[it] = 0; valid[it] = j < t.n;
       if (j < t.n) { rec[it] = a.in[t.first + j]; bin[it] = (u32)a.digit[t.first + j]; }
     }
   } else {
@@ -238,17 +245,18 @@ __global__ __launch_bounds__(kPtBlock) void part_scatter_kernel(const PartPassAr
 #pragma unroll
     for (u32 it = 0; it < kPtItems; it++) {
       const u32 j = it * kPtBlock + tid, i = t.first + j;
-      rec[it] = PartRec{kNil, 0u, 0u}; bin[it] = 0; lo[it] = 0;
+      rec[it] = PartRec{kNil, 0u, 0u}; bin[it] = 0; lo[it] = 0; valid[it] = false;
       if (j < t.n) {
         const u32 p = a.pid16[i];
         if (i < live) { rec[it].k0 = a.k0[i]; rec[it].k1 = a.pid.n_keys > 1 ? a.k1[i] : 0u; }
-        rec[it].row = a.pid.joins(rec[it].k0, rec[it].k1) ? i : kNil;
+        valid[it] = a.pid.joins(rec[it].k0, rec[it].k1);   // a row that joins nothing has no record (the histogram did not count it)
+        rec[it].row = i;
         bin[it] = p >> a.shift; lo[it] = p & 255u;
       }
     }
   }
 #pragma unroll
-  for (u32 it = 0; it < kPtItems; it++) rank[it] = wave_bin_add(cnt, bin[it], it * kPtBlock + tid < t.n);   // the row's place among the tile's rows of its bin
+  for (u32 it = 0; it < kPtItems; it++) rank[it] = wave_bin_add(cnt, bin[it], valid[it]);   // the row's place among the tile's rows of its bin
   __syncthreads();
   u32 c = 0, incl = 0;
   if (tid < 256) {                                                        // waves 0 - 3, whole: exclusive scan of the 256 counts
@@ -267,15 +275,15 @@ __global__ __launch_bounds__(kPtBlock) void part_scatter_kernel(const PartPassAr
   __syncthreads();
 #pragma unroll
   for (u32 it = 0; it < kPtItems; it++) {
-    const u32 j = it * kPtBlock + tid;
-    if (j < t.n) {
+    if (valid[it]) {
       const u32 p = lstart[bin[it]] + rank[it];
       s_row[p] = rec[it].row; s_k0[p] = rec[it].k0; s_k1[p] = rec[it].k1; s_bin[p] = (unsigned char)bin[it];
       if constexpr (!PASS_B) s_lo[p] = (unsigned char)lo[it];
     }
   }
   __syncthreads();
-  for (u32 j = tid; j < t.n; j += kPtBlock) {                             // consecutive lanes -> consecutive records of a run
+  const u32 n_valid = lstart[255] + cnt[255];                            // the tile's rows that have a record
+  for (u32 j = tid; j < n_valid; j += kPtBlock) {                         // consecutive lanes -> consecutive records of a run
     const u32 b = s_bin[j];
     const u64 at = (u64)gofs[b] + (j - lstart[b]);
     a.out[at] = PartRec{s_row[j], s_k0[j], s_k1[j]};
@@ -345,7 +353,7 @@ void part_pass_run(const PartPassBuffers& w, const PartPassPlan& pl, const u32* 
   b.shift = 0; b.nbins = 256;
   b.hist = w.hist_b; b.base = w.start; b.out = w.recs;
   hipLaunchKernelGGL(part_hist_kernel<true>, dim3(std::min<u32>(pl.max_tiles_b, 2048u)), dim3(kPhBlock), 0, s, b);
-  hipLaunchKernelGGL(part_row_scan_b_kernel, dim3((pl.nb_a * 256u + 3) / 4), dim3(256), 0, s, w.hist_b, w.tb, pl.nb_a, w.total, w.start + n_parts, (u32)cap);
+  hipLaunchKernelGGL(part_row_scan_b_kernel, dim3((pl.nb_a * 256u + 3) / 4), dim3(256), 0, s, w.hist_b, w.tb, pl.nb_a, w.total, w.start + n_parts, base_a + pl.nb_a);
   // the (bucket, bin) totals are the partition sizes: their exclusive scan = the partitions' first records (n_parts <= 65536: one workgroup)
   exclusive_scan_u32(w.total, w.start, (u64)n_parts, scan_temp, scan_temp_bytes, s);
   hipLaunchKernelGGL(part_scatter_kernel<true>, dim3(pl.max_tiles_b), dim3(kPtBlock), 0, s, b);
