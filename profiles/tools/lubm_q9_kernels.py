@@ -8,7 +8,7 @@ ds = lubm.generate(U)
 st = rf.GpuQuadStore(); st.extend(ds.g, ds.s, ds.p, ds.o); st.set_typed_values(ds.typed_values); st.set_strings(ds.str_offsets, ds.str_heap)
 for pattern, flags in (("^GraduateStudent1", ""), (".", ""), ("^GraduateStudent1", "")):
     plan = st.plan(lubm.q9_optional_regex_plan(ds, pattern, flags)).enable_kernel_timing(True)
-    for it in range(4):
+    for it in range(int(os.environ.get("REPS", "4"))):
         torch.cuda.synchronize(); t0 = time.perf_counter(); plan.execute(); rows, _ = plan.result_info(); dt = (time.perf_counter() - t0) * 1e3
         m = plan.metrics()
         print(pattern, "exec", it, "rows", rows, "ms %.2f" % dt, "syncs", m.host_syncs, "reruns", m.exact_reruns, flush=True)
