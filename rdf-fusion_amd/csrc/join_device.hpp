@@ -391,7 +391,8 @@ __device__ __forceinline__ void lds_join_body(const LdsJoinArgs& a) {
 #pragma unroll
         for (u32 u = 0; u < 4; u++) if (on[u]) {
           const u32 row = from[u] == 0 ? m.y : from[u] == 1 ? m.x : from[u] == 2 ? rr[0] : from[u] == 3 ? rr[1] : rr[2];
-          v[u] = from[u] == 1 ? bcol(a, src[u], row) : src[u][row];
+          if (from[u] == 1 && m.x == kOuterNull) v[u] = 0u;     // a preserved probe row without a match: the build side is null
+          else v[u] = from[u] == 1 ? bcol(a, src[u], row) : src[u][row];
         }
 #pragma unroll
         for (u32 u = 0; u < 4; u++) if (on[u]) dst[u][pos] = v[u];
@@ -401,6 +402,7 @@ __device__ __forceinline__ void lds_join_body(const LdsJoinArgs& a) {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   };
 
+  bool row_live[ITEMS], had[ITEMS];   // probe_outer: the lane has a probe row / the row has produced a candidate (a match or its null row)
   Keys key[ITEMS]; u32 h[ITEMS]; uint2 s[ITEMS]; bool walking[ITEMS]; u32 pend[ITEMS];
   bool exact[ITEMS];     // range-index mode: the row's candidate range is exactly the first stage's window (integer operands)
   bool q_exact = true;   // wave-uniform: every candidate in the queue comes from such a row => the first stage pass can be skipped
@@ -452,7 +454,9 @@ __device__ __forceinline__ void lds_join_body(const LdsJoinArgs& a) {
 #pragma unroll
         for (int k = 0; k < ITEMS; k++) {
           const u64 j = base + (((u32)k * kLdsBlock + tid) >> rl);
-          walking[k] = walking[k] && lprobe_filter<PFS>(a, j);
+          row_live[k] = j < np && lprobe_filter<PFS>(a, j);
+          had[k] = false;
+          walking[k] = walking[k] && row_live[k];
           s[k] = make_uint2(0u, kNil);
           if constexpr (DIRECT) {   // unique dense keys: the one candidate is a single 4-byte load, no chain
             h[k] = key[k].k[0] - a.direct_min;
@@ -551,6 +555,10 @@ __device__ __forceinline__ void lds_join_body(const LdsJoinArgs& a) {
                 if (eq) { hit = c.y; break; }
               }
             }
+          }
+          if (a.probe_outer) {                            // wave-uniform
+            if (hit == kNil && !walking[k] && row_live[k] && !had[k]) hit = kOuterNull;   // the row's walk is over and nothing matched: its one null-extended row
+            had[k] = had[k] || hit != kNil;
           }
           const unsigned long long found = __ballot(hit != kNil);
           if (found == 0) break;

@@ -178,6 +178,7 @@ struct ChainStage {
 
 // ---- K4+K5 fused: LDS-staged hash join for build sides that fit one workgroup's LDS ----
 constexpr u32 kLdsJoinMaxBuild = 8192;   // rows; 16384 slots x 8 B = 128 KiB of the CU's 160 KiB
+constexpr u32 kOuterNull = 0xFFFFFFFEu;   // build row of a probe row's "no match" candidate (LdsJoinArgs::probe_outer)
 struct LdsJoinArgs {
   const u32* cols[2 * kMaxCols];   // the operator's [left cols, right cols] schema, one pointer per column
   u32 n_left_cols;
@@ -213,6 +214,9 @@ struct LdsJoinArgs {
   u32 wave_q;               // entries of each wave's LDS candidate queue (>= 64; 8 queues x 8 B x wave_q of LDS)
   u32* overflow;            // set when the matches did not fit
   u8* visited;              // left join: per build row
+  u32 probe_outer;          // LEFT JOIN preserved on the PROBE side (the engine built on the right input's table): a probe row without a match is
+                            // emitted once with an all-null build side (candidate {kOuterNull, row}); needs no filter, no chain, one lane per row
+  u32 pad_outer;
   u32 has_filter, has_probe_filter;   // join filter: 0 none / 1 VM / 3 window ; probe filter: 0 none / 1 id-literal / 2 VM
   TypedTable tt;
   // Generic programs live in device memory (a 2.5 KB by-value kernarg block made the compiler copy the

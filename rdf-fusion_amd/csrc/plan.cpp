@@ -1127,7 +1127,17 @@ DevTable Plan::exec_topk(NodeInfo& nd) {
 // (an index nested-loop join against the store's own permutation: `PARAMS JOIN (?s p ?o)` touches |PARAMS| rows,
 // not the 5 M-row predicate partition).
 bool Plan::choose_build_left(const NodeInfo& nd, const DevTable& L, const DevTable& R, bool left_join, bool lf, bool rf, bool lpost, bool rpost) const {
-  if (left_join) return true;
+  if (left_join) {
+    // OPTIONAL: HashJoinExec(Left) builds on its left input and probes with the right one — every row of the right input is read, however few
+    // left rows there are.  When the right input is a store slice (its join table is cached per store version) and much larger than the left, the
+    // join is run the other way round and PRESERVES ITS PROBE SIDE: build = the slice's table, probe = the left rows, a probe row without a match is
+    // emitted once with a null right side (LdsJoinArgs::probe_outer).  Same multiset of rows.  Needs: no join filter, no fused filter.
+    const bool rs = R.stable_id != 0 && R.n_dev == nullptr && !rf && !lf;
+    if (rs && nd.d.kind == RDFGPU_NODE_HASH_JOIN && nd.shape == 0 && !opt.on(RDFGPU_OPT_NO_TABLE_CACHE) && !opt.on(RDFGPU_OPT_NO_INDEX_JOIN) &&
+        !opt.on(RDFGPU_OPT_NO_PROBE_OUTER_JOIN) && R.cap > 1024 && L.cap * 4 <= R.cap && L.cap < (1ull << 31))
+      return false;
+    return true;
+  }
   const bool smaller_left = L.cap <= R.cap;
   if (nd.d.kind != RDFGPU_NODE_HASH_JOIN || opt.on(RDFGPU_OPT_NO_TABLE_CACHE) || opt.on(RDFGPU_OPT_NO_INDEX_JOIN)) return smaller_left;
   // (a slice under a `col <=|!=> literal` FilterExec still counts: that filter can run as a conjunct of the join filter)
@@ -1628,7 +1638,10 @@ void Plan::build_dense_table(SliceTable* st, const u32* key, u64 n) {
 
 // HashJoinExec whose build side fits one workgroup's LDS: one fused kernel, optimistic output capacity.
 DevTable Plan::exec_lds_join(NodeInfo& nd, const DevTable& L, const DevTable& R, bool build_left, const NodeInfo* probe_filter, const NodeInfo* post_filter) {
-  const bool left_join = nd.d.join_type == RDFGPU_JOIN_LEFT;
+  // a LEFT join built on its right input preserves its PROBE side (choose_build_left): for everything below it is an inner join whose
+  // kernel adds one null-extended row per unmatched probe row — no visited flags, no tail pass
+  const bool probe_outer = nd.d.join_type == RDFGPU_JOIN_LEFT && !build_left;
+  const bool left_join = nd.d.join_type == RDFGPU_JOIN_LEFT && build_left;
   const DevTable& B = build_left ? L : R;
   const DevTable& P = build_left ? R : L;
   DevTable t;
@@ -1640,6 +1653,7 @@ DevTable Plan::exec_lds_join(NodeInfo& nd, const DevTable& L, const DevTable& R,
   a.n_left_cols = L.n_cols; a.n_out_cols = nd.n_proj;
   for (u32 c = 0; c < nd.n_proj; c++) a.proj[c] = nd.proj[c];
   a.build_is_left = build_left ? 1 : 0;
+  a.probe_outer = probe_outer ? 1u : 0u;
   a.n_keys = nd.d.n_keys;
   u32 build_keys[RDFGPU_MAX_KEYS] = {}, probe_keys[RDFGPU_MAX_KEYS] = {};
   for (u32 k = 0; k < a.n_keys; k++) {
@@ -1687,6 +1701,7 @@ DevTable Plan::exec_lds_join(NodeInfo& nd, const DevTable& L, const DevTable& R,
         u32 rl = 0;
         while (rl < (tiny ? 6u : 3u) && ((tiny ? 2ull : 16ull) << rl) <= fan && (P.cap << (rl + 1)) <= (1ull << 25)) rl++;
         if (opt.v[RDFGPU_OPT_CSR_ROW_LANES_LOG2]) rl = (u32)std::min<u64>(6, opt.v[RDFGPU_OPT_CSR_ROW_LANES_LOG2] - 1);
+        if (probe_outer) rl = 0;   // (one lane per probe row: the row's null-extended candidate is produced once)
         a.row_lanes_log2 = rl;
       } else if (st->direct) {
         a.direct = st->direct; a.direct_min = st->kmin; a.direct_n = st->kn;
@@ -1815,7 +1830,7 @@ DevTable Plan::exec_lds_join(NodeInfo& nd, const DevTable& L, const DevTable& R,
     NodeInfo* size_node = &nd;
     u64 stage_bytes = 0;
     BandArgs band{}; bool use_band = false;
-    if (pending_chain && pending_chain->base == &nd && !pending_chain->consumed && global_table && !use_part && !left_join && !probe_filter && nd.shape != 1 &&
+    if (pending_chain && pending_chain->base == &nd && !pending_chain->consumed && global_table && !use_part && !left_join && !probe_outer && !probe_filter && nd.shape != 1 &&
         apply_chain(*pending_chain, nd, L, R, build_left, a, stage_bytes, &band, &use_band)) {
       pending_chain->consumed = true;
       size_node = pending_chain->top;
@@ -1832,7 +1847,7 @@ DevTable Plan::exec_lds_join(NodeInfo& nd, const DevTable& L, const DevTable& R,
     // the matches are emitted in the slice's order (ordered_join.hip) — what consumes them partitioned by that column
     // (the band join above) then has nothing to sort; the chain's look-ups by table columns run once per table row.
     bool use_ordered = false;
-    if (!use_band && !opt.on(RDFGPU_OPT_NO_ORDERED_JOIN) && a.csr_off && !a.range_rows && !left_join && a.has_filter == 0 && !a.has_probe_filter && !a.has_post &&
+    if (!use_band && !probe_outer && !opt.on(RDFGPU_OPT_NO_ORDERED_JOIN) && a.csr_off && !a.range_rows && !left_join && a.has_filter == 0 && !a.has_probe_filter && !a.has_post &&
         a.n_keys == 1 && B.sorted_col >= 0 && (u32)B.sorted_col != build_keys[0] && !B.n_dev && B.stable_id && B.cap < (1ull << 32) && P.cap <= (1ull << 24) &&
         size_node->has_last && size_node->last_rows * 8 >= B.cap) {
       use_ordered = true;

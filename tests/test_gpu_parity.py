@@ -641,6 +641,53 @@ def test_partitioned_join_matches_oracle(torch_cuda, nb, npr, n_ids, min_build):
     del kb, kp
 
 
+@pytest.mark.parametrize("shape", ["unique keys (direct table)", "duplicate keys (CSR)", "two key columns (hash table)"])
+def test_left_join_preserved_on_the_probe_side(torch_cuda, shape):
+    """OPTIONAL with a small left input and a large store slice on the right: the engine builds on the slice's cached table and probes with
+    the left rows, emitting a left row without a match once with a null right side (LdsJoinArgs::probe_outer) — the multiset HashJoinExec(Left)
+    gives (join/rewrite.rs:126-168, NullEqualsNothing :89: a left row with a null key is kept, unmatched).  Left rows with null keys, keys
+    the slice does not hold, keys it holds once / many times; against the oracle and against the classic form (build left, visited flags,
+    tail pass), which RDFGPU_OPT_NO_PROBE_OUTER_JOIN brings back."""
+    rng = np.random.default_rng(len(shape))
+    n_quads, n_left = 400_000, 30_000
+    if shape.startswith("unique"):
+        s_ = np.arange(1000, 1000 + n_quads, dtype=np.uint32)                       # every subject once
+    else:
+        s_ = (1000 + rng.integers(0, n_quads // 7, n_quads)).astype(np.uint32)      # ~7 triples per subject, some subjects absent
+    o_ = (900_000 + rng.integers(0, 5000, n_quads)).astype(np.uint32)
+    quads = (np.zeros(n_quads, np.uint32), s_, np.full(n_quads, 7, np.uint32), o_)
+    gs, os_ = both_stores(quads)
+    two = shape.startswith("two")
+    Lk = (1000 + rng.integers(0, n_quads + 50_000, n_left)).astype(np.uint32)       # a good part of the keys are not in the slice
+    Lk[rng.random(n_left) < 0.05] = 0                                               # null keys: kept, never matched
+    L2 = (900_000 + rng.integers(0, 5000, n_left)).astype(np.uint32)
+    if two:                                                                           # half of the (s, o) pairs are triples of the slice
+        pick = rng.integers(0, n_quads, n_left); hit = rng.random(n_left) < 0.5
+        Lk[hit] = s_[pick[hit]]; L2[hit] = o_[pick[hit]]
+    Lt = [Lk, L2, np.arange(1, n_left + 1, dtype=np.uint32)]
+    keep, ptrs = table_on_device(torch_cuda, Lt)
+    pb = PlanBuilder()
+    on = [(0, 0), (1, 1)] if two else [(0, 0)]
+    desc = pb.build(pb.hash_join(pb.table(0, 3), pb.data_source(quad_pattern("s", 7, "o")), on=on, join_type=abi.JOIN_LEFT, projection=[0, 2, 4]))
+    exp, n_exp, _ = os_.execute(desc, [Lt])
+    want = ku.multiset(exp, n_exp)
+    assert (exp[2][:n_exp] == 0).sum() > n_left // 20 and (exp[2][:n_exp] != 0).sum() > n_left // 20      # both kinds of rows are there
+    for option, classic in ((None, False), ("NO_PROBE_OUTER_JOIN", True)):
+        plan = gs.plan(desc)
+        if option: plan.set_option(option, 1)
+        plan.bind_table(0, ptrs, n_left)
+        for rep in range(3):                         # exact first run, then speculative sizes
+            plan.enable_kernel_timing(True)
+            got = plan.execute().fetch()
+            assert plan.result_info()[0] == n_exp, (shape, option, rep)
+            np.testing.assert_array_equal(ku.multiset(got, n_exp), want, err_msg=f"{shape} {option} rep {rep}")
+        names = {k[0] for k in plan.kernel_stats()}
+        if not ENGINE_TOGGLED:
+            assert any("join_left_unmatched_kernel" in k for k in names) == classic, (shape, option, sorted(names))
+        plan.close()
+    del keep
+
+
 @pytest.mark.parametrize("nb,case", [(4096, "exact tile"), (4097, "tile + 1"), (8192, "two tiles"), (300_000, "all null"), (300_000, "one hot key"),
                                      (262_144, "one pass / two pass boundary"), (262_400, "one pass / two pass boundary"), (1_048_576, "clustered")])
 def test_partition_passes_edge_cases(torch_cuda, nb, case):
@@ -1533,7 +1580,7 @@ TOGGLES = ["RDFGPU_NO_CHAIN_FUSION", "RDFGPU_NO_INDEX_JOIN", "RDFGPU_NO_TABLE_CA
            "RDFGPU_NO_GLOBAL_TABLE_JOIN", "RDFGPU_NO_FILTER_FUSION", "RDFGPU_NO_VALUE_TABLES", "RDFGPU_NO_RANGE_INDEX",
            "RDFGPU_NO_BAND_JOIN", "RDFGPU_NO_PARTITIONED_JOIN", "RDFGPU_NO_JOIN_REORDER", "RDFGPU_NO_STRING_VERDICTS",
            "RDFGPU_NO_VALUE_VERDICTS", "RDFGPU_NO_RUN_COPY", "RDFGPU_NO_PRIMING", "RDFGPU_NO_ORDERED_JOIN", "RDFGPU_NO_BAND_PACK16", "RDFGPU_NO_RANGE_PARTITION",
-           "RDFGPU_NO_OWN_PARTITION_PASS", "RDFGPU_NO_BAND_COMPACT"]
+           "RDFGPU_NO_OWN_PARTITION_PASS", "RDFGPU_NO_BAND_COMPACT", "RDFGPU_NO_PROBE_OUTER_JOIN"]
 
 
 @pytest.mark.parametrize("toggle", TOGGLES)
