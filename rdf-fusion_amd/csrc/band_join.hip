@@ -172,6 +172,11 @@ __global__ __launch_bounds__(256) void band_decode_kernel(const BandArgs b) {
   uint4 rec; u32 flags;
   band_row_record(b, iy0, iy1, x, rec, flags);
   if (flags & 1u) atomicAdd(b.slow_rows, 1u);
+  if (b.compact) {                                     // the whole row record in 16 bytes (packed windows, id operand, one output value; BandArgs::compact)
+    const uint4 rc = make_uint4(rec.x, rec.y, x, rv[0]);
+    if (b.presorted) b.rec_s[j] = rc; else b.rec[j] = rc;
+    return;
+  }
   if (b.presorted) { b.rec_s[j] = rec; b.aux_s[j] = make_uint4(x, flags, rv[0], rv[1]); return; }   // row order IS the sorted order
   b.rec[2 * j] = rec;
   b.rec[2 * j + 1] = make_uint4(x, flags, rv[0], rv[1]);
@@ -211,6 +216,7 @@ __global__ __launch_bounds__(256) void band_rows_kernel(const BandArgs b) {
   const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= b.n_probe_cap || i >= b.poff[b.kn]) return;   // rows that join nothing sort to the end
   const u32 j = b.perm[i];
+  if (b.compact) { b.rec_s[i] = b.rec[j]; return; }
   b.rec_s[i] = b.rec[2 * (u64)j];
   b.aux_s[i] = b.rec[2 * (u64)j + 1];
 }
@@ -224,6 +230,7 @@ __global__ __launch_bounds__(256) void band_scatter_kernel(const BandArgs b) {
   const u32 pos = band_run_atomic_add(b.key_cursor, k, k < b.kn);   // a run of equal keys lands in consecutive positions
   if (k >= b.kn) return;                               // joins nothing: no position
   const_cast<u32*>(b.perm)[pos] = (u32)j;
+  if (b.compact) { b.rec_s[pos] = b.rec[j]; return; }
   b.rec_s[pos] = b.rec[2 * j];
   b.aux_s[pos] = b.rec[2 * j + 1];
 }

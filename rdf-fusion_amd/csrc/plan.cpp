@@ -2068,7 +2068,10 @@ void Plan::exec_band_join(LdsJoinArgs& a, BandArgs& b, const DevTable& B, const 
   while ((1ull << bits) <= kn) bits++;            // keys 0 .. kn (kn = joins nothing)
   u32* skey = scratch<u32>(np); u32* perm = scratch<u32>(np);
   if (presorted) { b.skey_in = skey; b.sval_in = perm; b.rec = nullptr; }
-  else { b.skey_in = scratch<u32>(np); b.sval_in = scratch<u32>(np); b.rec = scratch<uint4>(2 * np); }
+  // the packed pair test reads 8 bytes of window, the id operand and at most one output value per row: 16 bytes per row instead of 32
+  // whenever no full-semantics pass will want the flags (decode pass and ordered-join records alike)
+  b.compact = (b.pack16 && b.n_row_cols <= 1 && skip_slow && !opt.on(RDFGPU_OPT_NO_BAND_COMPACT)) ? 1u : 0u;
+  if (!presorted) { b.skey_in = scratch<u32>(np); b.sval_in = scratch<u32>(np); b.rec = scratch<uint4>((b.compact ? 1 : 2) * np); }
   b.skey = skey; b.perm = perm;
   b.rec_s = scratch<uint4>(np); b.aux_s = scratch<uint4>(np);
   b.slow_rows = reinterpret_cast<u32*>(new_counter());
