@@ -43,7 +43,7 @@ for it in range(6):
     plan_b.bind_table(0, c_ptrs, n_c); plan_b.execute(); b_rows = plan_b.result_info()[0]
     torch.cuda.synchronize(); t_b = (time.perf_counter() - t0) * 1e3
     rows.append((t_a, plan_a.metrics().elapsed_compute_ms, t_b, plan_b.metrics().elapsed_compute_ms, a_rows, n_c, b_rows))
-    print(f"it {it}: phase A {t_a:.3f} ms wall ({rows[-1][1]:.3f} device, {a_rows} rows of C), phase B {t_b:.3f} ms wall ({rows[-1][3]:.3f} device), C {n_c} rows, {b_rows} bindings; A: {plan_a.metrics().kernels_launched} launches {plan_a.metrics().host_syncs} syncs, B: {plan_b.metrics().kernels_launched} launches {plan_b.metrics().host_syncs} syncs", flush=True)
+    print(f"it {it}: phase A {t_a:.3f} ms wall ({rows[-1][1]:.3f} device, {a_rows} rows of C), phase B {t_b:.3f} ms wall ({rows[-1][3]:.3f} device), C {n_c} rows, {b_rows} bindings; A: {plan_a.metrics().kernels_launched} launches {plan_a.metrics().host_syncs} syncs, B: {plan_b.metrics().kernels_launched} launches {plan_b.metrics().host_syncs} syncs {plan_b.metrics().device_mallocs} mallocs ({plan_b.metrics().device_malloc_ms:.2f} ms) {plan_b.metrics().exact_reruns} reruns", flush=True)
 best = min(rows[2:], key=lambda r: r[0] + r[2])
 print({"ranks": N, "instances": Q, "phase_a_ms": round(best[0], 3), "phase_b_ms": round(best[2], 3), "c_rows": int(best[5]), "c_rows_of_this_rank": int(best[4]),
        "exchange_bytes_per_rank": int(best[4]) * 20, "bindings_of_this_rank": int(best[6])})
