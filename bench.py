@@ -655,18 +655,23 @@ def main():
     # ------------------------------------------------------------------ single-instance latency + CPU baseline, rank 0, N=1
     cpu = None
     single = None
+    single_drained = None
     timed_check = None
     if rank == 0 and world == 1:
         sample = [int(x) for x in products[:max(8, args.cpu_sample)]]
-        lat = []
-        for x in sample:                                   # the reference's per-query plan, one stream
-            d = bsbm.q5_plan(ds, x)
-            t1 = time.perf_counter()
+        lat, lat_drained = [], []
+        for x in sample + [int(y) for y in products[len(sample):len(sample) + 24]]:   # the reference's per-query protocol, one stream:
+            d = bsbm.q5_plan(ds, x)                                                     # compile a plan for ONE instance, execute, drain, drop
+            t1 = time.perf_counter()                                                    # (bench/benches/bsbm_explore.rs:23-95, utils/mod.rs:8-31)
             pl = store.plan(d).execute()
             pl.result_info()
-            lat.append((time.perf_counter() - t1) * 1e3)
+            t2 = time.perf_counter()
+            pl.fetch()
             pl.close()
+            t3 = time.perf_counter()
+            lat.append((t2 - t1) * 1e3); lat_drained.append((t3 - t1) * 1e3)
         single = round(float(np.median(lat)), 3)
+        single_drained = round(float(np.median(lat_drained)), 3)
     if rank == 0 and world == 1 and not args.no_cpu and args.cpu_sample > 0:
         from oracle import oracle as orc
         sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -800,6 +805,7 @@ def main():
                        "queries_per_s": round(n_q / elapsed, 2), "bindings": total_rows,
                        "host_threads": args.threads if args.per_instance else 1,
                        "single_instance_latency_ms": single,
+                       "single_instance_plan_execute_drain_drop_ms": single_drained,
                        "median_query_latency_ms": round(float(np.median(lat_ms)), 3) if lat_ms else None,
                        "load_seconds": round(load_s, 1), "cold_start": cold},
             "roofline": roofline,
