@@ -302,6 +302,10 @@ enum {
                                  mapped on the device; a string with a non-ASCII byte under a case mapping fails the execute with
                                  RDFGPU_ERR_UNSUPPORTED (Unicode case tables are not restated; never answered differently).      */
   RDFGPU_EX_LCASE = 34,       /* same: LCASE, scalar/strings/lcase.rs (str::to_lowercase)                                        */
+  RDFGPU_EX_STRBEFORE = 35,   /* TV TV -> TV(string)  STRBEFORE(a, b), scalar/strings/str_before.rs: both string literals, b without a
+                                 language or with a's (string_literal.rs:80-95, else error); the part of a before the first occurrence
+                                 of b with a's language — a VIEW of a, nothing is copied; b does not occur => the simple literal "".    */
+  RDFGPU_EX_STRAFTER = 36,    /* same: STRAFTER, scalar/strings/str_after.rs — the part of a behind the first occurrence of b             */
   RDFGPU_EX__COUNT
 };
 

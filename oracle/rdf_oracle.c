@@ -788,6 +788,23 @@ static int eval_prog(const orc_store* s, const rdfgpu_expr_node* p, u32 n, const
         memcpy(buf, q + b0, b1 - b0);
         v = tv_computed_string(buf, b1 - b0, a.aux);
         break; }
+      case RDFGPU_EX_STRBEFORE: case RDFGPU_EX_STRAFTER: {   /* str_before.rs / str_after.rs; argument compatibility string_literal.rs:80-95 */
+        if (sp < 2 || st[sp - 1].kind != 1 || st[sp - 2].kind != 1) FAIL("STRBEFORE / STRAFTER need two typed values");
+        val b = st[--sp], a = st[--sp];
+        const unsigned char *q, *r; size_t qn, rn;
+        v = tv_null();
+        if (a.tag != RDFGPU_TV_STRING || b.tag != RDFGPU_TV_STRING) break;
+        if (b.aux != 0 && b.aux != a.aux) break;
+        if (!str_bytes(s, &a, &q, &qn) || !str_bytes(s, &b, &r, &rn)) break;
+        size_t pos = (size_t)-1;
+        for (size_t i = 0; rn <= qn && i + rn <= qn; i++) if (memcmp(q + i, r, rn) == 0) { pos = i; break; }
+        if (pos == (size_t)-1) { v = tv_computed_string((const unsigned char*)"", 0, 0); break; }   /* "" without a language */
+        size_t b0 = e->op == RDFGPU_EX_STRAFTER ? pos + rn : 0, b1 = e->op == RDFGPU_EX_STRAFTER ? qn : pos;
+        unsigned char* buf = arena_take(b1 - b0);
+        if (!buf) FAIL("string arena exhausted");
+        memcpy(buf, q + b0, b1 - b0);
+        v = tv_computed_string(buf, b1 - b0, a.aux);
+        break; }
       case RDFGPU_EX_UCASE: case RDFGPU_EX_LCASE: {   /* ucase.rs / lcase.rs: str::to_uppercase / to_lowercase, language kept */
         if (sp < 1 || st[sp - 1].kind != 1) FAIL("UCASE / LCASE needs a typed value");
         val a = st[--sp]; const unsigned char* q; size_t qn;

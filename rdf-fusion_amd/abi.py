@@ -30,7 +30,7 @@ NT_IRI, NT_BNODE, NT_SIMPLE, NT_LANG, NT_TYPED = 1, 2, 3, 4, 5   # rdfgpu_ntripl
 (EX_COLUMN, EX_LIT_ID, EX_LIT_TV, EX_ENC_TV, EX_GT, EX_LT, EX_GEQ, EX_LEQ, EX_EQ, EX_ADD, EX_SUB,
  EX_EBV, EX_ID_EQ, EX_ID_NEQ, EX_AND, EX_OR, EX_NOT, EX_IS_COMPATIBLE, EX_BOUND, EX_BOOL_AS_TV,
  EX_LIT_BOOL, EX_NEQ, EX_REGEX, EX_CONTAINS, EX_STRSTARTS, EX_STRENDS, EX_LANG_IN, EX_REGEX_VAR,
- EX_STR, EX_LIT_STR, EX_STRLEN, EX_SUBSTR, EX_UCASE, EX_LCASE) = range(1, 35)
+ EX_STR, EX_LIT_STR, EX_STRLEN, EX_SUBSTR, EX_UCASE, EX_LCASE, EX_STRBEFORE, EX_STRAFTER) = range(1, 37)
 
 # plan nodes
 (NODE_DATA_SOURCE, NODE_FILTER, NODE_HASH_JOIN, NODE_CROSS_JOIN, NODE_NESTED_LOOP_JOIN,

@@ -384,6 +384,28 @@ __device__ __forceinline__ Val tv_case(const ExprProgram* prog, const TypedTable
   const uint64_t base = v.pad == 0 ? 0ull : ((uint64_t)v.lo >> 32);
   return val_str_view(v.pad == 0 ? 1 : v.pad, (uint32_t)v.hi, base, s.len, v.aux, upper ? kStrUpper : kStrLower);
 }
+// STRBEFORE / STRAFTER(a, b), str_before.rs / str_after.rs: both string literals, b without a language or with a's (string_literal.rs:80-95);
+// the part of a before / behind the first occurrence of b, with a's language — a window of a's bytes, nothing is copied (UTF-8 is
+// self-synchronising: a byte-wise match of valid UTF-8 starts on a character boundary); no occurrence => the simple literal "".
+__device__ __forceinline__ Val tv_strpart(const ExprProgram* prog, const TypedTable& t, const Val& a, const Val& b, bool after) {
+  if (a.tag != RDFGPU_TV_STRING || b.tag != RDFGPU_TV_STRING) return val_tv_null();
+  if (b.aux != 0 && b.aux != a.aux) return val_tv_null();                     // incompatible arguments: error
+  StrBytes x, y;
+  if (!str_bytes(prog, t, a, x) || !str_bytes(prog, t, b, y)) return val_tv_null();
+  const uint64_t base = a.pad == 0 ? 0ull : ((uint64_t)a.lo >> 32);
+  const uint8_t kind = a.pad == 0 ? 1 : a.pad, cs = (uint8_t)(a.flags & (kStrUpper | kStrLower));
+  uint64_t pos = ~0ull;
+  if (y.len <= x.len) {
+    for (uint64_t i = 0; i + y.len <= x.len && pos == ~0ull; i++) {
+      bool eq = true;
+      for (uint64_t j = 0; j < y.len && eq; j++) eq = str_at(x, i + j) == str_at(y, j);
+      if (eq) pos = i;
+    }
+  }
+  if (pos == ~0ull) return val_str_view(kind, (uint32_t)a.hi, base, 0, 0u, 0);  // "" without a language
+  return after ? val_str_view(kind, (uint32_t)a.hi, base + pos + y.len, x.len - pos - y.len, a.aux, cs)
+               : val_str_view(kind, (uint32_t)a.hi, base, pos, a.aux, cs);
+}
 // two strings of which at least one is a view: `str` order of their bytes (typed_value.rs:184-196 compares the values), same language only
 __device__ __forceinline__ bool str_is_view(const Val& v) { return v.tag == RDFGPU_TV_STRING && (v.pad != 0 || (v.flags & (kStrUpper | kStrLower))); }
 __device__ __forceinline__ int tv_cmp_string_views(const ExprProgram* prog, const TypedTable& t, const Val& a, const Val& b) {
@@ -436,6 +458,7 @@ __device__ __forceinline__ Val eval_program(const ExprProgram& prog, const Typed
       case RDFGPU_EX_STR: v = tv_str_of_id(tt, (uint32_t)st[--sp].lo); break;
       case RDFGPU_EX_LIT_STR: v = val_str_view(2, e.u, 0, prog.regex[e.u].n_pos, (uint32_t)(e.lo < 0 ? 0 : e.lo), 0); break;
       case RDFGPU_EX_STRLEN: v = tv_strlen(&prog, tt, st[--sp]); break;
+      case RDFGPU_EX_STRBEFORE: case RDFGPU_EX_STRAFTER: { const Val b2 = st[--sp]; const Val a2 = st[--sp]; v = tv_strpart(&prog, tt, a2, b2, e.op == RDFGPU_EX_STRAFTER); break; }
       case RDFGPU_EX_SUBSTR: {
         if (e.u == 3) { const Val ln = st[--sp]; const Val from = st[--sp]; const Val src = st[--sp]; v = tv_substr(&prog, tt, src, from, &ln); }
         else { const Val from = st[--sp]; const Val src = st[--sp]; v = tv_substr(&prog, tt, src, from, nullptr); }

@@ -75,6 +75,7 @@ u32 check_program(const rdfgpu_expr_node* p, u32 n, u32 n_cols, u32 n_regexes = 
         pop_bytes("SUBSTR");
         out = VK_TV; views = true; break;
       case RDFGPU_EX_UCASE: case RDFGPU_EX_LCASE: pop_bytes("UCASE / LCASE"); out = VK_TV; views = true; break;
+      case RDFGPU_EX_STRBEFORE: case RDFGPU_EX_STRAFTER: pop_bytes("STRBEFORE / STRAFTER"); pop_bytes("STRBEFORE / STRAFTER"); out = VK_TV; views = true; break;
       case RDFGPU_EX_REGEX_VAR:
         if (e.lo < 1 || (u64)e.u + (u64)e.lo > n_regexes) fail(RDFGPU_ERR_INVALID, "expression: REGEX pattern table %u .. +%lld out of range (%u patterns)", e.u, (long long)e.lo, n_regexes);
         pop(VK_TV, "REGEX pattern"); pop_bytes("REGEX"); out = VK_TV; break;
@@ -240,7 +241,7 @@ Plan* plan_compile(Store* store, const rdfgpu_plan_desc* d) {
 
   for (u32 i = 0; i < d->n_exprs; i++) {
     const u8 op = d->exprs[i].op;
-    if ((op == RDFGPU_EX_STR || op == RDFGPU_EX_STRLEN || op == RDFGPU_EX_SUBSTR || op == RDFGPU_EX_UCASE || op == RDFGPU_EX_LCASE) && !store->str_off)
+    if ((op == RDFGPU_EX_STR || op == RDFGPU_EX_STRLEN || op == RDFGPU_EX_SUBSTR || op == RDFGPU_EX_UCASE || op == RDFGPU_EX_LCASE || op == RDFGPU_EX_STRBEFORE || op == RDFGPU_EX_STRAFTER) && !store->str_off)
       fail(RDFGPU_ERR_INVALID, "plan uses string functions but the store has no strings (rdfgpu_store_set_strings)");
   }
   for (u32 i = 0; i < d->n_nodes; i++) {

@@ -242,6 +242,16 @@ def LCASE(e):
     return e._un(abi.EX_LCASE)
 
 
+def STRBEFORE(a, b):
+    """STRBEFORE(a, b) — scalar/strings/str_before.rs: the part of a before b's first occurrence (a's language), "" if there is none."""
+    return Expr(a.nodes + b.nodes + [(abi.EX_STRBEFORE, 0, 0, 0, 0, 0)])
+
+
+def STRAFTER(a, b):
+    """STRAFTER(a, b) — scalar/strings/str_after.rs."""
+    return Expr(a.nodes + b.nodes + [(abi.EX_STRAFTER, 0, 0, 0, 0, 0)])
+
+
 def lang_matches(language_tag, language_range):
     """LANGMATCHES on two plain strings, as scalar/strings/lang_matches.rs:52-69 evaluates it: "*" matches every
     non-empty tag; otherwise the subtags ('-' separated) are zipped with the longer side padded: a range subtag that is

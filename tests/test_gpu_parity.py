@@ -1051,7 +1051,7 @@ def test_string_valued_expressions_match_oracle(torch_cuda, kats):
     """STR / STRLEN / SUBSTR / UCASE / LCASE inside plan expressions: string VIEWS over the heap on the device against
     the oracle's materialised strings; the reference's STR vectors (unary__STR(PLAIN_TERM).snap, small_iri_str.rq) through the GPU;
     what the device does not restate fails the execute loudly."""
-    from rdf_fusion_amd.plan import STR, STRLEN, SUBSTR, UCASE, LCASE, lit_str
+    from rdf_fusion_amd.plan import STR, STRLEN, SUBSTR, UCASE, LCASE, STRBEFORE, STRAFTER, lit_str
     # the reference's vectors: STR(term) = its lexical form as written, for every kind of term
     cases = kats["str_plain_term"]
     tv, off, heap, _ = ku.term_dictionary([c["term"] for c in cases])
@@ -1091,6 +1091,15 @@ def test_string_valued_expressions_match_oracle(torch_cuda, kats):
         EBV(LT(SUBSTR(ENC_TV(col(0)), integer(1), integer(2)), SUBSTR(ENC_TV(col(0)), integer(2), integer(2)))),
         EBV(EQ(SUBSTR(STR(col(0)), integer(8), integer(40)), STR(col(0)))),
         NOT(EBV(EQ(STRLEN(SUBSTR(ENC_TV(col(0)), integer(2), integer(300))), integer(0)))),
+        # STRBEFORE / STRAFTER (str_before.rs / str_after.rs): views cut at the first occurrence; "" when absent; language rules
+        EBV(EQ(STRBEFORE(ENC_TV(col(0)), lit_str("b")), lit_str("a"))), EBV(EQ(STRBEFORE(ENC_TV(col(0)), lit_str("b")), lit_str("a", en))),
+        EBV(EQ(STRAFTER(STR(col(0)), lit_str("example.org/")), lit_str(ascii_words[2].strip()))), EBV(STRAFTER(ENC_TV(col(0)), lit_str("c"))),
+        EBV(EQ(STRLEN(STRBEFORE(ENC_TV(col(0)), lit_str(""))), integer(0))), EBV(EQ(STRAFTER(ENC_TV(col(0)), lit_str("")), ENC_TV(col(0)))),
+        EBV(STRBEFORE(ENC_TV(col(0)), lit_str("_", en))), EBV(GT(STRLEN(STRAFTER(ENC_TV(col(0)), lit_str("a", en))), integer(2))),
+        EBV(CONTAINS(STRAFTER(STRBEFORE(STR(col(0)), lit_str(".")), lit_str("a")), "b")), EBV(REGEX(STRAFTER(STR(col(0)), lit_str("://")), "^example")),
+        EBV(LT(STRBEFORE(ENC_TV(col(0)), lit_str(" ")), STRAFTER(ENC_TV(col(0)), lit_str(" ")))),
+        EBV(EQ(STRBEFORE(ENC_TV(col(0)), SUBSTR(ENC_TV(col(0)), integer(3), integer(1))), SUBSTR(ENC_TV(col(0)), integer(1), integer(2)))),
+        EBV(STRAFTER(ENC_TV(col(0)), lit_str("ä"))), EBV(EQ(STRBEFORE(ENC_TV(col(0)), lit_str("語")), lit_str("日本"))),
     ]
     for e in exprs_any:
         check_filter(torch_cuda, gs, os_, e, [ids])
@@ -1099,6 +1108,8 @@ def test_string_valued_expressions_match_oracle(torch_cuda, kats):
         EBV(REGEX(UCASE(STR(col(0))), "^HTTP://EXAMPLE")), EBV(LT(LCASE(STR(col(0))), lit_str("c"))),
         EBV(EQ(UCASE(SUBSTR(LCASE(ENC_TV(col(0))), integer(2), integer(2))), lit_str("BC"))),
         EBV(EQ(LCASE(ENC_TV(col(0))), UCASE(ENC_TV(col(0))))),
+        EBV(EQ(STRBEFORE(UCASE(ENC_TV(col(0))), lit_str("B")), lit_str("A"))), EBV(STRAFTER(LCASE(STR(col(0))), lit_str("example.org/a"))),
+        EBV(CONTAINS(UCASE(STRAFTER(ENC_TV(col(0)), lit_str("a"))), "C")),
     ]
     for e in exprs_ascii:
         check_filter(torch_cuda, gs, os_, e, [ascii_ids])

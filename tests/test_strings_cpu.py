@@ -6,7 +6,7 @@ import pytest
 
 from oracle import oracle as orc
 from rdf_fusion_amd import abi
-from rdf_fusion_amd.plan import (col, integer, int32, double, lit_str, STR, STRLEN, SUBSTR, UCASE, LCASE, ENC_TV, EQ, LT, GT, EBV,
+from rdf_fusion_amd.plan import (col, integer, int32, double, lit_str, STR, STRLEN, SUBSTR, UCASE, LCASE, STRBEFORE, STRAFTER, ENC_TV, EQ, LT, GT, EBV,
                                  CONTAINS, STRSTARTS, REGEX)
 import kat_util as ku
 
@@ -109,3 +109,36 @@ def test_computed_string_comparisons_follow_str_order():
             assert got.tolist() == [1 if f(w.encode("utf-8")) else 0 for w in words], (pivot, op.__name__)
     # different languages never compare (language_string.rs:44-52): the error value
     assert st.eval_bool(EBV(EQ(STR(col(0)), lit_str("a", language_id=3))), [ids[:5]]).tolist() == [2] * 5
+
+
+def test_strbefore_strafter_against_python():
+    """STRBEFORE / STRAFTER (str_before.rs / str_after.rs): the part of the first argument before / behind the first occurrence of the second,
+    with the first argument's language; no occurrence => the simple literal ""; the second argument has no language or the first one's
+    (string_literal.rs:80-95), anything else — and any argument that is no string literal — is the error value.  Against str.partition."""
+    subjects = WORDS + ["a-b-c", "--", "xyzxyz", "ünï-cödé-x"]
+    terms = [["literal", w, None] for w in subjects] + [["literal", w, "@en"] for w in subjects] + [["literal", w, "@de"] for w in subjects[:3]] + \
+            [["iri", "http://e/x-y"], ["literal", "12", "xsd:integer"]]
+    st, langs = store_of(terms)
+    ids = np.arange(1, len(terms) + 1, dtype=np.uint32)
+    en = langs.index("en")
+    for needle, needle_lang in (("-", 0), ("", 0), ("l", 0), ("yz", 0), ("ö", 0), ("zzz", 0), ("-", en), ("a", en)):
+        for fn, after in ((STRBEFORE, False), (STRAFTER, True)):
+            got = st.eval_str(fn(ENC_TV(col(0)), lit_str(needle, needle_lang)), [ids])
+            for k, t in enumerate(terms):
+                is_string = t[0] == "literal" and (t[2] is None or t[2].startswith("@"))
+                lang = 0 if not is_string or t[2] is None else langs.index(t[2][1:])
+                if not is_string or (needle_lang != 0 and needle_lang != lang):
+                    assert got[k] is None, (t, needle, needle_lang, fn.__name__)          # not a string literal / incompatible languages: error
+                    continue
+                head, sep, tail = t[1].partition(needle) if needle != "" else ("", "", t[1])     # the empty needle is found at position 0
+                want = ("", 0) if (sep == "" and needle != "") else ((tail if after else head), lang)
+                assert (got[k][0].decode("utf-8"), got[k][1]) == want, (t, needle, needle_lang, fn.__name__, got[k])
+    # views compose: STRAFTER(STRBEFORE(x, "-c"), "a-") of "a-b-c" is "b"; a case-mapped source is searched in its mapped form
+    one = st.eval_str(STRAFTER(STRBEFORE(ENC_TV(col(0)), lit_str("-c")), lit_str("a-")), [np.array([subjects.index("a-b-c") + 1], np.uint32)])
+    assert one[0] == (b"b", 0)
+    two = st.eval_str(STRBEFORE(UCASE(ENC_TV(col(0))), lit_str("-B")), [np.array([subjects.index("a-b-c") + 1], np.uint32)])
+    assert two[0] == (b"A", 0)
+    # STRLEN / CONTAINS / comparisons consume the views
+    lens, _ = st.eval_tv(STRLEN(STRAFTER(ENC_TV(col(0)), lit_str("-"))), [np.array([subjects.index("a-b-c") + 1], np.uint32)])
+    assert lens["lo"][0] == 3
+    assert st.eval_bool(EBV(EQ(STRBEFORE(ENC_TV(col(0)), lit_str("-")), lit_str("a"))), [np.array([subjects.index("a-b-c") + 1], np.uint32)])[0] == 1
