@@ -587,6 +587,7 @@ enum {
   RDFGPU_OPT_NO_OWN_PARTITION_PASS,     /* flag: partitioned join: partition ids materialised and sorted with rocPRIM's radix sort instead of the hand-written passes */
   RDFGPU_OPT_NO_BAND_COMPACT,           /* flag: band join fed by an ordered slice join: 32-byte {record, aux} row records even where 16 bytes would do */
   RDFGPU_OPT_NO_PROBE_OUTER_JOIN,       /* flag: LEFT joins always build on their left input (no probe-preserving form over the right input's slice table) */
+  RDFGPU_OPT_NO_STREAM_JOIN,            /* flag: joins against a direct-address table always take the generic queueing kernel (no register-resident streaming form) */
   RDFGPU_OPT__COUNT
 };
 int rdfgpu_store_set_option(rdfgpu_store* store, uint32_t option, uint64_t value);

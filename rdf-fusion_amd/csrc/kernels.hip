@@ -964,6 +964,7 @@ int lds_join_items(u64 n_probe_cap, bool global) {
 }
 int lds_join_mode(const LdsJoinArgs& a) { return a.csr_off ? kJoinTableCsr : a.direct ? kJoinTableDirect : a.gslots ? kJoinTableHash : kJoinTableLds; }
 void launch_lds_join(const LdsJoinArgs& a, hipStream_t s) {
+  if (a.stream_direct && direct_stream_join_ok(a)) return launch_direct_stream_join(a, s);
   const int mode = lds_join_mode(a);
   const bool global = mode != kJoinTableLds;
   const size_t tbl_lds = global ? 0 : (size_t)(a.tbl_mask + 1) * sizeof(uint2);

@@ -216,7 +216,7 @@ struct LdsJoinArgs {
   u8* visited;              // left join: per build row
   u32 probe_outer;          // LEFT JOIN preserved on the PROBE side (the engine built on the right input's table): a probe row without a match is
                             // emitted once with an all-null build side (candidate {kOuterNull, row}); needs no filter, no chain, one lane per row
-  u32 pad_outer;
+  u32 stream_direct;        // 1: a direct-address join of a shape stream_join.hip takes runs there (registers, no queue); 0: always the generic kernel
   u32 has_filter, has_probe_filter;   // join filter: 0 none / 1 VM / 3 window ; probe filter: 0 none / 1 id-literal / 2 VM
   TypedTable tt;
   // Generic programs live in device memory (a 2.5 KB by-value kernarg block made the compiler copy the
@@ -232,6 +232,10 @@ struct LdsJoinArgs {
   u32 has_post; IdFilter post;
 };
 void launch_lds_join(const LdsJoinArgs& a, hipStream_t s);
+// stream_join.hip: the same operator against a direct-address table as a streaming pass (launch_lds_join routes to it when a.stream_direct)
+bool direct_stream_join_ok(const LdsJoinArgs& a);
+int direct_stream_join_items(u64 n_probe_cap);
+void launch_direct_stream_join(const LdsJoinArgs& a, hipStream_t s);
 
 // ---- ordered slice join (ordered_join.hip): a small table against a store slice, matches emitted in the slice's order ----
 constexpr u32 kOjMaxOutCols = 8;   // output columns of an ordered slice join (its write kernel keeps the column schedule in SGPRs)

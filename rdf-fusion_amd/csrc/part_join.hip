@@ -123,7 +123,11 @@ __global__ __launch_bounds__(256) void part_range_bounds_kernel(const u32* col, 
   pstart[p] = (u32)lower_bound_u32(col, n, first);
 }
 
-template <int FS, bool RANGE>
+// BIG: the two-pass form of a join with a large output (pa.two_pass, known to the host).  There the kernel is bound by the latency of
+// the gathers behind every full queue — the filter's operands in both passes, the payload columns in the second — and not by the walk:
+// its resolve and write-out phases keep four 64-entry groups of the queue in flight at once (8 / 16 gathers per lane outstanding instead
+// of 2 / 4).  The single-pass form (small outputs: LUBM Q9's closing join) keeps the lean loops, whose registers its walk wants.
+template <int FS, bool RANGE, bool BIG>
 __global__ __launch_bounds__(kLdsBlock) __attribute__((amdgpu_waves_per_eu(4))) void part_join_kernel(const LdsJoinArgs a, const PartArgs pa) {
   extern __shared__ __align__(16) unsigned char lds_raw[];
   // dynamic LDS: [slots: tbl_mask + 1 x {key0, key1}; key0 == 0 = empty: a null key joins nothing and is never inserted]
@@ -154,15 +158,38 @@ __global__ __launch_bounds__(kLdsBlock) __attribute__((amdgpu_waves_per_eu(4))) 
         src[u] = a.cols[c];
         dst[u] = a.out[on[u] ? oc0 + u : oc0];
       }
-      for (u32 e = lane; e < qn; e += 64) {
-        const uint2 m = wq[e];
-        const u64 pos = base + e;
-        if (pos >= a.out_cap) continue;
-        u32 v[4];
+      if constexpr (BIG) {
+        for (u32 e0 = 0; e0 < qn; e0 += 256) {       // (qn > 0 inside: the clamped entry exists)
+          uint2 m[4]; bool live[4]; u32 v[4][4];
 #pragma unroll
-        for (u32 u = 0; u < 4; u++) if (on[u]) v[u] = src[u][from_build[u] ? m.x : m.y];
+          for (u32 g = 0; g < 4; g++) {
+            const u32 e = e0 + g * 64 + lane;
+            live[g] = e < qn && base + e < a.out_cap;
+            m[g] = wq[e < qn ? e : qn - 1];
+          }
 #pragma unroll
-        for (u32 u = 0; u < 4; u++) if (on[u]) dst[u][pos] = v[u];
+          for (u32 g = 0; g < 4; g++) {
+#pragma unroll
+            for (u32 u = 0; u < 4; u++) v[g][u] = src[u][from_build[u] ? m[g].x : m[g].y];   // (an unused column slot repeats column oc0)
+          }
+#pragma unroll
+          for (u32 g = 0; g < 4; g++) {
+            const u64 pos = base + e0 + g * 64 + lane;
+#pragma unroll
+            for (u32 u = 0; u < 4; u++) if (live[g] && on[u]) dst[u][pos] = v[g][u];
+          }
+        }
+      } else {
+        for (u32 e = lane; e < qn; e += 64) {
+          const uint2 m = wq[e];
+          const u64 pos = base + e;
+          if (pos >= a.out_cap) continue;
+          u32 v[4];
+#pragma unroll
+          for (u32 u = 0; u < 4; u++) if (on[u]) v[u] = src[u][from_build[u] ? m.x : m.y];
+#pragma unroll
+          for (u32 u = 0; u < 4; u++) if (on[u]) dst[u][pos] = v[u];
+        }
       }
     }
     if (a.visited) for (u32 e = lane; e < qn; e += 64) a.visited[wq[e].x] = 1;
@@ -175,6 +202,32 @@ __global__ __launch_bounds__(kLdsBlock) __attribute__((amdgpu_waves_per_eu(4))) 
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     if (FS == 0) return;
     u32 kept = 0;
+    if constexpr (BIG) {
+      for (u32 g0 = 0; g0 < qn; g0 += 256) {
+        uint2 m[4]; bool ok[4], slow[4];
+#pragma unroll
+        for (u32 g = 0; g < 4; g++) {
+          const u32 e = g0 + g * 64 + lane;
+          ok[g] = e < qn; slow[g] = false;
+          m[g] = wq[e < qn ? e : qn - 1];
+        }
+#pragma unroll
+        for (u32 g = 0; g < 4; g++) { bool sl; const bool f = ljoin_filter_fast<FS>(a, m[g].x, m[g].y, sl); slow[g] = ok[g] && sl; ok[g] = ok[g] && f; }   // (unconditional: the loads of all four groups leave together)
+        if constexpr (FS == 1 || FS == 3) {
+#pragma unroll
+          for (u32 g = 0; g < 4; g++) if (slow[g]) ok[g] = ljoin_filter_slow<FS>(a, m[g].x, m[g].y);
+        }
+#pragma unroll
+        for (u32 g = 0; g < 4; g++) {                // every read of this round is done: writing below g0 + 256 is safe
+          const unsigned long long mask = __ballot(ok[g]);
+          if (ok[g]) wq[kept + lane_prefix(mask)] = m[g];
+          kept += (u32)__popcll(mask);
+        }
+      }
+      qn = kept;
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      return;
+    }
     for (u32 g0 = 0; g0 < qn; g0 += 64) {
       const u32 e = g0 + lane;
       uint2 m = make_uint2(0u, 0u);
@@ -337,12 +390,16 @@ void part_sort(const u32* kin, u32* kout, const PartRec* vin, PartRec* vout, u64
 size_t part_join_lds_bytes(const LdsJoinArgs& a, const PartArgs& pa) {
   return (size_t)(pa.tbl_mask + 1) * (sizeof(uint2) + sizeof(u32)) + (size_t)(kLdsBlock / 64) * a.wave_q * sizeof(uint2) + 16;
 }
-template <int FS, bool RANGE> static void launch_part_join_fr(const LdsJoinArgs& a, const PartArgs& pa, dim3 g, size_t lds, hipStream_t s) {
+template <int FS, bool RANGE, bool BIG> static void launch_part_join_frb(const LdsJoinArgs& a, const PartArgs& pa, dim3 g, size_t lds, hipStream_t s) {
   static std::once_flag attr_once;
   std::call_once(attr_once, [] {
-    RDFGPU_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(part_join_kernel<FS, RANGE>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
+    RDFGPU_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(part_join_kernel<FS, RANGE, BIG>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
   });
-  hipLaunchKernelGGL((part_join_kernel<FS, RANGE>), g, dim3(kLdsBlock), lds, s, a, pa);
+  hipLaunchKernelGGL((part_join_kernel<FS, RANGE, BIG>), g, dim3(kLdsBlock), lds, s, a, pa);
+}
+template <int FS, bool RANGE> static void launch_part_join_fr(const LdsJoinArgs& a, const PartArgs& pa, dim3 g, size_t lds, hipStream_t s) {
+  if (pa.two_pass) launch_part_join_frb<FS, RANGE, true>(a, pa, g, lds, s);
+  else launch_part_join_frb<FS, RANGE, false>(a, pa, g, lds, s);
 }
 template <int FS> static void launch_part_join_fs(const LdsJoinArgs& a, const PartArgs& pa, dim3 g, size_t lds, hipStream_t s) {
   if (pa.ppart) launch_part_join_fr<FS, false>(a, pa, g, lds, s);

@@ -555,7 +555,7 @@ const char* kernel_class_name(int kc) {
       "rdfgpu::oj_probe_kernel", "rdfgpu::oj_count_kernel", "void rdfgpu::oj_write_kernel",
       "void rdfgpu::filter_write_kernel", "rdfgpu::part_keys_kernel", "void rdfgpu::part_join_kernel",
       "rdfgpu::oj_band_records_kernel", "rdfgpu::oj_write_band_kernel", "void rdfgpu::small_scan_kernel",
-      "rdfgpu::part_pass (hist + scan + scatter)"};
+      "rdfgpu::part_pass (hist + scan + scatter)", "void rdfgpu::stream_join_kernel"};
   if (kc < KC_LDS_JOIN0) return fixed[kc];
   static std::string names[192];
   static std::once_flag once;
@@ -1637,6 +1637,36 @@ void Plan::build_dense_table(SliceTable* st, const u32* key, u64 n) {
   st->dense_tried = true;
 }
 
+// The direct-address form for a build side that is NOT cached (RDFGPU_OPT_NO_TABLE_CACHE, or an intermediate with a host-known row
+// count): built inside this execution, in scratch memory, when the single key turns out unique over a dense id range — the same two
+// kernels as the cached form (min / max, then one store per row with a duplicate flag) and two host round trips.  4 bytes per ID
+// instead of 8 bytes per SLOT at load <= 0.5: the 285 k-row property slices of BSBM-100M are 1.1 MB (resident in every XCD's L2)
+// instead of an 8 MB hash table that 0.54 G random probes fetch from the Infinity Cache line by line.  false: not unique / not dense.
+bool Plan::build_transient_direct(LdsJoinArgs& a, u64 n) {
+  const u32* key = a.build_key[0];
+  u32* mm = reinterpret_cast<u32*>(new_counter());     // {min, max}
+  u32* flags = reinterpret_cast<u32*>(new_counter());  // {duplicate seen, -}
+  const u32 init[2] = {0xFFFFFFFFu, 0u};
+  RDFGPU_HIP(hipMemcpyAsync(mm, init, sizeof(init), hipMemcpyHostToDevice, stream));
+  timed(KC_MINMAX, 4ull * n, 0, nullptr, 0, nullptr, 0, 0, [&] { launch_minmax_u32(key, n, mm, stream); });
+  u32 got[2];
+  RDFGPU_HIP(hipMemcpyAsync(got, mm, sizeof(got), hipMemcpyDeviceToHost, stream));
+  RDFGPU_HIP(hipStreamSynchronize(stream)); metrics.host_syncs++;
+  const u64 range = got[0] <= got[1] ? (u64)(got[1] - got[0]) + 1 : ~0ull;
+  if (range > 4 * n + 1024 || n > range) return false;   // sparse ids, or more rows than ids (some key repeats)
+  const u32 kmin = got[0], kn = (u32)range;
+  u32* direct = scratch<u32>(kn);
+  RDFGPU_HIP(hipMemsetAsync(direct, 0xFF, (size_t)kn * sizeof(u32), stream));
+  timed(KC_GDIRECT_BUILD, 0, n, nullptr, 8, nullptr, 0, 0, [&] { launch_gdirect_build(key, n, direct, kmin, kn, flags, stream); });
+  u32 is_dup = 0;
+  RDFGPU_HIP(hipMemcpyAsync(&is_dup, flags, sizeof(u32), hipMemcpyDeviceToHost, stream));
+  RDFGPU_HIP(hipStreamSynchronize(stream)); metrics.host_syncs++;
+  if (is_dup) return false;
+  metrics.tables_built++;
+  a.direct = direct; a.direct_min = kmin; a.direct_n = kn;
+  return true;
+}
+
 // HashJoinExec whose build side fits one workgroup's LDS: one fused kernel, optimistic output capacity.
 DevTable Plan::exec_lds_join(NodeInfo& nd, const DevTable& L, const DevTable& R, bool build_left, const NodeInfo* probe_filter, const NodeInfo* post_filter) {
   // a LEFT join built on its right input preserves its PROBE side (choose_build_left): for everything below it is an inner join whose
@@ -1723,9 +1753,17 @@ DevTable Plan::exec_lds_join(NodeInfo& nd, const DevTable& L, const DevTable& R,
                B.cap < (1ull << 31) && P.cap < (1ull << 31)) {
       use_part = true;     // radix-partition both sides; every partition's table is built in LDS (part_join.hip)
     } else {
-      a.gslots = scratch<uint2>(slots);
-      build_now = true;
-      RDFGPU_HIP(hipMemsetAsync(a.gslots, 0xFF, (size_t)slots * sizeof(uint2), stream));
+      // a large probe side pays for two host round trips with every probe that hits a 4-byte entry in L2 instead of an 8-byte slot beyond it
+      bool direct_built = false;
+      if (a.n_keys == 1 && B.n_dev == nullptr && B.cap >= 4096 && P.cap >= (1ull << 22) && !nd.transient_direct_failed && !opt.on(RDFGPU_OPT_NO_DIRECT_TABLE)) {
+        direct_built = build_transient_direct(a, B.cap);
+        nd.transient_direct_failed = !direct_built;
+      }
+      if (!direct_built) {
+        a.gslots = scratch<uint2>(slots);
+        build_now = true;
+        RDFGPU_HIP(hipMemsetAsync(a.gslots, 0xFF, (size_t)slots * sizeof(uint2), stream));
+      }
     }
   }
   if (P.cap >= (1ull << 32)) fail(RDFGPU_ERR_UNSUPPORTED, "probe side of %llu rows", (unsigned long long)P.cap);
@@ -1771,6 +1809,7 @@ DevTable Plan::exec_lds_join(NodeInfo& nd, const DevTable& L, const DevTable& R,
     a.post.col = (build_left ? 0 : L.n_cols) + e[0].u; a.post.lit = e[1].u; a.post.is_eq = e[2].op == RDFGPU_EX_ID_EQ;
   }
   a.tt = typed_table();
+  a.stream_direct = opt.on(RDFGPU_OPT_NO_STREAM_JOIN) ? 0u : 1u;
   if (left_join) a.visited = scratch<u8>(L.cap);
   u64* n_out = new_counter();
   u32* overflow = reinterpret_cast<u32*>(new_counter());
@@ -1807,7 +1846,7 @@ DevTable Plan::exec_lds_join(NodeInfo& nd, const DevTable& L, const DevTable& R,
   const u64 part_fixed = (4ull * (a.n_keys + build_payload) + 8) * B.cap;
   auto launch_join = [&](int kc_lds, u64 fixed_bytes, u64 out_bytes_per_row) {
     if (use_part) timed(KC_PART_JOIN, part_fixed, P.cap, P.n_dev, 4ull * probe_cols + 8, n_out, 0, out_bytes_per_row, [&] { launch_part_join(a, part, stream); });
-    else timed(kc_lds, fixed_bytes, P.cap, P.n_dev, 4ull * probe_cols + 8, n_out, 0, out_bytes_per_row, [&] { launch_lds_join(a, stream); });
+    else timed(a.stream_direct && direct_stream_join_ok(a) ? (int)KC_STREAM_JOIN : kc_lds, fixed_bytes, P.cap, P.n_dev, 4ull * probe_cols + 8, n_out, 0, out_bytes_per_row, [&] { launch_lds_join(a, stream); });
   };
   if (build_now)   // build pass: keys read + one 8-byte slot written per build row
     timed(KC_GJOIN_BUILD, 0, B.cap, B.n_dev, 4ull * a.n_keys + 8, nullptr, 0, 0, [&] { launch_gjoin_build(a, stream); });

@@ -38,6 +38,7 @@ struct NodeInfo {
   u32 refs = 0;                   // how many operators consume this node
   u64 last_rows = 0; bool has_last = false;   // output cardinality of the previous execution (speculative sizing)
   bool last_scaled = false;
+  bool transient_direct_failed = false;        // a build side that is not cached turned out not to be unique and dense: do not try the direct-address form again
   u64 band_blocks = 0;                         // blocks of the band join based on this node in its previous execution (launch sizing)
   u64 band_run_stats = 0;                      // sampled rows << 32 | runs of equal neighbouring probe keys (a piecewise sorted probe side takes the counting partition)
   int parent = -1;                             // the one operator consuming this node (-1: the root, or several)
@@ -67,7 +68,7 @@ enum KernelClass {
   KC_FILTER_VERDICT, KC_REGEX_VERDICTS, KC_UNION,
   KC_BAND_SLOW, KC_RADIX_SORT, KC_BAND_BOUNDS, KC_BAND_BLOCKS, KC_BAND_DECODE, KC_BAND_MASK, KC_BAND_EMIT, KC_BAND_ENTRIES, KC_BAND_DESC, KC_BAND_PT, KC_BAND_ROWS,
   KC_FILTER_BITS_ID, KC_FILTER_BITS_TV, KC_FILTER_BITS_VERDICT, KC_FILTER_BITS_VALUE, KC_VALUE_VERDICTS, KC_VALUE_RUNS, KC_RUN_SCAN, KC_RUN_COPY, KC_OJ_PROBE, KC_OJ_COUNT, KC_OJ_WRITE, KC_FILTER_WRITE,
-  KC_PART_KEYS, KC_PART_JOIN, KC_OJ_BAND_RECORDS, KC_OJ_WRITE_BAND, KC_SMALL_SCAN, KC_PART_PASS,
+  KC_PART_KEYS, KC_PART_JOIN, KC_OJ_BAND_RECORDS, KC_OJ_WRITE_BAND, KC_SMALL_SCAN, KC_PART_PASS, KC_STREAM_JOIN,
   KC_LDS_JOIN0,                      // 192 names: lds_join_kernel<FS in {0..3}, PFS in {0,1,2}, ITEMS in {4,1}, MODE in {0,1,2,3}, CHAIN>
   KC__N = KC_LDS_JOIN0 + 192
 };
@@ -158,6 +159,7 @@ struct Plan {
   DevTable exec_lds_join(NodeInfo& nd, const DevTable& L, const DevTable& R, bool build_left, const NodeInfo* probe_filter, const NodeInfo* post_filter = nullptr);
   bool plan_chain(NodeInfo& top, ChainRequest& req);
   void build_dense_table(SliceTable* st, const u32* key, u64 n);
+  bool build_transient_direct(LdsJoinArgs& a, u64 n);
   bool apply_chain(const ChainRequest& req, NodeInfo& base, const DevTable& L, const DevTable& R, bool build_left, LdsJoinArgs& a, u64& stage_bytes, BandArgs* band, bool* use_band);
   void prepare_partitions(const LdsJoinArgs& a, const DevTable& B, const DevTable& P, PartArgs& pa);
   void exec_band_join(LdsJoinArgs& a, BandArgs& b, const DevTable& B, const DevTable& P, u64 build_bytes_per_row, u64 probe_bytes_per_row);

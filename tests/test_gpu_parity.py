@@ -165,9 +165,11 @@ JOIN_TABLE_MODES = {
     "lds_hash": ({}, 1, "lds_join_kernel<0, 0, "),                                  # every workgroup builds the table in LDS
     "lds_hash_scaled": ({"NO_INDEX_JOIN": 1, "NO_TABLE_CACHE": 1, "LDS_MAX_BUILD": 1 << 20}, 300, ", 0, false"),
     "classic_hbm_chains": ({"NO_LDS_JOIN": 1}, 1, "join_probe_kernel"),             # heads / next chains in HBM, count + scan + write
-    "hbm_hash_built_per_run": ({"LDS_MAX_BUILD": 1, "NO_TABLE_CACHE": 1, "NO_PARTITIONED_JOIN": 1}, 3000, ", 1, false"),
-    "hbm_hash_cached_slice": ({"LDS_MAX_BUILD": 1, "NO_DIRECT_TABLE": 1}, 3000, ", 1, false"),
-    "direct_address": ({"LDS_MAX_BUILD": 1}, 3000, ", 2, false"),                  # unique dense keys: row = direct[key - min]
+    "hbm_hash_built_per_run": ({"LDS_MAX_BUILD": 1, "NO_TABLE_CACHE": 1, "NO_PARTITIONED_JOIN": 1, "NO_STREAM_JOIN": 1}, 3000, ", 1, false"),
+    "hbm_hash_cached_slice": ({"LDS_MAX_BUILD": 1, "NO_DIRECT_TABLE": 1, "NO_STREAM_JOIN": 1}, 3000, ", 1, false"),
+    "hbm_hash_streamed": ({"LDS_MAX_BUILD": 1, "NO_TABLE_CACHE": 1, "NO_PARTITIONED_JOIN": 1}, 3000, "stream_join_kernel"),   # the same table, rows kept in registers (stream_join.hip)
+    "direct_address": ({"LDS_MAX_BUILD": 1}, 3000, "stream_join_kernel"),   # unique dense keys: row = direct[key - min]; rows stay in registers (stream_join.hip)
+    "direct_address_generic_kernel": ({"LDS_MAX_BUILD": 1, "NO_STREAM_JOIN": 1}, 3000, ", 2, false"),   # the same table under the queueing kernel
     "csr": ({"LDS_MAX_BUILD": 1}, 3000, ", 3, false"),                             # (the data gets duplicate keys, see below)
     "radix_partitioned": ({"LDS_MAX_BUILD": 1, "NO_TABLE_CACHE": 1, "PARTITION_MIN_BUILD": 1}, 3000, "part_join_kernel"),
 }
@@ -941,8 +943,9 @@ def test_index_join_against_store_slice(torch_cuda, shape, n_tab):
         np.testing.assert_array_equal(ku.multiset(again), ku.multiset(got))
         if n_tab == 700 and not ENGINE_TOGGLED:   # the table mode is the fourth template argument of the kernel name: 2 direct, 3 CSR, 1 hash
             mode = {"unique_dense": "2", "dup_sorted": "3", "dup_scattered": "3", "sparse": "1"}[shape]
-            joins = [k[0] for k in plan.kernel_stats() if "lds_join_kernel" in k[0]]
-            assert joins and all(k.rstrip(">").split(", ")[3] == mode for k in joins), (shape, joins)
+            # (a direct-address or hash table without a VM filter is probed by stream_join.hip's register-resident form)
+            joins = [k[0] for k in plan.kernel_stats() if "lds_join_kernel" in k[0] or "stream_join_kernel" in k[0]]
+            assert joins and all(("stream_join_kernel" in k and mode in "12") or k.rstrip(">").split(", ")[3] == mode for k in joins), (shape, joins)
         # and with the inputs swapped (the slice as the plan's left child: (s, o) at 0, 1; the table at 2, 3, 4)
         pb = PlanBuilder()
         scan = pb.data_source(quad_pattern("s", pred, "o"))
@@ -1591,7 +1594,7 @@ TOGGLES = ["RDFGPU_NO_CHAIN_FUSION", "RDFGPU_NO_INDEX_JOIN", "RDFGPU_NO_TABLE_CA
            "RDFGPU_NO_GLOBAL_TABLE_JOIN", "RDFGPU_NO_FILTER_FUSION", "RDFGPU_NO_VALUE_TABLES", "RDFGPU_NO_RANGE_INDEX",
            "RDFGPU_NO_BAND_JOIN", "RDFGPU_NO_PARTITIONED_JOIN", "RDFGPU_NO_JOIN_REORDER", "RDFGPU_NO_STRING_VERDICTS",
            "RDFGPU_NO_VALUE_VERDICTS", "RDFGPU_NO_RUN_COPY", "RDFGPU_NO_PRIMING", "RDFGPU_NO_ORDERED_JOIN", "RDFGPU_NO_BAND_PACK16", "RDFGPU_NO_RANGE_PARTITION",
-           "RDFGPU_NO_OWN_PARTITION_PASS", "RDFGPU_NO_BAND_COMPACT", "RDFGPU_NO_PROBE_OUTER_JOIN"]
+           "RDFGPU_NO_OWN_PARTITION_PASS", "RDFGPU_NO_BAND_COMPACT", "RDFGPU_NO_PROBE_OUTER_JOIN", "RDFGPU_NO_STREAM_JOIN"]
 
 
 @pytest.mark.parametrize("toggle", TOGGLES)
