@@ -588,6 +588,8 @@ enum {
   RDFGPU_OPT_NO_BAND_COMPACT,           /* flag: band join fed by an ordered slice join: 32-byte {record, aux} row records even where 16 bytes would do */
   RDFGPU_OPT_NO_PROBE_OUTER_JOIN,       /* flag: LEFT joins always build on their left input (no probe-preserving form over the right input's slice table) */
   RDFGPU_OPT_NO_STREAM_JOIN,            /* flag: joins against a direct-address table always take the generic queueing kernel (no register-resident streaming form) */
+  RDFGPU_OPT_PARTITION_ROWS,            /* value: build rows per partition a partitioned join aims for (0 = automatic: 1024)   */
+  RDFGPU_OPT_PARTITION_SLOTS,           /* value: slots of a partition's LDS table, a power of two from 1024 to 8192 (0 = automatic: 4096); a partition with more than slots / 2 build rows is joined chunk by chunk */
   RDFGPU_OPT__COUNT
 };
 int rdfgpu_store_set_option(rdfgpu_store* store, uint32_t option, uint64_t value);

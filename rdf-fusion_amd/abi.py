@@ -47,7 +47,7 @@ OP_EQ, OP_GT, OP_GTEQ, OP_LT, OP_LTEQ = range(5)
 OPTION_NAMES = ["FORCE_GENERIC_VM", "NO_JOIN_REORDER", "NO_SPECULATION", "NO_FIRST_RUN_SPECULATION", "NO_STRING_VERDICTS",
                 "NO_TABLE_CACHE", "NO_INDEX_JOIN", "NO_CHAIN_FUSION", "NO_VALUE_TABLES", "NO_RANGE_INDEX", "NO_FILTER_FUSION",
                 "NO_LDS_JOIN", "NO_GLOBAL_TABLE_JOIN", "NO_DIRECT_TABLE", "NO_BAND_JOIN", "NO_PARTITIONED_JOIN", "NO_VALUE_VERDICTS", "NO_PRIMING", "NO_ORDERED_JOIN", "NO_BAND_PACK16", "NO_RUN_COPY", "NO_RANGE_PARTITION",
-                "LDS_MAX_BUILD", "CSR_ROW_LANES_LOG2", "JOIN_WAVE_Q", "PARTITION_MIN_BUILD", "PARTITION_TWO_PASS_ROWS", "NO_OWN_PARTITION_PASS", "NO_BAND_COMPACT", "NO_PROBE_OUTER_JOIN", "NO_STREAM_JOIN"]
+                "LDS_MAX_BUILD", "CSR_ROW_LANES_LOG2", "JOIN_WAVE_Q", "PARTITION_MIN_BUILD", "PARTITION_TWO_PASS_ROWS", "NO_OWN_PARTITION_PASS", "NO_BAND_COMPACT", "NO_PROBE_OUTER_JOIN", "NO_STREAM_JOIN", "PARTITION_ROWS", "PARTITION_SLOTS"]
 OPTIONS = {name: i for i, name in enumerate(OPTION_NAMES)}
 
 

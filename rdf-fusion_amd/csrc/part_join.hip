@@ -247,7 +247,77 @@ __global__ __launch_bounds__(kLdsBlock) __attribute__((amdgpu_waves_per_eu(4))) 
   // microsecond, and an order of magnitude more when that rate collapsed (observed: the same join at 27 ms or at 250-350 ms).
   // A join with a small output (LUBM Q9's closing join: 2 M rows out of 98 M x 229 M) keeps the single pass: its few
   // reservations cost nothing, a second walk over the partition would.
+  // BIG, writing pass: filter and write-out in ONE memory round trip.  The filter's operands and the candidates' output columns (the
+  // first four) are requested together, for four 64-entry groups at once; the survivors' places come from the ballots and the
+  // partition's cursor in LDS, their values go from registers to the output — no compaction through the queue, no second gather.
+  // (The counting pass has told that the partition has survivors at all; a candidate the filter rejects costs its gathers.)
+  auto write_fused = [&]() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    const u32* src[4]; u32* dst[4]; bool from_build[4], on[4];
+#pragma unroll
+    for (u32 u = 0; u < 4; u++) {
+      on[u] = u < a.n_out_cols;
+      const u32 c = a.proj[on[u] ? u : 0u];
+      from_build[u] = (c < a.n_left_cols) == (a.build_is_left != 0);
+      src[u] = a.cols[c];
+      dst[u] = a.out[on[u] ? u : 0u];
+    }
+    for (u32 g0 = 0; g0 < qn; g0 += 256) {         // (qn > 0 inside: the clamped entry exists)
+      uint2 m[4]; bool ok[4], slow[4]; u32 v[4][4];
+#pragma unroll
+      for (u32 g = 0; g < 4; g++) {
+        const u32 e = g0 + g * 64 + lane;
+        ok[g] = e < qn; slow[g] = false;
+        m[g] = wq[e < qn ? e : qn - 1];
+      }
+#pragma unroll
+      for (u32 g = 0; g < 4; g++) {
+#pragma unroll
+        for (u32 u = 0; u < 4; u++) v[g][u] = src[u][from_build[u] ? m[g].x : m[g].y];   // (an unused column slot repeats column 0)
+      }
+      if constexpr (FS != 0) {
+#pragma unroll
+        for (u32 g = 0; g < 4; g++) { bool sl; const bool f = ljoin_filter_fast<FS>(a, m[g].x, m[g].y, sl); slow[g] = ok[g] && sl; ok[g] = ok[g] && f; }
+        if constexpr (FS == 1 || FS == 3) {
+#pragma unroll
+          for (u32 g = 0; g < 4; g++) if (slow[g]) ok[g] = ljoin_filter_slow<FS>(a, m[g].x, m[g].y);
+        }
+      }
+      unsigned long long mk[4]; u32 goff[4]; u32 n = 0;
+#pragma unroll
+      for (u32 g = 0; g < 4; g++) { mk[g] = __ballot(ok[g]); goff[g] = n; n += (u32)__popcll(mk[g]); }
+      u32 off = 0;
+      if (lane == 0 && n) off = atomicAdd(&wg_cursor, n);
+      off = __shfl(off, 0, 64);
+      u64 pos[4];
+#pragma unroll
+      for (u32 g = 0; g < 4; g++) { pos[g] = wg_base + off + goff[g] + lane_prefix(mk[g]); ok[g] = ok[g] && pos[g] < a.out_cap; }
+#pragma unroll
+      for (u32 g = 0; g < 4; g++) {
+#pragma unroll
+        for (u32 u = 0; u < 4; u++) if (ok[g] && on[u]) dst[u][pos[g]] = v[g][u];
+      }
+      for (u32 oc0 = 4; oc0 < a.n_out_cols; oc0 += 4) {   // further output columns: gathered for the survivors
+#pragma unroll
+        for (u32 u = 0; u < 4; u++) {
+          if (oc0 + u >= a.n_out_cols) break;
+          const u32 c = a.proj[oc0 + u];
+          const bool fb = (c < a.n_left_cols) == (a.build_is_left != 0);
+          const u32* sc = a.cols[c]; u32* dc = a.out[oc0 + u];
+#pragma unroll
+          for (u32 g = 0; g < 4; g++) if (ok[g]) dc[pos[g]] = sc[fb ? m[g].x : m[g].y];
+        }
+      }
+      if (a.visited) {
+#pragma unroll
+        for (u32 g = 0; g < 4; g++) if (ok[g]) a.visited[m[g].x] = 1;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+  };
   auto flush = [&](bool counting) {
+    if constexpr (BIG) { if (!counting) { write_fused(); qn = 0; return; } }
     resolve();
     if (counting) { if (lane == 0 && qn) atomicAdd(&wg_count, qn); }
     else if (!pa.two_pass) {

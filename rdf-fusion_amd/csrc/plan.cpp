@@ -1835,11 +1835,11 @@ DevTable Plan::exec_lds_join(NodeInfo& nd, const DevTable& L, const DevTable& R,
 
   if (use_part) {
     flush_pending_oj();
-    prepare_partitions(a, B, P, part);   // the build half of this HashJoinExec: inside the operator, every execution
     // output of the previous execution (none: single pass): above ~50 M rows the reservations of a single pass (one
     // same-address atomic per 256 rows, ~88 per microsecond) cost more than walking every partition twice
     const u64 expect_out = nd.has_last ? nd.last_rows : 0;
     part.two_pass = expect_out >= opt.v[RDFGPU_OPT_PARTITION_TWO_PASS_ROWS] ? 1u : 0u;
+    prepare_partitions(a, B, P, part);   // the build half of this HashJoinExec: inside the operator, every execution
   }
   // SURVEY 8d hash-join bytes of a partitioned join: both sides' key + payload columns and one 8-byte slot per row, the output;
   // the partition passes are in the time of the operator, not in its bytes
@@ -1992,9 +1992,19 @@ DevTable Plan::exec_lds_join(NodeInfo& nd, const DevTable& L, const DevTable& R,
 // partition, marked (row = kNil) so that the join skips them.
 void Plan::prepare_partitions(const LdsJoinArgs& a, const DevTable& B, const DevTable& P, PartArgs& pa) {
   u32 bits = 0;
-  while (bits < 16 && (B.cap >> bits) > kPartTargetRows) bits++;   // <= 16 bits = two radix passes; larger partitions are joined chunk by chunk
+  u32 target_rows = kPartTargetRows, part_slots = kPartSlots;
+  // a join with a large output is bound by the latency of its gathers (part_join.hip, BIG): a 2048-slot table (24 KB) lets three
+  // workgroups share a CU instead of two — 8.25 -> 7.5 ms on the 0.54 G-row candidate join of BSBM Q5 (profiles/tools/nc_variants.py)
+  if (pa.two_pass) { part_slots = 2048; target_rows = 512; }
+  if (opt.v[RDFGPU_OPT_PARTITION_SLOTS]) {
+    const u64 v = opt.v[RDFGPU_OPT_PARTITION_SLOTS];
+    if (v < 1024 || v > 8192 || (v & (v - 1))) fail(RDFGPU_ERR_INVALID, "PARTITION_SLOTS = %llu (a power of two from 1024 to 8192)", (unsigned long long)v);
+    part_slots = (u32)v; target_rows = part_slots / 4;
+  }
+  if (opt.v[RDFGPU_OPT_PARTITION_ROWS]) target_rows = (u32)std::min<u64>(opt.v[RDFGPU_OPT_PARTITION_ROWS], part_slots / 2);
+  while (bits < 16 && (B.cap >> bits) > target_rows) bits++;   // <= 16 bits = two radix passes; larger partitions are joined chunk by chunk
   const u32 n_parts = 1u << bits;
-  pa.n_parts = n_parts; pa.chunk = kPartChunk; pa.tbl_mask = kPartSlots - 1;
+  pa.n_parts = n_parts; pa.chunk = part_slots / 2; pa.tbl_mask = part_slots - 1;
   // The probe side is a store slice sorted by one of the join keys (and every row of it is live): its partitions are KEY RANGES
   // of that column — contiguous pieces of the slice, found by one binary search per partition and read in place; only the
   // build side goes through the partition sort (LUBM Q9's closing join: 98 M of 327 M rows).
