@@ -733,6 +733,55 @@ def test_partition_passes_edge_cases(torch_cuda, nb, case):
     del kb, kp
 
 
+@pytest.mark.parametrize("join_type", ["inner", "left"])
+def test_partitioned_join_large_output_form_and_table_geometry(torch_cuda, join_type):
+    """The partitioned join's large-output form (part_join.hip, BIG: a counting pass, one reservation per partition, then a writing pass that
+    filters and writes in one round trip) on a many-to-many join — ~40 partners per probe row — without a filter, with `col != col`, with a
+    window over typed values and with a VM filter; six output columns (the second column group of the write-out); under every table
+    geometry PARTITION_ROWS / PARTITION_SLOTS allow (partitions joined chunk by chunk included).  The form needs the previous
+    execution's cardinality: the first execution runs single-pass, the later ones two-pass; all equal the oracle's multiset."""
+    rng = np.random.default_rng(77)
+    nb, npr, n_keys = 60_000, 30_000, 1_500
+    tv, dec = typed_zoo()
+    n_tv = len(tv)
+    gs, os_ = both_stores((np.zeros(0, np.uint32),) * 4, typed=tv)
+    gs.set_option("PARTITION_MIN_BUILD", 1000)
+    gs.set_option("PARTITION_TWO_PASS_ROWS", 1)
+    B = [rng.integers(1, n_keys + 1, nb).astype(np.uint32), rng.integers(1, 40, nb).astype(np.uint32), rng.integers(1, n_tv, nb).astype(np.uint32)]
+    Pr = [rng.integers(1, n_keys + 20, npr).astype(np.uint32), rng.integers(1, 40, npr).astype(np.uint32), rng.integers(1, n_tv, npr).astype(np.uint32),
+          np.arange(1, npr + 1, dtype=np.uint32)]
+    B[0][rng.random(nb) < 0.01] = 0; Pr[0][rng.random(npr) < 0.01] = 0             # null keys join nothing
+    kb, pbp = table_on_device(torch_cuda, B)
+    kp, ppp = table_on_device(torch_cuda, Pr)
+    window = AND(EBV(LT(ENC_TV(col(2)), ADD(ENC_TV(col(5)), integer(40)))), EBV(GT(ENC_TV(col(2)), SUB(ENC_TV(col(5)), integer(40)))))
+    filters = [None, ID_NEQ(col(1), col(4)), window, EBV(GT(ADD(ENC_TV(col(2)), ENC_TV(col(5))), integer(3)))]
+    jt = abi.JOIN_INNER if join_type == "inner" else abi.JOIN_LEFT
+    for flt in filters:
+        pb = PlanBuilder()
+        desc = pb.build(pb.hash_join(pb.table(0, 3), pb.table(1, 4), on=[(0, 0)], filter=flt, join_type=jt, projection=[0, 1, 2, 4, 5, 6]))
+        exp, n_exp, _ = os_.execute(desc, [B, Pr])
+        want = ku.multiset(exp, n_exp)
+        for geometry in ({}, {"PARTITION_SLOTS": 1024, "PARTITION_ROWS": 512}, {"PARTITION_SLOTS": 8192, "PARTITION_ROWS": 4096}, {"PARTITION_ROWS": 16}, {"PARTITION_SLOTS": 4096, "PARTITION_ROWS": 100_000}):
+            plan = gs.plan(desc)
+            for name, value in geometry.items():
+                plan.set_option(name, value)
+            plan.bind_table(0, pbp, nb); plan.bind_table(1, ppp, npr)
+            for run in range(3):
+                plan.enable_kernel_timing(True)
+                got = plan.execute().fetch()
+                assert plan.result_info()[0] == n_exp, (join_type, geometry, run)
+                np.testing.assert_array_equal(ku.multiset(got, n_exp), want, err_msg=f"{join_type} {geometry} run {run}")
+                if not ENGINE_TOGGLED:
+                    assert any("part_join_kernel" in k[0] for k in plan.kernel_stats()), plan.kernel_stats()
+            plan.close()
+    plan = gs.plan(desc).set_option("PARTITION_SLOTS", 3000)                         # not a power of two: refused when the join is prepared
+    plan.bind_table(0, pbp, nb); plan.bind_table(1, ppp, npr)
+    with pytest.raises(RuntimeError):
+        plan.execute()
+    plan.close()
+    del kb, kp
+
+
 @pytest.mark.parametrize("n_quads,nb", [(300_000, 200_000), (2_500_000, 1_200_000)])
 def test_partitioned_join_over_sorted_slice(torch_cuda, n_quads, nb):
     """Partitioned join whose probe side is a store slice sorted by one of the join keys: the slice is read in place, its
