@@ -15,7 +15,8 @@ for rep in range(2):
     plan.bind_table(0, [t.data_ptr(), t.data_ptr() + 4 * B], B)
     torch.cuda.synchronize(); t0 = time.perf_counter(); plan.execute(); dt = time.perf_counter() - t0
     m = plan.metrics()
-    print("first execution of a fresh plan; store tables", "cold" if rep == 0 else "warm", "wall_ms", round(dt * 1e3, 3), "dev_ms", round(m.elapsed_compute_ms, 3), "kernels", m.kernels_launched, "syncs", m.host_syncs, "tables", m.tables_built)
+    print("first execution of a fresh plan; store tables", "cold" if rep == 0 else "warm", "wall_ms", round(dt * 1e3, 3), "dev_ms", round(m.elapsed_compute_ms, 3), "kernels", m.kernels_launched, "syncs", m.host_syncs, "tables", m.tables_built,
+          "hipMallocs", m.device_mallocs, "ms in them", round(m.device_malloc_ms, 3), "bytes", m.device_bytes)
     tot = 0
     for k in sorted(plan.kernel_stats(), key=lambda k: -k[2])[:14]:
         print("   %-60s x%-3d %8.3f ms" % (k[0][:60], k[1], k[2])); tot += k[2]

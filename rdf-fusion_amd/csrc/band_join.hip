@@ -713,4 +713,6 @@ void launch_csr_max_group(const u32* off, u32 kn, u32* out_dev, hipStream_t s) {
   hipLaunchKernelGGL(csr_max_group_kernel, dim3((unsigned)(g ? (g > 1024 ? 1024 : g) : 1)), dim3(256), 0, s, off, kn, out_dev);
 }
 
+// (kernels.hpp, preload_code_objects: the runtime loads a translation unit's code object at the first use of one of its kernels)
+void preload_tu_band_join() { hipFuncAttributes at; RDFGPU_HIP(hipFuncGetAttributes(&at, reinterpret_cast<const void*>(band_bounds_kernel))); }
 }  // namespace rdfgpu

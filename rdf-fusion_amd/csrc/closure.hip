@@ -229,4 +229,6 @@ u64 closure_exec(const u32* g, const u32* s, const u32* e, u64 n, bool cross_gra
   return na;
 }
 
+// (kernels.hpp, preload_code_objects: the runtime loads a translation unit's code object at the first use of one of its kernels)
+void preload_tu_closure() { hipFuncAttributes at; RDFGPU_HIP(hipFuncGetAttributes(&at, reinterpret_cast<const void*>(concat2_kernel))); }
 }  // namespace rdfgpu

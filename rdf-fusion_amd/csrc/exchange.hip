@@ -309,4 +309,6 @@ u64 exchange_repartition(Comm* c, const u32* const* cols, u32 n_cols, u64 n_rows
   return alltoallv_tables(c, send.data(), n_cols, rows.data(), off.data(), out_cols, 0);
 }
 
+// (kernels.hpp, preload_code_objects: the runtime loads a translation unit's code object at the first use of one of its kernels)
+void preload_tu_exchange() { hipFuncAttributes at; RDFGPU_HIP(hipFuncGetAttributes(&at, reinterpret_cast<const void*>(repart_count_kernel))); }
 }  // namespace rdfgpu

@@ -4,4 +4,6 @@
 
 namespace rdfgpu {
 RDFGPU_DEFINE_JOIN_FS(1)
+// (kernels.hpp, preload_code_objects: the runtime loads a translation unit's code object at the first use of one of its kernels)
+void preload_tu_join_fs1() { hipFuncAttributes at; RDFGPU_HIP(hipFuncGetAttributes(&at, reinterpret_cast<const void*>((lds_join_kernel<1, 0, 1, kJoinTableLds, false, 1>)))); }
 }  // namespace rdfgpu

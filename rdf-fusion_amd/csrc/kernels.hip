@@ -1194,4 +1194,6 @@ void sort_pairs_u64_u32(const u64* kin, u64* kout, const u32* vin, u32* vout, u6
   RDFGPU_HIP(rocprim::radix_sort_pairs(temp, temp_bytes, kin, kout, vin, vout, (size_t)n, 0, 64, s));
 }
 
+// (kernels.hpp, preload_code_objects: the runtime loads a translation unit's code object at the first use of one of its kernels)
+void preload_tu_kernels() { hipFuncAttributes at; RDFGPU_HIP(hipFuncGetAttributes(&at, reinterpret_cast<const void*>(locate_kernel))); }
 }  // namespace rdfgpu

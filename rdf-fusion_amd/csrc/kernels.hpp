@@ -231,6 +231,23 @@ struct LdsJoinArgs {
   // unfiltered): applied to every candidate pair as one more conjunct of the join filter.  post.col indexes cols[].
   u32 has_post; IdFilter post;
 };
+// The HIP runtime loads a translation unit's code object lazily, at the first use of one of its kernels: 3 - 35 ms each, which a first
+// query would pay (round 3's bench showed a 20 ms "cold start" of which 1.6 ms were kernels).  A store loads them all when it is created.
+void preload_code_objects();
+void preload_tu_kernels();
+void preload_tu_band_join();
+void preload_tu_ordered_join();
+void preload_tu_ntriples();
+void preload_tu_part_join();
+void preload_tu_part_pass();
+void preload_tu_stream_join();
+void preload_tu_exchange();
+void preload_tu_topk();
+void preload_tu_closure();
+void preload_tu_join_fs0();
+void preload_tu_join_fs1();
+void preload_tu_join_fs2();
+void preload_tu_join_fs3();
 void launch_lds_join(const LdsJoinArgs& a, hipStream_t s);
 // stream_join.hip: the same operator against a direct-address table as a streaming pass (launch_lds_join routes to it when a.stream_direct)
 bool direct_stream_join_ok(const LdsJoinArgs& a);

@@ -524,4 +524,6 @@ void ntriples_terms(const NTriples* t, u64* offsets, unsigned char* bytes) {
   if (bytes && t->term_total) RDFGPU_HIP(hipMemcpy(bytes, t->term_bytes, t->term_total, hipMemcpyDeviceToHost));
 }
 
+// (kernels.hpp, preload_code_objects: the runtime loads a translation unit's code object at the first use of one of its kernels)
+void preload_tu_ntriples() { hipFuncAttributes at; RDFGPU_HIP(hipFuncGetAttributes(&at, reinterpret_cast<const void*>(nt_line_flags_kernel))); }
 }  // namespace rdfgpu

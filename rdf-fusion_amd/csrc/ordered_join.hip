@@ -279,4 +279,6 @@ void launch_ordered_join_write(const OrderedJoinArgs& a, hipStream_t s) {
   fail(RDFGPU_ERR_INVALID, "ordered join with %u output columns", a.n_out_cols);
 }
 
+// (kernels.hpp, preload_code_objects: the runtime loads a translation unit's code object at the first use of one of its kernels)
+void preload_tu_ordered_join() { hipFuncAttributes at; RDFGPU_HIP(hipFuncGetAttributes(&at, reinterpret_cast<const void*>(oj_probe_kernel))); }
 }  // namespace rdfgpu

@@ -490,4 +490,6 @@ void launch_part_join(const LdsJoinArgs& a, const PartArgs& pa, hipStream_t s) {
   fail(RDFGPU_ERR_INVALID, "partitioned join: bad filter shape %u", a.has_filter);
 }
 
+// (kernels.hpp, preload_code_objects: the runtime loads a translation unit's code object at the first use of one of its kernels)
+void preload_tu_part_join() { hipFuncAttributes at; RDFGPU_HIP(hipFuncGetAttributes(&at, reinterpret_cast<const void*>(part_keys_kernel))); }
 }  // namespace rdfgpu

@@ -359,4 +359,6 @@ void part_pass_run(const PartPassBuffers& w, const PartPassPlan& pl, const u32* 
   hipLaunchKernelGGL(part_scatter_kernel<true>, dim3(pl.max_tiles_b), dim3(kPtBlock), 0, s, b);
 }
 
+// (kernels.hpp, preload_code_objects: the runtime loads a translation unit's code object at the first use of one of its kernels)
+void preload_tu_part_pass() { hipFuncAttributes at; RDFGPU_HIP(hipFuncGetAttributes(&at, reinterpret_cast<const void*>((part_hist_kernel<false>)))); }
 }  // namespace rdfgpu

@@ -160,7 +160,28 @@ Store* store_create(const rdfgpu_config* cfg) {
   s->gen = std::make_shared<IndexGeneration>();
   s->gen->device = dev;
   RDFGPU_HIP(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+  preload_code_objects();   // once per process: no query pays for the runtime's lazy code-object loading
   return s;
+}
+
+void preload_code_objects() {
+  static std::once_flag once;
+  std::call_once(once, [] {
+    preload_tu_kernels();
+    preload_tu_band_join();
+    preload_tu_ordered_join();
+    preload_tu_ntriples();
+    preload_tu_part_join();
+    preload_tu_part_pass();
+    preload_tu_stream_join();
+    preload_tu_exchange();
+    preload_tu_topk();
+    preload_tu_closure();
+    preload_tu_join_fs0();
+    preload_tu_join_fs1();
+    preload_tu_join_fs2();
+    preload_tu_join_fs3();
+  });
 }
 
 void Store::activate() const { RDFGPU_HIP(hipSetDevice(device)); }

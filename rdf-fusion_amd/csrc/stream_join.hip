@@ -222,4 +222,6 @@ void launch_direct_stream_join(const LdsJoinArgs& a, hipStream_t s) {
   fail(RDFGPU_ERR_INVALID, "streaming direct-table join: bad filter shape %u", a.has_filter);
 }
 
+// (kernels.hpp, preload_code_objects: the runtime loads a translation unit's code object at the first use of one of its kernels)
+void preload_tu_stream_join() { hipFuncAttributes at; RDFGPU_HIP(hipFuncGetAttributes(&at, reinterpret_cast<const void*>((stream_join_kernel<0, 0, 1, kJoinTableDirect>)))); }
 }  // namespace rdfgpu

@@ -138,4 +138,6 @@ void launch_topk_scatter(const TopkArgs& a, hipStream_t s) { hipLaunchKernelGGL(
 void launch_topk_select(const TopkArgs& a, hipStream_t s) { hipLaunchKernelGGL(topk_select_kernel, grid256((u64)a.n_groups * 64), dim3(256), 0, s, a); }
 void launch_topk_write(const TopkArgs& a, hipStream_t s) { hipLaunchKernelGGL(topk_write_kernel, grid256((u64)a.n_groups * a.k), dim3(256), 0, s, a); }
 
+// (kernels.hpp, preload_code_objects: the runtime loads a translation unit's code object at the first use of one of its kernels)
+void preload_tu_topk() { hipFuncAttributes at; RDFGPU_HIP(hipFuncGetAttributes(&at, reinterpret_cast<const void*>(topk_max_kernel))); }
 }  // namespace rdfgpu
