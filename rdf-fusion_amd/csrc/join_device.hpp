@@ -199,6 +199,26 @@ __device__ __forceinline__ bool window_fast_x(const TypedTable& tt, long long x,
   const u32 c0 = x < z0 ? 1u : x > z0 ? 4u : 2u, c1 = x < z1 ? 1u : x > z1 ? 4u : 2u;
   return !o0 && !o1 && (mask_of(l0.cmp_op) & c0) != 0 && (mask_of(l1.cmp_op) & c1) != 0;
 }
+// ... and with the two y operands known to be one column (same_y, wave-uniform): one typed-value gather per candidate
+__device__ __forceinline__ bool window_fast_xy(const TypedTable& tt, long long x, u32 iy0, u32 iy1, bool same_y, const TvLiteral& l0, const TvLiteral& l1, bool& undecided) {
+  if (tt.n_ids == 0) { undecided = true; return false; }
+  const u64 n_ids = tt.n_ids;
+  iy0 = iy0 < n_ids ? iy0 : 0u; iy1 = iy1 < n_ids ? iy1 : 0u;
+  const int4* tv = reinterpret_cast<const int4*>(tt.tv);
+  const int4 ry0 = tv[iy0];
+  const int4 ry1 = same_y ? ry0 : tv[iy1];
+  undecided = ((u32)ry0.w & 0xff) != RDFGPU_TV_INTEGER || ((u32)ry1.w & 0xff) != RDFGPU_TV_INTEGER || l0.tag != RDFGPU_TV_INTEGER || l1.tag != RDFGPU_TV_INTEGER;
+  auto i64 = [](const int4& r) { return (long long)(((u64)(u32)r.y << 32) | (u32)r.x); };
+  const bool neg0 = l0.arith_sub != 0, neg1 = l1.arith_sub != 0;
+  undecided = undecided || (neg0 && l0.lo == INT64_MIN) || (neg1 && l1.lo == INT64_MIN);
+  const long long d0 = neg0 ? -(long long)(l0.lo == INT64_MIN ? 0 : l0.lo) : (long long)l0.lo;
+  const long long d1 = neg1 ? -(long long)(l1.lo == INT64_MIN ? 0 : l1.lo) : (long long)l1.lo;
+  long long z0, z1;
+  const bool o0 = __builtin_add_overflow(i64(ry0), d0, &z0), o1 = __builtin_add_overflow(i64(ry1), d1, &z1);
+  auto mask_of = [](u8 op) -> u32 { return op == RDFGPU_EX_GT ? 4u : op == RDFGPU_EX_LT ? 1u : op == RDFGPU_EX_GEQ ? 6u : op == RDFGPU_EX_LEQ ? 3u : op == RDFGPU_EX_EQ ? 2u : 5u; };
+  const u32 c0 = x < z0 ? 1u : x > z0 ? 4u : 2u, c1 = x < z1 ? 1u : x > z1 ? 4u : 2u;
+  return !o0 && !o1 && (mask_of(l0.cmp_op) & c0) != 0 && (mask_of(l1.cmp_op) & c1) != 0;
+}
 __device__ __forceinline__ bool window_slow(const TypedTable& tt, u32 ix0, u32 iy0, u32 ix1, u32 iy1, const TvLiteral& l0, const TvLiteral& l1) {
   const Val x0 = enc_tv(tt, ix0), y0 = enc_tv(tt, iy0), x1 = enc_tv(tt, ix1), y1 = enc_tv(tt, iy1);
   const Val z0 = tv_arith(y0, lit_val(l0), l0.arith_sub != 0);

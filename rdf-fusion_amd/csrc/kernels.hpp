@@ -217,6 +217,10 @@ struct LdsJoinArgs {
   u32 probe_outer;          // LEFT JOIN preserved on the PROBE side (the engine built on the right input's table): a probe row without a match is
                             // emitted once with an all-null build side (candidate {kOuterNull, row}); needs no filter, no chain, one lane per row
   u32 stream_direct;        // 1: a direct-address join of a shape stream_join.hip takes runs there (registers, no queue); 0: always the generic kernel
+  // stream_join.hip, window filter whose x operand is ONE build column: that column's decoded xsd:integer by KEY (index key - direct_min; INT64_MIN = the
+  // table has no row for the key), built per execution next to the direct table — a probe row then costs one 8-byte gather instead of the dependent
+  // chain direct[] -> value id -> typed value.  stream_need_build_row: an output column or the post filter reads the build row (else direct[] is not read).
+  const long long* key_vals; u32 stream_need_build_row; u32 pad_stream;
   u32 has_filter, has_probe_filter;   // join filter: 0 none / 1 VM / 3 window ; probe filter: 0 none / 1 id-literal / 2 VM
   TypedTable tt;
   // Generic programs live in device memory (a 2.5 KB by-value kernarg block made the compiler copy the

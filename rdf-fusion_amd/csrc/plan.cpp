@@ -1844,9 +1844,34 @@ DevTable Plan::exec_lds_join(NodeInfo& nd, const DevTable& L, const DevTable& R,
   // SURVEY 8d hash-join bytes of a partitioned join: both sides' key + payload columns and one 8-byte slot per row, the output;
   // the partition passes are in the time of the operator, not in its bytes
   const u64 part_fixed = (4ull * (a.n_keys + build_payload) + 8) * B.cap;
+  bool stream_values_tried = false;
   auto launch_join = [&](int kc_lds, u64 fixed_bytes, u64 out_bytes_per_row) {
     if (use_part) timed(KC_PART_JOIN, part_fixed, P.cap, P.n_dev, 4ull * probe_cols + 8, n_out, 0, out_bytes_per_row, [&] { launch_part_join(a, part, stream); });
-    else timed(a.stream_direct && direct_stream_join_ok(a) ? (int)KC_STREAM_JOIN : kc_lds, fixed_bytes, P.cap, P.n_dev, 4ull * probe_cols + 8, n_out, 0, out_bytes_per_row, [&] { launch_lds_join(a, stream); });
+    else {
+      const bool streamed = a.stream_direct && direct_stream_join_ok(a);
+      // the streaming form over a direct table, window filter on ONE build column against probe columns, a probe side large enough to pay
+      // for a kernel and a host round trip: that column decoded per KEY (a.key_vals), once per execution
+      if (streamed && !stream_values_tried && a.direct && a.has_filter == 3 && a.has_probe_filter == 0 && B.n_dev == nullptr && a.tt.n_ids != 0 &&
+          direct_stream_join_items(P.cap) == 8 && P.cap >= (1ull << 22) && !opt.on(RDFGPU_OPT_NO_VALUE_TABLES)) {
+        stream_values_tried = true;
+        auto from_build = [&](u32 c) { return (c < L.n_cols) == build_left; };
+        if (a.win.x0 == a.win.x1 && from_build(a.win.x0) && !from_build(a.win.y0) && !from_build(a.win.y1)) {
+          long long* vals = scratch<long long>(a.direct_n);
+          u32* bad = reinterpret_cast<u32*>(new_counter());
+          launch_fill_i64(vals, INT64_MIN, a.direct_n, stream);
+          launch_direct_values(a.build_key[0], a.cols[a.win.x0], B.cap, a.direct_min, a.direct_n, a.tt, vals, bad, stream);
+          u32 is_bad = 0;
+          RDFGPU_HIP(hipMemcpyAsync(&is_bad, bad, sizeof(u32), hipMemcpyDeviceToHost, stream));
+          RDFGPU_HIP(hipStreamSynchronize(stream)); metrics.host_syncs++;
+          if (!is_bad) {
+            a.key_vals = vals; metrics.tables_built++;
+            a.stream_need_build_row = (a.has_post && from_build(a.post.col)) ? 1u : 0u;
+            for (u32 c = 0; c < nd.n_proj; c++) if (from_build(nd.proj[c])) a.stream_need_build_row = 1u;
+          }
+        }
+      }
+      timed(streamed ? (int)KC_STREAM_JOIN : kc_lds, fixed_bytes, P.cap, P.n_dev, 4ull * probe_cols + 8, n_out, 0, out_bytes_per_row, [&] { launch_lds_join(a, stream); });
+    }
   };
   if (build_now)   // build pass: keys read + one 8-byte slot written per build row
     timed(KC_GJOIN_BUILD, 0, B.cap, B.n_dev, 4ull * a.n_keys + 8, nullptr, 0, 0, [&] { launch_gjoin_build(a, stream); });

@@ -20,8 +20,10 @@ namespace rdfgpu {
 
 constexpr int kSjBlock = 512;
 
-template <int FS, int PFS, int IT, int MODE>
+// VT (direct table, window filter FS = 3 whose x operand is one build column): the operand comes decoded from a.key_vals, by key.
+template <int FS, int PFS, int IT, int MODE, bool VT = false>
 __global__ __launch_bounds__(kSjBlock) __attribute__((amdgpu_waves_per_eu(4))) void stream_join_kernel(const LdsJoinArgs a) {
+  static_assert(!VT || (FS == 3 && MODE == kJoinTableDirect), "value tables: direct-address joins with a window filter");
   constexpr bool HASH = MODE == kJoinTableHash;              // the {key, row} open-addressing table in HBM (gjoin_build_kernel); else the direct-address table
   __shared__ u32 wave_tot[kSjBlock / 64];
   __shared__ u64 wg_base;
@@ -30,14 +32,17 @@ __global__ __launch_bounds__(kSjBlock) __attribute__((amdgpu_waves_per_eu(4))) v
   constexpr u32 kTile = (u32)kSjBlock * IT;
   const u64 n_tiles = (np + kTile - 1) / kTile;
   const u32* pk = a.probe_key[0];
+  u32 nkey[HASH ? 1 : IT]; bool have_next = false;             // direct table: the next tile's keys, requested while this tile's output is reserved and written
   for (u64 tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {   // (np >= 1 inside)
     u64 j[IT]; u32 key[IT], b[IT]; bool ok[IT];
     u32 h[IT]; bool more[IT];                                  // HASH: where a row's walk stands; it stopped ON a further key-equal slot
+    long long xv[VT ? IT : 1];                                 // VT: the window's x operand of the row's key (INT64_MIN: no row)
 #pragma unroll
     for (int k = 0; k < IT; k++) {
       const u64 r = tile * kTile + (u32)k * kSjBlock + tid;
       ok[k] = r < np; j[k] = ok[k] ? r : np - 1;
-      key[k] = pk[j[k]];
+      if constexpr (HASH) key[k] = pk[j[k]];
+      else key[k] = have_next ? nkey[k] : pk[j[k]];            // (have_next is uniform)
     }
 #pragma unroll
     for (int k = 0; k < IT; k++) {
@@ -47,7 +52,10 @@ __global__ __launch_bounds__(kSjBlock) __attribute__((amdgpu_waves_per_eu(4))) v
       if constexpr (!HASH) {
         const u32 d = key[k] - a.direct_min;
         ok[k] = ok[k] && d < a.direct_n;                       // a key outside the table's range has no partner
-        b[k] = a.direct[ok[k] ? d : 0u];
+        if constexpr (VT) {
+          xv[k] = a.key_vals[ok[k] ? d : 0u];
+          b[k] = a.stream_need_build_row ? a.direct[ok[k] ? d : 0u] : 0u;   // (wave-uniform; else nothing reads the build row)
+        } else b[k] = a.direct[ok[k] ? d : 0u];
       }
     }
     if constexpr (HASH) {
@@ -82,7 +90,10 @@ __global__ __launch_bounds__(kSjBlock) __attribute__((amdgpu_waves_per_eu(4))) v
       }
     }
 #pragma unroll
-    for (int k = 0; k < IT; k++) { ok[k] = ok[k] && b[k] != kNil; b[k] = ok[k] ? b[k] : 0u; }
+    for (int k = 0; k < IT; k++) {
+      if constexpr (VT) { ok[k] = ok[k] && xv[k] != INT64_MIN; b[k] = ok[k] && b[k] != kNil ? b[k] : 0u; }
+      else { ok[k] = ok[k] && b[k] != kNil; b[k] = ok[k] ? b[k] : 0u; }
+    }
     for (;;) {   // one trip per tile, plus one per further match of its most duplicated key (HASH)
       if (a.has_post) {   // wave-uniform: the former build-side FilterExec (`col <=|!=> literal`), one more conjunct
         const bool post_from_build = (a.post.col < a.n_left_cols) == (a.build_is_left != 0);
@@ -93,7 +104,21 @@ __global__ __launch_bounds__(kSjBlock) __attribute__((amdgpu_waves_per_eu(4))) v
           ok[k] = ok[k] && v != 0 && a.post.lit != 0 && ((v == a.post.lit) == (a.post.is_eq != 0));
         }
       }
-      if constexpr (FS != 0) {
+      if constexpr (VT) {
+        const WindowFilter& w = a.win;
+        const bool same_y = w.y0 == w.y1;                        // wave-uniform
+        const u32* cy0 = a.cols[w.y0]; const u32* cy1 = a.cols[w.y1];
+        bool slow[IT];
+#pragma unroll
+        for (int k = 0; k < IT; k++) {
+          const u32 iy0 = cy0[j[k]], iy1 = same_y ? iy0 : cy1[j[k]];   // the probe side's operands: the lane's own row
+          bool sl;
+          const bool f = window_fast_xy(a.tt, xv[k], iy0, iy1, same_y, w.l0, w.l1, sl);
+          slow[k] = ok[k] && sl; ok[k] = ok[k] && f;
+        }
+#pragma unroll
+        for (int k = 0; k < IT; k++) if (slow[k]) ok[k] = ljoin_filter_slow<FS>(a, a.direct[key[k] - a.direct_min], (u32)j[k]);   // (rare: a non-integer y operand)
+      } else if constexpr (FS != 0) {
         bool slow[IT];
 #pragma unroll
         for (int k = 0; k < IT; k++) {                           // unconditional: the operand gathers of all IT rows leave together
@@ -104,6 +129,27 @@ __global__ __launch_bounds__(kSjBlock) __attribute__((amdgpu_waves_per_eu(4))) v
         if constexpr (FS == 3) {
 #pragma unroll
           for (int k = 0; k < IT; k++) if (slow[k]) ok[k] = ljoin_filter_slow<FS>(a, b[k], (u32)j[k]);   // (rare: non-integer operands)
+        }
+      }
+      // the first four output columns of every row are requested BEFORE the reservation (their addresses do not depend on it; a row the
+      // filter rejected shares its cache lines with rows it kept), and so are the next tile's keys: both are in flight across the two
+      // barriers and the atomic's round trip instead of queueing up behind them
+      const u32* src0[4]; u32* dst0[4]; bool on0[4]; u32 v0[IT][4];
+#pragma unroll
+      for (u32 u = 0; u < 4; u++) {
+        on0[u] = u < a.n_out_cols;
+        const u32 c = a.proj[on0[u] ? u : 0u];
+        const bool fb = (c < a.n_left_cols) == (a.build_is_left != 0);
+        src0[u] = a.cols[c]; dst0[u] = a.out[on0[u] ? u : 0u];
+#pragma unroll
+        for (int k = 0; k < IT; k++) v0[k][u] = fb ? src0[u][b[k]] : src0[u][j[k]];   // (an unused column slot repeats column 0)
+      }
+      if constexpr (!HASH) {
+        const u64 nt = tile + gridDim.x;
+        have_next = nt < n_tiles;                                // uniform
+        if (have_next) {
+#pragma unroll
+          for (int k = 0; k < IT; k++) { const u64 r = nt * kTile + (u32)k * kSjBlock + tid; nkey[k] = pk[r < np ? r : np - 1]; }
         }
       }
       // ---- positions: one reservation for the workgroup's tile; inside it (wave, item, lane) ----
@@ -129,8 +175,13 @@ __global__ __launch_bounds__(kSjBlock) __attribute__((amdgpu_waves_per_eu(4))) v
         u64 pos[IT];
 #pragma unroll
         for (int k = 0; k < IT; k++) { pos[k] = base + koff[k] + lane_prefix(mk[k]); ok[k] = ok[k] && pos[k] < a.out_cap; }
-        // ---- output: four columns at a time, the loads of a group of items before its stores ----
-        for (u32 oc0 = 0; oc0 < a.n_out_cols; oc0 += 4) {
+#pragma unroll
+        for (int k = 0; k < IT; k++) {
+#pragma unroll
+          for (u32 u = 0; u < 4; u++) if (ok[k] && on0[u]) dst0[u][pos[k]] = v0[k][u];
+        }
+        // ---- further output columns: four at a time, the loads of a group of items before its stores ----
+        for (u32 oc0 = 4; oc0 < a.n_out_cols; oc0 += 4) {
           const u32* src[4]; u32* dst[4]; bool from_build[4], on[4];
 #pragma unroll
           for (u32 u = 0; u < 4; u++) {
@@ -214,6 +265,11 @@ void launch_direct_stream_join(const LdsJoinArgs& a, hipStream_t s) {
   const u64 rows = (u64)kSjBlock * items;
   const u64 n_tiles = (a.n_probe_cap + rows - 1) / rows;
   const dim3 g((unsigned)(n_tiles < 8192 ? (n_tiles ? n_tiles : 1) : 8192));   // every workgroup strides over the tiles
+  if (a.key_vals != nullptr) {
+    if (a.has_filter != 3 || a.has_probe_filter != 0 || items != 8 || a.direct == nullptr) fail(RDFGPU_ERR_INVALID, "streaming join: a value table on an unsupported join shape");
+    hipLaunchKernelGGL((stream_join_kernel<3, 0, 8, kJoinTableDirect, true>), g, dim3(kSjBlock), 0, s, a);
+    return;
+  }
   switch (a.has_filter) {
     case 0: return launch_sj_f<0>(a, items, g, s);
     case 2: return launch_sj_f<2>(a, items, g, s);

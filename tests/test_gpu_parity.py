@@ -733,6 +733,57 @@ def test_partition_passes_edge_cases(torch_cuda, nb, case):
     del kb, kp
 
 
+@pytest.mark.parametrize("build_values", ["integers", "one_double"])
+def test_stream_join_with_key_value_table_matches_oracle(torch_cuda, build_values):
+    """stream_join.hip on a probe side of 4.3 M rows (from where a lane keeps eight rows and the window's build-side operand is decoded once per
+    KEY, a.key_vals): TABLE JOIN (?s <p> ?v) ON key = ?s with FILTER(?v < ?y + 30 && ?v > ?y - 30) — unique dense subjects (direct table),
+    keys without a row, null keys, non-integer ?y operands (the slow half of the filter), a projection without / with a build column; and a
+    slice holding ONE double value (no value table can be built: the kernel gathers typed values as before).  The oracle's multiset, the
+    queueing kernel (NO_STREAM_JOIN) and the re-execution agree."""
+    rng = np.random.default_rng(len(build_values))
+    n_sub, npr = 120_000, 4_300_000
+    n_val = 400
+    # ids: 1 .. n_val integer literals (value = id * 3), n_val + 1 a double, subjects from 10_000
+    tv = np.zeros(10_000 + n_sub + 10, dtype=TV_DTYPE)
+    tv["tag"][1:n_val + 1] = abi.TV_INTEGER; tv["lo"][1:n_val + 1] = np.arange(1, n_val + 1) * 3
+    tv["tag"][n_val + 1] = abi.TV_DOUBLE; tv["lo"][n_val + 1] = int(np.array([600.5]).view(np.int64)[0])
+    tv["tag"][10_000:] = abi.TV_NAMED_NODE; tv["lo"][10_000:] = np.arange(len(tv) - 10_000)
+    sub = (10_000 + np.arange(n_sub)).astype(np.uint32)
+    val = rng.integers(1, n_val + 1, n_sub).astype(np.uint32)
+    if build_values == "one_double":
+        val[777] = n_val + 1
+    quads = (np.zeros(n_sub, np.uint32), sub, np.full(n_sub, 5, np.uint32), val)
+    gs, os_ = both_stores(quads, typed=tv)
+    keys = (10_000 + rng.integers(0, n_sub + 8, npr)).astype(np.uint32)          # a few keys behind the slice's range
+    keys[rng.random(npr) < 0.01] = 0
+    ys = rng.integers(1, n_val + 1, npr).astype(np.uint32)
+    ys[rng.random(npr) < 0.001] = n_val + 1                                         # a double y operand: decided by the slow half
+    tab = [np.arange(1, npr + 1, dtype=np.uint32), keys, ys]
+    keep, ptrs = table_on_device(torch_cuda, tab)
+    window = AND(EBV(LT(ENC_TV(col(4)), ADD(ENC_TV(col(2)), integer(30)))), EBV(GT(ENC_TV(col(4)), SUB(ENC_TV(col(2)), integer(30)))))
+    for projection in ([0, 1, 2], [0, 4, 3]):
+        pb = PlanBuilder()
+        desc = pb.build(pb.hash_join(pb.table(0, 3), pb.data_source(quad_pattern("s", 5, "v")), on=[(1, 0)], filter=window, projection=projection))
+        exp, n_exp, _ = os_.execute(desc, [tab])
+        want = ku.multiset(exp, n_exp)
+        assert 100_000 < n_exp < npr // 2
+        for option in (None, "NO_STREAM_JOIN", "NO_VALUE_TABLES", "NO_TABLE_CACHE"):
+            plan = gs.plan(desc)
+            if option:
+                plan.set_option(option, 1)
+            plan.bind_table(0, ptrs, npr)
+            for run in range(2):
+                plan.enable_kernel_timing(True)
+                got = plan.execute().fetch()
+                assert plan.result_info()[0] == n_exp, (build_values, projection, option, run)
+                np.testing.assert_array_equal(ku.multiset(got, n_exp), want, err_msg=f"{build_values} {projection} {option} run {run}")
+            names = {k[0] for k in plan.kernel_stats()}
+            if not ENGINE_TOGGLED:
+                assert any("stream_join_kernel" in k for k in names) == (option != "NO_STREAM_JOIN"), (option, names)
+            plan.close()
+    del keep
+
+
 @pytest.mark.parametrize("join_type", ["inner", "left"])
 def test_partitioned_join_large_output_form_and_table_geometry(torch_cuda, join_type):
     """The partitioned join's large-output form (part_join.hip, BIG: a counting pass, one reservation per partition, then a writing pass that
