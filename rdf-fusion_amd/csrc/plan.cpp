@@ -688,9 +688,9 @@ void Plan::execute() {
   std::shared_lock<std::shared_mutex> lock(store->mu);   // a plan holds the snapshot while it runs (snapshot.rs:35-37)
   RDFGPU_HIP(hipStreamSynchronize(stream));
   release_intermediates();
-  // the pool keeps what an execution hands back for the next one — bounded by twice what the previous execution used
+  // the pool keeps what an execution hands back for the next one — bounded by twice what the previous executions (this plan's, or any plan's of the store) used
   // (+ 1 GiB): the giant blocks of a one-off exact run go back to the device instead of staying cached for ever
-  store->pool.trim_to(2 * std::max(scratch_hist[0], scratch_hist[1]) + (1ull << 30));
+  store->pool.trim_to(2 * std::max(std::max(scratch_hist[0], scratch_hist[1]), std::max(store->scratch_recent[0].load(), store->scratch_recent[1].load())) + (1ull << 30));
   held = store->gen;         // ... and the generation it read until its next execute: the result may be zero-copy slices of it
   metrics = rdfgpu_metrics{};
   const u64 mallocs0 = store->pool.mallocs() + store->table_pool.mallocs();
@@ -810,6 +810,7 @@ void Plan::execute() {
   resolve_timing();
   executed = true;
   scratch_hist[1] = scratch_hist[0]; scratch_hist[0] = metrics.device_bytes;
+  store->scratch_recent[1] = store->scratch_recent[0].load(); store->scratch_recent[0] = metrics.device_bytes;
 }
 
 DevTable Plan::exec_node(u32 idx) {

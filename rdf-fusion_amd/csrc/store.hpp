@@ -133,6 +133,10 @@ struct Store {
   // lexical forms of string ids (the slice of the dictionary string builtins read): offsets[n_str_ids + 1] + UTF-8 heap
   u64* str_off = nullptr; unsigned char* heap = nullptr; u64 n_str_ids = 0;
   DevicePool pool;
+  // intermediates of the store's last two completed executions, whatever plan ran them: a FRESH plan (the reference compiles one per query) has no
+  // history of its own, and trimming the pool to the fixed floor before its first execution handed ~20 cached blocks back to the device (0.2 ms of
+  // hipFree each: 4 ms around a 0.55 ms execution) only to allocate them again
+  std::atomic<u64> scratch_recent[2] = {{0}, {0}};
   // the slice join tables' own pool: a mutation drops every table, the next executions build them again — out of the blocks
   // the dropped ones gave back, not out of fresh hipMalloc calls (a store that is updated between queries pays kernels, not
   // the allocator, for its tables)
