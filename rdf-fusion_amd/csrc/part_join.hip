@@ -393,6 +393,10 @@ __global__ __launch_bounds__(kLdsBlock) __attribute__((amdgpu_waves_per_eu(4))) 
         // worked on: the loads of a partition overlap its LDS phases instead of heading each of them
         PartRec bnext = pa.bpart[cb + (tid < nb ? tid : nb - 1)];
         uint4 pnext = load_probe(ps, pe, tid);
+        // a partition of ONE chunk keeps its table from the counting pass to the writing pass (the probes do not change it): with
+        // ~100 rows per key the build is the most expensive phase of the partition, see below
+        const bool rebuild = counting || !pa.two_pass || be - bs > pa.chunk;   // uniform per workgroup
+        if (rebuild) {
         __syncthreads();                             // every wave is done with the previous table
         for (u32 s = tid; s <= pa.tbl_mask; s += kLdsBlock) slots[s] = make_uint2(0u, 0u);
         __syncthreads();
@@ -400,12 +404,32 @@ __global__ __launch_bounds__(kLdsBlock) __attribute__((amdgpu_waves_per_eu(4))) 
           const PartRec q = bnext;
           const u32 in = i0 + kLdsBlock + tid;
           bnext = pa.bpart[cb + (in < nb ? in : nb - 1)];
-          if (i0 + tid >= nb || q.row == kNil) continue;   // no row in this lane, or a row that joins nothing
-          u32 h = slot_of(q.k0, a.n_keys > 1 ? q.k1 : 0u);
+          const bool mine = i0 + tid < nb && q.row != kNil;   // else: no row in this lane, or a row that joins nothing
+          const u32 qk1 = a.n_keys > 1 ? q.k1 : 0u;
+          u32 h = slot_of(q.k0, qk1);
+          if constexpr (BIG) {
+            // Rows with EQUAL keys all start at the key's home slot and the loser of every CAS steps on by one: k rows of one key cost
+            // k^2 / 2 serialised same-address atomics — 108 rows per key made the build 2.8 of the candidate join's 6.9 ms (knock-out
+            // runs).  The equal-key lanes of a wave start on CONSECUTIVE slots instead, home + rank: every slot between home
+            // and a row's final place is still tried by someone (the lane of that rank, which takes it or finds it taken), so the
+            // chain a probe walks from home has no hole.
+            u32 rank = 0;
+            unsigned long long todo = __ballot(mine);
+            while (todo) {                           // one trip per distinct key among the wave's rows
+              const int leader = __builtin_ctzll(todo);
+              const u32 lk0 = (u32)__builtin_amdgcn_readlane((int)q.k0, leader), lk1 = (u32)__builtin_amdgcn_readlane((int)qk1, leader);
+              const unsigned long long same = __ballot(mine && q.k0 == lk0 && qk1 == lk1);
+              if ((same >> lane) & 1ull) rank = (u32)__popcll(same & ((1ull << lane) - 1ull));
+              todo &= ~same;
+            }
+            h = (h + rank) & pa.tbl_mask;
+          }
+          if (!mine) continue;
           for (;;) {
             if (atomicCAS(&slots[h].x, 0u, q.k0) == 0u) { slots[h].y = q.k1; rowof[h] = q.row; break; }
             h = (h + 1) & pa.tbl_mask;
           }
+        }
         }
         __syncthreads();
         for (u32 t0 = 0; t0 < n_probe; t0 += kLdsBlock) {   // uniform trip count per workgroup
