@@ -139,7 +139,9 @@ enum {
 #define RDFGPU_TVF_EMPTY_STRING 1u
 #define RDFGPU_TVF_NEEDS_HOST 0x80u   /* rdfgpu_ntriples_decoded only: the literal's value is left to the host's parser (see there) */
 
-/* MemQuadStorage::new (mem_storage.rs:31-65): creates the store on `cfg->device`. */
+/* MemQuadStorage::new (mem_storage.rs:31-65): creates the store on `cfg->device`.  The first store a process creates also has the HIP
+   runtime load every code object of this library (it would otherwise do so at the first launch from each translation unit: some
+   tens of milliseconds that the first query would pay). */
 int rdfgpu_store_create(const rdfgpu_config* cfg, rdfgpu_store** out);
 void rdfgpu_store_destroy(rdfgpu_store* store);
 
