@@ -637,6 +637,20 @@ def main():
                   f"{m_nc.kernels_launched} launches, {m_nc.device_bytes / 2**30:.1f} GiB of intermediates, {m_nc.exact_reruns} exact re-runs, "
                   f"{m_nc.device_mallocs} hipMallocs ({m_nc.device_malloc_ms:.1f} ms)", file=sys.stderr, flush=True)
         torch.cuda.synchronize()
+        # full-size cross-check of two executions that share no join kernel: the last step's bindings of the un-fused, un-cached plan (partitioned
+        # join + streaming joins) against the timed plan's (ordered slice join + band join) on the same batch — row count and an order-independent checksum
+        def checksum(cols):
+            mix = np.zeros(len(cols[0]), dtype=np.uint64)
+            with np.errstate(over="ignore"):
+                for k, c in enumerate(cols):
+                    mix ^= c.astype(np.uint64) * np.uint64([0x9E3779B97F4A7C15, 0xC2B2AE3D27D4EB4F, 0x165667B19E3779F9][k % 3])
+                return len(cols[0]), int(mix.sum(dtype=np.uint64))
+        chk_nc = checksum(plan_nc.fetch())
+        step(batches[-1], False)
+        chk_timed = checksum(plan.fetch())
+        if chk_nc != chk_timed:
+            raise SystemExit(f"[bench] the un-cached plan's bindings differ from the timed plan's on the same batch: {chk_nc} vs {chk_timed}")
+        step(batches[0], False)     # (leave the steady state as it was)
         # a side measurement over 5 long steps: the median, with the mean and the fastest beside it.  (Its 0.54 G-row candidate
         # join used to reserve output per full queue — 2.1 M same-address atomics — and ran at 27 ms or at 250-350 ms from step
         # to step; it now counts a partition's matches first and reserves once per partition: 30 ms per step, every step.)
@@ -647,6 +661,7 @@ def main():
         steady = elapsed * 1e3 / args.steps
         cold["no_table_cache"] = {"ms_per_step": round(ms_nc, 3), "ms_per_step_mean": round(float(np.mean(step_ms)), 3), "ms_per_step_min": round(float(np.min(step_ms)), 3), "bindings_per_s": round(rows_nc / n_nc / (ms_nc * 1e-3), 2), "steps": n_nc,
                                   "per_step": nc_detail,
+                                  "result_check": f"the last step's {chk_nc[0]} bindings: row count and order-independent checksum equal to the timed (fused, cached) plan's on the same batch",
                                   "what": "every join table (hash / CSR / direct) built inside the timed step: HashJoinExec-style per-query builds"}
         # the reference's protocol applied to the batch: a FRESH plan per batch — compile, bind, execute, row count, drop (store tables warm)
         fresh_ms = []

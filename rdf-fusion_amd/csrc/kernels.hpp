@@ -310,6 +310,10 @@ struct PartArgs {
   // range mode (ppart == nullptr): the probe side is a store slice sorted by one of the join keys and is read in place —
   // partition p = the slice rows pstart[p] .. pstart[p + 1] (key ranges of 2^shift ids), only the build side was partitioned
   const u32* pcol0; const u32* pcol1;
+  // large-output form, join filter `build column <=|!=> probe column` (FS = 2): the build side's operand lives in the LDS table beside the row id and
+  // the probe row's operand in a register — the filter is decided while the chain is walked, no candidate that fails it is queued, neither pass
+  // gathers for it.  inl_build / inl_probe: the two columns (null = the form is not used).
+  const u32* inl_build; const u32* inl_probe;
 };
 // range < 0: partition = top `bits` bits of the key hash.  Else the probe side is a slice sorted by key[range]: partitions are
 // key ranges of that column, equalised over the slice's rows through a coarse directory — coarse bucket c = (key - range_min)

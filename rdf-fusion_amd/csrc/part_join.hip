@@ -127,8 +127,12 @@ __global__ __launch_bounds__(256) void part_range_bounds_kernel(const u32* col, 
 // the gathers behind every full queue — the filter's operands in both passes, the payload columns in the second — and not by the walk:
 // its resolve and write-out phases keep four 64-entry groups of the queue in flight at once (8 / 16 gathers per lane outstanding instead
 // of 2 / 4).  The single-pass form (small outputs: LUBM Q9's closing join) keeps the lean loops, whose registers its walk wants.
-template <int FS, bool RANGE, bool BIG>
+// INL (BIG, FS = 2, one operand of the `col <=|!=> col` filter on each side): the filter is decided during the walk from the LDS table
+// (rowof holds {row, the build row's operand}) and the probe row's operand in a register.
+template <int FS, bool RANGE, bool BIG, bool INL = false>
 __global__ __launch_bounds__(kLdsBlock) __attribute__((amdgpu_waves_per_eu(4))) void part_join_kernel(const LdsJoinArgs a, const PartArgs pa) {
+  static_assert(!INL || (BIG && FS == 2), "the in-walk filter belongs to the large-output form of a col-col filter");
+  constexpr int FSQ = INL ? 0 : FS;                  // the filter shape the queue phases still have to evaluate
   extern __shared__ __align__(16) unsigned char lds_raw[];
   // dynamic LDS: [slots: tbl_mask + 1 x {key0, key1}; key0 == 0 = empty: a null key joins nothing and is never inserted]
   //              [rowof: tbl_mask + 1 build row ids, by slot] [8 wave queues]
@@ -138,7 +142,8 @@ __global__ __launch_bounds__(kLdsBlock) __attribute__((amdgpu_waves_per_eu(4))) 
   // closing join, waves executing 26 % of their cycles (profiles/r03_lubm_part_join_sq_counters_before.json).
   uint2* slots = reinterpret_cast<uint2*>(lds_raw);
   u32* rowof = reinterpret_cast<u32*>(slots + (pa.tbl_mask + 1u));
-  uint2* queues = reinterpret_cast<uint2*>(rowof + (pa.tbl_mask + 1u));
+  uint2* rowfv = reinterpret_cast<uint2*>(rowof);   // INL: {row, filter operand} by slot instead
+  uint2* queues = reinterpret_cast<uint2*>(rowof + (size_t)(pa.tbl_mask + 1u) * (INL ? 2u : 1u));
   u64& wg_base = *reinterpret_cast<u64*>(queues + (size_t)(kLdsBlock / 64) * a.wave_q);   // (behind the queues: the table starts at LDS address 0)
   u32& wg_count = reinterpret_cast<u32*>(&wg_base)[2];
   u32& wg_cursor = reinterpret_cast<u32*>(&wg_base)[3];
@@ -200,7 +205,7 @@ __global__ __launch_bounds__(kLdsBlock) __attribute__((amdgpu_waves_per_eu(4))) 
   };
   auto resolve = [&]() {   // join filter over the queued candidates, survivors compacted in place
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    if (FS == 0) return;
+    if (FSQ == 0) return;
     u32 kept = 0;
     if constexpr (BIG) {
       for (u32 g0 = 0; g0 < qn; g0 += 256) {
@@ -275,7 +280,7 @@ __global__ __launch_bounds__(kLdsBlock) __attribute__((amdgpu_waves_per_eu(4))) 
 #pragma unroll
         for (u32 u = 0; u < 4; u++) v[g][u] = src[u][from_build[u] ? m[g].x : m[g].y];   // (an unused column slot repeats column 0)
       }
-      if constexpr (FS != 0) {
+      if constexpr (FSQ != 0) {
 #pragma unroll
         for (u32 g = 0; g < 4; g++) { bool sl; const bool f = ljoin_filter_fast<FS>(a, m[g].x, m[g].y, sl); slow[g] = ok[g] && sl; ok[g] = ok[g] && f; }
         if constexpr (FS == 1 || FS == 3) {
@@ -361,6 +366,8 @@ __global__ __launch_bounds__(kLdsBlock) __attribute__((amdgpu_waves_per_eu(4))) 
     u32 hb = slot_of(r.y, r.z) << 3;                 // the walk keeps the slot's byte offset
     const bool dead = !live | (r.x == kNil) | (r.y == 0u) | ((a.n_keys > 1) & (r.z == 0u));   // no row in this lane, or NullEqualsNothing
     const unsigned char* sb = reinterpret_cast<const unsigned char*>(slots);
+    u32 pv = 0;
+    if constexpr (INL) pv = pa.inl_probe[dead ? 0u : r.x];   // the probe row's filter operand, once per row
     for (;;) {
       bool eq;
       for (;;) {                                     // (divergent, but the body is one read, three compares and one exit)
@@ -368,6 +375,21 @@ __global__ __launch_bounds__(kLdsBlock) __attribute__((amdgpu_waves_per_eu(4))) 
         eq = (c.x == r.y) & (c.y == r.z);
         if ((c.x == 0u) | eq | dead) break;
         hb = (hb + 8u) & wrap;
+      }
+      if constexpr (INL) {
+        const bool on_eq = eq & !dead;
+        if (__builtin_amdgcn_ballot_w64(on_eq) == 0) break;
+        const uint2 rf = rowfv[hb >> 3];             // (a lane that is not on a key-equal slot reads its slot's entry and ignores it)
+        const bool pass = on_eq && rf.y != 0u && pv != 0u && ((rf.y == pv) == (a.idp.is_eq != 0));   // null => not `true` (ljoin_filter_fast<2>)
+        const unsigned long long found = __builtin_amdgcn_ballot_w64(pass);
+        const u32 n_found = (u32)__popcll(found);
+        if (n_found) {
+          if (qn + n_found > qcap) flush(counting);
+          if (pass) wq[qn + lane_prefix(found)] = make_uint2(rf.x, r.x);
+          qn += n_found;
+        }
+        if (on_eq) hb = (hb + 8u) & wrap;
+        continue;
       }
       const bool hit = eq & !dead;                   // a live key is not 0: key-equal implies occupied
       const unsigned long long found = __builtin_amdgcn_ballot_w64(hit);
@@ -424,9 +446,15 @@ __global__ __launch_bounds__(kLdsBlock) __attribute__((amdgpu_waves_per_eu(4))) 
             }
             h = (h + rank) & pa.tbl_mask;
           }
+          u32 fvb = 0;
+          if constexpr (INL) fvb = pa.inl_build[mine ? q.row : 0u];
           if (!mine) continue;
           for (;;) {
-            if (atomicCAS(&slots[h].x, 0u, q.k0) == 0u) { slots[h].y = q.k1; rowof[h] = q.row; break; }
+            if (atomicCAS(&slots[h].x, 0u, q.k0) == 0u) {
+              slots[h].y = q.k1;
+              if constexpr (INL) rowfv[h] = make_uint2(q.row, fvb); else rowof[h] = q.row;
+              break;
+            }
             h = (h + 1) & pa.tbl_mask;
           }
         }
@@ -482,7 +510,7 @@ void part_sort(const u32* kin, u32* kout, const PartRec* vin, PartRec* vout, u64
   RDFGPU_HIP(rocprim::radix_sort_pairs(temp, temp_bytes, kin, kout, vin, vout, (size_t)n, 0, bits, s));
 }
 size_t part_join_lds_bytes(const LdsJoinArgs& a, const PartArgs& pa) {
-  return (size_t)(pa.tbl_mask + 1) * (sizeof(uint2) + sizeof(u32)) + (size_t)(kLdsBlock / 64) * a.wave_q * sizeof(uint2) + 16;
+  return (size_t)(pa.tbl_mask + 1) * (sizeof(uint2) + (pa.inl_build ? sizeof(uint2) : sizeof(u32))) + (size_t)(kLdsBlock / 64) * a.wave_q * sizeof(uint2) + 16;
 }
 template <int FS, bool RANGE, bool BIG> static void launch_part_join_frb(const LdsJoinArgs& a, const PartArgs& pa, dim3 g, size_t lds, hipStream_t s) {
   static std::once_flag attr_once;
@@ -492,6 +520,17 @@ template <int FS, bool RANGE, bool BIG> static void launch_part_join_frb(const L
   hipLaunchKernelGGL((part_join_kernel<FS, RANGE, BIG>), g, dim3(kLdsBlock), lds, s, a, pa);
 }
 template <int FS, bool RANGE> static void launch_part_join_fr(const LdsJoinArgs& a, const PartArgs& pa, dim3 g, size_t lds, hipStream_t s) {
+  if constexpr (FS == 2) {
+    if (pa.inl_build) {
+      if (!pa.two_pass || !pa.inl_probe) fail(RDFGPU_ERR_INVALID, "partitioned join: the in-walk filter belongs to the two-pass form");
+      static std::once_flag attr_once;
+      std::call_once(attr_once, [] {
+        RDFGPU_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(part_join_kernel<2, RANGE, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
+      });
+      hipLaunchKernelGGL((part_join_kernel<2, RANGE, true, true>), g, dim3(kLdsBlock), lds, s, a, pa);
+      return;
+    }
+  }
   if (pa.two_pass) launch_part_join_frb<FS, RANGE, true>(a, pa, g, lds, s);
   else launch_part_join_frb<FS, RANGE, false>(a, pa, g, lds, s);
 }

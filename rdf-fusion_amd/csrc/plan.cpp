@@ -1840,6 +1840,11 @@ DevTable Plan::exec_lds_join(NodeInfo& nd, const DevTable& L, const DevTable& R,
     // same-address atomic per 256 rows, ~88 per microsecond) cost more than walking every partition twice
     const u64 expect_out = nd.has_last ? nd.last_rows : 0;
     part.two_pass = expect_out >= opt.v[RDFGPU_OPT_PARTITION_TWO_PASS_ROWS] ? 1u : 0u;
+    if (part.two_pass && nd.shape == 2 && !left_join) {   // `build column <=|!=> probe column`: decided during the walk (part_join.hip, INL)
+      auto from_build = [&](u32 c) { return (c < L.n_cols) == build_left; };
+      const u32 ca = nd.prog.nodes[0].u, cb = nd.prog.nodes[1].u;
+      if (from_build(ca) != from_build(cb)) { part.inl_build = a.cols[from_build(ca) ? ca : cb]; part.inl_probe = a.cols[from_build(ca) ? cb : ca]; }
+    }
     prepare_partitions(a, B, P, part);   // the build half of this HashJoinExec: inside the operator, every execution
   }
   // SURVEY 8d hash-join bytes of a partitioned join: both sides' key + payload columns and one 8-byte slot per row, the output;

@@ -802,10 +802,12 @@ def test_partitioned_join_large_output_form_and_table_geometry(torch_cuda, join_
     Pr = [rng.integers(1, n_keys + 20, npr).astype(np.uint32), rng.integers(1, 40, npr).astype(np.uint32), rng.integers(1, n_tv, npr).astype(np.uint32),
           np.arange(1, npr + 1, dtype=np.uint32)]
     B[0][rng.random(nb) < 0.01] = 0; Pr[0][rng.random(npr) < 0.01] = 0             # null keys join nothing
+    B[1][rng.random(nb) < 0.02] = 0; Pr[1][rng.random(npr) < 0.02] = 0             # null operands of the `col != col` / `col = col` filters: never `true`
     kb, pbp = table_on_device(torch_cuda, B)
     kp, ppp = table_on_device(torch_cuda, Pr)
     window = AND(EBV(LT(ENC_TV(col(2)), ADD(ENC_TV(col(5)), integer(40)))), EBV(GT(ENC_TV(col(2)), SUB(ENC_TV(col(5)), integer(40)))))
-    filters = [None, ID_NEQ(col(1), col(4)), window, EBV(GT(ADD(ENC_TV(col(2)), ENC_TV(col(5))), integer(3)))]
+    # (inner join, `col <=|!=> col` with one operand per side: decided during the chain walk from the LDS table, part_join.hip INL)
+    filters = [None, ID_NEQ(col(1), col(4)), ID_EQ(col(4), col(1)), ID_NEQ(col(0), col(1)), window, EBV(GT(ADD(ENC_TV(col(2)), ENC_TV(col(5))), integer(3)))]
     jt = abi.JOIN_INNER if join_type == "inner" else abi.JOIN_LEFT
     for flt in filters:
         pb = PlanBuilder()
